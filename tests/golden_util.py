@@ -1,0 +1,58 @@
+"""Helpers shared by tests: load a golden fixture and rebuild its (seeded) inputs."""
+import ast
+import os
+
+import numpy as np
+import torch
+
+from scenerf_amd import synth
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["kitti_small_n64", "kitti_full_n64", "kitti_small_n128_chunks", "bf_small_n96"]
+OUT_KEYS = ["depth", "color", "gaussian_means", "gaussian_stds", "weights_at_depth", "closest_pts_to_depths",
+            "loss_kl", "alphas", "som_vars", "densities", "weights", "depth_volumes"]
+
+
+class Golden:
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.meta = ast.literal_eval(str(self.z["meta"]))
+        self.ctor = self.meta["ctor"]
+        self.variant = self.meta["variant"]
+        self.seed = self.meta["seed"]
+        self.cam_K = torch.from_numpy(self.z["cam_K"])
+        self.T = torch.from_numpy(self.z["T_source2infer"])
+        self.pixels = torch.from_numpy(self.z["pixels"])
+        self.noise_u = torch.from_numpy(self.z["noise_u"])
+        self.noise_g = torch.from_numpy(self.z["noise_g"])
+        self.chunk = self.meta["chunk"]
+
+    def out(self, key):
+        return torch.from_numpy(self.z["out/" + key])
+
+    def mlp_states(self):
+        return synth.mlp_state(self.seed + 1, 4), synth.mlp_state(self.seed + 2, 2, out_scale=4.0)
+
+    def feature_maps(self):
+        return synth.feature_maps(self.meta["sphere_W"], self.meta["sphere_H"], self.seed + 3,
+                                  smooth=self.meta["smooth"])
+
+    def cfg_kwargs(self):
+        """ctor kwargs -> the hot-path constants (names shared by OracleConfig and RenderConfig)."""
+        c = dict(self.ctor)
+        kw = dict(sphere_W=self.meta["sphere_W"], sphere_H=self.meta["sphere_H"],
+                  img_size=tuple(self.meta["img_size"]))
+        for k in ("n_pts_uni", "n_gaussians", "n_pts_per_gaussian", "std", "som_sigma", "add_fov_hor",
+                  "add_fov_ver", "max_sample_depth"):
+            if k in c:
+                kw[k] = c[k]
+        return kw
+
+    def grad_digest(self, name):
+        p = "grad/%s/" % name
+        return dict(norm=float(self.z[p + "norm"]), sum=float(self.z[p + "sum"]),
+                    idx=torch.from_numpy(self.z[p + "idx"]), val=torch.from_numpy(self.z[p + "val"]))
+
+    def grad_names(self):
+        return sorted({k.split("/")[1] for k in self.z.files if k.startswith("grad/")})

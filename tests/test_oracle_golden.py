@@ -1,0 +1,59 @@
+"""Pin the CPU oracle against the golden vectors minted from the real reference."""
+import pytest
+import torch
+
+import scenerf_oracle as orc
+from golden_util import CASES, OUT_KEYS, Golden
+
+
+def _cfg(g):
+    base = orc.OracleConfig.kitti if g.variant == "kitti" else orc.OracleConfig.bundlefusion
+    return base(**g.cfg_kwargs())
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_outputs_and_grads(name):
+    g = Golden(name)
+    cfg = _cfg(g)
+    mlp, mlpg = g.mlp_states()
+    for d in (mlp, mlpg):
+        for v in d.values():
+            v.requires_grad_(True)
+    maps = g.feature_maps()
+    for v in maps.values():
+        v.requires_grad_(True)
+    out = orc.render_rays_batch(cfg, mlp, mlpg, g.cam_K, g.T, maps, g.pixels, g.noise_u, g.noise_g,
+                                ray_batch_size=g.chunk)
+    for k in OUT_KEYS:
+        ref = g.out(k)
+        assert out[k].shape == ref.shape, k
+        torch.testing.assert_close(out[k].detach(), ref, rtol=2e-5, atol=2e-6, msg=lambda m: "%s: %s" % (k, m))
+    loss = orc.training_proxy_loss(out)
+    assert abs(loss.item() - float(g.z["loss"])) < 1e-4 * abs(float(g.z["loss"]))
+    loss.backward()
+    tensors = {}
+    for pn, p in mlp.items():
+        tensors["mlp." + pn] = p.grad
+    for pn, p in mlpg.items():
+        tensors["mlp_gaussian." + pn] = p.grad
+    for key, v in maps.items():
+        tensors["x_rgb." + key] = v.grad if v.grad is not None else torch.zeros_like(v)
+    assert set(g.grad_names()) == set(tensors)
+    for nm, grad in tensors.items():
+        d = g.grad_digest(nm)
+        flat = grad.reshape(-1)
+        assert abs(float(flat.double().norm()) - d["norm"]) <= 1e-4 * d["norm"] + 1e-9, nm
+        torch.testing.assert_close(flat[d["idx"]], d["val"], rtol=1e-4, atol=1e-7,
+                                   msg=lambda m: "%s: %s" % (nm, m))
+
+
+def test_sort_is_a_permutation_and_sorted():
+    g = Golden("kitti_small_n64")
+    cfg = _cfg(g)
+    mlp, mlpg = g.mlp_states()
+    out = orc.render_chunk(cfg, mlp, mlpg, g.cam_K, g.T, g.feature_maps(), g.pixels, g.noise_u, g.noise_g,
+                           keep_intermediates=True)
+    perm = out["_perm"]
+    assert torch.equal(torch.sort(perm, dim=1).values, torch.arange(perm.shape[1]).expand_as(perm))
+    d = out["_dist_sorted"]
+    assert bool((d[:, 1:] >= d[:, :-1]).all())
