@@ -1,0 +1,219 @@
+/*
+ * scenerf_hip.h -- C ABI of libscenerf_hip.so: the MI355X (gfx950) ray-rendering hot path of SceneRF.
+ *
+ * Drop-in boundary.  The reference has no FFI: its hot path is eager PyTorch inside
+ * `SceneRF.render_rays_batch` (reference scenerf/models/scenerf.py:392-471).  What a maintainer binds
+ * instead of those torch ops is this library, through ctypes (INTEGRATION.md shows the stub).  Every entry
+ * point takes plain device pointers + sizes + a hipStream_t (as void*); nothing here knows about torch.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`; all work is enqueued on `stream`
+ *     and returns immediately (no hidden synchronisation, no allocation, no global state => re-entrant,
+ *     one process per GPU, hipGraph-capturable);
+ *   - return value 0 = ok, otherwise an error code; `scenerf_hip_last_error()` gives the message.  Bad
+ *     arguments are reported, never abort();
+ *   - "rows" M = rays * points-per-ray.  Activation buffers are row-major [M][ld];
+ *   - precision: 0 = fp32 everywhere (fp32 MFMA v_mfma_f32_32x32x2_f32), 1 = bf16 GEMM operands /
+ *     fp32 accumulate, fp32 everything else (BASELINE.json config 2).  "act" buffers are float (0) or
+ *     bf16 (1);
+ *   - sample order, sphere indices and the sort permutation are int32 on the device (the reference's
+ *     int64 tensors are produced by the Python host when a caller asks for them).
+ *
+ * Each function names the reference code it replaces (paths relative to the reference repo).
+ */
+#ifndef SCENERF_HIP_H
+#define SCENERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCENERF_HIP_ABI_VERSION 1
+#define SCENERF_N_SCALES 5          /* feature maps "1_1","1_2","1_4","1_8","1_16" */
+#define SCENERF_D_LATENT 2480       /* 80+160+320+640+1280 (resnetfc d_latent, scenerf.py:100-114) */
+#define SCENERF_D_HIDDEN 512
+#define SCENERF_D_XENC 48           /* PE(39) + viewdir(3), zero-padded to a multiple of 16 */
+#define SCENERF_TILE_ROWS 128       /* granularity of the scale-activity mask (Q1 sparsity) */
+#define SCENERF_MAX_GAUSSIANS 8
+#define SCENERF_MAX_SAMPLES 512
+
+typedef void* scenerf_stream_t;     /* hipStream_t */
+
+/* Constants that reach the hot path (reference scenerf.py:23-116; BundleFusion deltas scenerf_bf.py:85-90,606-608). */
+typedef struct scenerf_cfg {
+    int32_t n_pts_uni;              /* U */
+    int32_t n_gaussians;            /* G */
+    int32_t n_pts_per_gaussian;     /* P */
+    int32_t n_samples;              /* N = U + G*P (U>0) or G*P */
+    int32_t sphere_W, sphere_H;     /* out_img_W/H */
+    float max_sample_depth;         /* D */
+    float uni_step;                 /* (D-0.2)/U, utils.py:77 */
+    float base_std;                 /* `std` ctor arg */
+    float som_sigma;
+    float gauss_floor;              /* 1.5 (KITTI) / 0.5 (BundleFusion) */
+    float kl_std_floor;             /* 1.5, ray_som_kl.py:83 */
+    float v_min, v_fov, h_min, h_fov; /* SphericalMapping, spherical_mapping.py:60-67 */
+    int32_t map_C[SCENERF_N_SCALES];  /* 80,160,320,640,1280 */
+    int32_t map_H[SCENERF_N_SCALES], map_W[SCENERF_N_SCALES]; /* round(H/s), round(W/s): unet2d_sphere.py:139 */
+    int32_t div_H[SCENERF_N_SCALES], div_W[SCENERF_N_SCALES]; /* H//s, W//s: scenerf.py:525 */
+    int32_t precision;              /* 0 fp32, 1 bf16 operands */
+} scenerf_cfg;
+
+/* Packed ResnetFC operands (built by the host from the nn.Linear parameters).
+ * T = float (precision 0) or bf16 (precision 1).  reference scenerf/models/resnetfc.py:88-118,133-164 */
+typedef struct scenerf_mlp_weights {
+    int32_t d_out;                  /* 4 (mlp) or 2 (mlp_gaussian) */
+    const float* w_in;              /* [512][48]  lin_in.weight zero-padded 42->48, always fp32 */
+    const float* b_in;              /* [512] */
+    const void* w_h[4];             /* T: [512][2480] = lin_z.0 ; [512][512+2480] = [fc_1.b | lin_z.(b+1)] b=0,1 ; [512][512] = fc_1.2 */
+    const float* b_h[4];            /* [512]: lin_z.0.bias ; fc_1.b.bias + lin_z.(b+1).bias ; fc_1.2.bias */
+    const void* w_fc0[3];           /* T: [512][512] blocks.b.fc_0.weight */
+    const float* b_fc0[3];
+    const float* w_out;             /* [d_out][512] fp32 */
+    const float* b_out;             /* [d_out] */
+    /* backward operands */
+    const void* w_fc0_t[3];         /* T: [512][512] = fc_0.weight^T */
+    const void* w_fc1_t[3];         /* T: [512][512] = fc_1.weight^T */
+    const void* w_z_t[SCENERF_N_SCALES]; /* T: [C_s][1536] = (cat_b lin_z.b.weight[:, slice_s])^T */
+} scenerf_mlp_weights;
+
+/* Gradients of the packed operands (fp32, accumulated with atomics: zero them first). */
+typedef struct scenerf_mlp_grads {
+    float* w_in;                    /* [512][48] */
+    float* b_in;                    /* [512] */
+    float* w_fc0[3];                /* [512][512] */
+    float* b_fc0[3];
+    float* w_fc1[3];                /* [512][512] */
+    float* b_fc1[3];
+    float* w_z;                     /* [1536][2480]  (rows 512b.. = lin_z.b) */
+    float* b_z;                     /* [1536] */
+    float* w_out;                   /* [d_out][512] */
+    float* b_out;                   /* [d_out] */
+} scenerf_mlp_grads;
+
+/* Saved activations of one ResnetFC evaluation over M rows (caller-allocated).
+ * act = T.  H[b] is the residual stream after adding lin_z.b (b<3) / the final one (b=3); N[b] = fc_0 output. */
+typedef struct scenerf_mlp_acts {
+    void* H[4];                     /* T [M][512] */
+    void* Nn[3];                    /* T [M][512] */
+    float* h0pre;                   /* fp32 [M][512] scratch: lin_in output */
+    float* logits;                  /* fp32 [M][d_out] */
+} scenerf_mlp_acts;
+
+int scenerf_hip_abi_version(void);
+const char* scenerf_hip_last_error(void);
+
+/* ---- feature-map layout ------------------------------------------------------------------------------- */
+/* (C,H,W) fp32 encoder output -> (H,W,C) act (bf16 or fp32): one sample's 2x2 gather becomes 4 contiguous
+ * channel runs.  Replaces the CHW strided reads of F.grid_sample, utils.py:239-245. */
+int scenerf_hip_maps_chw_to_hwc(const float* chw, void* hwc, int C, int H, int W, int precision, scenerf_stream_t stream);
+/* (H,W,C) fp32 gradient accumulator -> (C,H,W) fp32 (grid_sampler_2d_backward's output layout). */
+int scenerf_hip_grads_hwc_to_chw(const float* hwc, float* chw, int C, int H, int W, scenerf_stream_t stream);
+
+/* ---- ray / sample geometry ----------------------------------------------------------------------------- */
+/* utils.py:177-182 (unit dirs), utils.py:112-173 + 75-90 (uniform distances, un-normalised viewdir in the
+ * infer frame).  lin_u = torch.linspace(0.2, D, U); noise_u in [0,1) is the reference's rand_like. */
+int scenerf_hip_ray_setup(const scenerf_cfg* cfg, const float* pixels /*[R][2]*/, const float* inv_K /*[9]*/,
+                          const float* T_s2i /*[16]*/, const float* lin_u /*[U]*/, const float* noise_u /*[R][U]*/,
+                          int R, float* unit_dir /*[R][3]*/, float* viewdir /*[R][3]*/, float* dist_u /*[R][U]*/,
+                          scenerf_stream_t stream);
+
+/* scenerf.py:505-520 up to the gather: points = T @ (dist * unit_dir) (utils.py:158-166), cam_pts_2_pix
+ * (utils.py:298-315), SphericalMapping.from_pixels (spherical_mapping.py:80-115, round-half-even),
+ * PositionalEncoding (pe.py:32-43).  dist index = ray*dist_ray_stride + (row % pts_per_ray)
+ * (stride 0 broadcasts the G anchor distances, scenerf.py:554-572). */
+int scenerf_hip_encode_points(const scenerf_cfg* cfg, const float* dist, int dist_ray_stride, int pts_per_ray,
+                              const float* unit_dir, const float* viewdir, const float* K /*[9]*/,
+                              const float* inv_K /*[9]*/, const float* T_s2i /*[16]*/, int M,
+                              float* pts /*[M][3] or NULL*/, int32_t* sphere_idx /*[M][2]*/,
+                              float* xenc /*[M][48]*/, scenerf_stream_t stream);
+
+/* utils.py:232-247 x5 (scenerf.py:522-527): bilinear 2x2 gather of the 5 maps at idx/div*2-1 with zeros
+ * padding.  Writes Z rows only for (128-row tile, scale) pairs that have at least one in-range tap and
+ * records that in tile_mask (bit s); taps = {texel index or -1, weight} per (row, scale, tap) for backward. */
+int scenerf_hip_gather_features(const scenerf_cfg* cfg, const void* const maps_hwc[SCENERF_N_SCALES],
+                                const int32_t* sphere_idx, int M, void* Z /*act [Mpad][2480]*/,
+                                uint8_t* tile_mask /*[Mpad/128]*/, int32_t* tap_texel /*[M][5][4]*/,
+                                float* tap_weight /*[M][5][4]*/, scenerf_stream_t stream);
+
+/* ---- radiance MLP ---------------------------------------------------------------------------------------- */
+/* ResnetFC.forward, resnetfc.py:133-164.  Z/xenc as produced above.  Writes acts (kept for backward). */
+int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const float* xenc,
+                            const uint8_t* tile_mask, int M, const scenerf_mlp_acts* acts, scenerf_stream_t stream);
+
+/* autograd of ResnetFC.forward w.r.t. parameters and the gathered features; the feature gradient is
+ * scattered straight into the (H,W,C) fp32 map-gradient accumulators (grid_sampler_2d_backward).
+ * d_logits [M][d_out] fp32.  scratch: dH act [M][2048], dN act [M][512]. */
+int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const scenerf_mlp_grads* g,
+                             const void* Z, const float* xenc, const uint8_t* tile_mask,
+                             const int32_t* tap_texel, const float* tap_weight, int M,
+                             const scenerf_mlp_acts* acts, const float* d_logits, void* dH, void* dN,
+                             float* const gmaps_hwc[SCENERF_N_SCALES] /* may be NULL: skip map grads */,
+                             scenerf_stream_t stream);
+
+/* ---- probabilistic depth sampler ------------------------------------------------------------------------- */
+/* scenerf.py:585-596 (means/stds from the gaussian head), utils.py:186-229 (reparameterised samples,
+ * clamp at 0.1), scenerf.py:636-659 (merge with the uniform samples, argsort, gathers).  perm is the
+ * stable ascending order (ties by original index).  z = dist * unit_dir.z (depth in the source frame). */
+int scenerf_hip_gaussian_sample_sort(const scenerf_cfg* cfg, const float* offsets /*[R][G][2]*/,
+                                     const float* anchors /*[G]*/, const float* dist_u /*[R][U]*/,
+                                     const float* noise_g /*[R][G*P]*/, const float* unit_dir, int R,
+                                     float* gmeans /*[R][G]*/, float* gstds /*[R][G]*/, float* dist_sorted /*[R][N]*/,
+                                     float* z_sorted /*[R][N]*/, int32_t* perm /*[R][N]*/, scenerf_stream_t stream);
+
+/* ---- alpha compositing ------------------------------------------------------------------------------------ */
+/* scenerf.py:535-536 (sigmoid / softplus(x-1) heads) + render_depth_and_color scenerf.py:704-748. */
+int scenerf_hip_composite_forward(const float* logits /*[R*N][4]*/, const float* dist_sorted, const float* z_sorted,
+                                  int R, int N, float* densities, float* alphas, float* weights /*[R][N]*/,
+                                  float* depth /*[R]*/, float* color /*[R][3]*/, float* closest /*[R]*/,
+                                  float* weights_at_depth /*[R]*/, int32_t* closest_idx /*[R]*/,
+                                  scenerf_stream_t stream);
+/* its autograd: upstream grads of depth/color (required) and weights/alphas/densities/depth_volumes (NULL = 0). */
+int scenerf_hip_composite_backward(const float* logits, const float* dist_sorted, const float* z_sorted, int R, int N,
+                                   const float* g_depth, const float* g_color, const float* g_weights,
+                                   const float* g_alphas, const float* g_densities, const float* g_zvol,
+                                   float* d_logits /*[R*N][4]*/, float* d_dist /*[R][N]*/, float* d_z /*[R][N]*/,
+                                   scenerf_stream_t stream);
+
+/* ---- RaySOM KL ---------------------------------------------------------------------------------------------- */
+/* RaySOM.forward + kl_gauss, ray_som_kl.py:10-87.  kl_saved [R][G][3] = {som mean, clamped som std, mask}. */
+int scenerf_hip_raysom_forward(const scenerf_cfg* cfg, const float* gmeans, const float* gstds, const float* dist_sorted,
+                               const float* alphas, int R, float* loss_kl /*[R]*/, float* som_means /*[R][G]*/,
+                               float* som_vars /*[R][G]*/, float* kl_saved /*[R][G][3]*/, scenerf_stream_t stream);
+
+/* autograd of the sampler + KL w.r.t. the gaussian-head outputs: reparameterisation (utils.py:213, not
+ * through the 0.1 clamp), z = dist*unit.z, relu of scenerf.py:591-594, kl_gauss(m1,s1).  Upstream NULL = 0. */
+int scenerf_hip_sampler_backward(const scenerf_cfg* cfg, const float* offsets, const float* anchors, const float* noise_g,
+                                 const float* unit_dir, const float* gmeans, const float* gstds, const int32_t* perm,
+                                 const float* d_dist, const float* d_z, const float* kl_saved, const float* g_loss_kl,
+                                 const float* g_gmeans, const float* g_gstds, int R, float* d_offsets /*[R][G][2]*/,
+                                 scenerf_stream_t stream);
+
+/* ---- generic building blocks exported for unit tests ------------------------------------------------------- */
+/* C[M][N] = A[M][K] @ W[N][K]^T (+bias); act operands per `precision`, fp32 output. */
+int scenerf_hip_test_gemm_nt(int precision, const void* A, const void* W, const float* bias, int M, int N, int K,
+                             int relu_a, float* C, scenerf_stream_t stream);
+/* C[N][K] += D[M][N]^T @ A[M][K]; act operands, fp32 accumulate (atomics). */
+int scenerf_hip_test_gemm_tn(int precision, const void* D, const void* A, int M, int N, int K, int relu_a,
+                             float* C, scenerf_stream_t stream);
+
+/* ---- in-library kernel timing (bench.py's roofline leg) ----------------------------------------------------- */
+/* While enabled every kernel launch is bracketed by hipEvents on its own stream. */
+int scenerf_hip_profile_enable(int on);
+/* After a stream sync: copy up to `cap` records {name, launches, total_ms, flops, bytes}. Returns count. */
+typedef struct scenerf_prof_rec {
+    char name[48];
+    int32_t launches;
+    float total_ms;
+    double flops;                   /* algorithmic flops issued by these launches (MFMA kernels) */
+    double bytes;                   /* algorithmic bytes moved (HBM-bound kernels) */
+} scenerf_prof_rec;
+int scenerf_hip_profile_collect(scenerf_prof_rec* out_host, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCENERF_HIP_H */

@@ -1,0 +1,92 @@
+// Shared helpers for libscenerf_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/scenerf_hip.h"
+
+#define WAVE 64
+
+// ---- error plumbing: never abort, report through the C ABI ---------------------------------------------
+void srf_set_error(const char* fmt, ...);
+#define SRF_CHECK(cond, ...)                                                             \
+    do {                                                                                 \
+        if (!(cond)) { srf_set_error(__VA_ARGS__); return 1; }                           \
+    } while (0)
+#define SRF_HIP(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            srf_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return 2;                                                                    \
+        }                                                                                \
+    } while (0)
+
+// ---- launch + optional per-kernel timing ------------------------------------------------------------------
+bool srf_prof_on();
+void srf_prof_begin(hipStream_t s, const char* name, double flops, double bytes);
+void srf_prof_end(hipStream_t s);
+
+struct SrfLaunchScope {
+    hipStream_t s;
+    bool on;
+    SrfLaunchScope(hipStream_t s_, const char* name, double flops = 0, double bytes = 0) : s(s_), on(srf_prof_on()) {
+        if (on) srf_prof_begin(s, name, flops, bytes);
+    }
+    ~SrfLaunchScope() {
+        if (on) srf_prof_end(s);
+    }
+};
+#define SRF_LAUNCH_CHECK(name)                                                           \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess) { srf_set_error("launch %s: %s", name, hipGetErrorString(e_)); return 3; } \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline hipStream_t as_stream(scenerf_stream_t s) { return (hipStream_t)s; }
+
+// ---- bf16 bit helpers (round-to-nearest-even, like torch's .to(bfloat16)) -----------------------------------
+typedef uint16_t bf16_t;
+__host__ __device__ static inline float bf16_to_f32(bf16_t h) {
+    union { uint32_t u; float f; } v;
+    v.u = ((uint32_t)h) << 16;
+    return v.f;
+}
+__host__ __device__ static inline bf16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } v;
+    v.f = f;
+    uint32_t u = v.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+    uint32_t r = 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)((u + r) >> 16);
+}
+__device__ static inline uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ static inline float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ static inline float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+// relu on two packed bf16: zero each half whose sign bit is set
+__device__ static inline uint32_t relu_bf16x2(uint32_t w) {
+    uint32_t neg = (w >> 15) & 0x00010001u;
+    return w & ~(neg * 0xffffu);
+}
+
+template <typename T> struct ActIO;
+template <> struct ActIO<float> {
+    __device__ static inline float ld(const void* p, size_t i) { return ((const float*)p)[i]; }
+    __device__ static inline void st(void* p, size_t i, float v) { ((float*)p)[i] = v; }
+};
+template <> struct ActIO<bf16_t> {
+    __device__ static inline float ld(const void* p, size_t i) { return bf16_to_f32(((const bf16_t*)p)[i]); }
+    __device__ static inline void st(void* p, size_t i, float v) { ((bf16_t*)p)[i] = f32_to_bf16(v); }
+};
+
+// wave-level helpers (64 lanes)
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}

@@ -1,0 +1,58 @@
+// MFMA GEMM family for the ResnetFC pass (gfx950).  See gemm.hip for the kernels.
+#pragma once
+#include "common.h"
+
+#define GEMM_MAX_SEG 5
+
+// C[M][N] = epilogue( [A1 | A2-segments][M][K] @ W[N][K]^T )
+struct GemmNT {
+    // operand A, part 1: row-major [M][lda1], first K1 columns; optional relu on load
+    const void* A1 = nullptr;
+    int lda1 = 0, K1 = 0, relu1 = 0;
+    // operand A, part 2: the gathered-feature matrix Z [M][lda2] split in per-scale column segments; a
+    // segment is skipped for a 128-row tile when its bit in tile_mask is clear (exact zeros, Q1 in SURVEY §0)
+    const void* A2 = nullptr;
+    int lda2 = 0, nseg = 0;
+    int seg_off[GEMM_MAX_SEG] = {0, 0, 0, 0, 0};
+    int seg_len[GEMM_MAX_SEG] = {0, 0, 0, 0, 0};
+    const uint8_t* tile_mask = nullptr;
+    int skip_bit = -1;  // >= 0: drop the whole row-tile when that mask bit is clear (dZ of one scale)
+    // operand W: row-major [N][ldw], columns ordered [K1 | seg0 | seg1 ...]
+    const void* W = nullptr;
+    int ldw = 0;
+    int M = 0, N = 0;
+    // epilogue: v = acc + bias[n]; v += res; v = (maskp > 0 ? v : 0); v += res2; store
+    const float* bias = nullptr;
+    const void* res = nullptr;
+    int ldres = 0, res_f32 = 0;
+    const void* maskp = nullptr;
+    int ldmask = 0;
+    const void* res2 = nullptr;
+    int ldres2 = 0;
+    void* out = nullptr;
+    int ldout = 0, out_f32 = 0;
+    // scatter epilogue (grid_sampler backward): out is ignored; v * tap_weight is atomically added to
+    // gmap[texel][n] for the 4 taps of row m at scale `scatter_scale`
+    float* gmap = nullptr;
+    const int32_t* tap_texel = nullptr;
+    const float* tap_weight = nullptr;
+    int scatter_scale = -1;
+    const char* name = "gemm_nt";
+};
+
+// C[N][K] += D[M][N]^T @ act(A[M][K])   (fp32 atomics; contraction over the rows)
+struct GemmTN {
+    const void* D = nullptr;
+    int ldd = 0;
+    const void* A = nullptr;
+    int lda = 0, relu_a = 0;
+    int M = 0, N = 0, K = 0;
+    const uint8_t* tile_mask = nullptr;
+    int skip_bit = -1;
+    float* out = nullptr;
+    int ldo = 0;
+    const char* name = "gemm_tn";
+};
+
+int launch_gemm_nt(int precision, const GemmNT& p, hipStream_t s);
+int launch_gemm_tn(int precision, const GemmTN& p, hipStream_t s);

@@ -1,0 +1,412 @@
+// MFMA GEMM kernels for the ResnetFC pass, written for gfx950 (wave64, v_mfma_f32_32x32x16_bf16 /
+// v_mfma_f32_32x32x2_f32).  Two kernels:
+//   gemm_nt : C[M][N] = epi([A1 | Z-segments] @ W^T)      forward layers, dgrad, feature-gradient scatter
+//   gemm_tn : C[N][K] += D^T @ act(A)                      weight gradients (contraction over the M rows)
+// Tile 128x128 per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA 32x32 blocks, 64 acc VGPRs),
+// K streamed in 128-byte-per-row chunks through a double-buffered, 16-byte-padded LDS image (row stride 144 B
+// => conflict-free ds_read_b128 fragment reads), next chunk prefetched global->VGPR while the MFMAs run.
+// Both element types use the same fragment indexing: lane l holds k = (l>>5)*8 .. +8 of row (l&31); for
+// fp32 the 8 values feed 8 back-to-back 32x32x2 MFMAs (any bijective k-order is valid as A and B agree).
+#include "gemm.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+#define BM 128
+#define BN 128
+#define ROWB 144                    // bytes per LDS row: 128 data + 16 pad
+#define TILEB (128 * ROWB)          // one operand tile
+#define STAGEB (2 * TILEB)          // A + W
+#define MAX_CHUNKS 128
+#define LDS_BYTES (2 * STAGEB + MAX_CHUNKS * 16 + 16)
+
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> { static constexpr int BK = 64; };
+template <> struct Elem<float> { static constexpr int BK = 32; };
+
+__device__ static inline uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
+
+template <typename T> __device__ static inline uint4 relu16B(uint4 v);
+template <> __device__ inline uint4 relu16B<bf16_t>(uint4 v) {
+    return make_uint4(relu_bf16x2(v.x), relu_bf16x2(v.y), relu_bf16x2(v.z), relu_bf16x2(v.w));
+}
+template <> __device__ inline uint4 relu16B<float>(uint4 v) {
+    // negative floats have the sign bit set (-0 -> 0 is fine)
+    return make_uint4((v.x >> 31) ? 0u : v.x, (v.y >> 31) ? 0u : v.y, (v.z >> 31) ? 0u : v.z, (v.w >> 31) ? 0u : v.w);
+}
+
+// one 16-element k-step on a 64x64 wave tile
+template <typename T> struct WaveMma;
+template <> struct WaveMma<bf16_t> {
+    __device__ static inline void step(f32x16_t (&acc)[2][2], const char* As, const char* Ws, int kk, int lane, int wm, int wn) {
+        const int koff = (kk * 16 + (lane >> 5) * 8) * 2;
+        uint4 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *(const uint4*)(As + (wm * 64 + i * 32 + (lane & 31)) * ROWB + koff);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *(const uint4*)(Ws + (wn * 64 + j * 32 + (lane & 31)) * ROWB + koff);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i]),
+                                                                    __builtin_bit_cast(bf16x8_t, b[j]), acc[i][j], 0, 0, 0);
+    }
+};
+template <> struct WaveMma<float> {
+    __device__ static inline void step(f32x16_t (&acc)[2][2], const char* As, const char* Ws, int kk, int lane, int wm, int wn) {
+        const int koff = (kk * 16 + (lane >> 5) * 8) * 4;
+        float a[2][8], b[2][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* p = As + (wm * 64 + i * 32 + (lane & 31)) * ROWB + koff;
+            float4 lo = *(const float4*)p, hi = *(const float4*)(p + 16);
+            a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w;
+            a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char* p = Ws + (wn * 64 + j * 32 + (lane & 31)) * ROWB + koff;
+            float4 lo = *(const float4*)p, hi = *(const float4*)(p + 16);
+            b[j][0] = lo.x; b[j][1] = lo.y; b[j][2] = lo.z; b[j][3] = lo.w;
+            b[j][4] = hi.x; b[j][5] = hi.y; b[j][6] = hi.z; b[j][7] = hi.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+};
+
+// epilogue of one accumulator element: v = acc + bias; v += res; v = mask > 0 ? v : 0; v += res2; store | scatter
+template <typename T>
+__device__ __forceinline__ void epi_elem(const GemmNT& p, float a, int m, int n, float bv) {
+    if (m >= p.M || n >= p.N) return;
+    float v = a + bv;
+    if (p.res) v += p.res_f32 ? ((const float*)p.res)[(size_t)m * p.ldres + n] : ActIO<T>::ld(p.res, (size_t)m * p.ldres + n);
+    if (p.maskp) v = ActIO<T>::ld(p.maskp, (size_t)m * p.ldmask + n) > 0.f ? v : 0.f;
+    if (p.res2) v += ActIO<T>::ld(p.res2, (size_t)m * p.ldres2 + n);
+    if (p.scatter_scale >= 0) {
+        const size_t tb = ((size_t)m * 5 + p.scatter_scale) * 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int tx = p.tap_texel[tb + t];
+            if (tx >= 0) unsafeAtomicAdd(p.gmap + (size_t)tx * p.N + n, v * p.tap_weight[tb + t]);
+        }
+    } else if (p.out_f32) {
+        ((float*)p.out)[(size_t)m * p.ldout + n] = v;
+    } else {
+        ActIO<T>::st(p.out, (size_t)m * p.ldout + n, v);
+    }
+}
+
+// ================================================================================================ NT
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int4* chunks = (int4*)(lds + 2 * STAGEB);  // {src, a_col, w_col, kc}
+    // all LDS lives in the one dynamic region: a static __shared__ would shift its base off 16-byte alignment
+    int* s_n_ptr = (int*)(lds + 2 * STAGEB + MAX_CHUNKS * 16);
+    constexpr int BK = Elem<T>::BK;
+    constexpr int ES = (int)sizeof(T);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    unsigned mask = 0xffffffffu;
+    if (p.tile_mask) mask = p.tile_mask[m0 / SCENERF_TILE_ROWS];
+    if (p.skip_bit >= 0 && !((mask >> p.skip_bit) & 1u)) return;  // uniform: whole tile contributes exact zeros
+
+    if (tid == 0) {
+        int n = 0;
+        for (int k0 = 0; k0 < p.K1; k0 += BK) {
+            int kc = p.K1 - k0 < BK ? p.K1 - k0 : BK;
+            chunks[n++] = make_int4(0, k0, k0, kc);
+        }
+        int wbase = p.K1;
+#pragma unroll
+        for (int s = 0; s < GEMM_MAX_SEG; ++s) {  // constant trip count: keeps the by-value params out of scratch
+            if (s < p.nseg && ((mask >> s) & 1u)) {
+                for (int k0 = 0; k0 < p.seg_len[s]; k0 += BK) {
+                    int kc = p.seg_len[s] - k0 < BK ? p.seg_len[s] - k0 : BK;
+                    chunks[n++] = make_int4(1, p.seg_off[s] + k0, wbase + k0, kc);
+                }
+            }
+            if (s < p.nseg) wbase += p.seg_len[s];
+        }
+        *s_n_ptr = n;
+    }
+    __syncthreads();
+    const int nch = *s_n_ptr;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[4], rw[4];
+    auto load_chunk = [&](int c) {
+        const int4 ch = chunks[c];
+        const int ppr = ch.w * ES / 16;       // 16-byte pieces per row
+        const int np = 128 * ppr;
+        const char* Ab = (const char*)(ch.x == 0 ? p.A1 : p.A2);
+        const size_t lda = (size_t)(ch.x == 0 ? p.lda1 : p.lda2) * ES;
+        const bool relu = ch.x == 0 && p.relu1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int q = tid + i * 256;
+            ra[i] = zero4();
+            rw[i] = zero4();
+            if (q < np) {
+                int row = q / ppr, pc = q - row * ppr;
+                int gm = m0 + row, gn = n0 + row;
+                if (gm < p.M) {
+                    uint4 v = *(const uint4*)(Ab + (size_t)gm * lda + (size_t)ch.y * ES + pc * 16);
+                    ra[i] = relu ? relu16B<T>(v) : v;
+                }
+                if (gn < p.N) rw[i] = *(const uint4*)((const char*)p.W + ((size_t)gn * p.ldw + ch.z) * ES + pc * 16);
+            }
+        }
+    };
+    auto store_chunk = [&](int c, int buf) {
+        const int4 ch = chunks[c];
+        const int ppr = ch.w * ES / 16;
+        const int np = 128 * ppr;
+        char* As = lds + buf * STAGEB;
+        char* Ws = As + TILEB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int q = tid + i * 256;
+            if (q < np) {
+                int row = q / ppr, pc = q - row * ppr;
+                *(uint4*)(As + row * ROWB + pc * 16) = ra[i];
+                *(uint4*)(Ws + row * ROWB + pc * 16) = rw[i];
+            }
+        }
+    };
+
+    if (nch > 0) {
+        load_chunk(0);
+        store_chunk(0, 0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nch) load_chunk(c + 1);
+        const char* As = lds + buf * STAGEB;
+        const char* Ws = As + TILEB;
+        const int ks = chunks[c].w / 16;
+        for (int kk = 0; kk < ks; ++kk) WaveMma<T>::step(acc, As, Ws, kk, lane, wm, wn);
+        if (c + 1 < nch) store_chunk(c + 1, buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------
+    // expanded with constant register indices (a runtime-indexed accumulator vector would go to scratch)
+#define EPI_R(i, j, r) epi_elem<T>(p, acc[i][j][r], mrow##i + ((r) & 3) + 8 * ((r) >> 2), ncol##j, bias##j);
+#define EPI_TILE(i, j)                                                                                          \
+    EPI_R(i, j, 0) EPI_R(i, j, 1) EPI_R(i, j, 2) EPI_R(i, j, 3) EPI_R(i, j, 4) EPI_R(i, j, 5) EPI_R(i, j, 6)     \
+    EPI_R(i, j, 7) EPI_R(i, j, 8) EPI_R(i, j, 9) EPI_R(i, j, 10) EPI_R(i, j, 11) EPI_R(i, j, 12) EPI_R(i, j, 13) \
+    EPI_R(i, j, 14) EPI_R(i, j, 15)
+    const int mrow0 = m0 + wm * 64 + 4 * (lane >> 5), mrow1 = mrow0 + 32;
+    const int ncol0 = n0 + wn * 64 + (lane & 31), ncol1 = ncol0 + 32;
+    const float bias0 = (p.bias && ncol0 < p.N) ? p.bias[ncol0] : 0.f;
+    const float bias1 = (p.bias && ncol1 < p.N) ? p.bias[ncol1] : 0.f;
+    EPI_TILE(0, 0)
+    EPI_TILE(0, 1)
+    EPI_TILE(1, 0)
+    EPI_TILE(1, 1)
+#undef EPI_TILE
+#undef EPI_R
+}
+
+// ================================================================================================ TN
+// Transposing stage: each thread owns a square block (8x8 bf16 / 4x4 fp32) of the [rows m][cols] source
+// tile, loads it with coalesced 16-byte row reads, transposes it in registers and writes 16-byte rows of
+// the [col][m] LDS image, so fragment reads are the same ds_read_b128 as in the NT kernel.
+template <typename T> struct TnStage;
+template <> struct TnStage<bf16_t> {
+    static constexpr int MC = 64;  // contraction rows per chunk
+    uint4 r[8];
+    __device__ inline void load(const GemmTN& p, int tid, int mc, int n0, int k0) {
+        const int op = tid >> 7, b = tid & 127, mb = b >> 4, nb = b & 15;
+        const char* base = (const char*)(op == 0 ? p.D : p.A);
+        const size_t ld = (size_t)(op == 0 ? p.ldd : p.lda) * 2;
+        const int col = (op == 0 ? n0 : k0) + nb * 8;
+        const bool cok = col < (op == 0 ? p.N : p.K);
+        const bool relu = op == 1 && p.relu_a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int m = mc + mb * 8 + j;
+            uint4 v = zero4();
+            if (cok && m < p.M) v = *(const uint4*)(base + (size_t)m * ld + (size_t)col * 2);
+            r[j] = relu ? relu16B<bf16_t>(v) : v;
+        }
+    }
+    __device__ inline void store(char* stage, int tid) const {
+        const int op = tid >> 7, b = tid & 127, mb = b >> 4, nb = b & 15;
+        char* tile = stage + op * TILEB;
+        const uint32_t* w = (const uint32_t*)r;  // w[j*4 + q] = row j, column pair q
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t a = w[(2 * q) * 4 + (c >> 1)], bb = w[(2 * q + 1) * 4 + (c >> 1)];
+                o[q] = (c & 1) ? ((a >> 16) | (bb & 0xffff0000u)) : ((a & 0xffffu) | (bb << 16));
+            }
+            *(uint4*)(tile + (nb * 8 + c) * ROWB + mb * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+};
+template <> struct TnStage<float> {
+    static constexpr int MC = 32;
+    float4 r[2][4];
+    __device__ inline void load(const GemmTN& p, int tid, int mc, int n0, int k0) {
+        const int mb = tid >> 5, nb = tid & 31;
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {
+            const char* base = (const char*)(op == 0 ? p.D : p.A);
+            const size_t ld = (size_t)(op == 0 ? p.ldd : p.lda) * 4;
+            const int col = (op == 0 ? n0 : k0) + nb * 4;
+            const bool cok = col < (op == 0 ? p.N : p.K);
+            const bool relu = op == 1 && p.relu_a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int m = mc + mb * 4 + j;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cok && m < p.M) v = *(const float4*)(base + (size_t)m * ld + (size_t)col * 4);
+                if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                r[op][j] = v;
+            }
+        }
+    }
+    __device__ inline void store(char* stage, int tid) const {
+        const int mb = tid >> 5, nb = tid & 31;
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {
+            char* tile = stage + op * TILEB;
+            *(float4*)(tile + (nb * 4 + 0) * ROWB + mb * 16) = make_float4(r[op][0].x, r[op][1].x, r[op][2].x, r[op][3].x);
+            *(float4*)(tile + (nb * 4 + 1) * ROWB + mb * 16) = make_float4(r[op][0].y, r[op][1].y, r[op][2].y, r[op][3].y);
+            *(float4*)(tile + (nb * 4 + 2) * ROWB + mb * 16) = make_float4(r[op][0].z, r[op][1].z, r[op][2].z, r[op][3].z);
+            *(float4*)(tile + (nb * 4 + 3) * ROWB + mb * 16) = make_float4(r[op][0].w, r[op][1].w, r[op][2].w, r[op][3].w);
+        }
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_slice) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int MC = TnStage<T>::MC;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    const int n0 = blockIdx.x * BN, k0 = blockIdx.y * BN;
+    const int mbeg = blockIdx.z * rows_per_slice;
+    const int mend = (mbeg + rows_per_slice < p.M) ? mbeg + rows_per_slice : p.M;
+
+    auto next_valid = [&](int m) {
+        if (p.tile_mask && p.skip_bit >= 0) {
+            while (m < mend && !((p.tile_mask[m / SCENERF_TILE_ROWS] >> p.skip_bit) & 1u)) m += MC;
+        }
+        return m;
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    TnStage<T> st;
+    int c = next_valid(mbeg);
+    if (c >= mend) return;  // uniform
+    st.load(p, tid, c, n0, k0);
+    st.store(lds, tid);
+    __syncthreads();
+    int buf = 0;
+    while (c < mend) {
+        const int nx = next_valid(c + MC);
+        if (nx < mend) st.load(p, tid, nx, n0, k0);
+        const char* Dt = lds + buf * STAGEB;
+        const char* At = Dt + TILEB;
+#pragma unroll
+        for (int kk = 0; kk < MC / 16; ++kk) WaveMma<T>::step(acc, Dt, At, kk, lane, wm, wn);
+        if (nx < mend) st.store(lds + (buf ^ 1) * STAGEB, tid);
+        __syncthreads();
+        buf ^= 1;
+        c = nx;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n < p.N && k < p.K) unsafeAtomicAdd(p.out + (size_t)n * p.ldo + k, acc[i][j][r]);
+            }
+        }
+}
+
+// ================================================================================================ launchers
+template <typename T> static int launch_nt_t(const GemmNT& p, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_done = true;
+    }
+    dim3 grid(cdiv(p.M, BM), cdiv(p.N, BN));
+    double ktot = p.K1;
+    for (int i = 0; i < p.nseg; ++i) ktot += p.seg_len[i];
+    SrfLaunchScope ps(s, p.name, 2.0 * p.M * (double)p.N * ktot, 0);
+    gemm_nt_kernel<T><<<grid, 256, LDS_BYTES, s>>>(p);
+    SRF_LAUNCH_CHECK(p.name);
+    return 0;
+}
+
+int launch_gemm_nt(int precision, const GemmNT& p, hipStream_t s) {
+    SRF_CHECK(p.W && p.M > 0 && p.N > 0, "%s: bad operands", p.name);
+    SRF_CHECK(p.K1 % 16 == 0 && p.N % 8 == 0, "%s: K1=%d must be a multiple of 16, N=%d of 8", p.name, p.K1, p.N);
+    SRF_CHECK(p.K1 == 0 || p.A1, "%s: A1 NULL", p.name);
+    SRF_CHECK(p.nseg == 0 || p.A2, "%s: A2 NULL", p.name);
+    for (int i = 0; i < p.nseg; ++i) SRF_CHECK(p.seg_len[i] % 16 == 0 && p.seg_off[i] % 8 == 0, "%s: segment %d misaligned", p.name, i);
+    SRF_CHECK(p.scatter_scale >= 0 ? (p.gmap && p.tap_texel && p.tap_weight) : (p.out != nullptr), "%s: missing output", p.name);
+    return precision ? launch_nt_t<bf16_t>(p, s) : launch_nt_t<float>(p, s);
+}
+
+template <typename T> static int launch_tn_t(const GemmTN& p, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGEB));
+        attr_done = true;
+    }
+    constexpr int MC = TnStage<T>::MC;
+    int tiles = cdiv(p.N, BN) * cdiv(p.K, BN);
+    int chunks = cdiv(p.M, MC);
+    int slices = 1024 / tiles;
+    if (slices < 1) slices = 1;
+    if (slices > chunks) slices = chunks;
+    int cps = cdiv(chunks, slices);          // chunks per slice
+    // keep slices aligned to the 128-row mask granularity
+    int rows = cps * MC;
+    rows = cdiv(rows, SCENERF_TILE_ROWS) * SCENERF_TILE_ROWS;
+    slices = cdiv(p.M, rows);
+    dim3 grid(cdiv(p.N, BN), cdiv(p.K, BN), slices);
+    SrfLaunchScope ps(s, p.name, 2.0 * p.M * (double)p.N * p.K, 0);
+    gemm_tn_kernel<T><<<grid, 256, 2 * STAGEB, s>>>(p, rows);
+    SRF_LAUNCH_CHECK(p.name);
+    return 0;
+}
+
+int launch_gemm_tn(int precision, const GemmTN& p, hipStream_t s) {
+    SRF_CHECK(p.D && p.A && p.out && p.M > 0 && p.N > 0 && p.K > 0, "%s: bad operands", p.name);
+    SRF_CHECK(p.N % 8 == 0 && p.K % 8 == 0, "%s: N=%d and K=%d must be multiples of 8", p.name, p.N, p.K);
+    return precision ? launch_tn_t<bf16_t>(p, s) : launch_tn_t<float>(p, s);
+}

@@ -1,0 +1,381 @@
+// ResnetFC forward / backward as a sequence of MFMA GEMM launches with fused prologues/epilogues
+// (reference scenerf/models/resnetfc.py:133-164 and its autograd), plus the small memory-bound kernels
+// around them: lin_out (512 -> 4|2), bias-gradient column sums and an fp32->bf16 row conversion.
+#include "gemm.h"
+
+
+// ------------------------------------------------------------------------------------------------ lin_out
+template <typename T> __device__ static inline void load8(const void* base, size_t idx, float* v);
+template <> __device__ inline void load8<bf16_t>(const void* base, size_t idx, float* v) {
+    uint4 t = *(const uint4*)((const bf16_t*)base + idx);
+    v[0] = bf16lo(t.x); v[1] = bf16hi(t.x); v[2] = bf16lo(t.y); v[3] = bf16hi(t.y);
+    v[4] = bf16lo(t.z); v[5] = bf16hi(t.z); v[6] = bf16lo(t.w); v[7] = bf16hi(t.w);
+}
+template <> __device__ inline void load8<float>(const void* base, size_t idx, float* v) {
+    float4 a = *(const float4*)((const float*)base + idx), b = *(const float4*)((const float*)base + idx + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <typename T> __device__ static inline void store8(void* base, size_t idx, const float* v);
+template <> __device__ inline void store8<bf16_t>(void* base, size_t idx, const float* v) {
+    *(uint4*)((bf16_t*)base + idx) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                pack_bf16x2(v[6], v[7]));
+}
+template <> __device__ inline void store8<float>(void* base, size_t idx, const float* v) {
+    *(float4*)((float*)base + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)((float*)base + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// logits[m][j] = relu(H3[m][:]) . w_out[j][:] + b_out[j]; one wave per row, lane owns 8 of the 512 columns
+template <typename T, int DO>
+__global__ __launch_bounds__(256) void linout_fwd_kernel(const void* __restrict__ H3, const float* __restrict__ w_out,
+                                                         const float* __restrict__ b_out, int M, float* __restrict__ logits) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    float w[DO][8];
+#pragma unroll
+    for (int j = 0; j < DO; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[j][e] = w_out[j * SCENERF_D_HIDDEN + lane * 8 + e];
+    for (int m = wave; m < M; m += nwaves) {
+        float h[8];
+        load8<T>(H3, (size_t)m * SCENERF_D_HIDDEN + lane * 8, h);
+        float acc[DO];
+#pragma unroll
+        for (int j = 0; j < DO; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf(fmaxf(h[e], 0.f), w[j][e], a);
+            acc[j] = wave_sum(a);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < DO; ++j) logits[(size_t)m * DO + j] = acc[j] + b_out[j];
+        }
+    }
+}
+
+// dH3[m][k] = [H3>0] * sum_j dl[m][j] w_out[j][k];  dw_out[j][k] += sum_m dl[m][j] relu(H3[m][k]);  db_out[j] += sum_m dl[m][j]
+template <typename T, int DO>
+__global__ __launch_bounds__(256) void linout_bwd_kernel(const void* __restrict__ H3, const float* __restrict__ w_out,
+                                                         const float* __restrict__ dlog, int M, void* __restrict__ dH3, int lddh,
+                                                         float* __restrict__ dw_out, float* __restrict__ db_out) {
+    __shared__ float s_dw[4][DO][SCENERF_D_HIDDEN];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+    float w[DO][8], dw[DO][8], db[DO];
+#pragma unroll
+    for (int j = 0; j < DO; ++j) {
+        db[j] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            w[j][e] = w_out[j * SCENERF_D_HIDDEN + lane * 8 + e];
+            dw[j][e] = 0.f;
+        }
+    }
+    for (int m = wave; m < M; m += nwaves) {
+        float h[8], g[8], dl[DO];
+        load8<T>(H3, (size_t)m * SCENERF_D_HIDDEN + lane * 8, h);
+#pragma unroll
+        for (int j = 0; j < DO; ++j) {
+            dl[j] = dlog[(size_t)m * DO + j];
+            db[j] += dl[j];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < DO; ++j) {
+                a = fmaf(dl[j], w[j][e], a);
+                dw[j][e] = fmaf(dl[j], fmaxf(h[e], 0.f), dw[j][e]);
+            }
+            g[e] = h[e] > 0.f ? a : 0.f;
+        }
+        store8<T>(dH3, (size_t)m * lddh + lane * 8, g);
+    }
+#pragma unroll
+    for (int j = 0; j < DO; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_dw[wv][j][lane * 8 + e] = dw[j][e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < DO * SCENERF_D_HIDDEN; i += 256) {
+        int j = i / SCENERF_D_HIDDEN, k = i - j * SCENERF_D_HIDDEN;
+        float v = s_dw[0][j][k] + s_dw[1][j][k] + s_dw[2][j][k] + s_dw[3][j][k];
+        unsafeAtomicAdd(dw_out + i, v);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < DO; ++j) unsafeAtomicAdd(db_out + j, db[j]);
+    }
+}
+
+// out[c] += sum_m D[m][c], c in [0, ncols); block = 256 threads, thread owns 8 columns of a row slab
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ D, int ldd, int ncols, int M, int rows_per_block,
+                                                     float* __restrict__ out) {
+    const int groups = ncols / 8;                 // 8-column groups
+    const int tpr = groups < 256 ? groups : 256;  // threads per row
+    const int rpi = 256 / tpr;                    // rows per iteration
+    const int g = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    if (rl >= rpi) return;
+    const int mb = blockIdx.x * rows_per_block;
+    const int me = mb + rows_per_block < M ? mb + rows_per_block : M;
+    for (int gg = g; gg < groups; gg += tpr) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int m = mb + rl; m < me; m += rpi) {
+            float v[8];
+            load8<T>(D, (size_t)m * ldd + gg * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) unsafeAtomicAdd(out + gg * 8 + e, acc[e]);
+    }
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f32_to_bf16(in[i]);
+}
+
+template <typename T>
+static int launch_linout_fwd(int d_out, const void* H3, const float* w, const float* b, int M, float* logits, hipStream_t s) {
+    int grid = cdiv(M, 4 * 16);
+    if (grid > 2048) grid = 2048;
+    SrfLaunchScope ps(s, "linout_fwd", 0, (double)M * (512.0 * sizeof(T) + 4.0 * d_out));
+    if (d_out == 4) linout_fwd_kernel<T, 4><<<grid, 256, 0, s>>>(H3, w, b, M, logits);
+    else linout_fwd_kernel<T, 2><<<grid, 256, 0, s>>>(H3, w, b, M, logits);
+    SRF_LAUNCH_CHECK("linout_fwd_kernel");
+    return 0;
+}
+template <typename T>
+static int launch_linout_bwd(int d_out, const void* H3, const float* w, const float* dlog, int M, void* dH3, int lddh, float* dw,
+                             float* db, hipStream_t s) {
+    int grid = cdiv(M, 4 * 64);
+    if (grid > 1024) grid = 1024;
+    SrfLaunchScope ps(s, "linout_bwd", 0, (double)M * (1024.0 * sizeof(T) + 4.0 * d_out));
+    if (d_out == 4) linout_bwd_kernel<T, 4><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, dw, db);
+    else linout_bwd_kernel<T, 2><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, dw, db);
+    SRF_LAUNCH_CHECK("linout_bwd_kernel");
+    return 0;
+}
+template <typename T> static int launch_colsum(const void* D, int ldd, int ncols, int M, float* out, hipStream_t s) {
+    const int rows = 512;
+    SrfLaunchScope ps(s, "colsum", 0, (double)M * ncols * sizeof(T));
+    colsum_kernel<T><<<cdiv(M, rows), 256, 0, s>>>(D, ldd, ncols, M, rows, out);
+    SRF_LAUNCH_CHECK("colsum_kernel");
+    return 0;
+}
+
+// ================================================================================================ sequencing
+static void set_segments(GemmNT& g, const scenerf_cfg* cfg, const void* Z, const uint8_t* tile_mask) {
+    g.A2 = Z;
+    g.lda2 = SCENERF_D_LATENT;
+    g.nseg = 5;
+    int off = 0;
+    for (int s = 0; s < 5; ++s) {
+        g.seg_off[s] = off;
+        g.seg_len[s] = cfg->map_C[s];
+        off += cfg->map_C[s];
+    }
+    g.tile_mask = tile_mask;
+}
+
+extern "C" {
+
+int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const float* xenc,
+                            const uint8_t* tile_mask, int M, const scenerf_mlp_acts* a, scenerf_stream_t stream) {
+    SRF_CHECK(cfg && w && Z && xenc && tile_mask && a && M > 0, "mlp_forward: NULL argument");
+    SRF_CHECK(w->d_out == 4 || w->d_out == 2, "mlp_forward: d_out must be 4 or 2");
+    const int prec = cfg->precision;
+    hipStream_t s = as_stream(stream);
+    // lin_in (fp32 in both modes: raw xyz up to ~100 m enters here)
+    {
+        GemmNT g;
+        g.name = "gemm_lin_in";
+        g.A1 = xenc; g.lda1 = SCENERF_D_XENC; g.K1 = SCENERF_D_XENC;
+        g.W = w->w_in; g.ldw = SCENERF_D_XENC;
+        g.M = M; g.N = SCENERF_D_HIDDEN; g.bias = w->b_in;
+        g.out = a->h0pre; g.ldout = SCENERF_D_HIDDEN; g.out_f32 = 1;
+        if (int e = launch_gemm_nt(0, g, s)) return e;
+    }
+    // H0 = h0pre + lin_z.0(z)
+    {
+        GemmNT g;
+        g.name = "gemm_fwd_linz0";
+        set_segments(g, cfg, Z, tile_mask);
+        g.W = w->w_h[0]; g.ldw = SCENERF_D_LATENT;
+        g.M = M; g.N = SCENERF_D_HIDDEN; g.bias = w->b_h[0];
+        g.res = a->h0pre; g.ldres = SCENERF_D_HIDDEN; g.res_f32 = 1;
+        g.out = a->H[0]; g.ldout = SCENERF_D_HIDDEN;
+        if (int e = launch_gemm_nt(prec, g, s)) return e;
+    }
+    for (int b = 0; b < 3; ++b) {
+        {   // net = fc_0(relu(h))
+            GemmNT g;
+            g.name = "gemm_fwd_fc0";
+            g.A1 = a->H[b]; g.lda1 = SCENERF_D_HIDDEN; g.K1 = SCENERF_D_HIDDEN; g.relu1 = 1;
+            g.W = w->w_fc0[b]; g.ldw = SCENERF_D_HIDDEN;
+            g.M = M; g.N = SCENERF_D_HIDDEN; g.bias = w->b_fc0[b];
+            g.out = a->Nn[b]; g.ldout = SCENERF_D_HIDDEN;
+            if (int e = launch_gemm_nt(prec, g, s)) return e;
+        }
+        {   // h = h + fc_1(relu(net)) [+ lin_z.(b+1)(z)]
+            GemmNT g;
+            g.name = b < 2 ? "gemm_fwd_fc1_linz" : "gemm_fwd_fc1";
+            g.A1 = a->Nn[b]; g.lda1 = SCENERF_D_HIDDEN; g.K1 = SCENERF_D_HIDDEN; g.relu1 = 1;
+            g.ldw = SCENERF_D_HIDDEN;
+            if (b < 2) {
+                set_segments(g, cfg, Z, tile_mask);
+                g.ldw = SCENERF_D_HIDDEN + SCENERF_D_LATENT;
+            }
+            g.W = w->w_h[b + 1];
+            g.M = M; g.N = SCENERF_D_HIDDEN; g.bias = w->b_h[b + 1];
+            g.res = a->H[b]; g.ldres = SCENERF_D_HIDDEN;
+            g.out = a->H[b + 1]; g.ldout = SCENERF_D_HIDDEN;
+            if (int e = launch_gemm_nt(prec, g, s)) return e;
+        }
+    }
+    if (prec) return launch_linout_fwd<bf16_t>(w->d_out, a->H[3], w->w_out, w->b_out, M, a->logits, s);
+    return launch_linout_fwd<float>(w->d_out, a->H[3], w->w_out, w->b_out, M, a->logits, s);
+}
+
+int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const scenerf_mlp_grads* g_,
+                             const void* Z, const float* xenc, const uint8_t* tile_mask, const int32_t* tap_texel,
+                             const float* tap_weight, int M, const scenerf_mlp_acts* a, const float* d_logits, void* dH,
+                             void* dN, float* const gmaps_hwc[SCENERF_N_SCALES], scenerf_stream_t stream) {
+    SRF_CHECK(cfg && w && g_ && Z && xenc && tile_mask && a && d_logits && dH && dN && M > 0, "mlp_backward: NULL argument");
+    SRF_CHECK(!gmaps_hwc || (tap_texel && tap_weight), "mlp_backward: taps missing");
+    const int prec = cfg->precision;
+    const size_t es = prec ? 2 : 4;
+    hipStream_t s = as_stream(stream);
+    const int LDH = 4 * SCENERF_D_HIDDEN;  // dH row: [dH0 | dH1 | dH2 | dH3]
+    int kSegOff[5];
+    for (int i = 0, off = 0; i < 5; ++i) { kSegOff[i] = off; off += cfg->map_C[i]; }
+    auto dHcol = [&](int b) { return (void*)((char*)dH + (size_t)b * SCENERF_D_HIDDEN * es); };
+
+    // lin_out backward -> dH3, dw_out, db_out
+    if (prec) {
+        if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, s)) return e;
+    } else {
+        if (int e = launch_linout_bwd<float>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, s)) return e;
+    }
+    for (int b = 2; b >= 0; --b) {
+        {   // dW1_b += dH_{b+1}^T relu(N_b)
+            GemmTN t;
+            t.name = "gemm_wgrad_fc1";
+            t.D = dHcol(b + 1); t.ldd = LDH; t.A = a->Nn[b]; t.lda = SCENERF_D_HIDDEN; t.relu_a = 1;
+            t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc1[b]; t.ldo = SCENERF_D_HIDDEN;
+            if (int e = launch_gemm_tn(prec, t, s)) return e;
+        }
+        {   // dN_b = (dH_{b+1} @ W1_b) * [N_b > 0]
+            GemmNT g;
+            g.name = "gemm_dgrad_fc1";
+            g.A1 = dHcol(b + 1); g.lda1 = LDH; g.K1 = SCENERF_D_HIDDEN;
+            g.W = w->w_fc1_t[b]; g.ldw = SCENERF_D_HIDDEN;
+            g.M = M; g.N = SCENERF_D_HIDDEN;
+            g.maskp = a->Nn[b]; g.ldmask = SCENERF_D_HIDDEN;
+            g.out = dN; g.ldout = SCENERF_D_HIDDEN;
+            if (int e = launch_gemm_nt(prec, g, s)) return e;
+        }
+        {   // dW0_b += dN_b^T relu(H_b);  db0_b = colsum(dN_b)
+            GemmTN t;
+            t.name = "gemm_wgrad_fc0";
+            t.D = dN; t.ldd = SCENERF_D_HIDDEN; t.A = a->H[b]; t.lda = SCENERF_D_HIDDEN; t.relu_a = 1;
+            t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc0[b]; t.ldo = SCENERF_D_HIDDEN;
+            if (int e = launch_gemm_tn(prec, t, s)) return e;
+            int e = prec ? launch_colsum<bf16_t>(dN, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN, M, g_->b_fc0[b], s)
+                         : launch_colsum<float>(dN, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN, M, g_->b_fc0[b], s);
+            if (e) return e;
+        }
+        {   // dH_b = dH_{b+1} + (dN_b @ W0_b) * [H_b > 0]
+            GemmNT g;
+            g.name = "gemm_dgrad_fc0";
+            g.A1 = dN; g.lda1 = SCENERF_D_HIDDEN; g.K1 = SCENERF_D_HIDDEN;
+            g.W = w->w_fc0_t[b]; g.ldw = SCENERF_D_HIDDEN;
+            g.M = M; g.N = SCENERF_D_HIDDEN;
+            g.maskp = a->H[b]; g.ldmask = SCENERF_D_HIDDEN;
+            g.res2 = dHcol(b + 1); g.ldres2 = LDH;
+            g.out = dHcol(b); g.ldout = LDH;
+            if (int e = launch_gemm_nt(prec, g, s)) return e;
+        }
+    }
+    // bias gradients: S_b = colsum(dH_b).  lin_z.b.bias <- S_b (b<3); fc_1.b.bias <- S_{b+1}; lin_in.bias <- S_0.
+    // One pass over dH gives all four 512-column sums; the host copies S_0 into b_in and S_{1..3} into b_fc1.
+    {
+        // b_z holds [S0|S1|S2]; b_fc1[b] gets S_{b+1}
+        int e = prec ? launch_colsum<bf16_t>(dH, LDH, 3 * SCENERF_D_HIDDEN, M, g_->b_z, s)
+                     : launch_colsum<float>(dH, LDH, 3 * SCENERF_D_HIDDEN, M, g_->b_z, s);
+        if (e) return e;
+        e = prec ? launch_colsum<bf16_t>(dHcol(3), LDH, SCENERF_D_HIDDEN, M, g_->b_fc1[2], s)
+                 : launch_colsum<float>(dHcol(3), LDH, SCENERF_D_HIDDEN, M, g_->b_fc1[2], s);
+        if (e) return e;
+        // S_1, S_2, S_0 are plain copies of slices of b_z (device-to-device adds onto zeroed buffers)
+        SRF_HIP(hipMemcpyAsync(g_->b_fc1[0], g_->b_z + SCENERF_D_HIDDEN, SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s));
+        SRF_HIP(hipMemcpyAsync(g_->b_fc1[1], g_->b_z + 2 * SCENERF_D_HIDDEN, SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s));
+        SRF_HIP(hipMemcpyAsync(g_->b_in, g_->b_z, SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    // dWz[:, slice_s] += dH[:, 0:1536]^T Z[:, slice_s]   (row-tiles without scale s skipped)
+    for (int sc = 0; sc < 5; ++sc) {
+        GemmTN t;
+        t.name = "gemm_wgrad_linz";
+        t.D = dH; t.ldd = LDH;
+        t.A = (const char*)Z + (size_t)kSegOff[sc] * es; t.lda = SCENERF_D_LATENT;
+        t.M = M; t.N = 3 * SCENERF_D_HIDDEN; t.K = cfg->map_C[sc];
+        t.tile_mask = tile_mask; t.skip_bit = sc;
+        t.out = g_->w_z + kSegOff[sc]; t.ldo = SCENERF_D_LATENT;
+        if (int e = launch_gemm_tn(prec, t, s)) return e;
+    }
+    // dWin += dH0^T xenc   (xenc is fp32; in bf16 mode convert it into the now-free dN scratch)
+    {
+        GemmTN t;
+        t.name = "gemm_wgrad_lin_in";
+        t.D = dH; t.ldd = LDH;
+        t.lda = SCENERF_D_XENC;
+        if (prec) {
+            size_t n = (size_t)M * SCENERF_D_XENC;
+            f32_to_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(xenc, (bf16_t*)dN, n);
+            SRF_LAUNCH_CHECK("f32_to_bf16_kernel");
+            t.A = dN;
+        } else {
+            t.A = xenc;
+        }
+        t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_XENC; t.out = g_->w_in; t.ldo = SCENERF_D_XENC;
+        if (int e = launch_gemm_tn(prec, t, s)) return e;
+    }
+    // dZ[:, slice_s] = dH[:, 0:1536] @ Wz[:, slice_s], scattered straight into the (H,W,C) map gradients
+    if (gmaps_hwc) {
+        for (int sc = 0; sc < 5; ++sc) {
+            if (!gmaps_hwc[sc]) continue;
+            GemmNT g;
+            g.name = "gemm_dfeat_scatter";
+            g.A1 = dH; g.lda1 = LDH; g.K1 = 3 * SCENERF_D_HIDDEN;
+            g.W = w->w_z_t[sc]; g.ldw = 3 * SCENERF_D_HIDDEN;
+            g.M = M; g.N = cfg->map_C[sc];
+            g.tile_mask = tile_mask; g.skip_bit = sc;
+            g.gmap = gmaps_hwc[sc]; g.tap_texel = tap_texel; g.tap_weight = tap_weight; g.scatter_scale = sc;
+            if (int e = launch_gemm_nt(prec, g, s)) return e;
+        }
+    }
+    return 0;
+}
+
+int scenerf_hip_test_gemm_nt(int precision, const void* A, const void* W, const float* bias, int M, int N, int K, int relu_a,
+                             float* C, scenerf_stream_t stream) {
+    GemmNT g;
+    g.name = "test_gemm_nt";
+    g.A1 = A; g.lda1 = K; g.K1 = K; g.relu1 = relu_a;
+    g.W = W; g.ldw = K; g.M = M; g.N = N; g.bias = bias;
+    g.out = C; g.ldout = N; g.out_f32 = 1;
+    return launch_gemm_nt(precision, g, as_stream(stream));
+}
+
+int scenerf_hip_test_gemm_tn(int precision, const void* D, const void* A, int M, int N, int K, int relu_a, float* C,
+                             scenerf_stream_t stream) {
+    GemmTN t;
+    t.name = "test_gemm_tn";
+    t.D = D; t.ldd = N; t.A = A; t.lda = K; t.relu_a = relu_a;
+    t.M = M; t.N = N; t.K = K; t.out = C; t.ldo = K;
+    return launch_gemm_tn(precision, t, as_stream(stream));
+}
+
+}  // extern "C"

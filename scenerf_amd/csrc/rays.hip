@@ -1,0 +1,955 @@
+// Per-ray / per-sample kernels of the SceneRF hot path for gfx950 (wave64):
+//   ray setup, point encoding (projection + spherical index + positional encoding), HWC feature gather,
+//   gaussian sampling + in-LDS bitonic sort, wave-per-ray alpha compositing (fwd/bwd), RaySOM-KL (fwd),
+//   sampler/KL backward, and the CHW<->HWC feature-map layout changes.
+// Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf, so the rounding
+// sequence is the one documented next to each formula (it follows the reference's eager torch ops).
+#include "common.h"
+
+#define PI_F 3.14159265358979323846f
+#define HALF_PI_F 1.57079632679489661923f
+
+// k-ordered fma chain == what a BLAS sgemm micro-kernel does for a length-3/4 dot product
+__device__ static inline float dot3(float a0, float a1, float a2, float x, float y, float z) {
+    return fmaf(a2, z, fmaf(a1, y, a0 * x));
+}
+__device__ static inline float dot4(float a0, float a1, float a2, float a3, float x, float y, float z, float w) {
+    return fmaf(a3, w, fmaf(a2, z, fmaf(a1, y, a0 * x)));
+}
+
+// ------------------------------------------------------------------------------------------------ ray setup
+// one thread per (ray, j): j < U writes dist_u; j == 0 also writes unit_dir / viewdir.
+__global__ void ray_setup_kernel(const float* __restrict__ pixels, const float* __restrict__ iK,
+                                 const float* __restrict__ T, const float* __restrict__ lin_u,
+                                 const float* __restrict__ noise_u, int R, int U, float step,
+                                 float* __restrict__ unit_dir, float* __restrict__ viewdir, float* __restrict__ dist_u) {
+    int W = U > 0 ? U : 1;
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= R * W) return;
+    int r = gid / W, j = gid - r * W;
+    if (j < U) dist_u[(size_t)r * U + j] = lin_u[j] + noise_u[(size_t)r * U + j] * step;  // utils.py:84-85
+    if (j == 0) {
+        float u = pixels[2 * r], v = pixels[2 * r + 1];
+        float dx = dot3(iK[0], iK[1], iK[2], u, v, 1.f);
+        float dy = dot3(iK[3], iK[4], iK[5], u, v, 1.f);
+        float dz = dot3(iK[6], iK[7], iK[8], u, v, 1.f);
+        float n = sqrtf(dx * dx + dy * dy + dz * dz);
+        n = fmaxf(n, 1e-12f);  // F.normalize eps
+        unit_dir[3 * r + 0] = dx / n;
+        unit_dir[3 * r + 1] = dy / n;
+        unit_dir[3 * r + 2] = dz / n;
+        viewdir[3 * r + 0] = dot3(T[0], T[1], T[2], dx, dy, dz);   // utils.py:170 (un-normalised)
+        viewdir[3 * r + 1] = dot3(T[4], T[5], T[6], dx, dy, dz);
+        viewdir[3 * r + 2] = dot3(T[8], T[9], T[10], dx, dy, dz);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ encode
+struct SphereConsts {
+    float v_min, v_fov, h_min, h_fov;
+    int W, H;
+};
+
+__global__ void encode_points_kernel(const float* __restrict__ dist, int dist_ray_stride, int ppr,
+                                     const float* __restrict__ unit_dir, const float* __restrict__ viewdir,
+                                     const float* __restrict__ K, const float* __restrict__ iK,
+                                     const float* __restrict__ T, SphereConsts sc, int M,
+                                     float* __restrict__ pts_out, int32_t* __restrict__ sphere_idx,
+                                     float* __restrict__ xenc) {
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    int r = m / ppr, j = m - r * ppr;
+    float d = dist[(size_t)r * dist_ray_stride + j];
+    // source-frame point = dist * unit_dir (utils.py:87 / 217), then T @ [p,1] (utils.py:161-166)
+    float px = d * unit_dir[3 * r], py = d * unit_dir[3 * r + 1], pz = d * unit_dir[3 * r + 2];
+    float qx = dot4(T[0], T[1], T[2], T[3], px, py, pz, 1.f);
+    float qy = dot4(T[4], T[5], T[6], T[7], px, py, pz, 1.f);
+    float qz = dot4(T[8], T[9], T[10], T[11], px, py, pz, 1.f);
+    if (pts_out) {
+        pts_out[3 * (size_t)m] = qx;
+        pts_out[3 * (size_t)m + 1] = qy;
+        pts_out[3 * (size_t)m + 2] = qz;
+    }
+    // cam_pts_2_pix, utils.py:298-315
+    float h0 = dot3(K[0], K[1], K[2], qx, qy, qz);
+    float h1 = dot3(K[3], K[4], K[5], qx, qy, qz);
+    float h2 = dot3(K[6], K[7], K[8], qx, qy, qz);
+    float u = -1.f, v = -1.f;
+    if (h2 > 0.f) {
+        u = h0 / h2;
+        v = h1 / h2;
+    }
+    // SphericalMapping.from_pixels at depth 1, spherical_mapping.py:80-115
+    float cx = dot3(iK[0], iK[1], iK[2], u, v, 1.f);
+    float cy = dot3(iK[3], iK[4], iK[5], u, v, 1.f);
+    float cz = dot3(iK[6], iK[7], iK[8], u, v, 1.f);
+    float cd = sqrtf(cx * cx + cy * cy + cz * cz);
+    float v_angle = acosf(-cy / cd) / PI_F * 180.f;
+    float h_angle = 180.f - atan2f(cz, cx) / PI_F * 180.f;
+    float ox = (h_angle - sc.h_min) / sc.h_fov * (float)(sc.W - 1);
+    float oy = (v_angle - sc.v_min) / sc.v_fov * (float)(sc.H - 1);
+    // torch.round = half-to-even = rintf; clamp so the int conversion is defined for far-out points
+    ox = fminf(fmaxf(rintf(ox), -1.0e9f), 1.0e9f);
+    oy = fminf(fmaxf(rintf(oy), -1.0e9f), 1.0e9f);
+    if (!(ox == ox)) ox = -1.0e9f;
+    if (!(oy == oy)) oy = -1.0e9f;
+    sphere_idx[2 * (size_t)m] = (int32_t)ox;
+    sphere_idx[2 * (size_t)m + 1] = (int32_t)oy;
+    // PositionalEncoding pe.py:32-43: [x, sin(f0 x), sin(f0 x + pi/2), ...] then viewdir, zero pad to 48
+    float* o = xenc + (size_t)m * SCENERF_D_XENC;
+    float q[3] = {qx, qy, qz};
+    o[0] = qx;
+    o[1] = qy;
+    o[2] = qz;
+    float f = PI_F;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float a = q[c] * f;  // addcmul: phase + x*f, product rounded first
+            o[3 + (2 * k) * 3 + c] = sinf(a);
+            o[3 + (2 * k + 1) * 3 + c] = sinf(HALF_PI_F + a);
+        }
+        f *= 2.f;
+    }
+    o[39] = viewdir[3 * r];
+    o[40] = viewdir[3 * r + 1];
+    o[41] = viewdir[3 * r + 2];
+#pragma unroll
+    for (int c = 42; c < SCENERF_D_XENC; ++c) o[c] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------ gather
+struct GatherConsts {
+    int C[5], Hm[5], Wm[5], Hd[5], Wd[5], off[5];
+};
+
+template <typename T> struct Vec16;  // 16-byte vector of T
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    __device__ static inline void load(const float* p, float* v) {
+        float4 t = *(const float4*)p;
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    __device__ static inline void store(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    __device__ static inline void load(const bf16_t* p, float* v) {
+        uint4 t = *(const uint4*)p;
+        v[0] = bf16lo(t.x); v[1] = bf16hi(t.x); v[2] = bf16lo(t.y); v[3] = bf16hi(t.y);
+        v[4] = bf16lo(t.z); v[5] = bf16hi(t.z); v[6] = bf16lo(t.w); v[7] = bf16hi(t.w);
+    }
+    __device__ static inline void store(bf16_t* p, const float* v) {
+        *(uint4*)p = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                pack_bf16x2(v[6], v[7]));
+    }
+};
+
+struct MapPtrs {
+    const void* p[5];
+};
+
+// one 256-thread block per 128-row tile.  Phase 1: taps + validity per (row, scale); phase 2: blend.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts gc, const int32_t* __restrict__ sphere_idx,
+                                                     int M, T* __restrict__ Z, uint8_t* __restrict__ tile_mask,
+                                                     int32_t* __restrict__ tap_texel, float* __restrict__ tap_weight) {
+    __shared__ int s_tex[SCENERF_TILE_ROWS][5][4];
+    __shared__ float s_w[SCENERF_TILE_ROWS][5][4];
+    __shared__ unsigned s_mask;
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_mask = 0u;
+    __syncthreads();
+    if (tid < SCENERF_TILE_ROWS) {
+        int m = tile * SCENERF_TILE_ROWS + tid;
+        unsigned bits = 0u;
+        int ix = 0, iy = 0;
+        if (m < M) {
+            ix = sphere_idx[2 * (size_t)m];
+            iy = sphere_idx[2 * (size_t)m + 1];
+        }
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            int tex[4] = {-1, -1, -1, -1};
+            float w[4] = {0.f, 0.f, 0.f, 0.f};
+            if (m < M) {
+                // utils.py:237: idx / div * 2 - 1 ; ATen grid_sampler (align_corners=False): (g+1)*size/2 - 0.5
+                float gx = (float)ix / (float)gc.Wd[s] * 2.f - 1.f;
+                float gy = (float)iy / (float)gc.Hd[s] * 2.f - 1.f;
+                float fx = (gx + 1.f) * ((float)gc.Wm[s] * 0.5f) - 0.5f;
+                float fy = (gy + 1.f) * ((float)gc.Hm[s] * 0.5f) - 0.5f;
+                if (fx > -2.f && fx < (float)gc.Wm[s] + 1.f && fy > -2.f && fy < (float)gc.Hm[s] + 1.f) {
+                    float x0f = floorf(fx), y0f = floorf(fy);
+                    float wx = fx - x0f, ex = 1.f - wx, wy = fy - y0f, sy = 1.f - wy;
+                    int x0 = (int)x0f, y0 = (int)y0f;
+                    float ww[4] = {sy * ex, sy * wx, wy * ex, wy * wx};  // nw, ne, sw, se
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+                        if (xx >= 0 && xx < gc.Wm[s] && yy >= 0 && yy < gc.Hm[s]) {
+                            tex[t] = yy * gc.Wm[s] + xx;
+                            w[t] = ww[t];
+                            bits |= 1u << s;
+                        }
+                    }
+                }
+                size_t o = ((size_t)m * 5 + s) * 4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    tap_texel[o + t] = tex[t];
+                    tap_weight[o + t] = w[t];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s_tex[tid][s][t] = tex[t];
+                s_w[tid][s][t] = w[t];
+            }
+        }
+        if (bits) atomicOr(&s_mask, bits);
+    }
+    __syncthreads();
+    const unsigned mask = s_mask;
+    if (tid == 0) tile_mask[tile] = (uint8_t)mask;
+    constexpr int VN = Vec16<T>::N;
+    for (int s = 0; s < 5; ++s) {
+        if (!(mask & (1u << s))) continue;
+        const int C = gc.C[s];
+        const int chunks = C / VN;
+        const T* map = (const T*)maps.p[s];
+        const int items = SCENERF_TILE_ROWS * chunks;
+        for (int it = tid; it < items; it += 256) {
+            int row = it / chunks, ch = it - row * chunks;
+            float acc[VN];
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+            bool first = true;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int tx = s_tex[row][s][t];
+                if (tx >= 0) {
+                    float v[VN];
+                    Vec16<T>::load(map + (size_t)tx * C + ch * VN, v);
+                    float w = s_w[row][s][t];
+                    if (first) {
+#pragma unroll
+                        for (int e = 0; e < VN; ++e) acc[e] = v[e] * w;
+                        first = false;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VN; ++e) acc[e] = fmaf(v[e], w, acc[e]);
+                    }
+                }
+            }
+            size_t zrow = (size_t)tile * SCENERF_TILE_ROWS + row;
+            Vec16<T>::store(Z + zrow * SCENERF_D_LATENT + gc.off[s] + ch * VN, acc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ sampler + sort
+// one wave per ray; N <= 512 keys sorted with a bitonic network in LDS (stable via (key, index) compare).
+__global__ __launch_bounds__(64) void gaussian_sample_sort_kernel(
+    const float* __restrict__ offsets, const float* __restrict__ anchors, const float* __restrict__ dist_u,
+    const float* __restrict__ noise_g, const float* __restrict__ unit_dir, int R, int U, int G, int P, int N, int NP,
+    float base_std, float floor_, float* __restrict__ gmeans, float* __restrict__ gstds,
+    float* __restrict__ dist_sorted, float* __restrict__ z_sorted, int32_t* __restrict__ perm) {
+    __shared__ float s_key[SCENERF_MAX_SAMPLES];
+    __shared__ int s_idx[SCENERF_MAX_SAMPLES];
+    __shared__ float s_mean[SCENERF_MAX_GAUSSIANS], s_std[SCENERF_MAX_GAUSSIANS];
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (lane < G) {
+        float o0 = offsets[((size_t)r * G + lane) * 2], o1 = offsets[((size_t)r * G + lane) * 2 + 1];
+        float mean = fmaxf(anchors[lane] + o0, 0.f) + floor_;  // scenerf.py:588-592
+        float sd = fmaxf(o1 + base_std, 0.f) + floor_;         // scenerf.py:593-594
+        s_mean[lane] = mean;
+        s_std[lane] = sd;
+        gmeans[(size_t)r * G + lane] = mean;
+        gstds[(size_t)r * G + lane] = sd;
+    }
+    __syncthreads();
+    for (int j = lane; j < NP; j += 64) {
+        float key = __builtin_inff();
+        if (j < N) {
+            if (j < U) {
+                key = dist_u[(size_t)r * U + j];
+            } else {
+                int jj = j - U, g = jj / P;
+                float d = s_mean[g] + noise_g[(size_t)r * G * P + jj] * s_std[g];  // utils.py:213
+                key = d < 0.1f ? 0.1f : d;                                           // utils.py:214
+            }
+        }
+        s_key[j] = key;
+        s_idx[j] = j;
+    }
+    __syncthreads();
+    for (int k = 2; k <= NP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < NP / 2; t += 64) {
+                int i = ((t / j) * 2 * j) + (t % j);
+                int l = i + j;
+                bool up = (i & k) == 0;
+                float ka = s_key[i], kb = s_key[l];
+                int ia = s_idx[i], ib = s_idx[l];
+                bool gt = (ka > kb) || (ka == kb && ia > ib);
+                if (gt == up) {
+                    s_key[i] = kb; s_key[l] = ka;
+                    s_idx[i] = ib; s_idx[l] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const float uz = unit_dir[3 * r + 2];
+    for (int j = lane; j < N; j += 64) {
+        float d = s_key[j];
+        dist_sorted[(size_t)r * N + j] = d;
+        z_sorted[(size_t)r * N + j] = d * uz;  // cam_pts[:, :, 2], utils.py:159 / 219
+        perm[(size_t)r * N + j] = s_idx[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ compositing
+__device__ static inline float softplus_m1(float x) {  // nn.Softplus(beta=1)(x - 1), threshold 20
+    float y = x - 1.f;
+    return y > 20.f ? y : log1pf(expf(y));
+}
+__device__ static inline float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// wave-wide exclusive product scan of one value per lane
+__device__ static inline float wave_excl_prod(float p, int lane) {
+    float incl = p;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl *= t;
+    }
+    float ex = __shfl_up(incl, 1, WAVE);
+    return lane == 0 ? 1.f : ex;
+}
+// wave-wide exclusive suffix sum (sum over lanes > lane)
+__device__ static inline float wave_excl_suffix_sum(float v, int lane) {
+    float incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_down(incl, o, WAVE);
+        if (lane + o < 64) incl += t;
+    }
+    float ex = __shfl_down(incl, 1, WAVE);
+    return lane == 63 ? 0.f : ex;
+}
+
+// One wave per ray, C consecutive samples per lane (64*C >= N): per-ray state lives in VGPRs, the in-ray
+// transmittance product is a lane-local product + a 6-step wave scan.  4 rays (waves) per 256-thread block.
+template <int C>
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ dist,
+                                                            const float* __restrict__ zv, int R, int N,
+                                                            float* __restrict__ densities, float* __restrict__ alphas,
+                                                            float* __restrict__ weights, float* __restrict__ depth,
+                                                            float* __restrict__ color, float* __restrict__ closest,
+                                                            float* __restrict__ w_at, int32_t* __restrict__ closest_idx) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const size_t base = (size_t)r * N;
+    float d[C], z[C], sg[C], al[C], w[C], cr[C], cg[C], cb[C];
+    const int i0 = lane * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        int i = i0 + c;
+        bool ok = i < N;
+        float4 lg = ok ? *(const float4*)(logits + (base + i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float dd = ok ? dist[base + i] : 0.f;
+        d[c] = dd < 0.f ? 0.f : dd;  // scenerf.py:707
+        z[c] = ok ? zv[base + i] : 0.f;
+        sg[c] = softplus_m1(lg.w);
+        cr[c] = sigmoidf(lg.x);
+        cg[c] = sigmoidf(lg.y);
+        cb[c] = sigmoidf(lg.z);
+    }
+    float prev = __shfl_up(d[C - 1], 1, WAVE);  // last sample of the previous lane
+    float lp = 1.f;                              // lane-local product of (1 - alpha + 1e-10)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        int i = i0 + c;
+        float before = (c == 0) ? prev : d[c - 1];
+        float delta = (i == 0) ? d[c] : d[c] - before;  // scenerf.py:708-710
+        float a = (i < N) ? 1.f - expf(-delta * sg[c]) : 0.f;
+        al[c] = a;
+        lp *= (1.f - a + 1e-10f);
+    }
+    float Tr = wave_excl_prod(lp, lane);  // cumprod, scenerf.py:718-721
+    float sd = 0.f, sr = 0.f, sgc = 0.f, sb = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        w[c] = al[c] * Tr;  // scenerf.py:723
+        Tr *= (1.f - al[c] + 1e-10f);
+        sd += w[c] * z[c];
+        sr += w[c] * cr[c];
+        sgc += w[c] * cg[c];
+        sb += w[c] * cb[c];
+    }
+    sd = wave_sum(sd);
+    sr = wave_sum(sr);
+    sgc = wave_sum(sgc);
+    sb = wave_sum(sb);
+    // closest sample to the rendered depth (first minimum), scenerf.py:730-735
+    float best = __builtin_inff();
+    int bi = 0x7fffffff;
+    float bw = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        int i = i0 + c;
+        if (i < N) {
+            float a = fabsf(sd - z[c]);
+            if (a < best) { best = a; bi = i; bw = w[c]; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, WAVE);
+        int oi = __shfl_xor(bi, o, WAVE);
+        float ow = __shfl_xor(bw, o, WAVE);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; bw = ow; }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        int i = i0 + c;
+        if (i < N) {
+            densities[base + i] = sg[c];
+            alphas[base + i] = al[c];
+            weights[base + i] = w[c];
+        }
+    }
+    if (lane == 0) {
+        depth[r] = sd;
+        color[3 * r] = sr;
+        color[3 * r + 1] = sgc;
+        color[3 * r + 2] = sb;
+        closest[r] = best;
+        w_at[r] = bw;
+        closest_idx[r] = bi;
+    }
+}
+
+// backward: recompute sigma/alpha/T/w in-wave (nothing but the inputs is re-read), reverse scan for the
+// transmittance term.  dL/dalpha_i = gw_i T_i - (sum_{j>i} gw_j w_j) / (1 - alpha_i + 1e-10).
+template <int C>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ dist,
+                                                            const float* __restrict__ zv, int R, int N,
+                                                            const float* __restrict__ g_depth, const float* __restrict__ g_color,
+                                                            const float* __restrict__ g_weights, const float* __restrict__ g_alphas,
+                                                            const float* __restrict__ g_dens, const float* __restrict__ g_zvol,
+                                                            float* __restrict__ d_logits, float* __restrict__ d_dist,
+                                                            float* __restrict__ d_z) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const size_t base = (size_t)r * N;
+    const int i0 = lane * C;
+    float d[C], z[C], sg[C], al[C], w[C], cr[C], cg[C], cb[C], dl[C], Ti[C], o3[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        int i = i0 + c;
+        bool ok = i < N;
+        float4 lg = ok ? *(const float4*)(logits + (base + i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float dd = ok ? dist[base + i] : 0.f;
+        d[c] = dd < 0.f ? 0.f : dd;
+        z[c] = ok ? zv[base + i] : 0.f;
+        o3[c] = lg.w;
+        sg[c] = softplus_m1(lg.w);
+        cr[c] = sigmoidf(lg.x);
+        cg[c] = sigmoidf(lg.y);
+        cb[c] = sigmoidf(lg.z);
+    }
+    float prev = __shfl_up(d[C - 1], 1, WAVE);
+    float lp = 1.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        int i = i0 + c;
+        float before = (c == 0) ? prev : d[c - 1];
+        dl[c] = (i == 0) ? d[c] : d[c] - before;
+        al[c] = (i < N) ? 1.f - expf(-dl[c] * sg[c]) : 0.f;
+        lp *= (1.f - al[c] + 1e-10f);
+    }
+    float Tr = wave_excl_prod(lp, lane);
+    const float gd = g_depth[r];
+    const float gcr = g_color[3 * r], gcg = g_color[3 * r + 1], gcb = g_color[3 * r + 2];
+    float gw[C];
+    float lsum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        int i = i0 + c;
+        Ti[c] = Tr;
+        w[c] = al[c] * Tr;
+        Tr *= (1.f - al[c] + 1e-10f);
+        float g = gd * z[c] + gcr * cr[c] + gcg * cg[c] + gcb * cb[c];
+        if (g_weights && i < N) g += g_weights[base + i];
+        gw[c] = (i < N) ? g : 0.f;
+        lsum += gw[c] * w[c];
+    }
+    float S = wave_excl_suffix_sum(lsum, lane);  // sum over later lanes
+    float gdelta[C];
+    // walk this lane's samples backwards so S always holds sum_{j>i} gw_j w_j
+#pragma unroll
+    for (int c = C - 1; c >= 0; --c) {
+        int i = i0 + c;
+        float s_i = 1.f - al[c] + 1e-10f;
+        float ga = gw[c] * Ti[c] - S / s_i;
+        if (g_alphas && i < N) ga += g_alphas[base + i];
+        float one_m = expf(-dl[c] * sg[c]);  // = 1 - alpha
+        float gs = ga * dl[c] * one_m;
+        if (g_dens && i < N) gs += g_dens[base + i];
+        gdelta[c] = (i < N) ? ga * sg[c] * one_m : 0.f;
+        S += gw[c] * w[c];
+        if (i < N) {
+            float y = o3[c] - 1.f;
+            float dsig = y > 20.f ? 1.f : sigmoidf(y);  // softplus'
+            float4 o;
+            o.x = gcr * w[c] * cr[c] * (1.f - cr[c]);
+            o.y = gcg * w[c] * cg[c] * (1.f - cg[c]);
+            o.z = gcb * w[c] * cb[c] * (1.f - cb[c]);
+            o.w = gs * dsig;
+            *(float4*)(d_logits + (base + i) * 4) = o;
+            float gz = gd * w[c];
+            if (g_zvol) gz += g_zvol[base + i];
+            d_z[base + i] = gz;
+        }
+    }
+    // delta_i = d_i - d_{i-1}  =>  dL/dd_i = gdelta_i - gdelta_{i+1}
+    float next = __shfl_down(gdelta[0], 1, WAVE);
+    if (lane == 63) next = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        int i = i0 + c;
+        float after = (c == C - 1) ? next : gdelta[c + 1];
+        if (i < N) d_dist[base + i] = gdelta[c] - ((i + 1 < N) ? after : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ RaySOM
+#define MAXG SCENERF_MAX_GAUSSIANS
+// one wave per ray; lanes stride over the N samples.  ray_som_kl.py:10-87.
+__global__ __launch_bounds__(256) void raysom_fwd_kernel(const float* __restrict__ gmeans, const float* __restrict__ gstds,
+                                                         const float* __restrict__ dist, const float* __restrict__ alphas,
+                                                         int R, int N, int G, float som_sigma, float kl_floor,
+                                                         float* __restrict__ loss_kl, float* __restrict__ som_means,
+                                                         float* __restrict__ som_vars, float* __restrict__ kl_saved) {
+    __shared__ float s_nb[4][MAXG][MAXG], s_p12[4][MAXG][MAXG];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wv;
+    const bool active = r < R;
+    float m[MAXG], s[MAXG], var[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        bool ok = active && g < G;
+        m[g] = ok ? gmeans[(size_t)r * G + g] : 0.f;
+        s[g] = ok ? gstds[(size_t)r * G + g] : 1.f;
+        var[g] = s[g] * s[g];
+    }
+    const float two_sig2 = (float)(2.0 * (double)som_sigma * (double)som_sigma);
+    if (lane < MAXG * MAXG) {
+        int c2 = lane / MAXG, c1 = lane % MAXG;
+        float dm = m[0];  // select m[c2]-m[c1] without dynamic register indexing
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            if (g == c2) a = m[g];
+            if (g == c1) b = m[g];
+        }
+        dm = a - b;
+        s_nb[wv][c2][c1] = (c2 < G && c1 < G) ? expf(-(dm * dm) / two_sig2) : 0.f;  // ray_som_kl.py:89-91
+    }
+    __syncthreads();
+    if (lane < MAXG * MAXG) {
+        int c2 = lane / MAXG, c1 = lane % MAXG;
+        float sum = 0.f;
+        for (int g = 0; g < G; ++g) sum += s_nb[wv][c2][g];
+        s_p12[wv][c2][c1] = (c2 < G && c1 < G) ? s_nb[wv][c2][c1] / sum : 0.f;
+    }
+    __syncthreads();
+    if (!active) return;
+    const float sqrt2pi = 2.5066282746310002f;
+    float sw[MAXG], swd[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) { sw[g] = 0.f; swd[g] = 0.f; }
+    // pass 1: weighted means
+    for (int i = lane; i < N; i += 64) {
+        float d = dist[(size_t)r * N + i];
+        float dens = alphas[(size_t)r * N + i] + 1e-8f;
+        float pz1[MAXG];
+#pragma unroll
+        for (int c = 0; c < MAXG; ++c) {
+            float gap = fabsf(m[c] - d);
+            float p = expf(-(gap * gap) / (2.f * var[c])) / (sqrt2pi * s[c]) + 1e-5f;
+            pz1[c] = (c < G) ? p * dens + 1e-8f : 0.f;
+        }
+        float pbest = -1.f;
+        int bmu = 0;
+        for (int c2 = 0; c2 < G; ++c2) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c1 = 0; c1 < MAXG; ++c1)
+                if (c1 < G) acc += pz1[c1] * s_p12[wv][c2][c1] + 1e-8f;
+            if (acc > pbest) { pbest = acc; bmu = c2; }
+        }
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            if (g < G) {
+                float wgt = s_nb[wv][g][bmu] * pz1[g] / pbest + 1e-5f;
+                sw[g] += wgt;
+                swd[g] += wgt * d;
+            }
+        }
+    }
+    float nm[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        sw[g] = wave_sum(sw[g]);
+        swd[g] = wave_sum(swd[g]);
+        nm[g] = swd[g] / sw[g];
+    }
+    // pass 2: weighted variances around the new means (weights recomputed, not stored)
+    float sv[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) sv[g] = 0.f;
+    for (int i = lane; i < N; i += 64) {
+        float d = dist[(size_t)r * N + i];
+        float dens = alphas[(size_t)r * N + i] + 1e-8f;
+        float pz1[MAXG];
+#pragma unroll
+        for (int c = 0; c < MAXG; ++c) {
+            float gap = fabsf(m[c] - d);
+            float p = expf(-(gap * gap) / (2.f * var[c])) / (sqrt2pi * s[c]) + 1e-5f;
+            pz1[c] = (c < G) ? p * dens + 1e-8f : 0.f;
+        }
+        float pbest = -1.f;
+        int bmu = 0;
+        for (int c2 = 0; c2 < G; ++c2) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c1 = 0; c1 < MAXG; ++c1)
+                if (c1 < G) acc += pz1[c1] * s_p12[wv][c2][c1] + 1e-8f;
+            if (acc > pbest) { pbest = acc; bmu = c2; }
+        }
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            if (g < G) {
+                float wgt = s_nb[wv][g][bmu] * pz1[g] / pbest + 1e-5f;
+                float e = d - nm[g];
+                sv[g] += wgt * (e * e);
+            }
+        }
+    }
+    float klsum = 0.f;
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        sv[g] = wave_sum(sv[g]);
+        if (g < G) {
+            float nv = sv[g] / sw[g];
+            float mean_diff = fabsf(m[g] - nm[g]);
+            float std_diff = fabsf(sqrtf(var[g]) - sqrtf(nv));
+            float mk = ((mean_diff > 0.1f) && (nv > 0.f) && (std_diff > 0.1f)) ? 1.f : 0.f;  // ray_som_kl.py:66-70
+            float s2 = sqrtf(nv);
+            if (s2 < kl_floor) s2 = kl_floor;  // ray_som_kl.py:83
+            float dmm = m[g] - nm[g];
+            float kl = logf(s2 / s[g] + 1e-8f) + (s[g] * s[g] + dmm * dmm) / (2.f * (s2 * s2)) - 0.5f;
+            klsum += kl * mk;
+            if (lane == 0) {
+                som_means[(size_t)r * G + g] = nm[g];
+                som_vars[(size_t)r * G + g] = nv;
+                kl_saved[((size_t)r * G + g) * 3 + 0] = nm[g];
+                kl_saved[((size_t)r * G + g) * 3 + 1] = s2;
+                kl_saved[((size_t)r * G + g) * 3 + 2] = mk;
+            }
+        }
+    }
+    if (lane == 0) loss_kl[r] = klsum / (float)G;
+}
+
+// sampler + KL backward: one wave per ray, 4 rays per block.
+__global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restrict__ offsets, const float* __restrict__ anchors,
+                                                          const float* __restrict__ noise_g, const float* __restrict__ unit_dir,
+                                                          const float* __restrict__ gmeans, const float* __restrict__ gstds,
+                                                          const int32_t* __restrict__ perm, const float* __restrict__ d_dist,
+                                                          const float* __restrict__ d_z, const float* __restrict__ kl_saved,
+                                                          const float* __restrict__ g_loss_kl, const float* __restrict__ g_gmeans,
+                                                          const float* __restrict__ g_gstds, int R, int U, int G, int P, int N,
+                                                          float base_std, float* __restrict__ d_offsets) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float m[MAXG], s[MAXG], am[MAXG], as_[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        bool ok = g < G;
+        m[g] = ok ? gmeans[(size_t)r * G + g] : 0.f;
+        s[g] = ok ? gstds[(size_t)r * G + g] : 1.f;
+        am[g] = 0.f;
+        as_[g] = 0.f;
+    }
+    const float uz = unit_dir[3 * r + 2];
+    for (int i = lane; i < N; i += 64) {
+        int o = perm[(size_t)r * N + i];
+        if (o >= U) {
+            int jj = o - U, g = jj / P;
+            float nz = noise_g[(size_t)r * G * P + jj];
+            float tot = d_dist[(size_t)r * N + i] + d_z[(size_t)r * N + i] * uz;
+#pragma unroll
+            for (int gg = 0; gg < MAXG; ++gg) {
+                if (gg == g) {
+                    float raw = m[gg] + nz * s[gg];
+                    if (!(raw < 0.1f)) {  // the 0.1 clamp blocks the gradient, utils.py:214
+                        am[gg] += tot;
+                        as_[gg] += tot * nz;
+                    }
+                }
+            }
+        }
+    }
+    const float gkl = g_loss_kl ? g_loss_kl[r] : 0.f;
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        am[g] = wave_sum(am[g]);
+        as_[g] = wave_sum(as_[g]);
+        if (g < G && lane == 0) {
+            size_t q = (size_t)r * G + g;
+            float m2 = kl_saved[q * 3], s2 = kl_saved[q * 3 + 1], mk = kl_saved[q * 3 + 2];
+            float s1 = s[g], m1 = m[g];
+            float scale = gkl * mk / (float)G;
+            // d/dm1, d/ds1 of log(s2/s1 + 1e-8) + (s1^2 + (m1-m2)^2) / (2 s2^2) - 0.5
+            float dm = (m1 - m2) / (s2 * s2) * scale;
+            float ds = (-(s2 / (s1 * s1)) / (s2 / s1 + 1e-8f) + s1 / (s2 * s2)) * scale;
+            float tm = am[g] + dm + (g_gmeans ? g_gmeans[q] : 0.f);
+            float ts = as_[g] + ds + (g_gstds ? g_gstds[q] : 0.f);
+            float o0 = offsets[q * 2], o1 = offsets[q * 2 + 1];
+            d_offsets[q * 2] = (anchors[g] + o0 > 0.f) ? tm : 0.f;       // relu of scenerf.py:591
+            d_offsets[q * 2 + 1] = (o1 + base_std > 0.f) ? ts : 0.f;    // relu of scenerf.py:593
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ layout changes
+// in [A][B] (fp32) -> out [B][A] (TO). 32x32 tiles through LDS.
+template <typename TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, TO* __restrict__ out, int A, int B) {
+    __shared__ float tile[32][33];
+    int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx over B, by over A
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        int a = by + k, b = bx + tx;
+        tile[k][tx] = (a < A && b < B) ? in[(size_t)a * B + b] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        int b = bx + k, a = by + tx;
+        if (a < A && b < B) ActIO<TO>::st(out, (size_t)b * A + a, tile[tx][k]);
+    }
+}
+
+// ================================================================================================ C ABI
+static GatherConsts make_gc(const scenerf_cfg* cfg) {
+    GatherConsts gc;
+    int off = 0;
+    for (int s = 0; s < 5; ++s) {
+        gc.C[s] = cfg->map_C[s];
+        gc.Hm[s] = cfg->map_H[s];
+        gc.Wm[s] = cfg->map_W[s];
+        gc.Hd[s] = cfg->div_H[s];
+        gc.Wd[s] = cfg->div_W[s];
+        gc.off[s] = off;
+        off += cfg->map_C[s];
+    }
+    return gc;
+}
+
+static int check_cfg(const scenerf_cfg* cfg) {
+    SRF_CHECK(cfg != nullptr, "cfg is NULL");
+    SRF_CHECK(cfg->n_gaussians >= 1 && cfg->n_gaussians <= SCENERF_MAX_GAUSSIANS, "n_gaussians %d not in [1,%d]",
+              cfg->n_gaussians, SCENERF_MAX_GAUSSIANS);
+    SRF_CHECK(cfg->n_pts_uni >= 0 && cfg->n_pts_per_gaussian >= 1, "bad sample counts");
+    int n = (cfg->n_pts_uni > 0 ? cfg->n_pts_uni : 0) + cfg->n_gaussians * cfg->n_pts_per_gaussian;
+    SRF_CHECK(cfg->n_samples == n, "n_samples %d != U + G*P = %d", cfg->n_samples, n);
+    SRF_CHECK(n <= SCENERF_MAX_SAMPLES, "n_samples %d > %d", n, SCENERF_MAX_SAMPLES);
+    int csum = 0;
+    for (int s = 0; s < 5; ++s) {
+        SRF_CHECK(cfg->map_C[s] > 0 && cfg->map_C[s] % 16 == 0, "map_C[%d]=%d must be a positive multiple of 16", s, cfg->map_C[s]);
+        SRF_CHECK(cfg->div_W[s] > 0 && cfg->div_H[s] > 0 && cfg->map_W[s] > 0 && cfg->map_H[s] > 0, "bad map dims at scale %d", s);
+        csum += cfg->map_C[s];
+    }
+    SRF_CHECK(csum == SCENERF_D_LATENT, "sum(map_C)=%d != %d", csum, SCENERF_D_LATENT);
+    SRF_CHECK(cfg->precision == 0 || cfg->precision == 1, "precision must be 0 (fp32) or 1 (bf16)");
+    return 0;
+}
+
+extern "C" {
+
+int scenerf_hip_maps_chw_to_hwc(const float* chw, void* hwc, int C, int H, int W, int precision, scenerf_stream_t stream) {
+    SRF_CHECK(chw && hwc && C > 0 && H > 0 && W > 0, "maps_chw_to_hwc: bad args");
+    hipStream_t s = as_stream(stream);
+    int A = C, B = H * W;
+    dim3 grid(cdiv(B, 32), cdiv(A, 32));
+    SrfLaunchScope ps(s, "maps_chw_to_hwc", 0, (double)A * B * (4 + (precision ? 2 : 4)));
+    if (precision)
+        transpose_kernel<bf16_t><<<grid, 256, 0, s>>>(chw, (bf16_t*)hwc, A, B);
+    else
+        transpose_kernel<float><<<grid, 256, 0, s>>>(chw, (float*)hwc, A, B);
+    SRF_LAUNCH_CHECK("transpose_kernel");
+    return 0;
+}
+
+int scenerf_hip_grads_hwc_to_chw(const float* hwc, float* chw, int C, int H, int W, scenerf_stream_t stream) {
+    SRF_CHECK(chw && hwc && C > 0 && H > 0 && W > 0, "grads_hwc_to_chw: bad args");
+    hipStream_t s = as_stream(stream);
+    int A = H * W, B = C;
+    dim3 grid(cdiv(B, 32), cdiv(A, 32));
+    SrfLaunchScope ps(s, "grads_hwc_to_chw", 0, (double)A * B * 8);
+    transpose_kernel<float><<<grid, 256, 0, s>>>(hwc, chw, A, B);
+    SRF_LAUNCH_CHECK("transpose_kernel");
+    return 0;
+}
+
+int scenerf_hip_ray_setup(const scenerf_cfg* cfg, const float* pixels, const float* inv_K, const float* T_s2i,
+                          const float* lin_u, const float* noise_u, int R, float* unit_dir, float* viewdir, float* dist_u,
+                          scenerf_stream_t stream) {
+    if (check_cfg(cfg)) return 1;
+    SRF_CHECK(pixels && inv_K && T_s2i && unit_dir && viewdir && R > 0, "ray_setup: bad args");
+    int U = cfg->n_pts_uni;
+    SRF_CHECK(U == 0 || (lin_u && noise_u && dist_u), "ray_setup: uniform buffers missing");
+    hipStream_t s = as_stream(stream);
+    int total = R * (U > 0 ? U : 1);
+    SrfLaunchScope ps(s, "ray_setup", 0, (double)R * (8 + 24 + 8.0 * U));
+    ray_setup_kernel<<<cdiv(total, 256), 256, 0, s>>>(pixels, inv_K, T_s2i, lin_u, noise_u, R, U, cfg->uni_step, unit_dir,
+                                                      viewdir, dist_u);
+    SRF_LAUNCH_CHECK("ray_setup_kernel");
+    return 0;
+}
+
+int scenerf_hip_encode_points(const scenerf_cfg* cfg, const float* dist, int dist_ray_stride, int pts_per_ray,
+                              const float* unit_dir, const float* viewdir, const float* K, const float* inv_K,
+                              const float* T_s2i, int M, float* pts, int32_t* sphere_idx, float* xenc,
+                              scenerf_stream_t stream) {
+    if (check_cfg(cfg)) return 1;
+    SRF_CHECK(dist && unit_dir && viewdir && K && inv_K && T_s2i && sphere_idx && xenc, "encode_points: NULL argument");
+    SRF_CHECK(M > 0 && pts_per_ray > 0 && M % pts_per_ray == 0, "encode_points: M=%d not a multiple of pts_per_ray=%d", M, pts_per_ray);
+    hipStream_t s = as_stream(stream);
+    SphereConsts sc{cfg->v_min, cfg->v_fov, cfg->h_min, cfg->h_fov, cfg->sphere_W, cfg->sphere_H};
+    SrfLaunchScope ps(s, "encode_points", 0, (double)M * (4 + 8 + 4.0 * SCENERF_D_XENC));
+    encode_points_kernel<<<cdiv(M, 256), 256, 0, s>>>(dist, dist_ray_stride, pts_per_ray, unit_dir, viewdir, K, inv_K, T_s2i,
+                                                      sc, M, pts, sphere_idx, xenc);
+    SRF_LAUNCH_CHECK("encode_points_kernel");
+    return 0;
+}
+
+int scenerf_hip_gather_features(const scenerf_cfg* cfg, const void* const maps_hwc[SCENERF_N_SCALES],
+                                const int32_t* sphere_idx, int M, void* Z, uint8_t* tile_mask, int32_t* tap_texel,
+                                float* tap_weight, scenerf_stream_t stream) {
+    if (check_cfg(cfg)) return 1;
+    SRF_CHECK(maps_hwc && sphere_idx && Z && tile_mask && tap_texel && tap_weight && M > 0, "gather_features: NULL argument");
+    MapPtrs mp;
+    for (int i = 0; i < 5; ++i) {
+        SRF_CHECK(maps_hwc[i] != nullptr, "gather_features: map %d is NULL", i);
+        mp.p[i] = maps_hwc[i];
+    }
+    hipStream_t s = as_stream(stream);
+    GatherConsts gc = make_gc(cfg);
+    int tiles = cdiv(M, SCENERF_TILE_ROWS);
+    SrfLaunchScope ps(s, "gather_features", 0, 0);
+    if (cfg->precision)
+        gather_kernel<bf16_t><<<tiles, 256, 0, s>>>(mp, gc, sphere_idx, M, (bf16_t*)Z, tile_mask, tap_texel, tap_weight);
+    else
+        gather_kernel<float><<<tiles, 256, 0, s>>>(mp, gc, sphere_idx, M, (float*)Z, tile_mask, tap_texel, tap_weight);
+    SRF_LAUNCH_CHECK("gather_kernel");
+    return 0;
+}
+
+int scenerf_hip_gaussian_sample_sort(const scenerf_cfg* cfg, const float* offsets, const float* anchors, const float* dist_u,
+                                     const float* noise_g, const float* unit_dir, int R, float* gmeans, float* gstds,
+                                     float* dist_sorted, float* z_sorted, int32_t* perm, scenerf_stream_t stream) {
+    if (check_cfg(cfg)) return 1;
+    SRF_CHECK(offsets && anchors && noise_g && unit_dir && gmeans && gstds && dist_sorted && z_sorted && perm && R > 0,
+              "gaussian_sample_sort: NULL argument");
+    SRF_CHECK(cfg->n_pts_uni == 0 || dist_u, "gaussian_sample_sort: dist_u missing");
+    int N = cfg->n_samples, NP = 2;
+    while (NP < N) NP <<= 1;
+    hipStream_t s = as_stream(stream);
+    SrfLaunchScope ps(s, "gaussian_sample_sort", 0, (double)R * N * 20);
+    gaussian_sample_sort_kernel<<<R, 64, 0, s>>>(offsets, anchors, dist_u, noise_g, unit_dir, R, cfg->n_pts_uni,
+                                                 cfg->n_gaussians, cfg->n_pts_per_gaussian, N, NP, cfg->base_std,
+                                                 cfg->gauss_floor, gmeans, gstds, dist_sorted, z_sorted, perm);
+    SRF_LAUNCH_CHECK("gaussian_sample_sort_kernel");
+    return 0;
+}
+
+int scenerf_hip_composite_forward(const float* logits, const float* dist_sorted, const float* z_sorted, int R, int N,
+                                  float* densities, float* alphas, float* weights, float* depth, float* color, float* closest,
+                                  float* weights_at_depth, int32_t* closest_idx, scenerf_stream_t stream) {
+    SRF_CHECK(logits && dist_sorted && z_sorted && densities && alphas && weights && depth && color && closest &&
+                  weights_at_depth && closest_idx, "composite_forward: NULL argument");
+    SRF_CHECK(R > 0 && N > 0 && N <= SCENERF_MAX_SAMPLES, "composite_forward: bad R=%d N=%d", R, N);
+    hipStream_t s = as_stream(stream);
+    dim3 grid(cdiv(R, 4));
+    // algorithmic bytes: 32*N + 24 per ray
+    SrfLaunchScope ps(s, "composite_fwd", 0, (double)R * (32.0 * N + 24.0));
+#define CF(C) composite_fwd_kernel<C><<<grid, 256, 0, s>>>(logits, dist_sorted, z_sorted, R, N, densities, alphas, weights, depth, color, closest, weights_at_depth, closest_idx)
+    if (N <= 64) CF(1);
+    else if (N <= 128) CF(2);
+    else if (N <= 256) CF(4);
+    else CF(8);
+#undef CF
+    SRF_LAUNCH_CHECK("composite_fwd_kernel");
+    return 0;
+}
+
+int scenerf_hip_composite_backward(const float* logits, const float* dist_sorted, const float* z_sorted, int R, int N,
+                                   const float* g_depth, const float* g_color, const float* g_weights, const float* g_alphas,
+                                   const float* g_densities, const float* g_zvol, float* d_logits, float* d_dist, float* d_z,
+                                   scenerf_stream_t stream) {
+    SRF_CHECK(logits && dist_sorted && z_sorted && g_depth && g_color && d_logits && d_dist && d_z, "composite_backward: NULL argument");
+    SRF_CHECK(R > 0 && N > 0 && N <= SCENERF_MAX_SAMPLES, "composite_backward: bad R=%d N=%d", R, N);
+    hipStream_t s = as_stream(stream);
+    dim3 grid(cdiv(R, 4));
+    SrfLaunchScope ps(s, "composite_bwd", 0, (double)R * (48.0 * N + 40.0));
+#define CB(C) composite_bwd_kernel<C><<<grid, 256, 0, s>>>(logits, dist_sorted, z_sorted, R, N, g_depth, g_color, g_weights, g_alphas, g_densities, g_zvol, d_logits, d_dist, d_z)
+    if (N <= 64) CB(1);
+    else if (N <= 128) CB(2);
+    else if (N <= 256) CB(4);
+    else CB(8);
+#undef CB
+    SRF_LAUNCH_CHECK("composite_bwd_kernel");
+    return 0;
+}
+
+int scenerf_hip_raysom_forward(const scenerf_cfg* cfg, const float* gmeans, const float* gstds, const float* dist_sorted,
+                               const float* alphas, int R, float* loss_kl, float* som_means, float* som_vars, float* kl_saved,
+                               scenerf_stream_t stream) {
+    if (check_cfg(cfg)) return 1;
+    SRF_CHECK(gmeans && gstds && dist_sorted && alphas && loss_kl && som_means && som_vars && kl_saved && R > 0,
+              "raysom_forward: NULL argument");
+    hipStream_t s = as_stream(stream);
+    SrfLaunchScope ps(s, "raysom_fwd", 0, (double)R * cfg->n_samples * 16);
+    raysom_fwd_kernel<<<cdiv(R, 4), 256, 0, s>>>(gmeans, gstds, dist_sorted, alphas, R, cfg->n_samples, cfg->n_gaussians,
+                                                 cfg->som_sigma, cfg->kl_std_floor, loss_kl, som_means, som_vars, kl_saved);
+    SRF_LAUNCH_CHECK("raysom_fwd_kernel");
+    return 0;
+}
+
+int scenerf_hip_sampler_backward(const scenerf_cfg* cfg, const float* offsets, const float* anchors, const float* noise_g,
+                                 const float* unit_dir, const float* gmeans, const float* gstds, const int32_t* perm,
+                                 const float* d_dist, const float* d_z, const float* kl_saved, const float* g_loss_kl,
+                                 const float* g_gmeans, const float* g_gstds, int R, float* d_offsets, scenerf_stream_t stream) {
+    if (check_cfg(cfg)) return 1;
+    SRF_CHECK(offsets && anchors && noise_g && unit_dir && gmeans && gstds && perm && d_dist && d_z && kl_saved && d_offsets && R > 0,
+              "sampler_backward: NULL argument");
+    hipStream_t s = as_stream(stream);
+    SrfLaunchScope ps(s, "sampler_bwd", 0, (double)R * cfg->n_samples * 16);
+    sampler_bwd_kernel<<<cdiv(R, 4), 256, 0, s>>>(offsets, anchors, noise_g, unit_dir, gmeans, gstds, perm, d_dist, d_z, kl_saved,
+                                                  g_loss_kl, g_gmeans, g_gstds, R, cfg->n_pts_uni, cfg->n_gaussians,
+                                                  cfg->n_pts_per_gaussian, cfg->n_samples, cfg->base_std, d_offsets);
+    SRF_LAUNCH_CHECK("sampler_bwd_kernel");
+    return 0;
+}
+
+}  // extern "C"

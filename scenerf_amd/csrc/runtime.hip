@@ -1,0 +1,108 @@
+// Error reporting + optional per-launch hipEvent timing (used by bench.py's roofline leg).
+#include <stdarg.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void srf_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct ProfEntry {
+    std::string name;
+    hipEvent_t a, b;
+    double flops, bytes;
+};
+static bool g_prof = false;
+static std::vector<ProfEntry> g_entries;
+static std::vector<hipEvent_t> g_pool;
+
+bool srf_prof_on() { return g_prof; }
+
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void srf_prof_begin(hipStream_t s, const char* name, double flops, double bytes) {
+    ProfEntry p;
+    p.name = name;
+    p.flops = flops;
+    p.bytes = bytes;
+    p.a = get_event();
+    p.b = get_event();
+    if (p.a) (void)hipEventRecord(p.a, s);
+    g_entries.push_back(p);
+}
+
+void srf_prof_end(hipStream_t s) {
+    if (g_entries.empty()) return;
+    ProfEntry& p = g_entries.back();
+    if (p.b) (void)hipEventRecord(p.b, s);
+}
+
+extern "C" {
+
+int scenerf_hip_abi_version(void) { return SCENERF_HIP_ABI_VERSION; }
+const char* scenerf_hip_last_error(void) { return g_err; }
+
+int scenerf_hip_profile_enable(int on) {
+    g_prof = on != 0;
+    if (!g_prof) {
+        for (auto& p : g_entries) {
+            if (p.a) g_pool.push_back(p.a);
+            if (p.b) g_pool.push_back(p.b);
+        }
+        g_entries.clear();
+    }
+    return 0;
+}
+
+int scenerf_hip_profile_collect(scenerf_prof_rec* out, int cap) {
+    std::map<std::string, scenerf_prof_rec> agg;
+    std::vector<std::string> order;
+    for (auto& p : g_entries) {
+        float ms = 0.f;
+        if (p.a && p.b) {
+            (void)hipEventSynchronize(p.b);
+            if (hipEventElapsedTime(&ms, p.a, p.b) != hipSuccess) ms = 0.f;
+        }
+        auto it = agg.find(p.name);
+        if (it == agg.end()) {
+            scenerf_prof_rec r;
+            memset(&r, 0, sizeof(r));
+            strncpy(r.name, p.name.c_str(), sizeof(r.name) - 1);
+            it = agg.insert({p.name, r}).first;
+            order.push_back(p.name);
+        }
+        it->second.launches += 1;
+        it->second.total_ms += ms;
+        it->second.flops += p.flops;
+        it->second.bytes += p.bytes;
+        if (p.a) g_pool.push_back(p.a);
+        if (p.b) g_pool.push_back(p.b);
+    }
+    g_entries.clear();
+    int n = 0;
+    for (auto& nm : order) {
+        if (n >= cap) break;
+        out[n++] = agg[nm];
+    }
+    return n;
+}
+
+}  // extern "C"
