@@ -1,0 +1,133 @@
+"""ctypes binding of libscenerf_hip.so (the C ABI declared in include/scenerf_hip.h).
+
+There is NO fallback: if the shared library is missing or an entry point fails, a RuntimeError is
+raised.  The product never routes through the CPU oracle or eager PyTorch for the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libscenerf_hip.so")
+
+N_SCALES = 5
+D_LATENT = 2480
+D_HIDDEN = 512
+D_XENC = 48
+TILE_ROWS = 128
+ABI_VERSION = 1
+
+vp = C.c_void_p
+
+
+class Cfg(C.Structure):
+    _fields_ = [
+        ("n_pts_uni", C.c_int32), ("n_gaussians", C.c_int32), ("n_pts_per_gaussian", C.c_int32),
+        ("n_samples", C.c_int32), ("sphere_W", C.c_int32), ("sphere_H", C.c_int32),
+        ("max_sample_depth", C.c_float), ("uni_step", C.c_float), ("base_std", C.c_float),
+        ("som_sigma", C.c_float), ("gauss_floor", C.c_float), ("kl_std_floor", C.c_float),
+        ("v_min", C.c_float), ("v_fov", C.c_float), ("h_min", C.c_float), ("h_fov", C.c_float),
+        ("map_C", C.c_int32 * N_SCALES), ("map_H", C.c_int32 * N_SCALES), ("map_W", C.c_int32 * N_SCALES),
+        ("div_H", C.c_int32 * N_SCALES), ("div_W", C.c_int32 * N_SCALES),
+        ("precision", C.c_int32),
+    ]
+
+
+class MlpWeights(C.Structure):
+    _fields_ = [
+        ("d_out", C.c_int32),
+        ("w_in", vp), ("b_in", vp),
+        ("w_h", vp * 4), ("b_h", vp * 4),
+        ("w_fc0", vp * 3), ("b_fc0", vp * 3),
+        ("w_out", vp), ("b_out", vp),
+        ("w_fc0_t", vp * 3), ("w_fc1_t", vp * 3), ("w_z_t", vp * N_SCALES),
+    ]
+
+
+class MlpGrads(C.Structure):
+    _fields_ = [
+        ("w_in", vp), ("b_in", vp),
+        ("w_fc0", vp * 3), ("b_fc0", vp * 3),
+        ("w_fc1", vp * 3), ("b_fc1", vp * 3),
+        ("w_z", vp), ("b_z", vp), ("w_out", vp), ("b_out", vp),
+    ]
+
+
+class MlpActs(C.Structure):
+    _fields_ = [("H", vp * 4), ("Nn", vp * 3), ("h0pre", vp), ("logits", vp)]
+
+
+class ProfRec(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_float),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+i32 = C.c_int
+_PROTOS = {
+    "scenerf_hip_abi_version": (C.c_int, []),
+    "scenerf_hip_last_error": (C.c_char_p, []),
+    "scenerf_hip_maps_chw_to_hwc": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "scenerf_hip_grads_hwc_to_chw": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "scenerf_hip_ray_setup": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "scenerf_hip_encode_points": (C.c_int, [C.POINTER(Cfg), vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "scenerf_hip_gather_features": (C.c_int, [C.POINTER(Cfg), C.POINTER(vp * N_SCALES), vp, i32, vp, vp, vp, vp, vp]),
+    "scenerf_hip_mlp_forward": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpWeights), vp, vp, vp, i32, C.POINTER(MlpActs), vp]),
+    "scenerf_hip_mlp_backward": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpWeights), C.POINTER(MlpGrads), vp, vp, vp, vp, vp,
+                                           i32, C.POINTER(MlpActs), vp, vp, vp, C.POINTER(vp * N_SCALES), vp]),
+    "scenerf_hip_gaussian_sample_sort": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+    "scenerf_hip_composite_forward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "scenerf_hip_composite_backward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "scenerf_hip_raysom_forward": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "scenerf_hip_sampler_backward": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+    "scenerf_hip_test_gemm_nt": (C.c_int, [i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "scenerf_hip_test_gemm_tn": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "scenerf_hip_profile_enable": (C.c_int, [i32]),
+    "scenerf_hip_profile_collect": (C.c_int, [C.POINTER(ProfRec), i32]),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and type its entry points.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libscenerf_hip.so is not built (%s). Run `python -m scenerf_amd.build` (needs hipcc). "
+            "There is no CPU / eager fallback for the SceneRF hot path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.scenerf_hip_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError("libscenerf_hip.so ABI %d != binding ABI %d: rebuild" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().scenerf_hip_last_error()
+        raise RuntimeError("%s failed (code %d): %s" % (what, code, (msg or b"").decode("utf-8", "replace")))
+
+
+def ptr(t) -> Optional[int]:
+    """device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def profile_collect(cap: int = 256):
+    lib = load()
+    arr = (ProfRec * cap)()
+    n = lib.scenerf_hip_profile_collect(arr, cap)
+    return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms,
+                 flops=arr[i].flops, bytes=arr[i].bytes) for i in range(n)]

@@ -1,0 +1,108 @@
+"""Hot-path constants of SceneRF (what the reference keeps as LightningModule attributes).
+
+Mirrors the ctor arguments of reference scenerf/models/scenerf.py:23-116 (KITTI) and
+scenerf/models/scenerf_bf.py (BundleFusion) that reach ``render_rays_batch``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Tuple
+
+from . import _capi
+
+FEAT_SCALES = (1, 2, 4, 8, 16)
+FEAT_CHANNELS = (80, 160, 320, 640, 1280)
+
+# SphericalMapping FOV constants hard-coded in the reference (scenerf.py:83-88, scenerf_bf.py:85-90)
+KITTI_FOV = dict(v_angle_max=104.7294, v_angle_min=75.4815, h_angle_max=131.1128, h_angle_min=49.5950)
+BF_FOV = dict(v_angle_max=112.2911, v_angle_min=67.6248, h_angle_max=118.6861, h_angle_min=61.2383)
+
+
+@dataclass
+class RenderConfig:
+    img_size: Tuple[int, int] = (1220, 370)
+    sphere_W: int = 1500
+    sphere_H: int = 452
+    v_angle_max: float = KITTI_FOV["v_angle_max"]
+    v_angle_min: float = KITTI_FOV["v_angle_min"]
+    h_angle_max: float = KITTI_FOV["h_angle_max"]
+    h_angle_min: float = KITTI_FOV["h_angle_min"]
+    add_fov_hor: float = 0.0
+    add_fov_ver: float = 0.0
+    n_pts_uni: int = 32
+    n_gaussians: int = 4
+    n_pts_per_gaussian: int = 8
+    max_sample_depth: float = 100.0
+    std: float = 2.5
+    som_sigma: float = 2.0
+    gauss_floor: float = 1.5     # scenerf.py:591-594; 0.5 in scenerf_bf.py:606-608
+    kl_std_floor: float = 1.5    # ray_som_kl.py:83
+    precision: str = "bf16"      # "bf16": bf16 GEMM operands / fp32 accumulate; "fp32": fp32 MFMA everywhere
+    device_rng: bool = False     # False: gaussian noise drawn on CPU like the reference (utils.py:208-211)
+
+    # ---- derived -----------------------------------------------------------------------------------------
+    @property
+    def n_samples(self) -> int:
+        u = self.n_pts_uni if self.n_pts_uni > 0 else 0
+        return u + self.n_gaussians * self.n_pts_per_gaussian
+
+    @property
+    def fov(self):
+        v_max = self.v_angle_max + self.add_fov_ver
+        v_min = self.v_angle_min - self.add_fov_ver
+        h_max = self.h_angle_max + self.add_fov_hor
+        h_min = self.h_angle_min - self.add_fov_hor
+        return v_min, abs(v_max - v_min), h_min, abs(h_max - h_min)
+
+    @property
+    def precision_code(self) -> int:
+        if self.precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32', got %r" % (self.precision,))
+        return 1 if self.precision == "bf16" else 0
+
+    def map_shapes(self):
+        """(C, H, W) of the 5 encoder maps: round(size/scale), unet2d_sphere.py:139."""
+        return [(c, round(self.sphere_H / s), round(self.sphere_W / s)) for s, c in zip(FEAT_SCALES, FEAT_CHANNELS)]
+
+    def validate(self) -> None:
+        if not (1 <= self.n_gaussians <= 8):
+            raise ValueError("n_gaussians must be in [1, 8]")
+        if self.n_pts_per_gaussian < 1 or self.n_pts_uni < 0:
+            raise ValueError("bad sample counts")
+        if self.n_samples > 512:
+            raise ValueError("n_samples = %d exceeds the 512-sample limit of the wave-per-ray kernels" % self.n_samples)
+        _ = self.precision_code
+
+    def to_c(self) -> "_capi.Cfg":
+        self.validate()
+        c = _capi.Cfg()
+        c.n_pts_uni = self.n_pts_uni
+        c.n_gaussians = self.n_gaussians
+        c.n_pts_per_gaussian = self.n_pts_per_gaussian
+        c.n_samples = self.n_samples
+        c.sphere_W, c.sphere_H = self.sphere_W, self.sphere_H
+        c.max_sample_depth = self.max_sample_depth
+        c.uni_step = (self.max_sample_depth - 0.2) / self.n_pts_uni if self.n_pts_uni > 0 else 0.0
+        c.base_std = self.std
+        c.som_sigma = self.som_sigma
+        c.gauss_floor = self.gauss_floor
+        c.kl_std_floor = self.kl_std_floor
+        c.v_min, c.v_fov, c.h_min, c.h_fov = self.fov
+        for i, (s, (ch, h, w)) in enumerate(zip(FEAT_SCALES, self.map_shapes())):
+            c.map_C[i], c.map_H[i], c.map_W[i] = ch, h, w
+            c.div_H[i], c.div_W[i] = self.sphere_H // s, self.sphere_W // s   # scenerf.py:525
+        c.precision = self.precision_code
+        return c
+
+    @staticmethod
+    def kitti(**kw) -> "RenderConfig":
+        d = dict(add_fov_hor=20.0, add_fov_ver=8.0, std=2.0, som_sigma=2.0)  # scripts/train_kitti.py defaults
+        d.update(kw)
+        return RenderConfig(**d)
+
+    @staticmethod
+    def bundlefusion(**kw) -> "RenderConfig":
+        d = dict(img_size=(640, 480), sphere_W=960, sphere_H=720, add_fov_hor=14.0, add_fov_ver=11.0,
+                 max_sample_depth=12.0, std=0.1, som_sigma=0.02, gauss_floor=0.5, **BF_FOV)
+        d.update(kw)
+        return RenderConfig(**d)

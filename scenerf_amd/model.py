@@ -1,0 +1,232 @@
+"""Drop-in boundary: a ``SceneRF`` module with the reference's constructor, attributes, state_dict keys and
+``render_rays_batch`` signature (reference scenerf/models/scenerf.py:22-116, 392-471; BundleFusion variant
+scenerf/models/scenerf_bf.py), whose hot path runs in libscenerf_hip.so.
+
+What is kept identical for callers:
+  * ctor kwargs and defaults; attributes ``spherical_mapping, net_rgb, mlp, mlp_gaussian, pe, ray_som, n_rays,
+    img_size`` read by the evaluation / reconstruction scripts;
+  * parameter / buffer names: ``mlp.lin_in``, ``mlp.lin_z.{0,1,2}``, ``mlp.blocks.{0,1,2}.fc_{0,1}``,
+    ``mlp.lin_out`` (same under ``mlp_gaussian.``), ``pe._freqs``, ``pe._phases`` -> reference checkpoints load;
+  * ``render_rays_batch(cam_K, T_source2infer, x_rgb, depth_window=100, T_cam2velo=None, sampled_pixels=None,
+    ray_batch_size=128) -> dict`` with the 12 keys of scenerf.py:456-469.
+The image encoder (``net_rgb``) and the losses stay stock PyTorch and are injected by the caller.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .config import BF_FOV, KITTI_FOV, RenderConfig
+from .renderer import MLP_PARAM_NAMES, OUTPUT_KEYS, RenderSession
+
+try:  # the reference derives from pl.LightningModule; Lightning is optional here
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover - Lightning is not installed in the build image
+    class _Base(nn.Module):
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+
+class ResnetBlockFC(nn.Module):
+    """Parameter container for one block (resnetfc.py:20-52): fc_0, fc_1 with the reference initialisation."""
+
+    def __init__(self, size: int):
+        super().__init__()
+        self.fc_0 = nn.Linear(size, size)
+        self.fc_1 = nn.Linear(size, size)
+        nn.init.constant_(self.fc_0.bias, 0.0)
+        nn.init.kaiming_normal_(self.fc_0.weight, a=0, mode="fan_in")
+        nn.init.constant_(self.fc_1.bias, 0.0)
+        nn.init.zeros_(self.fc_1.weight)
+
+
+class ResnetFC(nn.Module):
+    """Parameter container with the reference's names/shapes/init (resnetfc.py:67-131).
+
+    It has no ``forward``: evaluation happens inside the HIP MLP pass (``scenerf_hip_mlp_forward``).
+    """
+
+    def __init__(self, d_in: int = 42, d_out: int = 4, n_blocks: int = 3, d_latent: int = 2480, d_hidden: int = 512):
+        super().__init__()
+        if (d_in, n_blocks, d_latent, d_hidden) != (42, 3, 2480, 512) or d_out not in (2, 4):
+            raise ValueError("the HIP MLP pass is built for ResnetFC(d_in=42, n_blocks=3, d_latent=2480, d_hidden=512, d_out in {2,4})")
+        self.d_in, self.d_out, self.n_blocks, self.d_latent, self.d_hidden = d_in, d_out, n_blocks, d_latent, d_hidden
+        self.lin_in = nn.Linear(d_in, d_hidden)
+        nn.init.constant_(self.lin_in.bias, 0.0)
+        nn.init.kaiming_normal_(self.lin_in.weight, a=0, mode="fan_in")
+        self.lin_out = nn.Linear(d_hidden, d_out)
+        nn.init.constant_(self.lin_out.bias, 0.0)
+        nn.init.kaiming_normal_(self.lin_out.weight, a=0, mode="fan_in")
+        self.blocks = nn.ModuleList([ResnetBlockFC(d_hidden) for _ in range(n_blocks)])
+        self.lin_z = nn.ModuleList([nn.Linear(d_latent, d_hidden) for _ in range(n_blocks)])
+        for i in range(n_blocks):
+            nn.init.constant_(self.lin_z[i].bias, 0.0)
+            nn.init.kaiming_normal_(self.lin_z[i].weight, a=0, mode="fan_in")
+
+    def ordered_params(self):
+        p = dict(self.named_parameters())
+        return [p[n] for n in MLP_PARAM_NAMES]
+
+    def forward(self, *a, **k):
+        raise RuntimeError("ResnetFC is evaluated by the HIP MLP pass; call SceneRF.render_rays_batch")
+
+
+class PositionalEncoding(nn.Module):
+    """Buffers of the reference encoding (pe.py:13-30); the encoding itself is fused into encode_points."""
+
+    def __init__(self, num_freqs: int = 6, d_in: int = 3, freq_factor: float = np.pi, include_input: bool = True):
+        super().__init__()
+        if num_freqs != 6 or d_in != 3 or not include_input:
+            raise ValueError("the HIP encoder is built for num_freqs=6, d_in=3, include_input=True")
+        self.num_freqs, self.d_in, self.include_input = num_freqs, d_in, include_input
+        self.freqs = freq_factor * 2.0 ** torch.arange(0, num_freqs)
+        self.d_out = num_freqs * 2 * d_in + d_in
+        self.register_buffer("_freqs", torch.repeat_interleave(self.freqs, 2).view(1, -1, 1))
+        ph = torch.zeros(2 * num_freqs)
+        ph[1::2] = np.pi * 0.5
+        self.register_buffer("_phases", ph.view(1, -1, 1))
+
+
+class RaySOM(nn.Module):
+    def __init__(self, som_sigma: float):
+        super().__init__()
+        self.som_sigma = som_sigma
+
+
+class SphericalMapping(nn.Module):
+    """Constants of the sphere projection + ``from_pixels`` for the encoder input (spherical_mapping.py:47-115).
+
+    ``from_pixels`` here serves the *encoder* (one call per image, off the hot path); the per-sample
+    spherical indices of the hot path are computed in the encode_points kernel.
+    """
+
+    def __init__(self, img_W, img_H, out_img_W, out_img_H, v_angle_max, v_angle_min, h_angle_max, h_angle_min):
+        super().__init__()
+        self.img_W, self.img_H, self.out_img_W, self.out_img_H = img_W, img_H, out_img_W, out_img_H
+        self.v_angle_max, self.v_angle_min = v_angle_max, v_angle_min
+        self.h_angle_max, self.h_angle_min = h_angle_max, h_angle_min
+        self.h_fov = abs(h_angle_max - h_angle_min)
+        self.v_fov = abs(v_angle_max - v_angle_min)
+
+    def from_pixels(self, inv_K, pix_coords=None):
+        if pix_coords is None:
+            ys, xs = torch.meshgrid(torch.arange(self.img_H), torch.arange(self.img_W), indexing="ij")
+            pix_coords = torch.stack([xs.reshape(-1), ys.reshape(-1)], 1).to(inv_K)
+        homo = torch.cat([pix_coords, torch.ones_like(pix_coords[:, :1])], dim=1)
+        cam = (inv_K @ homo.T).T
+        dist = torch.linalg.norm(cam, ord=2, dim=1)
+        v_angle = torch.acos(-cam[:, 1] / dist) / math.pi * 180
+        h_angle = 180 - torch.atan2(cam[:, 2], cam[:, 0]) / math.pi * 180
+        out = torch.zeros((cam.shape[0], 2)).type_as(cam)
+        out[:, 0] = (h_angle - self.h_angle_min) / self.h_fov * (self.out_img_W - 1)
+        out[:, 1] = (v_angle - self.v_angle_min) / self.v_fov * (self.out_img_H - 1)
+        return pix_coords, torch.round(out).long(), dist
+
+
+class SceneRF(_Base):
+    _VARIANT = "kitti"
+
+    def __init__(self, som_sigma, lr=1e-5, weight_decay=0, img_size=(1220, 370), n_rays=1200, max_infer_depth=120,
+                 max_sample_depth=100, eval_depth=80, std=2.5, n_gaussians=4, n_pts_uni=32, n_pts_per_gaussian=8,
+                 sampling_method="uniform", batch_size=1, add_fov_hor=0, add_fov_ver=0, sphere_H=452, sphere_W=1500,
+                 use_color=True, use_reprojection=True, net_rgb: Optional[nn.Module] = None, precision: str = "bf16",
+                 device_rng: bool = False):
+        super().__init__()
+        if sampling_method != "uniform":
+            raise ValueError("only sampling_method='uniform' is reachable in the reference (scenerf.py:612)")
+        self.use_color, self.use_reprojection = use_color, use_reprojection
+        self.lr, self.weight_decay = lr, weight_decay
+        self.img_size = img_size
+        self.sampling_method = sampling_method
+        self.n_rays = n_rays
+        self.n_pts_uni, self.n_gaussians, self.n_pts_per_gaussian = n_pts_uni, n_gaussians, n_pts_per_gaussian
+        self.std = std
+        self.batch_size = batch_size
+        self.max_infer_depth, self.max_sample_depth, self.eval_depth = max_infer_depth, max_sample_depth, eval_depth
+        self.out_img_W, self.out_img_H = sphere_W, sphere_H
+        fov = KITTI_FOV if self._VARIANT == "kitti" else BF_FOV
+        self.spherical_mapping = SphericalMapping(
+            v_angle_max=fov["v_angle_max"] + add_fov_ver, v_angle_min=fov["v_angle_min"] - add_fov_ver,
+            h_angle_max=fov["h_angle_max"] + add_fov_hor, h_angle_min=fov["h_angle_min"] - add_fov_hor,
+            img_W=img_size[0], img_H=img_size[1], out_img_W=sphere_W, out_img_H=sphere_H)
+        # the encoder stays stock PyTorch (EfficientNet-B7 U-Net in the reference, needs torch.hub); inject it
+        self.net_rgb = net_rgb if net_rgb is not None else nn.Module()
+        try:
+            self.save_hyperparameters(ignore=["net_rgb"])
+        except TypeError:
+            self.save_hyperparameters()
+        self.pe = PositionalEncoding(num_freqs=6, include_input=True)
+        self.mlp = ResnetFC(d_in=39 + 3, d_out=4, n_blocks=3, d_hidden=512, d_latent=2480)
+        self.mlp_gaussian = ResnetFC(d_in=39 + 3, d_out=2, n_blocks=3, d_hidden=512, d_latent=2480)
+        self.ray_som = RaySOM(som_sigma=som_sigma)
+        self.render_cfg = RenderConfig(
+            img_size=tuple(img_size), sphere_W=sphere_W, sphere_H=sphere_H, add_fov_hor=add_fov_hor,
+            add_fov_ver=add_fov_ver, n_pts_uni=n_pts_uni, n_gaussians=n_gaussians,
+            n_pts_per_gaussian=n_pts_per_gaussian, max_sample_depth=float(max_sample_depth), std=float(std),
+            som_sigma=float(som_sigma), gauss_floor=1.5 if self._VARIANT == "kitti" else 0.5,
+            precision=precision, device_rng=device_rng, **fov)
+        self.render_cfg.validate()
+
+    # ---- the hot path ---------------------------------------------------------------------------------------
+    def render_rays_batch(self, cam_K, T_source2infer, x_rgb: Dict[str, torch.Tensor], depth_window=100,
+                          T_cam2velo=None, sampled_pixels=None, ray_batch_size=128, noise=None):
+        """scenerf.py:392-471.  ``depth_window`` / ``T_cam2velo`` are accepted and unused, as in the reference.
+
+        ``noise=(noise_u (n,U,1), noise_g (n,G*P))`` optionally injects the sampling noise (tests / replay);
+        by default it is drawn like the reference does (rand on device, normal on CPU).
+        """
+        if sampled_pixels is None:
+            raise ValueError("sampled_pixels is required")
+        self.ray_som  # noqa: B018  (attribute kept for parity with the reference module tree)
+        cfg = self.render_cfg
+        cfg.som_sigma = float(self.ray_som.som_sigma)
+        inv_K = torch.inverse(cam_K)
+        sess = RenderSession(cfg, x_rgb, self.mlp.ordered_params(), self.mlp_gaussian.ordered_params())
+        outs = []
+        n = sampled_pixels.shape[0]
+        for s in range(0, n, ray_batch_size):
+            e = min(s + ray_batch_size, n)
+            nu = noise[0][s:e] if noise is not None else None
+            ng = noise[1][s:e] if noise is not None else None
+            outs.append(sess.render_chunk(sampled_pixels[s:e], cam_K, inv_K, T_source2infer, nu, ng))
+        if len(outs) == 1:
+            ret = outs[0]
+        else:
+            ret = {k: torch.cat([o[k] for o in outs], dim=0) for k in outs[0]}
+        return {k: ret[k] for k in OUTPUT_KEYS}
+
+    def configure_optimizers(self):
+        optimizer = torch.optim.AdamW(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=0.95)
+        return [optimizer], [scheduler]
+
+
+class SceneRFBundleFusion(SceneRF):
+    """scenerf/models/scenerf_bf.py: same kernels, indoor constants (FOV, +0.5 floors)."""
+    _VARIANT = "bf"
+
+    def __init__(self, som_sigma, lr=1e-4, weight_decay=0, img_size=(640, 480), sample_grid_size=2, n_rays=1000,
+                 max_sample_depth=12, eval_depth=10, std=0.2, n_gaussians=4, n_pts_uni=32, n_pts_per_gaussian=8,
+                 smooth_loss_weight=0, sampling_method="uniform", batch_size=1, net_2d="b7", add_fov_hor=0, add_fov_ver=0,
+                 sphere_H=480, sphere_W=640, use_color=True, use_reprojection=True, **kw):
+        if net_2d != "b7":
+            raise ValueError("net_2d not found")
+        super().__init__(som_sigma, lr=lr, weight_decay=weight_decay, img_size=img_size, n_rays=n_rays,
+                         max_sample_depth=max_sample_depth, eval_depth=eval_depth, std=std, n_gaussians=n_gaussians,
+                         n_pts_uni=n_pts_uni, n_pts_per_gaussian=n_pts_per_gaussian, sampling_method=sampling_method,
+                         batch_size=batch_size, add_fov_hor=add_fov_hor, add_fov_ver=add_fov_ver, sphere_H=sphere_H,
+                         sphere_W=sphere_W, use_color=use_color, use_reprojection=use_reprojection, **kw)
+        self.sample_grid_size = sample_grid_size
+        self.smooth_loss_weight = smooth_loss_weight

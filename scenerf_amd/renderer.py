@@ -1,0 +1,464 @@
+"""Host side of the MI355X ray renderer: memory, streams and autograd plumbing around the C ABI.
+
+Replaces the body of reference ``SceneRF.batchify_depth_and_color`` (scenerf/models/scenerf.py:598-700)
+and its autograd.  All arithmetic happens in libscenerf_hip.so; PyTorch only owns the device buffers,
+the current stream and the autograd graph edges:
+
+    PrepareMaps   (C,H,W) fp32 maps  -> (H,W,C) act maps, once per image; its backward hands the (H,W,C)
+                  fp32 gradient accumulators back as (C,H,W) grads after *all* chunks have scattered into them
+    PackMLP       nn.Linear parameters -> MFMA operand layout, once per call; backward unpacks the grads
+    RenderChunk   one chunk of rays: forward = 9 kernel stages, backward = their adjoints
+
+There is no eager/CPU fallback: without the built library every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _capi
+from .config import FEAT_CHANNELS, RenderConfig
+
+D_H = _capi.D_HIDDEN
+D_L = _capi.D_LATENT
+D_X = _capi.D_XENC
+
+# parameter order of one ResnetFC (reference state_dict names, resnetfc.py:88-118)
+MLP_PARAM_NAMES: List[str] = ["lin_in.weight", "lin_in.bias", "lin_out.weight", "lin_out.bias"]
+for _b in range(3):
+    MLP_PARAM_NAMES += ["blocks.%d.fc_0.weight" % _b, "blocks.%d.fc_0.bias" % _b,
+                        "blocks.%d.fc_1.weight" % _b, "blocks.%d.fc_1.bias" % _b,
+                        "lin_z.%d.weight" % _b, "lin_z.%d.bias" % _b]
+
+OUTPUT_KEYS = ["depth", "color", "gaussian_means", "gaussian_stds", "weights_at_depth", "closest_pts_to_depths",
+               "loss_kl", "alphas", "som_vars", "densities", "weights", "depth_volumes"]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (got %s): the SceneRF hot path has no CPU fallback" % (name, t.device))
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _act_dtype(prec: int):
+    return torch.bfloat16 if prec else torch.float32
+
+
+# ------------------------------------------------------------------------------------------------ feature maps
+class MapHolder:
+    """(H,W,C) copies of the 5 encoder maps + lazily allocated fp32 gradient accumulators."""
+
+    def __init__(self, cfg: RenderConfig):
+        self.cfg = cfg
+        self.hwc: List[torch.Tensor] = []
+        self.shapes = []
+        self.gmaps: Optional[List[torch.Tensor]] = None
+
+    def convert(self, chw: Sequence[torch.Tensor]) -> None:
+        lib = _capi.load()
+        prec = self.cfg.precision_code
+        want = self.cfg.map_shapes()
+        self.hwc, self.shapes = [], []
+        for i, t in enumerate(chw):
+            _require_cuda(t, "x_rgb map %d" % i)
+            if tuple(t.shape) != tuple(want[i]):
+                raise RuntimeError("feature map %d has shape %s, expected %s for sphere %dx%d" % (
+                    i, tuple(t.shape), want[i], self.cfg.sphere_W, self.cfg.sphere_H))
+            src = _f32c(t)
+            c, h, w = src.shape
+            dst = torch.empty((h, w, c), dtype=_act_dtype(prec), device=src.device)
+            _capi.check(lib.scenerf_hip_maps_chw_to_hwc(src.data_ptr(), dst.data_ptr(), c, h, w, prec, _stream()),
+                        "maps_chw_to_hwc")
+            self.hwc.append(dst)
+            self.shapes.append((c, h, w))
+
+    def grad_accumulators(self) -> List[torch.Tensor]:
+        if self.gmaps is None:
+            dev = self.hwc[0].device
+            self.gmaps = [torch.zeros((h, w, c), dtype=torch.float32, device=dev) for (c, h, w) in self.shapes]
+        return self.gmaps
+
+    def map_ptr_array(self):
+        return (C.c_void_p * 5)(*[t.data_ptr() for t in self.hwc])
+
+    def gmap_ptr_array(self):
+        return (C.c_void_p * 5)(*[t.data_ptr() for t in self.grad_accumulators()])
+
+
+class PrepareMaps(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, holder: MapHolder, *chw):
+        holder.convert(chw)
+        ctx.holder = holder
+        return torch.zeros(1, device=chw[0].device)
+
+    @staticmethod
+    def backward(ctx, _g):
+        holder: MapHolder = ctx.holder
+        if holder.gmaps is None:
+            return (None,) + tuple(None for _ in holder.shapes)
+        lib = _capi.load()
+        outs = []
+        for i, (c, h, w) in enumerate(holder.shapes):
+            if not ctx.needs_input_grad[1 + i]:
+                outs.append(None)
+                continue
+            g = torch.empty((c, h, w), dtype=torch.float32, device=holder.gmaps[i].device)
+            _capi.check(lib.scenerf_hip_grads_hwc_to_chw(holder.gmaps[i].data_ptr(), g.data_ptr(), c, h, w, _stream()),
+                        "grads_hwc_to_chw")
+            outs.append(g)
+        holder.gmaps = None
+        return (None,) + tuple(outs)
+
+
+# ------------------------------------------------------------------------------------------------ MLP operands
+class PackedMLP:
+    """ResnetFC parameters in the operand layout of include/scenerf_hip.h::scenerf_mlp_weights."""
+
+    def __init__(self, params: Sequence[torch.Tensor], d_out: int, cfg: RenderConfig):
+        p = dict(zip(MLP_PARAM_NAMES, [_f32c(t) for t in params]))
+        for n, t in p.items():
+            _require_cuda(t, n)
+        prec = cfg.precision_code
+        act = _act_dtype(prec)
+        dev = p["lin_in.weight"].device
+        if tuple(p["lin_out.weight"].shape) != (d_out, D_H) or tuple(p["lin_in.weight"].shape) != (D_H, 42):
+            raise RuntimeError("ResnetFC parameter shapes do not match d_in=42, d_hidden=512, d_out=%d" % d_out)
+        self.d_out = d_out
+        self.prec = prec
+        self.device = dev
+        w_in = torch.zeros((D_H, D_X), dtype=torch.float32, device=dev)
+        w_in[:, :42] = p["lin_in.weight"]
+        self.w_in, self.b_in = w_in, p["lin_in.bias"]
+        fc0 = [p["blocks.%d.fc_0.weight" % b] for b in range(3)]
+        fc1 = [p["blocks.%d.fc_1.weight" % b] for b in range(3)]
+        lz = [p["lin_z.%d.weight" % b] for b in range(3)]
+        self.w_h = [lz[0].to(act).contiguous(),
+                    torch.cat([fc1[0], lz[1]], dim=1).to(act).contiguous(),
+                    torch.cat([fc1[1], lz[2]], dim=1).to(act).contiguous(),
+                    fc1[2].to(act).contiguous()]
+        self.b_h = [p["lin_z.0.bias"],
+                    (p["blocks.0.fc_1.bias"] + p["lin_z.1.bias"]).contiguous(),
+                    (p["blocks.1.fc_1.bias"] + p["lin_z.2.bias"]).contiguous(),
+                    p["blocks.2.fc_1.bias"]]
+        self.w_fc0 = [w.to(act).contiguous() for w in fc0]
+        self.b_fc0 = [p["blocks.%d.fc_0.bias" % b] for b in range(3)]
+        self.w_out, self.b_out = p["lin_out.weight"], p["lin_out.bias"]
+        self.w_fc0_t = [w.t().contiguous().to(act) for w in fc0]
+        self.w_fc1_t = [w.t().contiguous().to(act) for w in fc1]
+        wz_cat = torch.cat(lz, dim=0)  # [1536][2480]
+        self.w_z_t = []
+        off = 0
+        for c in FEAT_CHANNELS:
+            self.w_z_t.append(wz_cat[:, off:off + c].t().contiguous().to(act))
+            off += c
+        s = _capi.MlpWeights()
+        s.d_out = d_out
+        s.w_in, s.b_in = self.w_in.data_ptr(), self.b_in.data_ptr()
+        for i in range(4):
+            s.w_h[i], s.b_h[i] = self.w_h[i].data_ptr(), self.b_h[i].data_ptr()
+        for i in range(3):
+            s.w_fc0[i], s.b_fc0[i] = self.w_fc0[i].data_ptr(), self.b_fc0[i].data_ptr()
+            s.w_fc0_t[i], s.w_fc1_t[i] = self.w_fc0_t[i].data_ptr(), self.w_fc1_t[i].data_ptr()
+        s.w_out, s.b_out = self.w_out.data_ptr(), self.b_out.data_ptr()
+        for i in range(5):
+            s.w_z_t[i] = self.w_z_t[i].data_ptr()
+        self.c = s
+        # gradient sink (flat fp32 buffer carved into the scenerf_mlp_grads fields), allocated on first backward
+        self.gflat: Optional[torch.Tensor] = None
+        self.gviews: Dict[str, torch.Tensor] = {}
+        self.gc: Optional[_capi.MlpGrads] = None
+
+    _GRAD_FIELDS = None
+
+    def grad_sink(self) -> "_capi.MlpGrads":
+        if self.gc is not None:
+            return self.gc
+        d = self.d_out
+        fields = [("w_in", (D_H, D_X)), ("b_in", (D_H,))]
+        for b in range(3):
+            fields += [("w_fc0.%d" % b, (D_H, D_H)), ("b_fc0.%d" % b, (D_H,)),
+                       ("w_fc1.%d" % b, (D_H, D_H)), ("b_fc1.%d" % b, (D_H,))]
+        fields += [("w_z", (3 * D_H, D_L)), ("b_z", (3 * D_H,)), ("w_out", (d, D_H)), ("b_out", (d,))]
+        total = sum(int(torch.tensor(s).prod()) for _, s in fields)
+        self.gflat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        off = 0
+        for name, shp in fields:
+            n = 1
+            for x in shp:
+                n *= x
+            self.gviews[name] = self.gflat[off:off + n].view(*shp)
+            off += n
+        g = _capi.MlpGrads()
+        g.w_in, g.b_in = self.gviews["w_in"].data_ptr(), self.gviews["b_in"].data_ptr()
+        for b in range(3):
+            g.w_fc0[b], g.b_fc0[b] = self.gviews["w_fc0.%d" % b].data_ptr(), self.gviews["b_fc0.%d" % b].data_ptr()
+            g.w_fc1[b], g.b_fc1[b] = self.gviews["w_fc1.%d" % b].data_ptr(), self.gviews["b_fc1.%d" % b].data_ptr()
+        g.w_z, g.b_z = self.gviews["w_z"].data_ptr(), self.gviews["b_z"].data_ptr()
+        g.w_out, g.b_out = self.gviews["w_out"].data_ptr(), self.gviews["b_out"].data_ptr()
+        self.gc = g
+        return g
+
+    def unpack_grads(self) -> List[Optional[torch.Tensor]]:
+        """Gradients in MLP_PARAM_NAMES order (None if no chunk ran a backward)."""
+        if self.gflat is None:
+            return [None] * len(MLP_PARAM_NAMES)
+        v = self.gviews
+        out = {"lin_in.weight": v["w_in"][:, :42].contiguous(), "lin_in.bias": v["b_in"],
+               "lin_out.weight": v["w_out"], "lin_out.bias": v["b_out"]}
+        for b in range(3):
+            out["blocks.%d.fc_0.weight" % b] = v["w_fc0.%d" % b]
+            out["blocks.%d.fc_0.bias" % b] = v["b_fc0.%d" % b]
+            out["blocks.%d.fc_1.weight" % b] = v["w_fc1.%d" % b]
+            out["blocks.%d.fc_1.bias" % b] = v["b_fc1.%d" % b]
+            out["lin_z.%d.weight" % b] = v["w_z"][b * D_H:(b + 1) * D_H]
+            out["lin_z.%d.bias" % b] = v["b_z"][b * D_H:(b + 1) * D_H]
+        return [out[n] for n in MLP_PARAM_NAMES]
+
+
+class MlpHolder:
+    def __init__(self):
+        self.packed: Optional[PackedMLP] = None
+
+
+class PackMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, holder: MlpHolder, d_out: int, cfg: RenderConfig, *params):
+        holder.packed = PackedMLP(params, d_out, cfg)
+        ctx.holder = holder
+        return torch.zeros(1, device=params[0].device)
+
+    @staticmethod
+    def backward(ctx, _g):
+        pk: PackedMLP = ctx.holder.packed
+        grads = pk.unpack_grads()
+        grads = [g if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(grads)]
+        pk.gflat, pk.gc, pk.gviews = None, None, {}
+        return (None, None, None) + tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------------ one MLP evaluation
+class _MlpRun:
+    """Buffers of one ResnetFC evaluation over M rows (kept for backward when grad is enabled)."""
+
+    def __init__(self, M: int, d_out: int, prec: int, dev):
+        act = _act_dtype(prec)
+        self.M = M
+        self.Mpad = (M + _capi.TILE_ROWS - 1) // _capi.TILE_ROWS * _capi.TILE_ROWS
+        self.sphere_idx = torch.empty((M, 2), dtype=torch.int32, device=dev)
+        self.xenc = torch.empty((M, D_X), dtype=torch.float32, device=dev)
+        self.Z = torch.empty((self.Mpad, D_L), dtype=act, device=dev)
+        self.tile_mask = torch.empty((self.Mpad // _capi.TILE_ROWS,), dtype=torch.uint8, device=dev)
+        self.tap_texel = torch.empty((M, 5, 4), dtype=torch.int32, device=dev)
+        self.tap_weight = torch.empty((M, 5, 4), dtype=torch.float32, device=dev)
+        self.H = [torch.empty((M, D_H), dtype=act, device=dev) for _ in range(4)]
+        self.Nn = [torch.empty((M, D_H), dtype=act, device=dev) for _ in range(3)]
+        self.h0pre = torch.empty((M, D_H), dtype=torch.float32, device=dev)
+        self.logits = torch.empty((M, d_out), dtype=torch.float32, device=dev)
+        a = _capi.MlpActs()
+        for i in range(4):
+            a.H[i] = self.H[i].data_ptr()
+        for i in range(3):
+            a.Nn[i] = self.Nn[i].data_ptr()
+        a.h0pre = self.h0pre.data_ptr()
+        a.logits = self.logits.data_ptr()
+        self.c = a
+
+
+def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dist_ray_stride, ppr, unit_dir, viewdir,
+              K, inv_K, T, M) -> _MlpRun:
+    lib = _capi.load()
+    st = _stream()
+    run = _MlpRun(M, pk.d_out, cfg.precision_code, dist.device)
+    _capi.check(lib.scenerf_hip_encode_points(C.byref(ccfg), dist.data_ptr(), dist_ray_stride, ppr, unit_dir.data_ptr(),
+                                              viewdir.data_ptr(), K.data_ptr(), inv_K.data_ptr(), T.data_ptr(), M, None,
+                                              run.sphere_idx.data_ptr(), run.xenc.data_ptr(), st), "encode_points")
+    _capi.check(lib.scenerf_hip_gather_features(C.byref(ccfg), C.byref(maps.map_ptr_array()), run.sphere_idx.data_ptr(), M,
+                                                run.Z.data_ptr(), run.tile_mask.data_ptr(), run.tap_texel.data_ptr(),
+                                                run.tap_weight.data_ptr(), st), "gather_features")
+    _capi.check(lib.scenerf_hip_mlp_forward(C.byref(ccfg), C.byref(pk.c), run.Z.data_ptr(), run.xenc.data_ptr(),
+                                            run.tile_mask.data_ptr(), M, C.byref(run.c), st), "mlp_forward")
+    return run
+
+
+def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: _MlpRun, d_logits, want_map_grads: bool):
+    lib = _capi.load()
+    act = _act_dtype(cfg.precision_code)
+    dev = d_logits.device
+    dH = torch.empty((run.M, 4 * D_H), dtype=act, device=dev)
+    dN = torch.empty((run.M, D_H), dtype=act, device=dev)
+    g = pk.grad_sink()
+    gm = C.byref(maps.gmap_ptr_array()) if want_map_grads else None
+    _capi.check(lib.scenerf_hip_mlp_backward(C.byref(ccfg), C.byref(pk.c), C.byref(g), run.Z.data_ptr(), run.xenc.data_ptr(),
+                                             run.tile_mask.data_ptr(), run.tap_texel.data_ptr(), run.tap_weight.data_ptr(),
+                                             run.M, C.byref(run.c), d_logits.data_ptr(), dH.data_ptr(), dN.data_ptr(), gm,
+                                             _stream()), "mlp_backward")
+
+
+# ------------------------------------------------------------------------------------------------ one chunk of rays
+class RenderChunk(torch.autograd.Function):
+    """scenerf.py:598-700 for one chunk; differentiable w.r.t. the maps and both MLPs (through the tokens)."""
+
+    @staticmethod
+    def forward(ctx, cfg: RenderConfig, maps: MapHolder, mlp: MlpHolder, mlpg: MlpHolder, pixels, cam_K, inv_K, T_s2i,
+                noise_u, noise_g, tok_maps, tok_mlp, tok_mlpg):
+        lib = _capi.load()
+        st = _stream()
+        ccfg = cfg.to_c()
+        dev = pixels.device
+        R = pixels.shape[0]
+        U, G, P, N = cfg.n_pts_uni, cfg.n_gaussians, cfg.n_pts_per_gaussian, cfg.n_samples
+        f32 = dict(dtype=torch.float32, device=dev)
+        pixels, K, iK, T = _f32c(pixels), _f32c(cam_K), _f32c(inv_K), _f32c(T_s2i)
+        noise_u = _f32c(noise_u).reshape(R, max(U, 0)) if U > 0 else None
+        noise_g = _f32c(noise_g).reshape(R, G * P)
+        # constants the reference builds with torch.linspace (utils.py:79-81, scenerf.py:556-560)
+        lin_u = torch.linspace(0.2, cfg.max_sample_depth, steps=U, **f32) if U > 0 else None
+        step = cfg.max_sample_depth * 1.0 / G
+        anchors = torch.linspace(step / 2, cfg.max_sample_depth - step / 2, steps=G, **f32)
+
+        unit_dir = torch.empty((R, 3), **f32)
+        viewdir = torch.empty((R, 3), **f32)
+        dist_u = torch.empty((R, U), **f32) if U > 0 else None
+        _capi.check(lib.scenerf_hip_ray_setup(C.byref(ccfg), pixels.data_ptr(), iK.data_ptr(), T.data_ptr(), _capi.ptr(lin_u),
+                                              _capi.ptr(noise_u), R, unit_dir.data_ptr(), viewdir.data_ptr(),
+                                              _capi.ptr(dist_u), st), "ray_setup")
+        # gaussian head on the G anchors per ray (scenerf.py:549-596)
+        run_g = _mlp_eval(ccfg, cfg, maps, mlpg.packed, anchors, 0, G, unit_dir, viewdir, K, iK, T, R * G)
+        gmeans = torch.empty((R, G), **f32)
+        gstds = torch.empty((R, G), **f32)
+        dist_s = torch.empty((R, N), **f32)
+        z_s = torch.empty((R, N), **f32)
+        perm = torch.empty((R, N), dtype=torch.int32, device=dev)
+        _capi.check(lib.scenerf_hip_gaussian_sample_sort(C.byref(ccfg), run_g.logits.data_ptr(), anchors.data_ptr(),
+                                                         _capi.ptr(dist_u), noise_g.data_ptr(), unit_dir.data_ptr(), R,
+                                                         gmeans.data_ptr(), gstds.data_ptr(), dist_s.data_ptr(), z_s.data_ptr(),
+                                                         perm.data_ptr(), st), "gaussian_sample_sort")
+        # radiance MLP on the sorted samples (scenerf.py:661-665)
+        run_m = _mlp_eval(ccfg, cfg, maps, mlp.packed, dist_s, N, N, unit_dir, viewdir, K, iK, T, R * N)
+        dens = torch.empty((R, N), **f32)
+        alphas = torch.empty((R, N), **f32)
+        weights = torch.empty((R, N), **f32)
+        depth = torch.empty((R,), **f32)
+        color = torch.empty((R, 3), **f32)
+        closest = torch.empty((R,), **f32)
+        w_at = torch.empty((R,), **f32)
+        closest_idx = torch.empty((R,), dtype=torch.int32, device=dev)
+        _capi.check(lib.scenerf_hip_composite_forward(run_m.logits.data_ptr(), dist_s.data_ptr(), z_s.data_ptr(), R, N,
+                                                      dens.data_ptr(), alphas.data_ptr(), weights.data_ptr(), depth.data_ptr(),
+                                                      color.data_ptr(), closest.data_ptr(), w_at.data_ptr(),
+                                                      closest_idx.data_ptr(), st), "composite_forward")
+        loss_kl = torch.empty((R,), **f32)
+        som_means = torch.empty((R, G), **f32)
+        som_vars = torch.empty((R, G), **f32)
+        kl_saved = torch.empty((R, G, 3), **f32)
+        _capi.check(lib.scenerf_hip_raysom_forward(C.byref(ccfg), gmeans.data_ptr(), gstds.data_ptr(), dist_s.data_ptr(),
+                                                   alphas.data_ptr(), R, loss_kl.data_ptr(), som_means.data_ptr(),
+                                                   som_vars.data_ptr(), kl_saved.data_ptr(), st), "raysom_forward")
+        # keep what backward needs (plain attributes: these are internal buffers, not graph tensors)
+        ctx.cfg, ctx.ccfg, ctx.maps, ctx.mlp, ctx.mlpg = cfg, ccfg, maps, mlp, mlpg
+        ctx.keep = dict(R=R, anchors=anchors, noise_g=noise_g, unit_dir=unit_dir, gmeans=gmeans, gstds=gstds, perm=perm,
+                        dist_s=dist_s, z_s=z_s, kl_saved=kl_saved, run_g=run_g, run_m=run_m)
+        ctx.mark_non_differentiable(w_at, closest, som_vars, som_means)
+        ctx.aux = dict(perm=perm, sphere_idx=run_m.sphere_idx, closest_idx=closest_idx, tile_mask=run_m.tile_mask,
+                       offsets=run_g.logits, logits=run_m.logits, dist_sorted=dist_s, xenc=run_m.xenc,
+                       sphere_idx_g=run_g.sphere_idx, unit_dir=unit_dir, viewdir=viewdir, dist_u=dist_u,
+                       tile_mask_g=run_g.tile_mask)
+        RenderChunk.last_aux = ctx.aux
+        # order = OUTPUT_KEYS + som_means
+        return depth, color, gmeans, gstds, w_at, closest, loss_kl, alphas, som_vars, dens, weights, z_s, som_means
+
+    last_aux: Dict[str, torch.Tensor] = {}
+
+    @staticmethod
+    def backward(ctx, g_depth, g_color, g_gmeans, g_gstds, _g_wat, _g_closest, g_kl, g_alphas, _g_somv, g_dens, g_weights,
+                 g_zvol, _g_somm):
+        lib = _capi.load()
+        st = _stream()
+        k = ctx.keep
+        cfg, ccfg = ctx.cfg, ctx.ccfg
+        R, N, G = k["R"], cfg.n_samples, cfg.n_gaussians
+        dev = k["dist_s"].device
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        def c(t):
+            return None if t is None else _f32c(t)
+
+        g_depth = c(g_depth) if g_depth is not None else torch.zeros((R,), **f32)
+        g_color = c(g_color) if g_color is not None else torch.zeros((R, 3), **f32)
+        g_gmeans, g_gstds, g_kl, g_alphas, g_dens, g_weights, g_zvol = map(c, (g_gmeans, g_gstds, g_kl, g_alphas, g_dens,
+                                                                              g_weights, g_zvol))
+        run_m, run_g = k["run_m"], k["run_g"]
+        d_logits = torch.empty((R * N, 4), **f32)
+        d_dist = torch.empty((R, N), **f32)
+        d_z = torch.empty((R, N), **f32)
+        _capi.check(lib.scenerf_hip_composite_backward(run_m.logits.data_ptr(), k["dist_s"].data_ptr(), k["z_s"].data_ptr(), R, N,
+                                                       g_depth.data_ptr(), g_color.data_ptr(), _capi.ptr(g_weights),
+                                                       _capi.ptr(g_alphas), _capi.ptr(g_dens), _capi.ptr(g_zvol),
+                                                       d_logits.data_ptr(), d_dist.data_ptr(), d_z.data_ptr(), st),
+                    "composite_backward")
+        d_off = torch.empty((R, G, 2), **f32)
+        _capi.check(lib.scenerf_hip_sampler_backward(C.byref(ccfg), run_g.logits.data_ptr(), k["anchors"].data_ptr(),
+                                                     k["noise_g"].data_ptr(), k["unit_dir"].data_ptr(), k["gmeans"].data_ptr(),
+                                                     k["gstds"].data_ptr(), k["perm"].data_ptr(), d_dist.data_ptr(),
+                                                     d_z.data_ptr(), k["kl_saved"].data_ptr(), _capi.ptr(g_kl),
+                                                     _capi.ptr(g_gmeans), _capi.ptr(g_gstds), R, d_off.data_ptr(), st),
+                    "sampler_backward")
+        want_maps = bool(ctx.needs_input_grad[10])
+        if ctx.needs_input_grad[11] or want_maps:
+            _mlp_backward(ccfg, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps)
+        if ctx.needs_input_grad[12] or want_maps:
+            _mlp_backward(ccfg, cfg, ctx.maps, ctx.mlpg.packed, run_g, d_off.view(R * G, 2), want_maps)
+        ctx.keep = None
+        z1 = torch.zeros(1, **f32)
+        return (None, None, None, None, None, None, None, None, None, None,
+                z1 if ctx.needs_input_grad[10] else None, z1 if ctx.needs_input_grad[11] else None,
+                z1 if ctx.needs_input_grad[12] else None)
+
+
+# ------------------------------------------------------------------------------------------------ public API
+class RenderSession:
+    """Per-call state of ``render_rays_batch``: converted maps + packed MLPs, shared by all chunks."""
+
+    def __init__(self, cfg: RenderConfig, x_rgb: Dict[str, torch.Tensor], mlp_params: Sequence[torch.Tensor],
+                 mlpg_params: Sequence[torch.Tensor]):
+        _capi.load()
+        cfg.validate()
+        self.cfg = cfg
+        chw = [x_rgb["1_%d" % s] for s in (1, 2, 4, 8, 16)]
+        self.maps = MapHolder(cfg)
+        self.tok_maps = PrepareMaps.apply(self.maps, *chw)
+        self.mlp, self.mlpg = MlpHolder(), MlpHolder()
+        self.tok_mlp = PackMLP.apply(self.mlp, 4, cfg, *mlp_params)
+        self.tok_mlpg = PackMLP.apply(self.mlpg, 2, cfg, *mlpg_params)
+
+    def draw_noise(self, R: int, device):
+        """The reference's in-path RNG calls, same generators and order (SURVEY §5 RNG row)."""
+        cfg = self.cfg
+        U, GP = cfg.n_pts_uni, cfg.n_gaussians * cfg.n_pts_per_gaussian
+        nu = torch.rand((R, U, 1), dtype=torch.float32, device=device) if U > 0 else torch.empty((R, 0, 1), device=device)
+        if cfg.device_rng:
+            ng = torch.randn((R, GP), dtype=torch.float32, device=device)
+        else:
+            ng = torch.normal(mean=torch.zeros((R, GP)), std=torch.ones((R, GP))).to(device, non_blocking=True)  # utils.py:208-211
+        return nu, ng
+
+    def render_chunk(self, pixels, cam_K, inv_K, T_s2i, noise_u=None, noise_g=None) -> Dict[str, torch.Tensor]:
+        _require_cuda(pixels, "sampled_pixels")
+        if noise_u is None or noise_g is None:
+            nu, ng = self.draw_noise(pixels.shape[0], pixels.device)
+            noise_u = nu if noise_u is None else noise_u
+            noise_g = ng if noise_g is None else noise_g
+        outs = RenderChunk.apply(self.cfg, self.maps, self.mlp, self.mlpg, pixels, cam_K, inv_K, T_s2i, noise_u, noise_g,
+                                 self.tok_maps, self.tok_mlp, self.tok_mlpg)
+        ret = dict(zip(OUTPUT_KEYS + ["som_means"], outs))
+        return ret

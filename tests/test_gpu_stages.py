@@ -1,0 +1,430 @@
+"""Per-kernel parity on the GPU: every stage of the hot path is driven through the C ABI (ctypes) with the
+oracle's intermediates as inputs and compared with the oracle's outputs of the same stage.
+
+Index outputs (sort permutation, closest-sample index, BMU-derived masks) are compared exactly given identical
+inputs.  Spherical indices depend on acos/atan2 whose last-ulp results differ between libm implementations
+(torch-CPU's SLEEF vs the GPU's ocml -- the reference itself is not bit-reproducible across devices there), so
+they must be bit-exact except where the oracle's pre-rounding coordinate sits within 2e-3 px of a .5 boundary.
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+import scenerf_oracle as orc
+from golden_util import Golden
+from scenerf_amd import _capi
+from scenerf_amd.config import RenderConfig
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _cfgs(g: Golden, precision="fp32"):
+    ocfg = (orc.OracleConfig.kitti if g.variant == "kitti" else orc.OracleConfig.bundlefusion)(**g.cfg_kwargs())
+    rcfg = (RenderConfig.kitti if g.variant == "kitti" else RenderConfig.bundlefusion)(precision=precision, **g.cfg_kwargs())
+    return ocfg, rcfg
+
+
+@pytest.fixture(scope="module")
+def case():
+    """Oracle run with intermediates for one golden case (small sphere so the maps are cheap)."""
+    g = Golden("kitti_small_n64")
+    ocfg, _ = _cfgs(g)
+    mlp, mlpg = g.mlp_states()
+    maps = g.feature_maps()
+    out = orc.render_chunk(ocfg, mlp, mlpg, g.cam_K, g.T, maps, g.pixels, g.noise_u, g.noise_g, keep_intermediates=True)
+    return dict(g=g, ocfg=ocfg, mlp=mlp, mlpg=mlpg, maps=maps, out=out)
+
+
+def dv(t, dtype=None):
+    t = t.detach()
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.contiguous().to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM building blocks
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(300, 136, 80), (128, 128, 64), (517, 512, 560), (256, 80, 1536)])
+def test_gemm_nt_matches_fp64(prec, M, N, K):
+    lib = _capi.load()
+    gen = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=gen)
+    W = torch.randn(N, K, generator=gen) * 0.1  # asymmetric operands: catches transposed fragments / outputs
+    b = torch.randn(N, generator=gen)
+    dt = torch.bfloat16 if prec else torch.float32
+    Ad, Wd = dv(A, dt), dv(W, dt)
+    Cd = torch.full((M, N), float("nan"), device=DEV)
+    _capi.check(lib.scenerf_hip_test_gemm_nt(prec, Ad.data_ptr(), Wd.data_ptr(), dv(b).data_ptr(), M, N, K, 1, Cd.data_ptr(), _st()), "gemm_nt")
+    ref = torch.relu(Ad.float().double().cpu()) @ Wd.float().double().cpu().T + b.double()
+    scale = (torch.relu(Ad.float().cpu()).abs().double() @ Wd.float().cpu().abs().double().T).max()
+    err = (Cd.double().cpu() - ref).abs().max()
+    assert err <= 2e-6 * scale, "max err %.3e (scale %.3e)" % (err, scale)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(300, 136, 80), (1000, 512, 48), (4099, 256, 160)])
+def test_gemm_tn_matches_fp64(prec, M, N, K):
+    lib = _capi.load()
+    gen = torch.Generator().manual_seed(M + N * 5 + K * 11)
+    D = torch.randn(M, N, generator=gen) * 0.1
+    A = torch.randn(M, K, generator=gen)
+    dt = torch.bfloat16 if prec else torch.float32
+    Dd, Ad = dv(D, dt), dv(A, dt)
+    Cd = torch.zeros((N, K), device=DEV)
+    _capi.check(lib.scenerf_hip_test_gemm_tn(prec, Dd.data_ptr(), Ad.data_ptr(), M, N, K, 1, Cd.data_ptr(), _st()), "gemm_tn")
+    ref = Dd.float().double().cpu().T @ torch.relu(Ad.float().double().cpu())
+    scale = (Dd.float().cpu().abs().double().T @ torch.relu(Ad.float().cpu()).abs().double()).max()
+    err = (Cd.double().cpu() - ref).abs().max()
+    assert err <= 5e-6 * scale, "max err %.3e (scale %.3e)" % (err, scale)
+
+
+# ------------------------------------------------------------------------------------------------ geometry
+def _ray_setup(case, rcfg):
+    lib = _capi.load()
+    g, o = case["g"], case["out"]
+    cc = rcfg.to_c()
+    R, U = g.pixels.shape[0], rcfg.n_pts_uni
+    iK = torch.inverse(g.cam_K)
+    lin = torch.linspace(0.2, rcfg.max_sample_depth, steps=U)
+    unit = torch.empty((R, 3), device=DEV)
+    vd = torch.empty((R, 3), device=DEV)
+    du = torch.empty((R, U), device=DEV)
+    _capi.check(lib.scenerf_hip_ray_setup(C.byref(cc), dv(g.pixels).data_ptr(), dv(iK).data_ptr(), dv(g.T).data_ptr(),
+                                          dv(lin).data_ptr(), dv(g.noise_u.reshape(R, U)).data_ptr(), R, unit.data_ptr(),
+                                          vd.data_ptr(), du.data_ptr(), _st()), "ray_setup")
+    return unit, vd, du
+
+
+def test_ray_setup(case):
+    _, rcfg = _cfgs(case["g"])
+    unit, vd, du = _ray_setup(case, rcfg)
+    o = case["out"]
+    torch.testing.assert_close(unit.cpu(), o["_unit"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(vd.cpu(), o["_viewdir"], rtol=1e-6, atol=1e-7)
+    assert torch.equal(du.cpu(), o["_dist_u"]), "uniform sample distances must be bit-exact"
+
+
+def _encode(case, rcfg, dist, stride, ppr, M):
+    lib = _capi.load()
+    g, o = case["g"], case["out"]
+    cc = rcfg.to_c()
+    iK = torch.inverse(g.cam_K)
+    pts = torch.empty((M, 3), device=DEV)
+    idx = torch.empty((M, 2), dtype=torch.int32, device=DEV)
+    xenc = torch.empty((M, 48), device=DEV)
+    _capi.check(lib.scenerf_hip_encode_points(C.byref(cc), dist.data_ptr(), stride, ppr, dv(o["_unit"]).data_ptr(),
+                                              dv(o["_viewdir"]).data_ptr(), dv(g.cam_K).data_ptr(), dv(iK).data_ptr(),
+                                              dv(g.T).data_ptr(), M, pts.data_ptr(), idx.data_ptr(), xenc.data_ptr(), _st()),
+                "encode_points")
+    return pts, idx, xenc
+
+
+def _check_sphere_idx(idx_gpu, pts_oracle, g, ocfg):
+    pix = orc.project_to_pixels(pts_oracle, g.cam_K)
+    idx_ref, fl = orc.sphere_coords(pix, torch.inverse(g.cam_K), ocfg, return_float=True)
+    frac = (fl - torch.floor(fl) - 0.5).abs()          # distance of the pre-round value to a rounding boundary
+    ambiguous = (frac < 2e-3).any(dim=1)
+    diff = (idx_gpu.cpu().long() - idx_ref).abs()
+    assert bool((diff[~ambiguous] == 0).all()), "sphere indices differ away from rounding boundaries: %d rows" % int((diff[~ambiguous] != 0).any(1).sum())
+    assert bool((diff[ambiguous] <= 1).all())
+    assert ambiguous.float().mean() < 0.02
+    return int((diff != 0).any(1).sum()), int(ambiguous.sum())
+
+
+def test_encode_points_main_samples(case):
+    g, o, ocfg = case["g"], case["out"], case["ocfg"]
+    _, rcfg = _cfgs(g)
+    R, N = o["_dist_sorted"].shape
+    pts, idx, xenc = _encode(case, rcfg, dv(o["_dist_sorted"]), N, N, R * N)
+    torch.testing.assert_close(pts.cpu(), o["_pts_sorted"].reshape(-1, 3), rtol=1e-6, atol=1e-5)
+    n_diff, n_amb = _check_sphere_idx(idx, o["_pts_sorted"].reshape(-1, 3), g, ocfg)
+    print("sphere idx: %d rows differ, %d ambiguous of %d" % (n_diff, n_amb, R * N))
+    ref = o["_xin"][:, 2480:]
+    x = xenc.cpu()
+    assert torch.equal(x[:, 42:], torch.zeros(R * N, 6))
+    torch.testing.assert_close(x[:, 39:42], ref[:, 39:42], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(x[:, :3], ref[:, :3], rtol=1e-6, atol=1e-5)
+    # PE: fp32 argument rounding at |x| f ~ 1e4 rad allows ~1e-3; tight where the argument is small
+    arg = (ref[:, :3].abs().max(dim=1).values * 3.1416 * 32)
+    small = arg < 100
+    torch.testing.assert_close(x[small, 3:39], ref[small, 3:39], rtol=0, atol=2e-5)
+    torch.testing.assert_close(x[:, 3:39], ref[:, 3:39], rtol=0, atol=4e-3)
+
+
+def test_encode_points_anchors(case):
+    g, o, ocfg = case["g"], case["out"], case["ocfg"]
+    _, rcfg = _cfgs(g)
+    R = g.pixels.shape[0]
+    G = rcfg.n_gaussians
+    anchors = orc.gaussian_anchor_distances(ocfg)
+    pts, idx, xenc = _encode(case, rcfg, dv(anchors), 0, G, R * G)
+    torch.testing.assert_close(pts.cpu(), o["_anchor_pts"], rtol=1e-6, atol=1e-5)
+    _check_sphere_idx(idx, o["_anchor_pts"], g, ocfg)
+
+
+# ------------------------------------------------------------------------------------------------ gather
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_gather_features(case, precision):
+    lib = _capi.load()
+    g, o = case["g"], case["out"]
+    _, rcfg = _cfgs(g, precision)
+    cc = rcfg.to_c()
+    prec = rcfg.precision_code
+    act = torch.bfloat16 if prec else torch.float32
+    hwc = []
+    for (c, h, w), key in zip(rcfg.map_shapes(), ["1_1", "1_2", "1_4", "1_8", "1_16"]):
+        src = dv(case["maps"][key])
+        dst = torch.empty((h, w, c), dtype=act, device=DEV)
+        _capi.check(lib.scenerf_hip_maps_chw_to_hwc(src.data_ptr(), dst.data_ptr(), c, h, w, prec, _st()), "maps_chw_to_hwc")
+        torch.testing.assert_close(dst.float().cpu(), case["maps"][key].permute(1, 2, 0).to(act).float(), rtol=0, atol=0)
+        hwc.append(dst)
+    idx = o["_idx"].to(torch.int32)
+    M = idx.shape[0]
+    Mpad = (M + 127) // 128 * 128
+    Z = torch.full((Mpad, 2480), float("nan"), dtype=act, device=DEV)
+    mask = torch.zeros((Mpad // 128,), dtype=torch.uint8, device=DEV)
+    tex = torch.empty((M, 5, 4), dtype=torch.int32, device=DEV)
+    tw = torch.empty((M, 5, 4), device=DEV)
+    arr = (C.c_void_p * 5)(*[t.data_ptr() for t in hwc])
+    _capi.check(lib.scenerf_hip_gather_features(C.byref(cc), C.byref(arr), dv(idx).data_ptr(), M, Z.data_ptr(), mask.data_ptr(),
+                                                tex.data_ptr(), tw.data_ptr(), _st()), "gather_features")
+    ref = o["_xin"][:, :2480]
+    Zc, mk = Z.float().cpu(), mask.cpu()
+    off = 0
+    for s, (c, h, w) in enumerate(rcfg.map_shapes()):
+        for t in range(Mpad // 128):
+            rows = slice(t * 128, min((t + 1) * 128, M))
+            r = ref[rows, off:off + c]
+            if (mk[t] >> s) & 1:
+                tol = 1e-5 if prec == 0 else 1.2e-2
+                torch.testing.assert_close(Zc[rows, off:off + c], r, rtol=tol, atol=tol)
+            else:
+                assert float(r.abs().max()) == 0.0, "tile %d scale %d skipped but the oracle has non-zero features" % (t, s)
+        off += c
+    # taps are a faithful description of the gather: re-applying them on the CHW map reproduces the oracle
+    key = "1_1"
+    fm = case["maps"][key].reshape(80, -1)
+    texc, twc = tex[:, 0].cpu().long(), tw[:, 0].cpu()
+    rec = torch.zeros(M, 80)
+    for t in range(4):
+        ok = texc[:, t] >= 0
+        rec[ok] += (fm[:, texc[ok, t]] * twc[ok, t]).T
+    torch.testing.assert_close(rec, ref[:, :80], rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ sampler + sort
+def test_gaussian_sample_sort(case):
+    lib = _capi.load()
+    g, o, ocfg = case["g"], case["out"], case["ocfg"]
+    _, rcfg = _cfgs(g)
+    cc = rcfg.to_c()
+    R, N, G = g.pixels.shape[0], rcfg.n_samples, rcfg.n_gaussians
+    anchors = orc.gaussian_anchor_distances(ocfg)
+    gm = torch.empty((R, G), device=DEV)
+    gs = torch.empty((R, G), device=DEV)
+    ds = torch.empty((R, N), device=DEV)
+    zs = torch.empty((R, N), device=DEV)
+    perm = torch.empty((R, N), dtype=torch.int32, device=DEV)
+    _capi.check(lib.scenerf_hip_gaussian_sample_sort(C.byref(cc), dv(o["_offsets"]).data_ptr(), dv(anchors).data_ptr(),
+                                                     dv(o["_dist_u"]).data_ptr(), dv(g.noise_g).data_ptr(), dv(o["_unit"]).data_ptr(),
+                                                     R, gm.data_ptr(), gs.data_ptr(), ds.data_ptr(), zs.data_ptr(), perm.data_ptr(),
+                                                     _st()), "gaussian_sample_sort")
+    assert torch.equal(gm.cpu(), o["gaussian_means"].detach())
+    assert torch.equal(gs.cpu(), o["gaussian_stds"].detach())
+    assert torch.equal(ds.cpu(), o["_dist_sorted"].detach()), "sorted distances must be bit-exact"
+    assert torch.equal(zs.cpu(), o["depth_volumes"].detach())
+    # permutation: bit-exact where keys are unique (ties = identical clamped samples, order irrelevant; torch's
+    # CPU argsort is not stable there)
+    p_ref = o["_perm"]
+    d = o["_dist_sorted"].detach()
+    uniq = torch.ones_like(d, dtype=torch.bool)
+    uniq[:, 1:] &= d[:, 1:] != d[:, :-1]
+    uniq[:, :-1] &= d[:, 1:] != d[:, :-1]
+    assert torch.equal(perm.cpu().long()[uniq], p_ref[uniq])
+    assert torch.equal(torch.sort(perm.cpu().long(), dim=1).values, torch.arange(N).expand(R, N))
+
+
+# ------------------------------------------------------------------------------------------------ compositing
+def _composite_inputs(case):
+    o = case["out"]
+    return o["_mlp_out"].detach(), o["_dist_sorted"].detach(), o["depth_volumes"].detach()
+
+
+def test_composite_forward(case):
+    lib = _capi.load()
+    o = case["out"]
+    logits, dist, z = _composite_inputs(case)
+    R, N = dist.shape
+    f = lambda *s: torch.empty(s, device=DEV)
+    dens, al, w, dep, col, clo, wat = f(R, N), f(R, N), f(R, N), f(R), f(R, 3), f(R), f(R)
+    ci = torch.empty((R,), dtype=torch.int32, device=DEV)
+    _capi.check(lib.scenerf_hip_composite_forward(dv(logits).data_ptr(), dv(dist).data_ptr(), dv(z).data_ptr(), R, N, dens.data_ptr(),
+                                                  al.data_ptr(), w.data_ptr(), dep.data_ptr(), col.data_ptr(), clo.data_ptr(),
+                                                  wat.data_ptr(), ci.data_ptr(), _st()), "composite_forward")
+    tol = dict(rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(dens.cpu(), o["densities"].detach(), **tol)
+    torch.testing.assert_close(al.cpu(), o["alphas"].detach(), **tol)
+    torch.testing.assert_close(w.cpu(), o["weights"].detach(), **tol)
+    torch.testing.assert_close(dep.cpu(), o["depth"].detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(col.cpu(), o["color"].detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(clo.cpu(), o["closest_pts_to_depths"].detach(), rtol=1e-4, atol=2e-5)
+    assert torch.equal(ci.cpu().long(), o["_closest_idx"]), "closest-sample index must be bit-exact"
+    torch.testing.assert_close(wat.cpu(), o["weights_at_depth"].detach(), **tol)
+
+
+@pytest.mark.parametrize("N", [64, 96, 128, 512])
+def test_composite_forward_backward_vs_autograd(N):
+    """All lane layouts (1/2/4/8 samples per lane, ragged N=96) against torch autograd of the oracle."""
+    lib = _capi.load()
+    gen = torch.Generator().manual_seed(N)
+    R = 37
+    logits = torch.randn(R * N, 4, generator=gen)
+    logits[:, 3] -= 2.0
+    dist = torch.sort(torch.rand(R, N, generator=gen) * 100 + 0.1, dim=1).values
+    dist[:, 5] = dist[:, 4]  # a tie: delta = 0
+    z = dist * 0.97
+    lg = logits.clone().requires_grad_(True)
+    dd = dist.clone().requires_grad_(True)
+    zz = z.clone().requires_grad_(True)
+    col = torch.sigmoid(lg[:, :3]).reshape(R, N, 3)
+    den = orc.density_activation(lg[:, 3:4]).reshape(R, N)
+    comp = orc.composite(den, dd.clone(), zz, col)
+    gd, gc = torch.randn(R, generator=gen), torch.randn(R, 3, generator=gen)
+    gw, ga = torch.randn(R, N, generator=gen) * 0.1, torch.randn(R, N, generator=gen) * 0.1
+    gden, gz = torch.randn(R, N, generator=gen) * 0.1, torch.randn(R, N, generator=gen) * 0.1
+    loss = (comp["depth"] * gd).sum() + (comp["color"] * gc).sum() + (comp["weights"] * gw).sum() + (comp["alphas"] * ga).sum() \
+        + (den * gden).sum() + (zz * gz).sum()
+    loss.backward()
+    f = lambda *s: torch.empty(s, device=DEV)
+    dens, al, w, dep, colr, clo, wat = f(R, N), f(R, N), f(R, N), f(R), f(R, 3), f(R), f(R)
+    ci = torch.empty((R,), dtype=torch.int32, device=DEV)
+    L, D, Z = dv(logits), dv(dist), dv(z)
+    _capi.check(lib.scenerf_hip_composite_forward(L.data_ptr(), D.data_ptr(), Z.data_ptr(), R, N, dens.data_ptr(), al.data_ptr(),
+                                                  w.data_ptr(), dep.data_ptr(), colr.data_ptr(), clo.data_ptr(), wat.data_ptr(),
+                                                  ci.data_ptr(), _st()), "composite_forward")
+    torch.testing.assert_close(w.cpu(), comp["weights"].detach(), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(dep.cpu(), comp["depth"].detach(), rtol=2e-5, atol=2e-5)
+    assert torch.equal(ci.cpu().long(), comp["closest_idx"])
+    dl, ddist, dz = f(R * N, 4), f(R, N), f(R, N)
+    _capi.check(lib.scenerf_hip_composite_backward(L.data_ptr(), D.data_ptr(), Z.data_ptr(), R, N, dv(gd).data_ptr(), dv(gc).data_ptr(),
+                                                   dv(gw).data_ptr(), dv(ga).data_ptr(), dv(gden).data_ptr(), dv(gz).data_ptr(),
+                                                   dl.data_ptr(), ddist.data_ptr(), dz.data_ptr(), _st()), "composite_backward")
+    torch.testing.assert_close(dl.cpu(), lg.grad, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(ddist.cpu(), dd.grad, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(dz.cpu(), zz.grad, rtol=2e-4, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ RaySOM
+def test_raysom_forward_and_sampler_backward(case):
+    lib = _capi.load()
+    g, o, ocfg = case["g"], case["out"], case["ocfg"]
+    _, rcfg = _cfgs(g)
+    cc = rcfg.to_c()
+    R, N, G, U, P = g.pixels.shape[0], rcfg.n_samples, rcfg.n_gaussians, rcfg.n_pts_uni, rcfg.n_pts_per_gaussian
+    gm, gs = o["gaussian_means"].detach(), o["gaussian_stds"].detach()
+    dist, al = o["_dist_sorted"].detach(), o["alphas"].detach()
+    f = lambda *s: torch.empty(s, device=DEV)
+    lk, sm, sv, ks = f(R), f(R, G), f(R, G), f(R, G, 3)
+    _capi.check(lib.scenerf_hip_raysom_forward(C.byref(cc), dv(gm).data_ptr(), dv(gs).data_ptr(), dv(dist).data_ptr(), dv(al).data_ptr(), R,
+                                               lk.data_ptr(), sm.data_ptr(), sv.data_ptr(), ks.data_ptr(), _st()), "raysom_forward")
+    torch.testing.assert_close(sm.cpu(), o["som_means"].detach(), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(sv.cpu(), o["som_vars"].detach(), rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(lk.cpu(), o["loss_kl"].detach(), rtol=2e-4, atol=2e-5)
+
+    # sampler + KL backward vs autograd of the oracle's sampler/KL sub-graph
+    offs = o["_offsets"].detach().clone().requires_grad_(True)
+    anchors = orc.gaussian_anchor_distances(ocfg)
+    means = torch.relu(anchors.reshape(1, G) + offs[:, :, 0]) + ocfg.gauss_floor
+    stds = torch.relu(offs[:, :, 1] + ocfg.std) + ocfg.gauss_floor
+    dg = means.repeat_interleave(P, dim=1) + g.noise_g * stds.repeat_interleave(P, dim=1)
+    dg = torch.where(dg < 0.1, torch.full_like(dg, 0.1), dg)
+    dall = torch.cat([o["_dist_u"], dg], dim=1)
+    perm = o["_perm"]
+    dsorted = torch.gather(dall, 1, perm)
+    zsorted = dsorted * o["_unit"][:, 2:3]
+    gen = torch.Generator().manual_seed(5)
+    g_dd, g_dz = torch.randn(R, N, generator=gen), torch.randn(R, N, generator=gen)
+    g_kl, g_gm, g_gs = torch.randn(R, generator=gen), torch.randn(R, G, generator=gen), torch.randn(R, G, generator=gen)
+    kl, _, _, _ = orc.ray_som_kl(means, stds, dsorted, al, ocfg.som_sigma, ocfg.kl_std_floor)
+    loss = (dsorted * g_dd).sum() + (zsorted * g_dz).sum() + (kl * g_kl).sum() + (means * g_gm).sum() + (stds * g_gs).sum()
+    loss.backward()
+    doff = f(R, G, 2)
+    _capi.check(lib.scenerf_hip_sampler_backward(C.byref(cc), dv(o["_offsets"]).data_ptr(), dv(anchors).data_ptr(), dv(g.noise_g).data_ptr(),
+                                                 dv(o["_unit"]).data_ptr(), dv(gm).data_ptr(), dv(gs).data_ptr(),
+                                                 dv(perm.to(torch.int32)).data_ptr(), dv(g_dd).data_ptr(), dv(g_dz).data_ptr(),
+                                                 ks.data_ptr(), dv(g_kl).data_ptr(), dv(g_gm).data_ptr(), dv(g_gs).data_ptr(), R,
+                                                 doff.data_ptr(), _st()), "sampler_backward")
+    torch.testing.assert_close(doff.cpu(), offs.grad, rtol=2e-4, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ MLP pass
+def _mlp_case(case, precision, which):
+    """Feed the oracle's x_in to the HIP MLP pass; returns everything needed to compare."""
+    from scenerf_amd.renderer import MLP_PARAM_NAMES, PackedMLP
+    o = case["out"]
+    g = case["g"]
+    _, rcfg = _cfgs(g, precision)
+    xin = (o["_xin"] if which == "mlp" else o["_xin_g"]).detach()
+    state = case["mlp"] if which == "mlp" else case["mlpg"]
+    d_out = 4 if which == "mlp" else 2
+    params = [dv(state[n]) for n in MLP_PARAM_NAMES]
+    pk = PackedMLP(params, d_out, rcfg)
+    return rcfg, xin, state, d_out, pk
+
+
+@pytest.mark.parametrize("precision,which", [("fp32", "mlp"), ("fp32", "gauss"), ("bf16", "mlp")])
+def test_mlp_forward_backward(case, precision, which):
+    from scenerf_amd.renderer import MLP_PARAM_NAMES, _MlpRun
+    lib = _capi.load()
+    rcfg, xin, state, d_out, pk = _mlp_case(case, precision, which)
+    cc = rcfg.to_c()
+    prec = rcfg.precision_code
+    act = torch.bfloat16 if prec else torch.float32
+    M = xin.shape[0]
+    run = _MlpRun(M, d_out, prec, torch.device(DEV))
+    run.Z.zero_()
+    run.Z[:M] = dv(xin[:, :2480], act)
+    xe = torch.zeros((M, 48))
+    xe[:, :42] = xin[:, 2480:]
+    run.xenc.copy_(dv(xe))
+    run.tile_mask.fill_(31)
+    _capi.check(lib.scenerf_hip_mlp_forward(C.byref(cc), C.byref(pk.c), run.Z.data_ptr(), run.xenc.data_ptr(), run.tile_mask.data_ptr(), M,
+                                            C.byref(run.c), _st()), "mlp_forward")
+    # oracle with autograd
+    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    xr = xin.clone().requires_grad_(True)
+    keep = {}
+    ref = orc.resnetfc_forward(p, xr, keep=keep)
+    scale = float(ref.abs().max())
+    tol = 2e-5 if prec == 0 else 3e-2
+    err = float((run.logits.cpu() - ref.detach()).abs().max())
+    print("%s %s logits max err %.3e (scale %.2f)" % (precision, which, err, scale))
+    assert err <= tol * max(scale, 1.0)
+    for b in range(4):
+        e = float((run.H[b].float().cpu() - keep["h%d" % b].detach()).abs().max())
+        assert e <= tol * max(float(keep["h%d" % b].abs().max()), 1.0), "H%d err %.3e" % (b, e)
+    # backward: random upstream, no map scatter here (features' gradient checked end-to-end)
+    gen = torch.Generator().manual_seed(3)
+    dl = torch.randn(M, d_out, generator=gen)
+    (ref * dl).sum().backward()
+    gsink = pk.grad_sink()
+    dH = torch.empty((M, 2048), dtype=act, device=DEV)
+    dN = torch.empty((M, 512), dtype=act, device=DEV)
+    tex = torch.full((M, 5, 4), -1, dtype=torch.int32, device=DEV)
+    tw = torch.zeros((M, 5, 4), device=DEV)
+    _capi.check(lib.scenerf_hip_mlp_backward(C.byref(cc), C.byref(pk.c), C.byref(gsink), run.Z.data_ptr(), run.xenc.data_ptr(),
+                                             run.tile_mask.data_ptr(), tex.data_ptr(), tw.data_ptr(), M, C.byref(run.c),
+                                             dv(dl).data_ptr(), dH.data_ptr(), dN.data_ptr(), None, _st()), "mlp_backward")
+    grads = dict(zip(MLP_PARAM_NAMES, pk.unpack_grads()))
+    gtol = 2e-4 if prec == 0 else 5e-2
+    for n in MLP_PARAM_NAMES:
+        r = p[n].grad
+        e = float((grads[n].cpu() - r).abs().max())
+        s = float(r.abs().max())
+        assert e <= gtol * max(s, 1e-6), "%s: grad err %.3e vs scale %.3e" % (n, e, s)
