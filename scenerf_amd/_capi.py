@@ -9,6 +9,10 @@ import ctypes as C
 import os
 from typing import Optional
 
+# torch first: libscenerf_hip.so must bind to the HIP runtime torch has already loaded (one runtime per process;
+# loading /opt/rocm's copy before torch's bundled one leaves the library without a visible device).
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libscenerf_hip.so")
 

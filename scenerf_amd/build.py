@@ -26,12 +26,24 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+STAMP = LIB + ".stamp"
+
+
+def _digest() -> str:
+    """Content hash of sources + flags (mtimes are meaningless after the tree is copied to the GPU box)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as fh:
+        return fh.read().strip() != _digest()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -61,6 +73,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as fh:
+        fh.write(_digest())
     return LIB
 
 

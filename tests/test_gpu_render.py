@@ -61,8 +61,11 @@ def test_render_matches_reference_golden(name, precision):
     assert report["depth_volumes"] == 1.0 or precision == "bf16"
     smooth = g.meta["smooth"]
     need = 0.98 if smooth else 0.85
-    for k in ("depth", "color", "weights", "alphas", "densities", "loss_kl", "gaussian_means", "gaussian_stds"):
+    for k in ("depth", "color", "weights", "alphas", "densities", "gaussian_means", "gaussian_stds"):
         assert report[k] >= need, "%s: only %.3f of the rays within tolerance" % (k, report[k])
+    # loss_kl contains hard thresholds (|mean diff| > 0.1, |std diff| > 0.1, ray_som_kl.py:66-70): a ray whose SOM
+    # statistics sit at a threshold flips a mask term under bf16-level perturbations of the gaussian head
+    assert report["loss_kl"] >= (0.98 if precision == "fp32" else 0.85), report["loss_kl"]
     # aggregate (the training loss proxy) must agree closely: outliers are few and small
     loss = out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
     ref_loss = float(g.z["loss"])
