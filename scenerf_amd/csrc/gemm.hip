@@ -7,6 +7,8 @@
 // => conflict-free ds_read_b128 fragment reads), next chunk prefetched global->VGPR while the MFMAs run.
 // Both element types use the same fragment indexing: lane l holds k = (l>>5)*8 .. +8 of row (l&31); for
 // fp32 the 8 values feed 8 back-to-back 32x32x2 MFMAs (any bijective k-order is valid as A and B agree).
+#include <vector>
+
 #include "gemm.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -356,6 +358,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
 }
 
 // ================================================================================================ launchers
+// FLOPs actually issued (profile mode only; synchronises to read the scale-activity mask): row tiles whose
+// mask bit is clear skip that segment (or the whole tile when skip_bit is set), so dense 2*M*N*K would overstate.
+static std::vector<uint8_t> read_mask(const uint8_t* d, int n, hipStream_t s) {
+    std::vector<uint8_t> h(n, 0x1f);
+    if (d && hipMemcpyAsync(h.data(), d, n, hipMemcpyDeviceToHost, s) == hipSuccess) (void)hipStreamSynchronize(s);
+    return h;
+}
+static double nt_issued_flops(const GemmNT& p, hipStream_t s) {
+    int tiles = cdiv(p.M, SCENERF_TILE_ROWS);
+    if (!p.tile_mask) {
+        double k = p.K1;
+        for (int i = 0; i < p.nseg; ++i) k += p.seg_len[i];
+        return 2.0 * p.M * (double)p.N * k;
+    }
+    std::vector<uint8_t> m = read_mask(p.tile_mask, tiles, s);
+    double f = 0;
+    for (int t = 0; t < tiles; ++t) {
+        int rows = p.M - t * SCENERF_TILE_ROWS < SCENERF_TILE_ROWS ? p.M - t * SCENERF_TILE_ROWS : SCENERF_TILE_ROWS;
+        if (p.skip_bit >= 0 && !((m[t] >> p.skip_bit) & 1)) continue;
+        double k = p.K1;
+        for (int i = 0; i < p.nseg; ++i) if ((m[t] >> i) & 1) k += p.seg_len[i];
+        f += 2.0 * rows * (double)p.N * k;
+    }
+    return f;
+}
+static double tn_issued_flops(const GemmTN& p, hipStream_t s) {
+    if (!p.tile_mask || p.skip_bit < 0) return 2.0 * p.M * (double)p.N * p.K;
+    int tiles = cdiv(p.M, SCENERF_TILE_ROWS);
+    std::vector<uint8_t> m = read_mask(p.tile_mask, tiles, s);
+    double f = 0;
+    for (int t = 0; t < tiles; ++t) {
+        int rows = p.M - t * SCENERF_TILE_ROWS < SCENERF_TILE_ROWS ? p.M - t * SCENERF_TILE_ROWS : SCENERF_TILE_ROWS;
+        if ((m[t] >> p.skip_bit) & 1) f += 2.0 * rows * (double)p.N * p.K;
+    }
+    return f;
+}
 template <typename T> static int launch_nt_t(const GemmNT& p, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
@@ -363,9 +401,9 @@ template <typename T> static int launch_nt_t(const GemmNT& p, hipStream_t s) {
         attr_done = true;
     }
     dim3 grid(cdiv(p.M, BM), cdiv(p.N, BN));
-    double ktot = p.K1;
-    for (int i = 0; i < p.nseg; ++i) ktot += p.seg_len[i];
-    SrfLaunchScope ps(s, p.name, 2.0 * p.M * (double)p.N * ktot, 0);
+    double flops = 0;
+    if (srf_prof_on()) flops = nt_issued_flops(p, s);
+    SrfLaunchScope ps(s, p.name, flops, 0);
     gemm_nt_kernel<T><<<grid, 256, LDS_BYTES, s>>>(p);
     SRF_LAUNCH_CHECK(p.name);
     return 0;
@@ -399,7 +437,9 @@ template <typename T> static int launch_tn_t(const GemmTN& p, hipStream_t s) {
     rows = cdiv(rows, SCENERF_TILE_ROWS) * SCENERF_TILE_ROWS;
     slices = cdiv(p.M, rows);
     dim3 grid(cdiv(p.N, BN), cdiv(p.K, BN), slices);
-    SrfLaunchScope ps(s, p.name, 2.0 * p.M * (double)p.N * p.K, 0);
+    double flops = 0;
+    if (srf_prof_on()) flops = tn_issued_flops(p, s);
+    SrfLaunchScope ps(s, p.name, flops, 0);
     gemm_tn_kernel<T><<<grid, 256, 2 * STAGEB, s>>>(p, rows);
     SRF_LAUNCH_CHECK(p.name);
     return 0;

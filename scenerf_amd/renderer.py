@@ -449,7 +449,9 @@ class RenderSession:
         if cfg.device_rng:
             ng = torch.randn((R, GP), dtype=torch.float32, device=device)
         else:
-            ng = torch.normal(mean=torch.zeros((R, GP)), std=torch.ones((R, GP))).to(device, non_blocking=True)  # utils.py:208-211
+            # utils.py:208-211 draws N(0,1) on the CPU generator.  Same stream here (bit-identical to
+            # torch.normal(zeros, ones)), but into pinned memory so the H2D copy does not stall the host.
+            ng = torch.empty((R, GP), dtype=torch.float32, pin_memory=True).normal_().to(device, non_blocking=True)
         return nu, ng
 
     def render_chunk(self, pixels, cam_K, inv_K, T_s2i, noise_u=None, noise_g=None) -> Dict[str, torch.Tensor]:
