@@ -84,6 +84,27 @@ template <> struct ActIO<bf16_t> {
     __device__ static inline void st(void* p, size_t i, float v) { ((bf16_t*)p)[i] = f32_to_bf16(v); }
 };
 
+// 8 consecutive activations <-> 8 floats (16 B for bf16, 32 B for fp32)
+template <typename T> __device__ static inline void load8(const void* base, size_t idx, float* v);
+template <> __device__ inline void load8<bf16_t>(const void* base, size_t idx, float* v) {
+    uint4 t = *(const uint4*)((const bf16_t*)base + idx);
+    v[0] = bf16lo(t.x); v[1] = bf16hi(t.x); v[2] = bf16lo(t.y); v[3] = bf16hi(t.y);
+    v[4] = bf16lo(t.z); v[5] = bf16hi(t.z); v[6] = bf16lo(t.w); v[7] = bf16hi(t.w);
+}
+template <> __device__ inline void load8<float>(const void* base, size_t idx, float* v) {
+    float4 a = *(const float4*)((const float*)base + idx), b = *(const float4*)((const float*)base + idx + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <typename T> __device__ static inline void store8(void* base, size_t idx, const float* v);
+template <> __device__ inline void store8<bf16_t>(void* base, size_t idx, const float* v) {
+    *(uint4*)((bf16_t*)base + idx) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                pack_bf16x2(v[6], v[7]));
+}
+template <> __device__ inline void store8<float>(void* base, size_t idx, const float* v) {
+    *(float4*)((float*)base + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)((float*)base + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
 // wave-level helpers (64 lanes)
 __device__ static inline float wave_sum(float v) {
 #pragma unroll

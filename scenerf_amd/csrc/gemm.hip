@@ -21,12 +21,23 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 #define STAGEB (2 * TILEB)          // A + W
 #define MAX_CHUNKS 128
 #define LDS_BYTES (2 * STAGEB + MAX_CHUNKS * 16 + 16)
+#define CLD 132                     // fp32 C tile row stride in LDS (128 + 4 pad): 128*132*4 = 67584 B <= 2*STAGEB
 
 template <typename T> struct Elem;
 template <> struct Elem<bf16_t> { static constexpr int BK = 64; };
 template <> struct Elem<float> { static constexpr int BK = 32; };
 
 __device__ static inline uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
+
+// XCD-aware block order: the dispatcher places block b on XCD b % 8 (observed, used for speed only).  Give each
+// XCD one contiguous range of the linear tile index, so tiles that share an operand panel (the column tiles of
+// one row tile; all output tiles of one M-slice) run back-to-back on the SAME XCD and hit its private L2.
+// Bijective for any block count (cdna_hip_programming.md T1).
+__device__ static inline int xcd_remap(int id, int total) {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = id & 7, slot = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
 
 template <typename T> __device__ static inline uint4 relu16B(uint4 v);
 template <> __device__ inline uint4 relu16B<bf16_t>(uint4 v) {
@@ -83,25 +94,48 @@ template <> struct WaveMma<float> {
     }
 };
 
-// epilogue of one accumulator element: v = acc + bias; v += res; v = mask > 0 ? v : 0; v += res2; store | scatter
+// epilogue of 8 consecutive columns of one row: v = acc + bias; v += res; v = mask > 0 ? v : 0; v += res2; store | scatter
 template <typename T>
-__device__ __forceinline__ void epi_elem(const GemmNT& p, float a, int m, int n, float bv) {
-    if (m >= p.M || n >= p.N) return;
-    float v = a + bv;
-    if (p.res) v += p.res_f32 ? ((const float*)p.res)[(size_t)m * p.ldres + n] : ActIO<T>::ld(p.res, (size_t)m * p.ldres + n);
-    if (p.maskp) v = ActIO<T>::ld(p.maskp, (size_t)m * p.ldmask + n) > 0.f ? v : 0.f;
-    if (p.res2) v += ActIO<T>::ld(p.res2, (size_t)m * p.ldres2 + n);
+__device__ __forceinline__ void epi_item(const GemmNT& p, float* v, int m, int n) {
+    if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+    }
+    if (p.res) {
+        float r[8];
+        if (p.res_f32) load8<float>(p.res, (size_t)m * p.ldres + n, r);
+        else load8<T>(p.res, (size_t)m * p.ldres + n, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+    if (p.maskp) {
+        float r[8];
+        load8<T>(p.maskp, (size_t)m * p.ldmask + n, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = r[e] > 0.f ? v[e] : 0.f;
+    }
+    if (p.res2) {
+        float r[8];
+        load8<T>(p.res2, (size_t)m * p.ldres2 + n, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
     if (p.scatter_scale >= 0) {
         const size_t tb = ((size_t)m * 5 + p.scatter_scale) * 4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            int tx = p.tap_texel[tb + t];
-            if (tx >= 0) unsafeAtomicAdd(p.gmap + (size_t)tx * p.N + n, v * p.tap_weight[tb + t]);
+            const int tx = p.tap_texel[tb + t];
+            if (tx >= 0) {
+                const float w = p.tap_weight[tb + t];
+                float* dst = p.gmap + (size_t)tx * p.N + n;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, v[e] * w);
+            }
         }
     } else if (p.out_f32) {
-        ((float*)p.out)[(size_t)m * p.ldout + n] = v;
+        store8<float>(p.out, (size_t)m * p.ldout + n, v);
     } else {
-        ActIO<T>::st(p.out, (size_t)m * p.ldout + n, v);
+        store8<T>(p.out, (size_t)m * p.ldout + n, v);
     }
 }
 
@@ -115,7 +149,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     constexpr int BK = Elem<T>::BK;
     constexpr int ES = (int)sizeof(T);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lin / tiles_n) * BM, n0 = (lin % tiles_n) * BN;
 
     unsigned mask = 0xffffffffu;
     if (p.tile_mask) mask = p.tile_mask[m0 / SCENERF_TILE_ROWS];
@@ -208,23 +244,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
         __syncthreads();
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------------------
-    // expanded with constant register indices (a runtime-indexed accumulator vector would go to scratch)
-#define EPI_R(i, j, r) epi_elem<T>(p, acc[i][j][r], mrow##i + ((r) & 3) + 8 * ((r) >> 2), ncol##j, bias##j);
-#define EPI_TILE(i, j)                                                                                          \
-    EPI_R(i, j, 0) EPI_R(i, j, 1) EPI_R(i, j, 2) EPI_R(i, j, 3) EPI_R(i, j, 4) EPI_R(i, j, 5) EPI_R(i, j, 6)     \
-    EPI_R(i, j, 7) EPI_R(i, j, 8) EPI_R(i, j, 9) EPI_R(i, j, 10) EPI_R(i, j, 11) EPI_R(i, j, 12) EPI_R(i, j, 13) \
-    EPI_R(i, j, 14) EPI_R(i, j, 15)
-    const int mrow0 = m0 + wm * 64 + 4 * (lane >> 5), mrow1 = mrow0 + 32;
-    const int ncol0 = n0 + wn * 64 + (lane & 31), ncol1 = ncol0 + 32;
-    const float bias0 = (p.bias && ncol0 < p.N) ? p.bias[ncol0] : 0.f;
-    const float bias1 = (p.bias && ncol1 < p.N) ? p.bias[ncol1] : 0.f;
-    EPI_TILE(0, 0)
-    EPI_TILE(0, 1)
-    EPI_TILE(1, 0)
-    EPI_TILE(1, 1)
-#undef EPI_TILE
-#undef EPI_R
+    // ---- epilogue: stage the 128x128 fp32 tile in LDS (reusing the operand buffers), then every thread handles
+    // 8 consecutive columns of a row with 16/32-byte global accesses (the MFMA C layout gives a lane one column of
+    // 16 scattered rows: storing from it directly means 2-byte strided accesses and was the dominant cost) ------
+    float* Cs = (float*)lds;
+#define CS_W(i, j, r) Cs[(wm * 64 + (i) * 32 + ((r) & 3) + 8 * ((r) >> 2) + 4 * (lane >> 5)) * CLD + wn * 64 + (j) * 32 + (lane & 31)] = acc[i][j][r];
+#define CS_TILE(i, j)                                                                                               \
+    CS_W(i, j, 0) CS_W(i, j, 1) CS_W(i, j, 2) CS_W(i, j, 3) CS_W(i, j, 4) CS_W(i, j, 5) CS_W(i, j, 6) CS_W(i, j, 7) \
+    CS_W(i, j, 8) CS_W(i, j, 9) CS_W(i, j, 10) CS_W(i, j, 11) CS_W(i, j, 12) CS_W(i, j, 13) CS_W(i, j, 14) CS_W(i, j, 15)
+    CS_TILE(0, 0)
+    CS_TILE(0, 1)
+    CS_TILE(1, 0)
+    CS_TILE(1, 1)
+#undef CS_TILE
+#undef CS_W
+    __syncthreads();
+#pragma unroll 2
+    for (int it = tid; it < BM * (BN / 8); it += 256) {
+        const int row = it >> 4, cg = it & 15;
+        const int m = m0 + row, n = n0 + cg * 8;
+        if (m < p.M && n < p.N) {
+            float v[8];
+            const float4 lo = *(const float4*)(Cs + row * CLD + cg * 8), hi = *(const float4*)(Cs + row * CLD + cg * 8 + 4);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            epi_item<T>(p, v, m, n);
+        }
+    }
 }
 
 // ================================================================================================ TN
@@ -306,8 +351,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int MC = TnStage<T>::MC;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-    const int n0 = blockIdx.x * BN, k0 = blockIdx.y * BN;
-    const int mbeg = blockIdx.z * rows_per_slice;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_k = (p.K + BN - 1) / BN;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);   // lin = slice * (tiles_n*tiles_k) + tile
+    const int tile = lin % (tiles_n * tiles_k);
+    const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BN;
+    const int mbeg = (lin / (tiles_n * tiles_k)) * rows_per_slice;
     const int mend = (mbeg + rows_per_slice < p.M) ? mbeg + rows_per_slice : p.M;
 
     auto next_valid = [&](int m) {
@@ -400,7 +448,7 @@ template <typename T> static int launch_nt_t(const GemmNT& p, hipStream_t s) {
         SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_done = true;
     }
-    dim3 grid(cdiv(p.M, BM), cdiv(p.N, BN));
+    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN));
     double flops = 0;
     if (srf_prof_on()) flops = nt_issued_flops(p, s);
     SrfLaunchScope ps(s, p.name, flops, 0);
@@ -436,7 +484,7 @@ template <typename T> static int launch_tn_t(const GemmTN& p, hipStream_t s) {
     int rows = cps * MC;
     rows = cdiv(rows, SCENERF_TILE_ROWS) * SCENERF_TILE_ROWS;
     slices = cdiv(p.M, rows);
-    dim3 grid(cdiv(p.N, BN), cdiv(p.K, BN), slices);
+    dim3 grid(cdiv(p.N, BN) * cdiv(p.K, BN) * slices);
     double flops = 0;
     if (srf_prof_on()) flops = tn_issued_flops(p, s);
     SrfLaunchScope ps(s, p.name, flops, 0);

@@ -5,26 +5,6 @@
 
 
 // ------------------------------------------------------------------------------------------------ lin_out
-template <typename T> __device__ static inline void load8(const void* base, size_t idx, float* v);
-template <> __device__ inline void load8<bf16_t>(const void* base, size_t idx, float* v) {
-    uint4 t = *(const uint4*)((const bf16_t*)base + idx);
-    v[0] = bf16lo(t.x); v[1] = bf16hi(t.x); v[2] = bf16lo(t.y); v[3] = bf16hi(t.y);
-    v[4] = bf16lo(t.z); v[5] = bf16hi(t.z); v[6] = bf16lo(t.w); v[7] = bf16hi(t.w);
-}
-template <> __device__ inline void load8<float>(const void* base, size_t idx, float* v) {
-    float4 a = *(const float4*)((const float*)base + idx), b = *(const float4*)((const float*)base + idx + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-template <typename T> __device__ static inline void store8(void* base, size_t idx, const float* v);
-template <> __device__ inline void store8<bf16_t>(void* base, size_t idx, const float* v) {
-    *(uint4*)((bf16_t*)base + idx) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                                pack_bf16x2(v[6], v[7]));
-}
-template <> __device__ inline void store8<float>(void* base, size_t idx, const float* v) {
-    *(float4*)((float*)base + idx) = make_float4(v[0], v[1], v[2], v[3]);
-    *(float4*)((float*)base + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
-}
-
 // logits[m][j] = relu(H3[m][:]) . w_out[j][:] + b_out[j]; one wave per row, lane owns 8 of the 512 columns
 template <typename T, int DO>
 __global__ __launch_bounds__(256) void linout_fwd_kernel(const void* __restrict__ H3, const float* __restrict__ w_out,
@@ -108,7 +88,8 @@ __global__ __launch_bounds__(256) void linout_bwd_kernel(const void* __restrict_
     }
 }
 
-// out[c] += sum_m D[m][c], c in [0, ncols); block = 256 threads, thread owns 8 columns of a row slab
+// out[c] += sum_m D[m][c], c in [0, ncols).  Block = 256 threads over a slab of rows; a thread owns one 8-column
+// group and strides over the slab's rows with 4 independent loads in flight; one atomic per column per block.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ D, int ldd, int ncols, int M, int rows_per_block,
                                                      float* __restrict__ out) {
@@ -121,7 +102,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ D,
     const int me = mb + rows_per_block < M ? mb + rows_per_block : M;
     for (int gg = g; gg < groups; gg += tpr) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int m = mb + rl; m < me; m += rpi) {
+        int m = mb + rl;
+        for (; m + 3 * rpi < me; m += 4 * rpi) {
+            float v0[8], v1[8], v2[8], v3[8];
+            load8<T>(D, (size_t)m * ldd + gg * 8, v0);
+            load8<T>(D, (size_t)(m + rpi) * ldd + gg * 8, v1);
+            load8<T>(D, (size_t)(m + 2 * rpi) * ldd + gg * 8, v2);
+            load8<T>(D, (size_t)(m + 3 * rpi) * ldd + gg * 8, v3);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+        }
+        for (; m < me; m += rpi) {
             float v[8];
             load8<T>(D, (size_t)m * ldd + gg * 8, v);
 #pragma unroll
@@ -159,7 +150,7 @@ static int launch_linout_bwd(int d_out, const void* H3, const float* w, const fl
     return 0;
 }
 template <typename T> static int launch_colsum(const void* D, int ldd, int ncols, int M, float* out, hipStream_t s) {
-    const int rows = 512;
+    const int rows = 128;
     SrfLaunchScope ps(s, "colsum", 0, (double)M * ncols * sizeof(T));
     colsum_kernel<T><<<cdiv(M, rows), 256, 0, s>>>(D, ldd, ncols, M, rows, out);
     SRF_LAUNCH_CHECK("colsum_kernel");
