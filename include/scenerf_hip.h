@@ -193,12 +193,13 @@ int scenerf_hip_sampler_backward(const scenerf_cfg* cfg, const float* offsets, c
                                  scenerf_stream_t stream);
 
 /* ---- generic building blocks exported for unit tests ------------------------------------------------------- */
-/* C[M][N] = A[M][K] @ W[N][K]^T (+bias); act operands per `precision`, fp32 output. */
+/* C[M][N] = relu?(A[M][K]) @ W[N][K]^T (+bias); act operands per `precision`, fp32 output.
+ * tile: 0 = chosen by shape, 1 = 128x128 workgroup tile, 2 = 128x512 (N must be 512). */
 int scenerf_hip_test_gemm_nt(int precision, const void* A, const void* W, const float* bias, int M, int N, int K,
-                             int relu_a, float* C, scenerf_stream_t stream);
-/* C[N][K] += D[M][N]^T @ A[M][K]; act operands, fp32 accumulate (atomics). */
+                             int relu_a, int tile, float* C, scenerf_stream_t stream);
+/* C[N][K] += D[M][N]^T @ relu?(A[M][K]); colsum[N] += column sums of D (may be NULL); fp32 atomics. */
 int scenerf_hip_test_gemm_tn(int precision, const void* D, const void* A, int M, int N, int K, int relu_a,
-                             float* C, scenerf_stream_t stream);
+                             float* C, float* colsum, scenerf_stream_t stream);
 
 /* ---- in-library kernel timing (bench.py's roofline leg) ----------------------------------------------------- */
 /* While enabled every kernel launch is bracketed by hipEvents on its own stream. */

@@ -37,6 +37,7 @@ struct GemmNT {
     const int32_t* tap_texel = nullptr;
     const float* tap_weight = nullptr;
     int scatter_scale = -1;
+    int force_tile = 0;  // 0 = pick by shape, 1 = 128x128 tile, 2 = 128x512 tile (needs N == 512)
     const char* name = "gemm_nt";
 };
 
@@ -51,6 +52,7 @@ struct GemmTN {
     int skip_bit = -1;
     float* out = nullptr;
     int ldo = 0;
+    float* colsum = nullptr;  // optional [N]: += sum_m D[m][n]  (bias gradient, folded into the k-tile-0 workgroups)
     const char* name = "gemm_tn";
 };
 

@@ -1,12 +1,19 @@
 // MFMA GEMM kernels for the ResnetFC pass, written for gfx950 (wave64, v_mfma_f32_32x32x16_bf16 /
 // v_mfma_f32_32x32x2_f32).  Two kernels:
 //   gemm_nt : C[M][N] = epi([A1 | Z-segments] @ W^T)      forward layers, dgrad, feature-gradient scatter
-//   gemm_tn : C[N][K] += D^T @ act(A)                      weight gradients (contraction over the M rows)
-// Tile 128x128 per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA 32x32 blocks, 64 acc VGPRs),
-// K streamed in 128-byte-per-row chunks through a double-buffered, 16-byte-padded LDS image (row stride 144 B
-// => conflict-free ds_read_b128 fragment reads), next chunk prefetched global->VGPR while the MFMAs run.
-// Both element types use the same fragment indexing: lane l holds k = (l>>5)*8 .. +8 of row (l&31); for
-// fp32 the 8 values feed 8 back-to-back 32x32x2 MFMAs (any bijective k-order is valid as A and B agree).
+//   gemm_tn : C[N][K] += D^T @ act(A)  (+ column sums of D) weight and bias gradients (contraction over the M rows)
+//
+// gemm_nt comes in two tile shapes:
+//   wide  128 x 512, 8 waves (2 x 4, each 64 x 128 = 2 x 4 MFMA 32x32 blocks, 128 accumulator VGPRs).  A CU can
+//         only pull ~10 B/clk from HBM, so the hidden-layer GEMMs (N = 512) let ONE workgroup own all 512 output
+//         columns of its 128 rows: the activation stream is read from HBM exactly once and the 512 x K weight panel
+//         streams from L2 (shared by all 1200 row tiles).
+//   small 128 x 128, 4 waves (2 x 2, each 64 x 64) for narrow outputs (per-scale feature gradients, N = 80..1280),
+//         small M (the gaussian head: 4 points per ray) and the unit tests.
+// K is streamed in chunks through a double-buffered LDS image whose rows are padded by 16 bytes (conflict-free
+// ds_read_b128 fragment reads); the next chunk is prefetched global->VGPR while the MFMAs of the current one run.
+// Both element types use the same fragment indexing: lane l holds k = (l>>5)*8 .. +8 of row (l&31); for fp32 the
+// 8 values feed 8 back-to-back 32x32x2 MFMAs (any bijective k-order is valid as long as A and B agree).
 #include <vector>
 
 #include "gemm.h"
@@ -15,24 +22,31 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 #define BM 128
-#define BN 128
-#define ROWB 144                    // bytes per LDS row: 128 data + 16 pad
-#define TILEB (128 * ROWB)          // one operand tile
-#define STAGEB (2 * TILEB)          // A + W
-#define MAX_CHUNKS 128
-#define LDS_BYTES (2 * STAGEB + MAX_CHUNKS * 16 + 16)
-#define CLD 132                     // fp32 C tile row stride in LDS (128 + 4 pad): 128*132*4 = 67584 B <= 2*STAGEB
+#define MAX_CHUNKS 192
+#define CLD 132  // fp32 C tile row stride in LDS (128 + 4 pad): 128*132*4 = 67584 B
 
-template <typename T> struct Elem;
-template <> struct Elem<bf16_t> { static constexpr int BK = 64; };
-template <> struct Elem<float> { static constexpr int BK = 32; };
+template <int TJ_, int NWN_, int RB_> struct TileCfg {
+    static constexpr int TJ = TJ_;              // 32-wide MFMA blocks per wave along N
+    static constexpr int NWN = NWN_;            // waves along N (2 along M)
+    static constexpr int RB = RB_;              // LDS row bytes: data + 16 pad
+    static constexpr int BN = NWN_ * TJ_ * 32;
+    static constexpr int NT = 2 * NWN_ * 64;    // threads
+    static constexpr int TILE_A = BM * RB_;
+    static constexpr int TILE_W = BN * RB_;
+    static constexpr int STAGE = TILE_A + TILE_W;
+    static constexpr int PPR = (RB_ - 16) / 16; // 16-byte pieces per full row
+    static constexpr int NPA = (BM * PPR + NT - 1) / NT;
+    static constexpr int NPW = (BN * PPR + NT - 1) / NT;
+    static constexpr int LDS = 2 * STAGE + MAX_CHUNKS * 16 + 16;
+};
+typedef TileCfg<2, 2, 144> CfgS;  // 128 x 128, 256 threads, 128 B of K per row per chunk
+typedef TileCfg<4, 4, 80> CfgW;   // 128 x 512, 512 threads,  64 B of K per row per chunk
 
 __device__ static inline uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
 
 // XCD-aware block order: the dispatcher places block b on XCD b % 8 (observed, used for speed only).  Give each
-// XCD one contiguous range of the linear tile index, so tiles that share an operand panel (the column tiles of
-// one row tile; all output tiles of one M-slice) run back-to-back on the SAME XCD and hit its private L2.
-// Bijective for any block count (cdna_hip_programming.md T1).
+// XCD one contiguous range of the linear tile index, so tiles that share an operand panel run back-to-back on the
+// SAME XCD and hit its private L2.  Bijective for any block count (cdna_hip_programming.md T1).
 __device__ static inline int xcd_remap(int id, int total) {
     const int q = total >> 3, r = total & 7;
     const int xcd = id & 7, slot = id >> 3;
@@ -48,38 +62,38 @@ template <> __device__ inline uint4 relu16B<float>(uint4 v) {
     return make_uint4((v.x >> 31) ? 0u : v.x, (v.y >> 31) ? 0u : v.y, (v.z >> 31) ? 0u : v.z, (v.w >> 31) ? 0u : v.w);
 }
 
-// one 16-element k-step on a 64x64 wave tile
-template <typename T> struct WaveMma;
-template <> struct WaveMma<bf16_t> {
-    __device__ static inline void step(f32x16_t (&acc)[2][2], const char* As, const char* Ws, int kk, int lane, int wm, int wn) {
+// one 16-element k-step on a (64 x TJ*32) wave tile
+template <typename T, int TJ, int RB> struct WaveMma;
+template <int TJ, int RB> struct WaveMma<bf16_t, TJ, RB> {
+    __device__ static inline void step(f32x16_t (&acc)[2][TJ], const char* As, const char* Ws, int kk, int lane, int wm, int wn) {
         const int koff = (kk * 16 + (lane >> 5) * 8) * 2;
-        uint4 a[2], b[2];
+        uint4 a[2], b[TJ];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *(const uint4*)(As + (wm * 64 + i * 32 + (lane & 31)) * ROWB + koff);
+        for (int i = 0; i < 2; ++i) a[i] = *(const uint4*)(As + (wm * 64 + i * 32 + (lane & 31)) * RB + koff);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = *(const uint4*)(Ws + (wn * 64 + j * 32 + (lane & 31)) * ROWB + koff);
+        for (int j = 0; j < TJ; ++j) b[j] = *(const uint4*)(Ws + (wn * TJ * 32 + j * 32 + (lane & 31)) * RB + koff);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i]),
                                                                     __builtin_bit_cast(bf16x8_t, b[j]), acc[i][j], 0, 0, 0);
     }
 };
-template <> struct WaveMma<float> {
-    __device__ static inline void step(f32x16_t (&acc)[2][2], const char* As, const char* Ws, int kk, int lane, int wm, int wn) {
+template <int TJ, int RB> struct WaveMma<float, TJ, RB> {
+    __device__ static inline void step(f32x16_t (&acc)[2][TJ], const char* As, const char* Ws, int kk, int lane, int wm, int wn) {
         const int koff = (kk * 16 + (lane >> 5) * 8) * 4;
-        float a[2][8], b[2][8];
+        float a[2][8], b[TJ][8];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const char* p = As + (wm * 64 + i * 32 + (lane & 31)) * ROWB + koff;
+            const char* p = As + (wm * 64 + i * 32 + (lane & 31)) * RB + koff;
             float4 lo = *(const float4*)p, hi = *(const float4*)(p + 16);
             a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w;
             a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const char* p = Ws + (wn * 64 + j * 32 + (lane & 31)) * ROWB + koff;
+        for (int j = 0; j < TJ; ++j) {
+            const char* p = Ws + (wn * TJ * 32 + j * 32 + (lane & 31)) * RB + koff;
             float4 lo = *(const float4*)p, hi = *(const float4*)(p + 16);
             b[j][0] = lo.x; b[j][1] = lo.y; b[j][2] = lo.z; b[j][3] = lo.w;
             b[j][4] = hi.x; b[j][5] = hi.y; b[j][6] = hi.z; b[j][7] = hi.w;
@@ -89,12 +103,12 @@ template <> struct WaveMma<float> {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
     }
 };
 
-// epilogue of 8 consecutive columns of one row: v = acc + bias; v += res; v = mask > 0 ? v : 0; v += res2; store | scatter
+// epilogue of 8 consecutive columns of one row: v = acc + bias; v += res; v = mask > 0 ? v : 0; v += res2; store
 template <typename T>
 __device__ __forceinline__ void epi_item(const GemmNT& p, float* v, int m, int n) {
     if (p.bias) {
@@ -120,35 +134,21 @@ __device__ __forceinline__ void epi_item(const GemmNT& p, float* v, int m, int n
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += r[e];
     }
-    if (p.scatter_scale >= 0) {
-        const size_t tb = ((size_t)m * 5 + p.scatter_scale) * 4;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int tx = p.tap_texel[tb + t];
-            if (tx >= 0) {
-                const float w = p.tap_weight[tb + t];
-                float* dst = p.gmap + (size_t)tx * p.N + n;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, v[e] * w);
-            }
-        }
-    } else if (p.out_f32) {
-        store8<float>(p.out, (size_t)m * p.ldout + n, v);
-    } else {
-        store8<T>(p.out, (size_t)m * p.ldout + n, v);
-    }
+    if (p.out_f32) store8<float>(p.out, (size_t)m * p.ldout + n, v);
+    else store8<T>(p.out, (size_t)m * p.ldout + n, v);
 }
 
 // ================================================================================================ NT
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    int4* chunks = (int4*)(lds + 2 * STAGEB);  // {src, a_col, w_col, kc}
+template <typename T, typename CF>
+__global__ __launch_bounds__(CF::NT) void gemm_nt_kernel(GemmNT p) {
     // all LDS lives in the one dynamic region: a static __shared__ would shift its base off 16-byte alignment
-    int* s_n_ptr = (int*)(lds + 2 * STAGEB + MAX_CHUNKS * 16);
-    constexpr int BK = Elem<T>::BK;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int4* chunks = (int4*)(lds + 2 * CF::STAGE);  // {src, a_col, w_col, kc}
+    int* s_n_ptr = (int*)(lds + 2 * CF::STAGE + MAX_CHUNKS * 16);
     constexpr int ES = (int)sizeof(T);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    constexpr int BK = (CF::RB - 16) / ES;
+    constexpr int TJ = CF::TJ, NWN = CF::NWN, RB = CF::RB, BN = CF::BN, NT = CF::NT;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv / NWN, wn = wv % NWN;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (lin / tiles_n) * BM, n0 = (lin % tiles_n) * BN;
@@ -179,34 +179,41 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     __syncthreads();
     const int nch = *s_n_ptr;
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[2][TJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[4], rw[4];
+    uint4 ra[CF::NPA], rw[CF::NPW];
     auto load_chunk = [&](int c) {
         const int4 ch = chunks[c];
-        const int ppr = ch.w * ES / 16;       // 16-byte pieces per row
-        const int np = 128 * ppr;
+        const int ppr = ch.w * ES / 16;  // 16-byte pieces per row
         const char* Ab = (const char*)(ch.x == 0 ? p.A1 : p.A2);
         const size_t lda = (size_t)(ch.x == 0 ? p.lda1 : p.lda2) * ES;
         const bool relu = ch.x == 0 && p.relu1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int q = tid + i * 256;
+        for (int i = 0; i < CF::NPA; ++i) {
+            const int q = tid + i * NT;
             ra[i] = zero4();
-            rw[i] = zero4();
-            if (q < np) {
-                int row = q / ppr, pc = q - row * ppr;
-                int gm = m0 + row, gn = n0 + row;
+            if (q < BM * ppr) {
+                const int row = q / ppr, pc = q - row * ppr;
+                const int gm = m0 + row;
                 if (gm < p.M) {
                     uint4 v = *(const uint4*)(Ab + (size_t)gm * lda + (size_t)ch.y * ES + pc * 16);
                     ra[i] = relu ? relu16B<T>(v) : v;
                 }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CF::NPW; ++i) {
+            const int q = tid + i * NT;
+            rw[i] = zero4();
+            if (q < BN * ppr) {
+                const int row = q / ppr, pc = q - row * ppr;
+                const int gn = n0 + row;
                 if (gn < p.N) rw[i] = *(const uint4*)((const char*)p.W + ((size_t)gn * p.ldw + ch.z) * ES + pc * 16);
             }
         }
@@ -214,16 +221,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     auto store_chunk = [&](int c, int buf) {
         const int4 ch = chunks[c];
         const int ppr = ch.w * ES / 16;
-        const int np = 128 * ppr;
-        char* As = lds + buf * STAGEB;
-        char* Ws = As + TILEB;
+        char* As = lds + buf * CF::STAGE;
+        char* Ws = As + CF::TILE_A;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int q = tid + i * 256;
-            if (q < np) {
-                int row = q / ppr, pc = q - row * ppr;
-                *(uint4*)(As + row * ROWB + pc * 16) = ra[i];
-                *(uint4*)(Ws + row * ROWB + pc * 16) = rw[i];
+        for (int i = 0; i < CF::NPA; ++i) {
+            const int q = tid + i * NT;
+            if (q < BM * ppr) {
+                const int row = q / ppr, pc = q - row * ppr;
+                *(uint4*)(As + row * RB + pc * 16) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CF::NPW; ++i) {
+            const int q = tid + i * NT;
+            if (q < BN * ppr) {
+                const int row = q / ppr, pc = q - row * ppr;
+                *(uint4*)(Ws + row * RB + pc * 16) = rw[i];
             }
         }
     };
@@ -236,46 +249,86 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     for (int c = 0; c < nch; ++c) {
         const int buf = c & 1;
         if (c + 1 < nch) load_chunk(c + 1);
-        const char* As = lds + buf * STAGEB;
-        const char* Ws = As + TILEB;
+        const char* As = lds + buf * CF::STAGE;
+        const char* Ws = As + CF::TILE_A;
         const int ks = chunks[c].w / 16;
-        for (int kk = 0; kk < ks; ++kk) WaveMma<T>::step(acc, As, Ws, kk, lane, wm, wn);
+        for (int kk = 0; kk < ks; ++kk) WaveMma<T, TJ, RB>::step(acc, As, Ws, kk, lane, wm, wn);
         if (c + 1 < nch) store_chunk(c + 1, buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: stage the 128x128 fp32 tile in LDS (reusing the operand buffers), then every thread handles
-    // 8 consecutive columns of a row with 16/32-byte global accesses (the MFMA C layout gives a lane one column of
-    // 16 scattered rows: storing from it directly means 2-byte strided accesses and was the dominant cost) ------
+    // ---- epilogue: stage 128 x 128 fp32 column passes in LDS (reusing the operand buffers), then every thread
+    // handles 8 consecutive columns of a row with 16/32-byte global accesses (the MFMA C layout gives a lane one
+    // column of 16 scattered rows: storing from it directly means 2-byte strided accesses) -------------------------
     float* Cs = (float*)lds;
-#define CS_W(i, j, r) Cs[(wm * 64 + (i) * 32 + ((r) & 3) + 8 * ((r) >> 2) + 4 * (lane >> 5)) * CLD + wn * 64 + (j) * 32 + (lane & 31)] = acc[i][j][r];
+    constexpr int NPASS = BN / 128;
+    constexpr int WCOLS = TJ * 32;  // columns owned by one wave
+#define CS_W(i, j, r) Cs[(wm * 64 + (i) * 32 + ((r) & 3) + 8 * ((r) >> 2) + 4 * (lane >> 5)) * CLD + cbase + (j) * 32 + (lane & 31)] = acc[i][j][r];
 #define CS_TILE(i, j)                                                                                               \
     CS_W(i, j, 0) CS_W(i, j, 1) CS_W(i, j, 2) CS_W(i, j, 3) CS_W(i, j, 4) CS_W(i, j, 5) CS_W(i, j, 6) CS_W(i, j, 7) \
     CS_W(i, j, 8) CS_W(i, j, 9) CS_W(i, j, 10) CS_W(i, j, 11) CS_W(i, j, 12) CS_W(i, j, 13) CS_W(i, j, 14) CS_W(i, j, 15)
-    CS_TILE(0, 0)
-    CS_TILE(0, 1)
-    CS_TILE(1, 0)
-    CS_TILE(1, 1)
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        if ((wn * WCOLS) / 128 == pass) {
+            const int cbase = (wn * WCOLS) % 128;
+            CS_TILE(0, 0)
+            CS_TILE(0, 1)
+            CS_TILE(1, 0)
+            CS_TILE(1, 1)
+            if constexpr (TJ == 4) {
+                CS_TILE(0, 2)
+                CS_TILE(0, 3)
+                CS_TILE(1, 2)
+                CS_TILE(1, 3)
+            }
+        }
+        __syncthreads();
+        const int nb = n0 + pass * 128;
+        if (p.scatter_scale >= 0) {
+            // grid_sampler backward: lanes span 64 consecutive channels of one row, so each atomic instruction adds a
+            // contiguous 256-byte run of the (H,W,C) gradient map; the 4 taps of the row are wave-uniform.
+            for (int row = wv; row < BM; row += NT / 64) {
+                const int m = m0 + row;
+                if (m >= p.M) break;
+                const size_t tb = ((size_t)m * 5 + p.scatter_scale) * 4;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int col = h * 64 + lane, n = nb + col;
+                    if (n < p.N) {
+                        const float v = Cs[row * CLD + col];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int tx = p.tap_texel[tb + t];
+                            if (tx >= 0) unsafeAtomicAdd(p.gmap + (size_t)tx * p.N + n, v * p.tap_weight[tb + t]);
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int it = tid; it < BM * 16; it += NT) {
+                const int row = it >> 4, cg = it & 15;
+                const int m = m0 + row, n = nb + cg * 8;
+                if (m < p.M && n < p.N) {
+                    float v[8];
+                    const float4 lo = *(const float4*)(Cs + row * CLD + cg * 8), hi = *(const float4*)(Cs + row * CLD + cg * 8 + 4);
+                    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+                    epi_item<T>(p, v, m, n);
+                }
+            }
+        }
+        if (pass + 1 < NPASS) __syncthreads();
+    }
 #undef CS_TILE
 #undef CS_W
-    __syncthreads();
-#pragma unroll 2
-    for (int it = tid; it < BM * (BN / 8); it += 256) {
-        const int row = it >> 4, cg = it & 15;
-        const int m = m0 + row, n = n0 + cg * 8;
-        if (m < p.M && n < p.N) {
-            float v[8];
-            const float4 lo = *(const float4*)(Cs + row * CLD + cg * 8), hi = *(const float4*)(Cs + row * CLD + cg * 8 + 4);
-            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-            epi_item<T>(p, v, m, n);
-        }
-    }
 }
 
 // ================================================================================================ TN
 // Transposing stage: each thread owns a square block (8x8 bf16 / 4x4 fp32) of the [rows m][cols] source
 // tile, loads it with coalesced 16-byte row reads, transposes it in registers and writes 16-byte rows of
 // the [col][m] LDS image, so fragment reads are the same ds_read_b128 as in the NT kernel.
+#define TN_RB 144
+#define TN_TILE (128 * TN_RB)
+#define TN_STAGE (2 * TN_TILE)
 template <typename T> struct TnStage;
 template <> struct TnStage<bf16_t> {
     static constexpr int MC = 64;  // contraction rows per chunk
@@ -297,7 +350,7 @@ template <> struct TnStage<bf16_t> {
     }
     __device__ inline void store(char* stage, int tid) const {
         const int op = tid >> 7, b = tid & 127, mb = b >> 4, nb = b & 15;
-        char* tile = stage + op * TILEB;
+        char* tile = stage + op * TN_TILE;
         const uint32_t* w = (const uint32_t*)r;  // w[j*4 + q] = row j, column pair q
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -307,8 +360,18 @@ template <> struct TnStage<bf16_t> {
                 uint32_t a = w[(2 * q) * 4 + (c >> 1)], bb = w[(2 * q + 1) * 4 + (c >> 1)];
                 o[q] = (c & 1) ? ((a >> 16) | (bb & 0xffff0000u)) : ((a & 0xffffu) | (bb << 16));
             }
-            *(uint4*)(tile + (nb * 8 + c) * ROWB + mb * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+            *(uint4*)(tile + (nb * 8 + c) * TN_RB + mb * 16) = make_uint4(o[0], o[1], o[2], o[3]);
         }
+    }
+    // sum of the MC staged values of D-tile row `row` (one output column n)
+    __device__ static inline float rowsum(const char* Dt, int row) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            uint4 t = *(const uint4*)(Dt + row * TN_RB + q * 16);
+            s += (bf16lo(t.x) + bf16hi(t.x)) + (bf16lo(t.y) + bf16hi(t.y)) + (bf16lo(t.z) + bf16hi(t.z)) + (bf16lo(t.w) + bf16hi(t.w));
+        }
+        return s;
     }
 };
 template <> struct TnStage<float> {
@@ -337,12 +400,21 @@ template <> struct TnStage<float> {
         const int mb = tid >> 5, nb = tid & 31;
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
-            char* tile = stage + op * TILEB;
-            *(float4*)(tile + (nb * 4 + 0) * ROWB + mb * 16) = make_float4(r[op][0].x, r[op][1].x, r[op][2].x, r[op][3].x);
-            *(float4*)(tile + (nb * 4 + 1) * ROWB + mb * 16) = make_float4(r[op][0].y, r[op][1].y, r[op][2].y, r[op][3].y);
-            *(float4*)(tile + (nb * 4 + 2) * ROWB + mb * 16) = make_float4(r[op][0].z, r[op][1].z, r[op][2].z, r[op][3].z);
-            *(float4*)(tile + (nb * 4 + 3) * ROWB + mb * 16) = make_float4(r[op][0].w, r[op][1].w, r[op][2].w, r[op][3].w);
+            char* tile = stage + op * TN_TILE;
+            *(float4*)(tile + (nb * 4 + 0) * TN_RB + mb * 16) = make_float4(r[op][0].x, r[op][1].x, r[op][2].x, r[op][3].x);
+            *(float4*)(tile + (nb * 4 + 1) * TN_RB + mb * 16) = make_float4(r[op][0].y, r[op][1].y, r[op][2].y, r[op][3].y);
+            *(float4*)(tile + (nb * 4 + 2) * TN_RB + mb * 16) = make_float4(r[op][0].z, r[op][1].z, r[op][2].z, r[op][3].z);
+            *(float4*)(tile + (nb * 4 + 3) * TN_RB + mb * 16) = make_float4(r[op][0].w, r[op][1].w, r[op][2].w, r[op][3].w);
         }
+    }
+    __device__ static inline float rowsum(const char* Dt, int row) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float4 t = *(const float4*)(Dt + row * TN_RB + q * 16);
+            s += (t.x + t.y) + (t.z + t.w);
+        }
+        return s;
     }
 };
 
@@ -350,13 +422,15 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_slice) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int MC = TnStage<T>::MC;
+    constexpr int BN = 128;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_k = (p.K + BN - 1) / BN;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);   // lin = slice * (tiles_n*tiles_k) + tile
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);  // lin = slice * (tiles_n*tiles_k) + tile
     const int tile = lin % (tiles_n * tiles_k);
     const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BN;
     const int mbeg = (lin / (tiles_n * tiles_k)) * rows_per_slice;
     const int mend = (mbeg + rows_per_slice < p.M) ? mbeg + rows_per_slice : p.M;
+    const bool do_colsum = p.colsum != nullptr && k0 == 0 && tid < 128;
 
     auto next_valid = [&](int m) {
         if (p.tile_mask && p.skip_bit >= 0) {
@@ -372,6 +446,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float csum = 0.f;
 
     TnStage<T> st;
     int c = next_valid(mbeg);
@@ -383,11 +458,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
     while (c < mend) {
         const int nx = next_valid(c + MC);
         if (nx < mend) st.load(p, tid, nx, n0, k0);
-        const char* Dt = lds + buf * STAGEB;
-        const char* At = Dt + TILEB;
+        const char* Dt = lds + buf * TN_STAGE;
+        const char* At = Dt + TN_TILE;
 #pragma unroll
-        for (int kk = 0; kk < MC / 16; ++kk) WaveMma<T>::step(acc, Dt, At, kk, lane, wm, wn);
-        if (nx < mend) st.store(lds + (buf ^ 1) * STAGEB, tid);
+        for (int kk = 0; kk < MC / 16; ++kk) WaveMma<T, 2, TN_RB>::step(acc, Dt, At, kk, lane, wm, wn);
+        if (do_colsum) csum += TnStage<T>::rowsum(Dt, tid);  // bias gradient: column sums of D (staged rows are zero-padded)
+        if (nx < mend) st.store(lds + (buf ^ 1) * TN_STAGE, tid);
         __syncthreads();
         buf ^= 1;
         c = nx;
@@ -403,6 +479,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
                 if (n < p.N && k < p.K) unsafeAtomicAdd(p.out + (size_t)n * p.ldo + k, acc[i][j][r]);
             }
         }
+    if (do_colsum && n0 + tid < p.N) unsafeAtomicAdd(p.colsum + n0 + tid, csum);
 }
 
 // ================================================================================================ launchers
@@ -426,7 +503,8 @@ static double nt_issued_flops(const GemmNT& p, hipStream_t s) {
         int rows = p.M - t * SCENERF_TILE_ROWS < SCENERF_TILE_ROWS ? p.M - t * SCENERF_TILE_ROWS : SCENERF_TILE_ROWS;
         if (p.skip_bit >= 0 && !((m[t] >> p.skip_bit) & 1)) continue;
         double k = p.K1;
-        for (int i = 0; i < p.nseg; ++i) if ((m[t] >> i) & 1) k += p.seg_len[i];
+        for (int i = 0; i < p.nseg; ++i)
+            if ((m[t] >> i) & 1) k += p.seg_len[i];
         f += 2.0 * rows * (double)p.N * k;
     }
     return f;
@@ -442,17 +520,18 @@ static double tn_issued_flops(const GemmTN& p, hipStream_t s) {
     }
     return f;
 }
-template <typename T> static int launch_nt_t(const GemmNT& p, hipStream_t s) {
+
+template <typename T, typename CF> static int launch_nt_t(const GemmNT& p, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
         attr_done = true;
     }
-    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN));
+    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, CF::BN));
     double flops = 0;
     if (srf_prof_on()) flops = nt_issued_flops(p, s);
     SrfLaunchScope ps(s, p.name, flops, 0);
-    gemm_nt_kernel<T><<<grid, 256, LDS_BYTES, s>>>(p);
+    gemm_nt_kernel<T, CF><<<grid, CF::NT, CF::LDS, s>>>(p);
     SRF_LAUNCH_CHECK(p.name);
     return 0;
 }
@@ -464,31 +543,34 @@ int launch_gemm_nt(int precision, const GemmNT& p, hipStream_t s) {
     SRF_CHECK(p.nseg == 0 || p.A2, "%s: A2 NULL", p.name);
     for (int i = 0; i < p.nseg; ++i) SRF_CHECK(p.seg_len[i] % 16 == 0 && p.seg_off[i] % 8 == 0, "%s: segment %d misaligned", p.name, i);
     SRF_CHECK(p.scatter_scale >= 0 ? (p.gmap && p.tap_texel && p.tap_weight) : (p.out != nullptr), "%s: missing output", p.name);
-    return precision ? launch_nt_t<bf16_t>(p, s) : launch_nt_t<float>(p, s);
+    // wide tile when the output is a full 512-column hidden layer and there are enough row tiles to fill the chip
+    const bool wide = (p.N == 512) && (p.force_tile == 2 || (p.force_tile == 0 && cdiv(p.M, BM) >= 192));
+    if (wide) return precision ? launch_nt_t<bf16_t, CfgW>(p, s) : launch_nt_t<float, CfgW>(p, s);
+    return precision ? launch_nt_t<bf16_t, CfgS>(p, s) : launch_nt_t<float, CfgS>(p, s);
 }
 
 template <typename T> static int launch_tn_t(const GemmTN& p, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        SRF_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGEB));
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE));
         attr_done = true;
     }
     constexpr int MC = TnStage<T>::MC;
-    int tiles = cdiv(p.N, BN) * cdiv(p.K, BN);
+    int tiles = cdiv(p.N, 128) * cdiv(p.K, 128);
     int chunks = cdiv(p.M, MC);
     int slices = 1024 / tiles;
     if (slices < 1) slices = 1;
     if (slices > chunks) slices = chunks;
-    int cps = cdiv(chunks, slices);          // chunks per slice
+    int cps = cdiv(chunks, slices);  // chunks per slice
     // keep slices aligned to the 128-row mask granularity
     int rows = cps * MC;
     rows = cdiv(rows, SCENERF_TILE_ROWS) * SCENERF_TILE_ROWS;
     slices = cdiv(p.M, rows);
-    dim3 grid(cdiv(p.N, BN) * cdiv(p.K, BN) * slices);
+    dim3 grid(tiles * slices);
     double flops = 0;
     if (srf_prof_on()) flops = tn_issued_flops(p, s);
     SrfLaunchScope ps(s, p.name, flops, 0);
-    gemm_tn_kernel<T><<<grid, 256, 2 * STAGEB, s>>>(p, rows);
+    gemm_tn_kernel<T><<<grid, 256, 2 * TN_STAGE, s>>>(p, rows);
     SRF_LAUNCH_CHECK(p.name);
     return 0;
 }

@@ -256,6 +256,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             t.name = "gemm_wgrad_fc1";
             t.D = dHcol(b + 1); t.ldd = LDH; t.A = a->Nn[b]; t.lda = SCENERF_D_HIDDEN; t.relu_a = 1;
             t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc1[b]; t.ldo = SCENERF_D_HIDDEN;
+            t.colsum = g_->b_fc1[b];  // fc_1.b.bias gradient = column sums of dH_{b+1}
             if (int e = launch_gemm_tn(prec, t, s)) return e;
         }
         {   // dN_b = (dH_{b+1} @ W1_b) * [N_b > 0]
@@ -268,15 +269,13 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             g.out = dN; g.ldout = SCENERF_D_HIDDEN;
             if (int e = launch_gemm_nt(prec, g, s)) return e;
         }
-        {   // dW0_b += dN_b^T relu(H_b);  db0_b = colsum(dN_b)
+        {   // dW0_b += dN_b^T relu(H_b);  db0_b = column sums of dN_b
             GemmTN t;
             t.name = "gemm_wgrad_fc0";
             t.D = dN; t.ldd = SCENERF_D_HIDDEN; t.A = a->H[b]; t.lda = SCENERF_D_HIDDEN; t.relu_a = 1;
             t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc0[b]; t.ldo = SCENERF_D_HIDDEN;
+            t.colsum = g_->b_fc0[b];
             if (int e = launch_gemm_tn(prec, t, s)) return e;
-            int e = prec ? launch_colsum<bf16_t>(dN, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN, M, g_->b_fc0[b], s)
-                         : launch_colsum<float>(dN, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN, M, g_->b_fc0[b], s);
-            if (e) return e;
         }
         {   // dH_b = dH_{b+1} + (dN_b @ W0_b) * [H_b > 0]
             GemmNT g;
@@ -289,21 +288,6 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             g.out = dHcol(b); g.ldout = LDH;
             if (int e = launch_gemm_nt(prec, g, s)) return e;
         }
-    }
-    // bias gradients: S_b = colsum(dH_b).  lin_z.b.bias <- S_b (b<3); fc_1.b.bias <- S_{b+1}; lin_in.bias <- S_0.
-    // One pass over dH gives all four 512-column sums; the host copies S_0 into b_in and S_{1..3} into b_fc1.
-    {
-        // b_z holds [S0|S1|S2]; b_fc1[b] gets S_{b+1}
-        int e = prec ? launch_colsum<bf16_t>(dH, LDH, 3 * SCENERF_D_HIDDEN, M, g_->b_z, s)
-                     : launch_colsum<float>(dH, LDH, 3 * SCENERF_D_HIDDEN, M, g_->b_z, s);
-        if (e) return e;
-        e = prec ? launch_colsum<bf16_t>(dHcol(3), LDH, SCENERF_D_HIDDEN, M, g_->b_fc1[2], s)
-                 : launch_colsum<float>(dHcol(3), LDH, SCENERF_D_HIDDEN, M, g_->b_fc1[2], s);
-        if (e) return e;
-        // S_1, S_2, S_0 are plain copies of slices of b_z (device-to-device adds onto zeroed buffers)
-        SRF_HIP(hipMemcpyAsync(g_->b_fc1[0], g_->b_z + SCENERF_D_HIDDEN, SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s));
-        SRF_HIP(hipMemcpyAsync(g_->b_fc1[1], g_->b_z + 2 * SCENERF_D_HIDDEN, SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s));
-        SRF_HIP(hipMemcpyAsync(g_->b_in, g_->b_z, SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     // dWz[:, slice_s] += dH[:, 0:1536]^T Z[:, slice_s]   (row-tiles without scale s skipped)
     for (int sc = 0; sc < 5; ++sc) {
@@ -331,8 +315,13 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             t.A = xenc;
         }
         t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_XENC; t.out = g_->w_in; t.ldo = SCENERF_D_XENC;
+        t.colsum = g_->b_in;  // lin_in.bias gradient = column sums of dH_0
         if (int e = launch_gemm_tn(prec, t, s)) return e;
     }
+    // lin_z.b.bias is added at the same place as lin_in.bias (b=0) / fc_1.(b-1).bias: same column sums of dH_b
+    SRF_HIP(hipMemcpyAsync(g_->b_z, g_->b_in, SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s));
+    SRF_HIP(hipMemcpyAsync(g_->b_z + SCENERF_D_HIDDEN, g_->b_fc1[0], SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s));
+    SRF_HIP(hipMemcpyAsync(g_->b_z + 2 * SCENERF_D_HIDDEN, g_->b_fc1[1], SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s));
     // dZ[:, slice_s] = dH[:, 0:1536] @ Wz[:, slice_s], scattered straight into the (H,W,C) map gradients
     if (gmaps_hwc) {
         for (int sc = 0; sc < 5; ++sc) {
@@ -351,9 +340,10 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
 }
 
 int scenerf_hip_test_gemm_nt(int precision, const void* A, const void* W, const float* bias, int M, int N, int K, int relu_a,
-                             float* C, scenerf_stream_t stream) {
+                             int tile, float* C, scenerf_stream_t stream) {
     GemmNT g;
     g.name = "test_gemm_nt";
+    g.force_tile = tile;
     g.A1 = A; g.lda1 = K; g.K1 = K; g.relu1 = relu_a;
     g.W = W; g.ldw = K; g.M = M; g.N = N; g.bias = bias;
     g.out = C; g.ldout = N; g.out_f32 = 1;
@@ -361,9 +351,10 @@ int scenerf_hip_test_gemm_nt(int precision, const void* A, const void* W, const 
 }
 
 int scenerf_hip_test_gemm_tn(int precision, const void* D, const void* A, int M, int N, int K, int relu_a, float* C,
-                             scenerf_stream_t stream) {
+                             float* colsum, scenerf_stream_t stream) {
     GemmTN t;
     t.name = "test_gemm_tn";
+    t.colsum = colsum;
     t.D = D; t.ldd = N; t.A = A; t.lda = K; t.relu_a = relu_a;
     t.M = M; t.N = N; t.K = K; t.out = C; t.ldo = K;
     return launch_gemm_tn(precision, t, as_stream(stream));

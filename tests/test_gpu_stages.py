@@ -63,8 +63,9 @@ def dv(t, dtype=None):
 
 # ------------------------------------------------------------------------------------------------ GEMM building blocks
 @pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(300, 136, 80), (128, 128, 64), (517, 512, 560), (256, 80, 1536)])
-def test_gemm_nt_matches_fp64(prec, M, N, K):
+@pytest.mark.parametrize("M,N,K,tile", [(300, 136, 80, 1), (128, 128, 64, 1), (517, 512, 560, 1), (256, 80, 1536, 1),
+                                        (517, 512, 560, 2), (130, 512, 48, 2), (1000, 512, 512, 2)])
+def test_gemm_nt_matches_fp64(prec, M, N, K, tile):
     lib = _capi.load()
     gen = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     A = torch.randn(M, K, generator=gen)
@@ -73,7 +74,7 @@ def test_gemm_nt_matches_fp64(prec, M, N, K):
     dt = torch.bfloat16 if prec else torch.float32
     Ad, Wd = dv(A, dt), dv(W, dt)
     Cd = torch.full((M, N), float("nan"), device=DEV)
-    _capi.check(lib.scenerf_hip_test_gemm_nt(prec, Ad.data_ptr(), Wd.data_ptr(), dv(b).data_ptr(), M, N, K, 1, Cd.data_ptr(), _st()), "gemm_nt")
+    _capi.check(lib.scenerf_hip_test_gemm_nt(prec, Ad.data_ptr(), Wd.data_ptr(), dv(b).data_ptr(), M, N, K, 1, tile, Cd.data_ptr(), _st()), "gemm_nt")
     ref = torch.relu(Ad.float().double().cpu()) @ Wd.float().double().cpu().T + b.double()
     scale = (torch.relu(Ad.float().cpu()).abs().double() @ Wd.float().cpu().abs().double().T).max()
     err = (Cd.double().cpu() - ref).abs().max()
@@ -90,7 +91,11 @@ def test_gemm_tn_matches_fp64(prec, M, N, K):
     dt = torch.bfloat16 if prec else torch.float32
     Dd, Ad = dv(D, dt), dv(A, dt)
     Cd = torch.zeros((N, K), device=DEV)
-    _capi.check(lib.scenerf_hip_test_gemm_tn(prec, Dd.data_ptr(), Ad.data_ptr(), M, N, K, 1, Cd.data_ptr(), _st()), "gemm_tn")
+    cs = torch.zeros((N,), device=DEV)
+    _capi.check(lib.scenerf_hip_test_gemm_tn(prec, Dd.data_ptr(), Ad.data_ptr(), M, N, K, 1, Cd.data_ptr(), cs.data_ptr(), _st()), "gemm_tn")
+    cref = Dd.float().double().cpu().sum(0)
+    cerr = (cs.double().cpu() - cref).abs().max()
+    assert cerr <= 1e-5 * Dd.float().abs().double().cpu().sum(0).max(), "colsum err %.3e" % cerr
     ref = Dd.float().double().cpu().T @ torch.relu(Ad.float().double().cpu())
     scale = (Dd.float().cpu().abs().double().T @ torch.relu(Ad.float().cpu()).abs().double()).max()
     err = (Cd.double().cpu() - ref).abs().max()
