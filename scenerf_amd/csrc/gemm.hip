@@ -43,6 +43,7 @@ typedef TileCfg<2, 2, 144> CfgS;  // 128 x 128, 256 threads, 128 B of K per row 
 typedef TileCfg<4, 4, 80> CfgW;   // 128 x 512, 512 threads,  64 B of K per row per chunk
 
 __device__ static inline uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
+__device__ static inline int pieces_shift(int ppr) { return ppr >= 8 ? 3 : ppr >= 4 ? 2 : ppr >= 2 ? 1 : 0; }
 
 // XCD-aware block order: the dispatcher places block b on XCD b % 8 (observed, used for speed only).  Give each
 // XCD one contiguous range of the linear tile index, so tiles that share an operand panel run back-to-back on the
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(CF::NT) void gemm_nt_kernel(GemmNT p) {
         int n = 0;
         for (int k0 = 0; k0 < p.K1; k0 += BK) {
             int kc = p.K1 - k0 < BK ? p.K1 - k0 : BK;
-            chunks[n++] = make_int4(0, k0, k0, kc);
+            chunks[n++] = make_int4(0, k0, k0, kc | (pieces_shift(kc * ES / 16) << 16));
         }
         int wbase = p.K1;
 #pragma unroll
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(CF::NT) void gemm_nt_kernel(GemmNT p) {
             if (s < p.nseg && ((mask >> s) & 1u)) {
                 for (int k0 = 0; k0 < p.seg_len[s]; k0 += BK) {
                     int kc = p.seg_len[s] - k0 < BK ? p.seg_len[s] - k0 : BK;
-                    chunks[n++] = make_int4(1, p.seg_off[s] + k0, wbase + k0, kc);
+                    chunks[n++] = make_int4(1, p.seg_off[s] + k0, wbase + k0, kc | (pieces_shift(kc * ES / 16) << 16));
                 }
             }
             if (s < p.nseg) wbase += p.seg_len[s];
@@ -187,56 +188,54 @@ __global__ __launch_bounds__(CF::NT) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Prefetch discipline: load_chunk is branch-free straight-line code that only ISSUES global loads (indices
+    // clamped, nothing consumes the data), so all loads of a chunk go out back-to-back and hipcc's s_waitcnt lands in
+    // store_chunk, after the MFMAs of the current chunk.  (A guarded load sits in its own basic block and hipcc then
+    // waits vmcnt(0) in front of every one of them: each load paid a full memory latency.)  ReLU and the zeroing of
+    // out-of-range rows happen on the way into LDS.  Pieces per row is a power of two: row/piece via shifts.
     uint4 ra[CF::NPA], rw[CF::NPW];
     auto load_chunk = [&](int c) {
         const int4 ch = chunks[c];
-        const int ppr = ch.w * ES / 16;  // 16-byte pieces per row
+        const int sh = ch.w >> 16;             // log2(16-byte pieces per row)
+        const int pm = (1 << sh) - 1;
         const char* Ab = (const char*)(ch.x == 0 ? p.A1 : p.A2);
         const size_t lda = (size_t)(ch.x == 0 ? p.lda1 : p.lda2) * ES;
-        const bool relu = ch.x == 0 && p.relu1;
 #pragma unroll
         for (int i = 0; i < CF::NPA; ++i) {
-            const int q = tid + i * NT;
-            ra[i] = zero4();
-            if (q < BM * ppr) {
-                const int row = q / ppr, pc = q - row * ppr;
-                const int gm = m0 + row;
-                if (gm < p.M) {
-                    uint4 v = *(const uint4*)(Ab + (size_t)gm * lda + (size_t)ch.y * ES + pc * 16);
-                    ra[i] = relu ? relu16B<T>(v) : v;
-                }
-            }
+            const int q = min(tid + i * NT, (BM << sh) - 1);
+            const int gm = min(m0 + (q >> sh), p.M - 1);
+            ra[i] = *(const uint4*)(Ab + (size_t)gm * lda + (size_t)ch.y * ES + (q & pm) * 16);
         }
 #pragma unroll
         for (int i = 0; i < CF::NPW; ++i) {
-            const int q = tid + i * NT;
-            rw[i] = zero4();
-            if (q < BN * ppr) {
-                const int row = q / ppr, pc = q - row * ppr;
-                const int gn = n0 + row;
-                if (gn < p.N) rw[i] = *(const uint4*)((const char*)p.W + ((size_t)gn * p.ldw + ch.z) * ES + pc * 16);
-            }
+            const int q = min(tid + i * NT, (BN << sh) - 1);
+            const int gn = min(n0 + (q >> sh), p.N - 1);
+            rw[i] = *(const uint4*)((const char*)p.W + ((size_t)gn * p.ldw + ch.z) * ES + (q & pm) * 16);
         }
     };
     auto store_chunk = [&](int c, int buf) {
         const int4 ch = chunks[c];
-        const int ppr = ch.w * ES / 16;
+        const int sh = ch.w >> 16;
+        const int pm = (1 << sh) - 1;
+        const bool relu = ch.x == 0 && p.relu1;
         char* As = lds + buf * CF::STAGE;
         char* Ws = As + CF::TILE_A;
 #pragma unroll
         for (int i = 0; i < CF::NPA; ++i) {
             const int q = tid + i * NT;
-            if (q < BM * ppr) {
-                const int row = q / ppr, pc = q - row * ppr;
-                *(uint4*)(As + row * RB + pc * 16) = ra[i];
+            if (q < (BM << sh)) {
+                const int row = q >> sh;
+                uint4 v = (m0 + row < p.M) ? ra[i] : zero4();
+                if (relu) v = relu16B<T>(v);
+                *(uint4*)(As + row * RB + (q & pm) * 16) = v;
             }
         }
 #pragma unroll
         for (int i = 0; i < CF::NPW; ++i) {
             const int q = tid + i * NT;
-            if (q < BN * ppr) {
-                const int row = q / ppr, pc = q - row * ppr;
-                *(uint4*)(Ws + row * RB + pc * 16) = rw[i];
+            if (q < (BN << sh)) {
+                const int row = q >> sh;
+                *(uint4*)(Ws + row * RB + (q & pm) * 16) = (n0 + row < p.N) ? rw[i] : zero4();
             }
         }
     };
@@ -248,10 +247,10 @@ __global__ __launch_bounds__(CF::NT) void gemm_nt_kernel(GemmNT p) {
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nch) load_chunk(c + 1);
+        load_chunk(c + 1 < nch ? c + 1 : c);  // unconditional (the last iteration re-reads its own chunk, unused)
         const char* As = lds + buf * CF::STAGE;
         const char* Ws = As + CF::TILE_A;
-        const int ks = chunks[c].w / 16;
+        const int ks = (chunks[c].w & 0xffff) / 16;
         for (int kk = 0; kk < ks; ++kk) WaveMma<T, TJ, RB>::step(acc, As, Ws, kk, lane, wm, wn);
         if (c + 1 < nch) store_chunk(c + 1, buf ^ 1);
         __syncthreads();
@@ -333,24 +332,29 @@ template <typename T> struct TnStage;
 template <> struct TnStage<bf16_t> {
     static constexpr int MC = 64;  // contraction rows per chunk
     uint4 r[8];
+    // load() only issues the global loads (clamped indices, no consumer) so the wait lands in store()
     __device__ inline void load(const GemmTN& p, int tid, int mc, int n0, int k0) {
         const int op = tid >> 7, b = tid & 127, mb = b >> 4, nb = b & 15;
         const char* base = (const char*)(op == 0 ? p.D : p.A);
         const size_t ld = (size_t)(op == 0 ? p.ldd : p.lda) * 2;
-        const int col = (op == 0 ? n0 : k0) + nb * 8;
-        const bool cok = col < (op == 0 ? p.N : p.K);
+        const int lim = (op == 0 ? p.N : p.K) - 8;
+        const int col = min((op == 0 ? n0 : k0) + nb * 8, lim);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = min(mc + mb * 8 + j, p.M - 1);
+            r[j] = *(const uint4*)(base + (size_t)m * ld + (size_t)col * 2);
+        }
+    }
+    __device__ inline void store(const GemmTN& p, char* stage, int tid, int mc, int n0, int k0) {
+        const int op = tid >> 7, b = tid & 127, mb = b >> 4, nb = b & 15;
+        char* tile = stage + op * TN_TILE;
+        const bool cok = (op == 0 ? n0 : k0) + nb * 8 < (op == 0 ? p.N : p.K);
         const bool relu = op == 1 && p.relu_a;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            int m = mc + mb * 8 + j;
-            uint4 v = zero4();
-            if (cok && m < p.M) v = *(const uint4*)(base + (size_t)m * ld + (size_t)col * 2);
+            uint4 v = (cok && mc + mb * 8 + j < p.M) ? r[j] : zero4();
             r[j] = relu ? relu16B<bf16_t>(v) : v;
         }
-    }
-    __device__ inline void store(char* stage, int tid) const {
-        const int op = tid >> 7, b = tid & 127, mb = b >> 4, nb = b & 15;
-        char* tile = stage + op * TN_TILE;
         const uint32_t* w = (const uint32_t*)r;  // w[j*4 + q] = row j, column pair q
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -383,24 +387,28 @@ template <> struct TnStage<float> {
         for (int op = 0; op < 2; ++op) {
             const char* base = (const char*)(op == 0 ? p.D : p.A);
             const size_t ld = (size_t)(op == 0 ? p.ldd : p.lda) * 4;
-            const int col = (op == 0 ? n0 : k0) + nb * 4;
-            const bool cok = col < (op == 0 ? p.N : p.K);
-            const bool relu = op == 1 && p.relu_a;
+            const int lim = (op == 0 ? p.N : p.K) - 4;
+            const int col = min((op == 0 ? n0 : k0) + nb * 4, lim);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int m = mc + mb * 4 + j;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cok && m < p.M) v = *(const float4*)(base + (size_t)m * ld + (size_t)col * 4);
-                if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                r[op][j] = v;
+                const int m = min(mc + mb * 4 + j, p.M - 1);
+                r[op][j] = *(const float4*)(base + (size_t)m * ld + (size_t)col * 4);
             }
         }
     }
-    __device__ inline void store(char* stage, int tid) const {
+    __device__ inline void store(const GemmTN& p, char* stage, int tid, int mc, int n0, int k0) {
         const int mb = tid >> 5, nb = tid & 31;
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
             char* tile = stage + op * TN_TILE;
+            const bool cok = (op == 0 ? n0 : k0) + nb * 4 < (op == 0 ? p.N : p.K);
+            const bool relu = op == 1 && p.relu_a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 v = (cok && mc + mb * 4 + j < p.M) ? r[op][j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                r[op][j] = v;
+            }
             *(float4*)(tile + (nb * 4 + 0) * TN_RB + mb * 16) = make_float4(r[op][0].x, r[op][1].x, r[op][2].x, r[op][3].x);
             *(float4*)(tile + (nb * 4 + 1) * TN_RB + mb * 16) = make_float4(r[op][0].y, r[op][1].y, r[op][2].y, r[op][3].y);
             *(float4*)(tile + (nb * 4 + 2) * TN_RB + mb * 16) = make_float4(r[op][0].z, r[op][1].z, r[op][2].z, r[op][3].z);
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
     int c = next_valid(mbeg);
     if (c >= mend) return;  // uniform
     st.load(p, tid, c, n0, k0);
-    st.store(lds, tid);
+    st.store(p, lds, tid, c, n0, k0);
     __syncthreads();
     int buf = 0;
     while (c < mend) {
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
 #pragma unroll
         for (int kk = 0; kk < MC / 16; ++kk) WaveMma<T, 2, TN_RB>::step(acc, Dt, At, kk, lane, wm, wn);
         if (do_colsum) csum += TnStage<T>::rowsum(Dt, tid);  // bias gradient: column sums of D (staged rows are zero-padded)
-        if (nx < mend) st.store(lds + (buf ^ 1) * TN_STAGE, tid);
+        if (nx < mend) st.store(p, lds + (buf ^ 1) * TN_STAGE, tid, nx, n0, k0);
         __syncthreads();
         buf ^= 1;
         c = nx;
