@@ -25,7 +25,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 #define MAX_CHUNKS 192
 #define CLD 132  // fp32 C tile row stride in LDS (128 + 4 pad): 128*132*4 = 67584 B
 
-template <int TJ_, int NWN_, int RB_> struct TileCfg {
+template <int TJ_, int NWN_, int RB_, int PF_> struct TileCfg {
+    static constexpr int PF = PF_;              // prefetch depth: chunks in flight global->VGPR
     static constexpr int TJ = TJ_;              // 32-wide MFMA blocks per wave along N
     static constexpr int NWN = NWN_;            // waves along N (2 along M)
     static constexpr int RB = RB_;              // LDS row bytes: data + 16 pad
@@ -39,11 +40,19 @@ template <int TJ_, int NWN_, int RB_> struct TileCfg {
     static constexpr int NPW = (BN * PPR + NT - 1) / NT;
     static constexpr int LDS = 2 * STAGE + MAX_CHUNKS * 16 + 16;
 };
-typedef TileCfg<2, 2, 144> CfgS;  // 128 x 128, 256 threads, 128 B of K per row per chunk
-typedef TileCfg<4, 4, 80> CfgW;   // 128 x 512, 512 threads,  64 B of K per row per chunk
+typedef TileCfg<2, 2, 144, 2> CfgS;  // 128 x 128, 256 threads, 128 B of K per row per chunk
+typedef TileCfg<4, 4, 80, 3> CfgW;  // 128 x 512, 512 threads,  64 B of K per row per chunk
 
 __device__ static inline uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
 __device__ static inline int pieces_shift(int ppr) { return ppr >= 8 ? 3 : ppr >= 4 ? 2 : ppr >= 2 ? 1 : 0; }
+// next chunk length (elements): at most BK, a multiple of 16 elements, and a power-of-two number of 16-byte pieces
+template <int ES> __device__ static inline int chunk_len(int remaining, int bk) {
+    int kc = remaining < bk ? remaining : bk;
+    int pieces = kc * ES / 16;
+    int p2 = 1 << pieces_shift(pieces);
+    int len = p2 * 16 / ES;
+    return len < 16 ? 16 : len;
+}
 
 // XCD-aware block order: the dispatcher places block b on XCD b % 8 (observed, used for speed only).  Give each
 // XCD one contiguous range of the linear tile index, so tiles that share an operand panel run back-to-back on the
@@ -160,17 +169,19 @@ __global__ __launch_bounds__(CF::NT) void gemm_nt_kernel(GemmNT p) {
 
     if (tid == 0) {
         int n = 0;
-        for (int k0 = 0; k0 < p.K1; k0 += BK) {
-            int kc = p.K1 - k0 < BK ? p.K1 - k0 : BK;
+        for (int k0 = 0; k0 < p.K1;) {
+            const int kc = chunk_len<ES>(p.K1 - k0, BK);
             chunks[n++] = make_int4(0, k0, k0, kc | (pieces_shift(kc * ES / 16) << 16));
+            k0 += kc;
         }
         int wbase = p.K1;
 #pragma unroll
         for (int s = 0; s < GEMM_MAX_SEG; ++s) {  // constant trip count: keeps the by-value params out of scratch
             if (s < p.nseg && ((mask >> s) & 1u)) {
-                for (int k0 = 0; k0 < p.seg_len[s]; k0 += BK) {
-                    int kc = p.seg_len[s] - k0 < BK ? p.seg_len[s] - k0 : BK;
+                for (int k0 = 0; k0 < p.seg_len[s];) {
+                    const int kc = chunk_len<ES>(p.seg_len[s] - k0, BK);
                     chunks[n++] = make_int4(1, p.seg_off[s] + k0, wbase + k0, kc | (pieces_shift(kc * ES / 16) << 16));
+                    k0 += kc;
                 }
             }
             if (s < p.nseg) wbase += p.seg_len[s];
@@ -193,8 +204,8 @@ __global__ __launch_bounds__(CF::NT) void gemm_nt_kernel(GemmNT p) {
     // store_chunk, after the MFMAs of the current chunk.  (A guarded load sits in its own basic block and hipcc then
     // waits vmcnt(0) in front of every one of them: each load paid a full memory latency.)  ReLU and the zeroing of
     // out-of-range rows happen on the way into LDS.  Pieces per row is a power of two: row/piece via shifts.
-    uint4 ra[CF::NPA], rw[CF::NPW];
-    auto load_chunk = [&](int c) {
+    uint4 ra[CF::PF][CF::NPA], rw[CF::PF][CF::NPW];
+    auto load_chunk = [&](int c, uint4 (&ra)[CF::NPA], uint4 (&rw)[CF::NPW]) {
         const int4 ch = chunks[c];
         const int sh = ch.w >> 16;             // log2(16-byte pieces per row)
         const int pm = (1 << sh) - 1;
@@ -213,7 +224,7 @@ __global__ __launch_bounds__(CF::NT) void gemm_nt_kernel(GemmNT p) {
             rw[i] = *(const uint4*)((const char*)p.W + ((size_t)gn * p.ldw + ch.z) * ES + (q & pm) * 16);
         }
     };
-    auto store_chunk = [&](int c, int buf) {
+    auto store_chunk = [&](int c, int buf, const uint4 (&ra)[CF::NPA], const uint4 (&rw)[CF::NPW]) {
         const int4 ch = chunks[c];
         const int sh = ch.w >> 16;
         const int pm = (1 << sh) - 1;
@@ -240,20 +251,31 @@ __global__ __launch_bounds__(CF::NT) void gemm_nt_kernel(GemmNT p) {
         }
     };
 
+    // Software pipeline, depth PF: chunk k lives in register set k % PF.  Iteration c issues the loads of chunk
+    // c + PF (into the set chunk c just vacated), runs the MFMAs of chunk c from LDS buffer c & 1, then moves chunk
+    // c + 1 (loaded PF - 1 iterations ago) into the other LDS buffer: the wait there is a counted vmcnt that leaves
+    // the younger PF - 1 chunks in flight.  Unrolled by PF so every register-set index is a compile-time constant.
+    constexpr int PF = CF::PF;
     if (nch > 0) {
-        load_chunk(0);
-        store_chunk(0, 0);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) load_chunk(u < nch ? u : nch - 1, ra[u], rw[u]);
+        store_chunk(0, 0, ra[0], rw[0]);
     }
     __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-        const int buf = c & 1;
-        load_chunk(c + 1 < nch ? c + 1 : c);  // unconditional (the last iteration re-reads its own chunk, unused)
-        const char* As = lds + buf * CF::STAGE;
-        const char* Ws = As + CF::TILE_A;
-        const int ks = (chunks[c].w & 0xffff) / 16;
-        for (int kk = 0; kk < ks; ++kk) WaveMma<T, TJ, RB>::step(acc, As, Ws, kk, lane, wm, wn);
-        if (c + 1 < nch) store_chunk(c + 1, buf ^ 1);
-        __syncthreads();
+    for (int c0 = 0; c0 < nch; c0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int c = c0 + u;
+            if (c < nch) {
+                load_chunk(c + PF < nch ? c + PF : nch - 1, ra[u], rw[u]);
+                const char* As = lds + (c & 1) * CF::STAGE;
+                const char* Ws = As + CF::TILE_A;
+                const int ks = (chunks[c].w & 0xffff) / 16;
+                for (int kk = 0; kk < ks; ++kk) WaveMma<T, TJ, RB>::step(acc, As, Ws, kk, lane, wm, wn);
+                if (c + 1 < nch) store_chunk(c + 1, (c + 1) & 1, ra[(u + 1) % PF], rw[(u + 1) % PF]);
+                __syncthreads();
+            }
+        }
     }
 
     // ---- epilogue: stage 128 x 128 fp32 column passes in LDS (reusing the operand buffers), then every thread

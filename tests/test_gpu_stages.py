@@ -440,11 +440,17 @@ def test_mlp_forward_backward(case, precision, which):
                                              run.tile_mask.data_ptr(), tex.data_ptr(), tw.data_ptr(), M, C.byref(run.c),
                                              dv(dl).data_ptr(), dH.data_ptr(), dN.data_ptr(), None, _st()), "mlp_backward")
     grads = dict(zip(MLP_PARAM_NAMES, pk.unpack_grads()))
+    # gradients: relative L2 error per parameter (bf16 operands: activations AND upstream gradients are rounded to
+    # 8 bits at every layer, so the deepest gradients carry a few percent), plus a loose element-wise bound
     gtol = 2e-4 if prec == 0 else 5e-2
+    worst = {}
     for n in MLP_PARAM_NAMES:
         r = p[n].grad
-        e = float((grads[n].cpu() - r).abs().max())
+        got = grads[n].cpu()
+        rel = float((got - r).norm() / max(float(r.norm()), 1e-12))
+        e = float((got - r).abs().max())
         s = float(r.abs().max())
-        # lin_in.weight sums xyz values of up to ~100 m: with bf16 operands its cancellation error is larger
-        lim = gtol * (3.0 if (prec and n == "lin_in.weight") else 1.0)
-        assert e <= lim * max(s, 1e-6), "%s: grad err %.3e vs scale %.3e" % (n, e, s)
+        worst[n] = (rel, e / max(s, 1e-12))
+        assert rel <= gtol, "%s: relative L2 grad error %.3e" % (n, rel)
+        assert e <= 4 * gtol * max(s, 1e-6), "%s: grad err %.3e vs scale %.3e" % (n, e, s)
+    print("worst grad errors:", sorted(worst.items(), key=lambda kv: -kv[1][0])[:3])
