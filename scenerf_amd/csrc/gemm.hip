@@ -39,7 +39,9 @@ template <int TJ_, int NWN_, int RB_, int PF_, int OCC_> struct TileCfg {
     static constexpr int PPR = (RB_ - 16) / 16; // 16-byte pieces per full row
     static constexpr int NPA = (BM * PPR + NT - 1) / NT;
     static constexpr int NPW = (BN * PPR + NT - 1) / NT;
-    static constexpr int LDS = 2 * STAGE + MAX_CHUNKS * 16 + 16;
+    static constexpr int LDS_LOOP = 2 * STAGE + MAX_CHUNKS * 16 + 16;  // operand ring + chunk table
+    static constexpr int LDS_EPI = BM * CLD * 4;                       // fp32 C staging of one 128-column pass
+    static constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
 };
 typedef TileCfg<2, 2, 144, 2, 2> CfgS;  // 128 x 128, 256 threads, 128 B of K per row per chunk
 typedef TileCfg<4, 4, 80, 3, 2> CfgW;

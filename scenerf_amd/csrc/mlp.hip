@@ -178,11 +178,12 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
     SRF_CHECK(cfg && w && Z && xenc && tile_mask && a && M > 0, "mlp_forward: NULL argument");
     SRF_CHECK(w->d_out == 4 || w->d_out == 2, "mlp_forward: d_out must be 4 or 2");
     const int prec = cfg->precision;
+    const bool head = w->d_out == 2;  // profile names: ".../g" = gaussian head (4 points per ray)
     hipStream_t s = as_stream(stream);
     // lin_in (fp32 in both modes: raw xyz up to ~100 m enters here)
     {
         GemmNT g;
-        g.name = "gemm_lin_in";
+        g.name = head ? "gemm_lin_in/g" : "gemm_lin_in";
         g.A1 = xenc; g.lda1 = SCENERF_D_XENC; g.K1 = SCENERF_D_XENC;
         g.W = w->w_in; g.ldw = SCENERF_D_XENC;
         g.M = M; g.N = SCENERF_D_HIDDEN; g.bias = w->b_in;
@@ -192,7 +193,7 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
     // H0 = h0pre + lin_z.0(z)
     {
         GemmNT g;
-        g.name = "gemm_fwd_linz0";
+        g.name = head ? "gemm_fwd_linz0/g" : "gemm_fwd_linz0";
         set_segments(g, cfg, Z, tile_mask);
         g.W = w->w_h[0]; g.ldw = SCENERF_D_LATENT;
         g.M = M; g.N = SCENERF_D_HIDDEN; g.bias = w->b_h[0];
@@ -203,7 +204,7 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
     for (int b = 0; b < 3; ++b) {
         {   // net = fc_0(relu(h))
             GemmNT g;
-            g.name = "gemm_fwd_fc0";
+            g.name = head ? "gemm_fwd_fc0/g" : "gemm_fwd_fc0";
             g.A1 = a->H[b]; g.lda1 = SCENERF_D_HIDDEN; g.K1 = SCENERF_D_HIDDEN; g.relu1 = 1;
             g.W = w->w_fc0[b]; g.ldw = SCENERF_D_HIDDEN;
             g.M = M; g.N = SCENERF_D_HIDDEN; g.bias = w->b_fc0[b];
@@ -212,7 +213,7 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
         }
         {   // h = h + fc_1(relu(net)) [+ lin_z.(b+1)(z)]
             GemmNT g;
-            g.name = b < 2 ? "gemm_fwd_fc1_linz" : "gemm_fwd_fc1";
+            g.name = b < 2 ? (head ? "gemm_fwd_fc1_linz/g" : "gemm_fwd_fc1_linz") : (head ? "gemm_fwd_fc1/g" : "gemm_fwd_fc1");
             g.A1 = a->Nn[b]; g.lda1 = SCENERF_D_HIDDEN; g.K1 = SCENERF_D_HIDDEN; g.relu1 = 1;
             g.ldw = SCENERF_D_HIDDEN;
             if (b < 2) {
@@ -237,6 +238,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     SRF_CHECK(cfg && w && g_ && Z && xenc && tile_mask && a && d_logits && dH && dN && M > 0, "mlp_backward: NULL argument");
     SRF_CHECK(!gmaps_hwc || (tap_texel && tap_weight), "mlp_backward: taps missing");
     const int prec = cfg->precision;
+    const bool head = w->d_out == 2;
     const size_t es = prec ? 2 : 4;
     hipStream_t s = as_stream(stream);
     const int LDH = 4 * SCENERF_D_HIDDEN;  // dH row: [dH0 | dH1 | dH2 | dH3]
@@ -253,7 +255,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     for (int b = 2; b >= 0; --b) {
         {   // dW1_b += dH_{b+1}^T relu(N_b)
             GemmTN t;
-            t.name = "gemm_wgrad_fc1";
+            t.name = head ? "gemm_wgrad_fc1/g" : "gemm_wgrad_fc1";
             t.D = dHcol(b + 1); t.ldd = LDH; t.A = a->Nn[b]; t.lda = SCENERF_D_HIDDEN; t.relu_a = 1;
             t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc1[b]; t.ldo = SCENERF_D_HIDDEN;
             t.colsum = g_->b_fc1[b];  // fc_1.b.bias gradient = column sums of dH_{b+1}
@@ -261,7 +263,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         }
         {   // dN_b = (dH_{b+1} @ W1_b) * [N_b > 0]
             GemmNT g;
-            g.name = "gemm_dgrad_fc1";
+            g.name = head ? "gemm_dgrad_fc1/g" : "gemm_dgrad_fc1";
             g.A1 = dHcol(b + 1); g.lda1 = LDH; g.K1 = SCENERF_D_HIDDEN;
             g.W = w->w_fc1_t[b]; g.ldw = SCENERF_D_HIDDEN;
             g.M = M; g.N = SCENERF_D_HIDDEN;
@@ -271,7 +273,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         }
         {   // dW0_b += dN_b^T relu(H_b);  db0_b = column sums of dN_b
             GemmTN t;
-            t.name = "gemm_wgrad_fc0";
+            t.name = head ? "gemm_wgrad_fc0/g" : "gemm_wgrad_fc0";
             t.D = dN; t.ldd = SCENERF_D_HIDDEN; t.A = a->H[b]; t.lda = SCENERF_D_HIDDEN; t.relu_a = 1;
             t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc0[b]; t.ldo = SCENERF_D_HIDDEN;
             t.colsum = g_->b_fc0[b];
@@ -279,7 +281,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         }
         {   // dH_b = dH_{b+1} + (dN_b @ W0_b) * [H_b > 0]
             GemmNT g;
-            g.name = "gemm_dgrad_fc0";
+            g.name = head ? "gemm_dgrad_fc0/g" : "gemm_dgrad_fc0";
             g.A1 = dN; g.lda1 = SCENERF_D_HIDDEN; g.K1 = SCENERF_D_HIDDEN;
             g.W = w->w_fc0_t[b]; g.ldw = SCENERF_D_HIDDEN;
             g.M = M; g.N = SCENERF_D_HIDDEN;
@@ -292,7 +294,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     // dWz[:, slice_s] += dH[:, 0:1536]^T Z[:, slice_s]   (row-tiles without scale s skipped)
     for (int sc = 0; sc < 5; ++sc) {
         GemmTN t;
-        t.name = "gemm_wgrad_linz";
+        t.name = head ? "gemm_wgrad_linz/g" : "gemm_wgrad_linz";
         t.D = dH; t.ldd = LDH;
         t.A = (const char*)Z + (size_t)kSegOff[sc] * es; t.lda = SCENERF_D_LATENT;
         t.M = M; t.N = 3 * SCENERF_D_HIDDEN; t.K = cfg->map_C[sc];
@@ -303,7 +305,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     // dWin += dH0^T xenc   (xenc is fp32; in bf16 mode convert it into the now-free dN scratch)
     {
         GemmTN t;
-        t.name = "gemm_wgrad_lin_in";
+        t.name = head ? "gemm_wgrad_lin_in/g" : "gemm_wgrad_lin_in";
         t.D = dH; t.ldd = LDH;
         t.lda = SCENERF_D_XENC;
         if (prec) {
@@ -327,7 +329,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         for (int sc = 0; sc < 5; ++sc) {
             if (!gmaps_hwc[sc]) continue;
             GemmNT g;
-            g.name = "gemm_dfeat_scatter";
+            g.name = head ? "gemm_dfeat_scatter/g" : "gemm_dfeat_scatter";
             g.A1 = dH; g.lda1 = LDH; g.K1 = 3 * SCENERF_D_HIDDEN;
             g.W = w->w_z_t[sc]; g.ldw = 3 * SCENERF_D_HIDDEN;
             g.M = M; g.N = cfg->map_C[sc];
