@@ -68,8 +68,9 @@ typedef struct scenerf_mlp_weights {
     int32_t d_out;                  /* 4 (mlp) or 2 (mlp_gaussian) */
     const float* w_in;              /* [512][48]  lin_in.weight zero-padded 42->48, always fp32 */
     const float* b_in;              /* [512] */
-    const void* w_h[4];             /* T: [512][2480] = lin_z.0 ; [512][512+2480] = [fc_1.b | lin_z.(b+1)] b=0,1 ; [512][512] = fc_1.2 */
-    const float* b_h[4];            /* [512]: lin_z.0.bias ; fc_1.b.bias + lin_z.(b+1).bias ; fc_1.2.bias */
+    const void* w_h[4];             /* T: w_h[0] = [512][2480] lin_z.0 (fp32 mode) or [512][144+2480] = [w_in_hi | w_in_hi | w_in_lo | lin_z.0]
+                                       (bf16 mode, split-bf16 lin_in fused in); [512][512+2480] = [fc_1.b | lin_z.(b+1)] b=0,1 ; [512][512] = fc_1.2 */
+    const float* b_h[4];            /* [512]: lin_z.0.bias (+ lin_in.bias in bf16 mode) ; fc_1.b.bias + lin_z.(b+1).bias ; fc_1.2.bias */
     const void* w_fc0[3];           /* T: [512][512] blocks.b.fc_0.weight */
     const float* b_fc0[3];
     const float* w_out;             /* [d_out][512] fp32 */
@@ -99,7 +100,7 @@ typedef struct scenerf_mlp_grads {
 typedef struct scenerf_mlp_acts {
     void* H[4];                     /* T [M][512] */
     void* Nn[3];                    /* T [M][512] */
-    float* h0pre;                   /* fp32 [M][512] scratch: lin_in output */
+    float* h0pre;                   /* [M][512] fp32 scratch: lin_in output (fp32 mode) / split-bf16 encoding [M][144] (bf16 mode) */
     float* logits;                  /* fp32 [M][d_out] */
 } scenerf_mlp_acts;
 

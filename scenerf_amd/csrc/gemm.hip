@@ -40,7 +40,7 @@ template <int TJ_, int NWN_, int RB_, int PF_, int OCC_> struct TileCfg {
     static constexpr int NPA = (BM * PPR + NT - 1) / NT;
     static constexpr int NPW = (BN * PPR + NT - 1) / NT;
     static constexpr int LDS_LOOP = 2 * STAGE + MAX_CHUNKS * 16 + 16;  // operand ring + chunk table
-    static constexpr int LDS_EPI = BM * CLD * 4;                       // fp32 C staging of one 128-column pass
+    static constexpr int LDS_EPI = BM * CLD * 4 + BM * 4 * 8;          // fp32 C staging of one 128-column pass + taps
     static constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
 };
 typedef TileCfg<2, 2, 144, 2, 2> CfgS;  // 128 x 128, 256 threads, 128 B of K per row per chunk
@@ -292,6 +292,16 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_nt_kernel(GemmNT p) {
 #define CS_TILE(i, j)                                                                                               \
     CS_W(i, j, 0) CS_W(i, j, 1) CS_W(i, j, 2) CS_W(i, j, 3) CS_W(i, j, 4) CS_W(i, j, 5) CS_W(i, j, 6) CS_W(i, j, 7) \
     CS_W(i, j, 8) CS_W(i, j, 9) CS_W(i, j, 10) CS_W(i, j, 11) CS_W(i, j, 12) CS_W(i, j, 13) CS_W(i, j, 14) CS_W(i, j, 15)
+    int* s_tx = (int*)(lds + BM * CLD * 4);  // taps of this row tile (scatter mode): [128][4] texel, [128][4] weight
+    float* s_tw = (float*)(s_tx + BM * 4);
+    if (p.scatter_scale >= 0) {
+        for (int i = tid; i < BM * 4; i += NT) {
+            const int m = m0 + (i >> 2);
+            const size_t o = ((size_t)m * 5 + p.scatter_scale) * 4 + (i & 3);
+            s_tx[i] = m < p.M ? p.tap_texel[o] : -1;
+            s_tw[i] = m < p.M ? p.tap_weight[o] : 0.f;
+        }
+    }
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
         if ((wn * WCOLS) / 128 == pass) {
@@ -310,24 +320,34 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_nt_kernel(GemmNT p) {
         __syncthreads();
         const int nb = n0 + pass * 128;
         if (p.scatter_scale >= 0) {
-            // grid_sampler backward: lanes span 64 consecutive channels of one row, so each atomic instruction adds a
-            // contiguous 256-byte run of the (H,W,C) gradient map; the 4 taps of the row are wave-uniform.
-            for (int row = wv; row < BM; row += NT / 64) {
-                const int m = m0 + row;
-                if (m >= p.M) break;
-                const size_t tb = ((size_t)m * 5 + p.scatter_scale) * 4;
+            // grid_sampler backward.  Lanes span 64 consecutive channels of one row, so each atomic instruction adds
+            // a contiguous 256-byte run of the (H,W,C) gradient map.  The taps of a row depend only on its spherical
+            // pixel; consecutive samples of a ray often share it (far samples converge), and same-address atomics
+            // serialise in L2 -- so rows of a wave's contiguous block with identical taps are summed first and
+            // scattered once.
+            constexpr int RPW = BM / (NT / 64);
+            int r = wv * RPW;
+            const int rend = min(r + RPW, p.M - m0);
+            while (r < rend) {
+                const int t0 = s_tx[r * 4], t1 = s_tx[r * 4 + 1], t2 = s_tx[r * 4 + 2], t3 = s_tx[r * 4 + 3];
+                int e = r + 1;
+                while (e < rend && s_tx[e * 4] == t0 && s_tx[e * 4 + 1] == t1 && s_tx[e * 4 + 2] == t2 && s_tx[e * 4 + 3] == t3) ++e;
+                if ((t0 & t1 & t2 & t3) >= 0 || t0 >= 0 || t1 >= 0 || t2 >= 0 || t3 >= 0) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int col = h * 64 + lane, n = nb + col;
-                    if (n < p.N) {
-                        const float v = Cs[row * CLD + col];
+                    for (int h = 0; h < 2; ++h) {
+                        const int col = h * 64 + lane, n = nb + col;
+                        if (n < p.N) {
+                            float v = 0.f;
+                            for (int q = r; q < e; ++q) v += Cs[q * CLD + col];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int tx = p.tap_texel[tb + t];
-                            if (tx >= 0) unsafeAtomicAdd(p.gmap + (size_t)tx * p.N + n, v * p.tap_weight[tb + t]);
+                            for (int t = 0; t < 4; ++t) {
+                                const int tx = s_tx[r * 4 + t];
+                                if (tx >= 0) unsafeAtomicAdd(p.gmap + (size_t)tx * p.N + n, v * s_tw[r * 4 + t]);
+                            }
                         }
                     }
                 }
+                r = e;
             }
         } else {
             for (int it = tid; it < BM * 16; it += NT) {

@@ -123,9 +123,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ D,
     }
 }
 
-__global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
+// bf16 mode: lin_in runs inside the first hidden GEMM as three extra K-segments.  x = hi + lo with hi = bf16(x),
+// lo = bf16(x - hi) (16 significant bits: raw xyz reaches ~100 m), and the weight is split the same way on the host;
+// x_hi.w_hi + x_lo.w_hi + x_hi.w_lo reproduces the fp32 product to ~2^-16.  Row layout: [hi(48) | lo(48) | hi(48)].
+__global__ void split_xenc_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int M) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = f32_to_bf16(in[i]);
+    if (i >= (size_t)M * SCENERF_D_XENC) return;
+    const size_t m = i / SCENERF_D_XENC;
+    const int c = (int)(i - m * SCENERF_D_XENC);
+    const float x = in[i];
+    const bf16_t hi = f32_to_bf16(x);
+    const bf16_t lo = f32_to_bf16(x - bf16_to_f32(hi));
+    bf16_t* o = out + m * (3 * SCENERF_D_XENC);
+    o[c] = hi;
+    o[SCENERF_D_XENC + c] = lo;
+    o[2 * SCENERF_D_XENC + c] = hi;
 }
 
 template <typename T>
@@ -180,24 +192,41 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
     const int prec = cfg->precision;
     const bool head = w->d_out == 2;  // profile names: ".../g" = gaussian head (4 points per ray)
     hipStream_t s = as_stream(stream);
-    // lin_in (fp32 in both modes: raw xyz up to ~100 m enters here)
-    {
-        GemmNT g;
-        g.name = head ? "gemm_lin_in/g" : "gemm_lin_in";
-        g.A1 = xenc; g.lda1 = SCENERF_D_XENC; g.K1 = SCENERF_D_XENC;
-        g.W = w->w_in; g.ldw = SCENERF_D_XENC;
-        g.M = M; g.N = SCENERF_D_HIDDEN; g.bias = w->b_in;
-        g.out = a->h0pre; g.ldout = SCENERF_D_HIDDEN; g.out_f32 = 1;
-        if (int e = launch_gemm_nt(0, g, s)) return e;
-    }
-    // H0 = h0pre + lin_z.0(z)
-    {
+    if (prec == 0) {
+        // fp32 mode: lin_in as its own fp32-MFMA GEMM, then H0 = h0pre + lin_z.0(z)
+        {
+            GemmNT g;
+            g.name = head ? "gemm_lin_in/g" : "gemm_lin_in";
+            g.A1 = xenc; g.lda1 = SCENERF_D_XENC; g.K1 = SCENERF_D_XENC;
+            g.W = w->w_in; g.ldw = SCENERF_D_XENC;
+            g.M = M; g.N = SCENERF_D_HIDDEN; g.bias = w->b_in;
+            g.out = a->h0pre; g.ldout = SCENERF_D_HIDDEN; g.out_f32 = 1;
+            if (int e = launch_gemm_nt(0, g, s)) return e;
+        }
         GemmNT g;
         g.name = head ? "gemm_fwd_linz0/g" : "gemm_fwd_linz0";
         set_segments(g, cfg, Z, tile_mask);
         g.W = w->w_h[0]; g.ldw = SCENERF_D_LATENT;
         g.M = M; g.N = SCENERF_D_HIDDEN; g.bias = w->b_h[0];
         g.res = a->h0pre; g.ldres = SCENERF_D_HIDDEN; g.res_f32 = 1;
+        g.out = a->H[0]; g.ldout = SCENERF_D_HIDDEN;
+        if (int e = launch_gemm_nt(prec, g, s)) return e;
+    } else {
+        // bf16 mode: H0 = [x_hi | x_lo | x_hi | z] @ [w_hi | w_hi | w_lo | lin_z.0]^T + (lin_in.bias + lin_z.0.bias); the
+        // split encoding lives in the (otherwise unused) h0pre scratch and is reused by the lin_in weight gradient
+        bf16_t* x3 = (bf16_t*)a->h0pre;
+        {
+            SrfLaunchScope ps(s, "split_xenc", 0, (double)M * SCENERF_D_XENC * 10);
+            size_t n = (size_t)M * SCENERF_D_XENC;
+            split_xenc_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(xenc, x3, M);
+            SRF_LAUNCH_CHECK("split_xenc_kernel");
+        }
+        GemmNT g;
+        g.name = head ? "gemm_fwd_in_linz0/g" : "gemm_fwd_in_linz0";
+        g.A1 = x3; g.lda1 = 3 * SCENERF_D_XENC; g.K1 = 3 * SCENERF_D_XENC;
+        set_segments(g, cfg, Z, tile_mask);
+        g.W = w->w_h[0]; g.ldw = 3 * SCENERF_D_XENC + SCENERF_D_LATENT;
+        g.M = M; g.N = SCENERF_D_HIDDEN; g.bias = w->b_h[0];
         g.out = a->H[0]; g.ldout = SCENERF_D_HIDDEN;
         if (int e = launch_gemm_nt(prec, g, s)) return e;
     }
@@ -302,19 +331,15 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         t.out = g_->w_z + kSegOff[sc]; t.ldo = SCENERF_D_LATENT;
         if (int e = launch_gemm_tn(prec, t, s)) return e;
     }
-    // dWin += dH0^T xenc   (xenc is fp32; in bf16 mode convert it into the now-free dN scratch)
+    // dWin += dH0^T xenc   (bf16 mode: the hi part of the split encoding kept in h0pre is bf16(xenc))
     {
         GemmTN t;
         t.name = head ? "gemm_wgrad_lin_in/g" : "gemm_wgrad_lin_in";
         t.D = dH; t.ldd = LDH;
-        t.lda = SCENERF_D_XENC;
         if (prec) {
-            size_t n = (size_t)M * SCENERF_D_XENC;
-            f32_to_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(xenc, (bf16_t*)dN, n);
-            SRF_LAUNCH_CHECK("f32_to_bf16_kernel");
-            t.A = dN;
+            t.A = a->h0pre; t.lda = 3 * SCENERF_D_XENC;
         } else {
-            t.A = xenc;
+            t.A = xenc; t.lda = SCENERF_D_XENC;
         }
         t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_XENC; t.out = g_->w_in; t.ldo = SCENERF_D_XENC;
         t.colsum = g_->b_in;  // lin_in.bias gradient = column sums of dH_0

@@ -142,11 +142,19 @@ class PackedMLP:
         fc0 = [p["blocks.%d.fc_0.weight" % b] for b in range(3)]
         fc1 = [p["blocks.%d.fc_1.weight" % b] for b in range(3)]
         lz = [p["lin_z.%d.weight" % b] for b in range(3)]
-        self.w_h = [lz[0].to(act).contiguous(),
+        if prec:
+            # bf16 mode: lin_in rides in the first hidden GEMM as [w_hi | w_hi | w_lo] against [x_hi | x_lo | x_hi]
+            w_hi = w_in.to(torch.bfloat16)
+            w_lo = (w_in - w_hi.float()).to(torch.bfloat16)
+            first = torch.cat([w_hi, w_hi, w_lo, lz[0].to(act)], dim=1).contiguous()
+            first_bias = (p["lin_in.bias"] + p["lin_z.0.bias"]).contiguous()
+        else:
+            first, first_bias = lz[0].to(act).contiguous(), p["lin_z.0.bias"]
+        self.w_h = [first,
                     torch.cat([fc1[0], lz[1]], dim=1).to(act).contiguous(),
                     torch.cat([fc1[1], lz[2]], dim=1).to(act).contiguous(),
                     fc1[2].to(act).contiguous()]
-        self.b_h = [p["lin_z.0.bias"],
+        self.b_h = [first_bias,
                     (p["blocks.0.fc_1.bias"] + p["lin_z.1.bias"]).contiguous(),
                     (p["blocks.1.fc_1.bias"] + p["lin_z.2.bias"]).contiguous(),
                     p["blocks.2.fc_1.bias"]]
