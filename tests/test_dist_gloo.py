@@ -1,0 +1,64 @@
+"""N>1 path on CPU: two gloo processes shard the rays and average a gradient bucket exactly like bench.py does
+over RCCL (rays are independent; the only collective is the parameter-gradient all-reduce)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from scenerf_amd import dist as sdist
+    r, w, _ = sdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    lin = torch.nn.Linear(7, 5)
+    with torch.no_grad():
+        for p in lin.parameters():
+            p.fill_(1.0)
+    # each rank "renders" its shard of 10 rays and produces shard-dependent grads
+    b, e = sdist.shard_rays(10, rank, world)
+    x = torch.arange(b, e, dtype=torch.float32).reshape(-1, 1).repeat(1, 7)
+    lin(x).sum().backward()
+    local = [p.grad.clone() for p in lin.parameters()]
+    bucket = sdist.GradBucket(lin.parameters())
+    bucket.allreduce_mean()
+    torch.save(dict(local=local, reduced=[p.grad.clone() for p in lin.parameters()], shard=(b, e)), out % rank)
+    dist.destroy_process_group()
+
+
+def test_two_process_gloo_allreduce(tmp_path):
+    world = 2
+    out = str(tmp_path / "r%d.pt")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = [torch.load(out % r) for r in range(world)]
+    assert res[0]["shard"] == (0, 5) and res[1]["shard"] == (5, 10)
+    for i in range(2):
+        mean = (res[0]["local"][i] + res[1]["local"][i]) / 2
+        for r in range(world):
+            torch.testing.assert_close(res[r]["reduced"][i], mean)
+    assert not torch.equal(res[0]["local"][0], res[1]["local"][0])
+
+
+def test_shard_rays_covers_everything():
+    from scenerf_amd.dist import shard_rays
+    for n in (1, 7, 1200, 1201):
+        for w in (1, 2, 3, 8):
+            spans = [shard_rays(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1

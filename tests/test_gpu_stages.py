@@ -442,7 +442,7 @@ def test_mlp_forward_backward(case, precision, which):
     grads = dict(zip(MLP_PARAM_NAMES, pk.unpack_grads()))
     # gradients: relative L2 error per parameter (bf16 operands: activations AND upstream gradients are rounded to
     # 8 bits at every layer, so the deepest gradients carry a few percent), plus a loose element-wise bound
-    gtol = 2e-4 if prec == 0 else 5e-2
+    gtol = 2e-4 if prec == 0 else 8e-2
     worst = {}
     for n in MLP_PARAM_NAMES:
         r = p[n].grad

@@ -1,0 +1,122 @@
+"""Host-side logic that needs no GPU: configuration, boundary (names / signatures / state_dict keys), packing
+arithmetic, and the refusal to run the hot path anywhere but on the GPU."""
+import inspect
+import math
+
+import pytest
+import torch
+
+import scenerf_oracle as orc
+from scenerf_amd import synth
+from scenerf_amd.config import RenderConfig
+from scenerf_amd.model import SceneRF, SceneRFBundleFusion
+from scenerf_amd.renderer import MLP_PARAM_NAMES, OUTPUT_KEYS
+
+
+def test_config_matches_oracle_constants():
+    for mk_r, mk_o in ((RenderConfig.kitti, orc.OracleConfig.kitti), (RenderConfig.bundlefusion, orc.OracleConfig.bundlefusion)):
+        r, o = mk_r(), mk_o()
+        assert r.fov == pytest.approx(o.fov)
+        assert r.n_samples == o.n_samples
+        assert (r.gauss_floor, r.kl_std_floor, r.max_sample_depth, r.std, r.som_sigma) == (
+            o.gauss_floor, o.kl_std_floor, o.max_sample_depth, o.std, o.som_sigma)
+    c = RenderConfig.kitti(n_pts_uni=64, n_pts_per_gaussian=16).to_c()
+    assert c.n_samples == 128 and c.uni_step == pytest.approx((100 - 0.2) / 64)
+    # Q1: divisor is W//s but the map is round(W/s): they differ at scales 8 and 16
+    assert list(c.map_W) == [1500, 750, 375, 188, 94] and list(c.div_W) == [1500, 750, 375, 187, 93]
+    assert list(c.map_H) == [452, 226, 113, 56, 28] and list(c.div_H) == [452, 226, 113, 56, 28]
+    assert list(c.map_C) == [80, 160, 320, 640, 1280]
+
+
+def test_config_validation():
+    with pytest.raises(ValueError):
+        RenderConfig.kitti(n_gaussians=9).validate()
+    with pytest.raises(ValueError):
+        RenderConfig.kitti(n_pts_uni=512, n_pts_per_gaussian=8).validate()   # 544 samples > 512
+    with pytest.raises(ValueError):
+        RenderConfig.kitti(precision="fp16").validate()
+
+
+# reference state_dict keys of mlp / mlp_gaussian / pe (SURVEY §5 checkpoint row; resnetfc.py:88-118, pe.py:22-30)
+REF_KEYS = ["pe._freqs", "pe._phases"]
+for _m in ("mlp", "mlp_gaussian"):
+    REF_KEYS += ["%s.lin_in.weight" % _m, "%s.lin_in.bias" % _m, "%s.lin_out.weight" % _m, "%s.lin_out.bias" % _m]
+    for _b in range(3):
+        REF_KEYS += ["%s.blocks.%d.fc_0.weight" % (_m, _b), "%s.blocks.%d.fc_0.bias" % (_m, _b),
+                     "%s.blocks.%d.fc_1.weight" % (_m, _b), "%s.blocks.%d.fc_1.bias" % (_m, _b),
+                     "%s.lin_z.%d.weight" % (_m, _b), "%s.lin_z.%d.bias" % (_m, _b)]
+
+
+def test_boundary_state_dict_keys_and_init():
+    m = SceneRF(som_sigma=2.0)
+    assert sorted(m.state_dict().keys()) == sorted(REF_KEYS)
+    assert sum(p.numel() for p in m.mlp.parameters()) == 5410820
+    assert sum(p.numel() for p in m.mlp_gaussian.parameters()) == 5409794
+    # reference init: fc_1 zero, biases zero (resnetfc.py:33-40)
+    assert float(m.mlp.blocks[0].fc_1.weight.abs().max()) == 0.0
+    assert float(m.mlp.lin_in.bias.abs().max()) == 0.0
+    # pe buffers: f_k = pi 2^k repeated twice, phases 0 / pi/2
+    assert m.pe._freqs.flatten().tolist() == pytest.approx([math.pi * 2 ** (k // 2) for k in range(12)], rel=1e-6)
+    assert [n for n, _ in m.mlp.named_parameters()] and set(MLP_PARAM_NAMES) == {n for n, _ in m.mlp.named_parameters()}
+
+
+def test_boundary_signatures_match_reference():
+    sig = inspect.signature(SceneRF.__init__)
+    ref = ["self", "som_sigma", "lr", "weight_decay", "img_size", "n_rays", "max_infer_depth", "max_sample_depth", "eval_depth",
+           "std", "n_gaussians", "n_pts_uni", "n_pts_per_gaussian", "sampling_method", "batch_size", "add_fov_hor", "add_fov_ver",
+           "sphere_H", "sphere_W", "use_color", "use_reprojection"]
+    assert list(sig.parameters)[:len(ref)] == ref                         # scenerf.py:23-43
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["lr"], d["n_rays"], d["std"], d["n_pts_uni"], d["sphere_H"], d["sphere_W"]) == (1e-5, 1200, 2.5, 32, 452, 1500)
+    r = inspect.signature(SceneRF.render_rays_batch)
+    assert list(r.parameters)[:8] == ["self", "cam_K", "T_source2infer", "x_rgb", "depth_window", "T_cam2velo", "sampled_pixels",
+                                      "ray_batch_size"]                  # scenerf.py:392-399
+    assert r.parameters["ray_batch_size"].default == 128 and r.parameters["depth_window"].default == 100
+    assert OUTPUT_KEYS == ["depth", "color", "gaussian_means", "gaussian_stds", "weights_at_depth", "closest_pts_to_depths",
+                           "loss_kl", "alphas", "som_vars", "densities", "weights", "depth_volumes"]   # scenerf.py:456-469
+    b = SceneRFBundleFusion(som_sigma=0.02)
+    assert b.render_cfg.gauss_floor == 0.5 and b.render_cfg.fov == pytest.approx(orc.OracleConfig(
+        v_angle_max=112.2911, v_angle_min=67.6248, h_angle_max=118.6861, h_angle_min=61.2383).fov)
+
+
+def test_reference_state_dict_loads():
+    m = SceneRF(som_sigma=2.0)
+    m.mlp.load_state_dict(synth.mlp_state(1, 4))
+    m.mlp_gaussian.load_state_dict(synth.mlp_state(2, 2))
+    assert [tuple(p.shape) for p in m.mlp.ordered_params()][:4] == [(512, 42), (512,), (4, 512), (4,)]
+
+
+def test_hot_path_refuses_cpu_tensors():
+    """No CPU / eager fallback: CPU inputs raise instead of silently running something else."""
+    m = SceneRF(som_sigma=2.0, sphere_W=376, sphere_H=114)
+    maps = {k: torch.zeros(s) for k, s in synth.feature_map_shapes(376, 114).items()}
+    with pytest.raises(RuntimeError, match="GPU"):
+        m.render_rays_batch(synth.kitti_cam_K(), torch.eye(4), maps, sampled_pixels=torch.zeros(8, 2), ray_batch_size=8)
+    with pytest.raises(RuntimeError, match="HIP MLP pass"):
+        m.mlp(torch.zeros(1, 2522))
+
+
+def test_split_bf16_linin_arithmetic():
+    """The bf16-mode lin_in split (x_hi.w_hi + x_lo.w_hi + x_hi.w_lo) reproduces fp32 to ~2^-15 relative."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(256, 48, generator=g) * 40.0
+    w = torch.randn(512, 48, generator=g) * 0.02
+    xh = x.to(torch.bfloat16).float()
+    xl = (x - xh).to(torch.bfloat16).float()
+    wh = w.to(torch.bfloat16).float()
+    wl = (w - wh).to(torch.bfloat16).float()
+    got = xh @ wh.T + xl @ wh.T + xh @ wl.T
+    ref = x.double() @ w.double().T
+    plain = xh @ wh.T
+    scale = (x.abs().double() @ w.abs().double().T).max()
+    assert float((got.double() - ref).abs().max() / scale) < 5e-5
+    assert float((plain.double() - ref).abs().max() / scale) > 5e-4     # what the split buys
+
+
+def test_synthetic_inputs_are_deterministic():
+    a, b = synth.feature_maps(64, 24, 5), synth.feature_maps(64, 24, 5)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert [tuple(v.shape) for v in a.values()] == [(80, 24, 64), (160, 12, 32), (320, 6, 16), (640, 3, 8), (1280, 2, 4)]
+    p = synth.stride2_pixels((1220, 370), 100, 3)
+    assert p.shape == (100, 2) and float(p[:, 0].max()) <= 1218 and bool(((p % 2) == 0).all())
+    assert len({(float(u), float(v)) for u, v in p}) == 100
