@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void linout_fwd_kernel(const void* __restrict_
 }
 
 // dH3[m][k] = [H3>0] * sum_j dl[m][j] w_out[j][k];  dw_out[j][k] += sum_m dl[m][j] relu(H3[m][k]);  db_out[j] += sum_m dl[m][j]
+// one wave per row, lane owns 8 of the 512 columns; 4 rows per iteration so 4 independent 16-byte loads are in flight
 template <typename T, int DO>
 __global__ __launch_bounds__(256) void linout_bwd_kernel(const void* __restrict__ H3, const float* __restrict__ w_out,
                                                          const float* __restrict__ dlog, int M, void* __restrict__ dH3, int lddh,
@@ -52,25 +53,33 @@ __global__ __launch_bounds__(256) void linout_bwd_kernel(const void* __restrict_
             dw[j][e] = 0.f;
         }
     }
-    for (int m = wave; m < M; m += nwaves) {
-        float h[8], g[8], dl[DO];
-        load8<T>(H3, (size_t)m * SCENERF_D_HIDDEN + lane * 8, h);
+    constexpr int RU = 4;
+    for (int mb = wave * RU; mb < M; mb += nwaves * RU) {
+        float h[RU][8], dl[RU][DO];
 #pragma unroll
-        for (int j = 0; j < DO; ++j) {
-            dl[j] = dlog[(size_t)m * DO + j];
-            db[j] += dl[j];
+        for (int u = 0; u < RU; ++u) {
+            const int m = min(mb + u, M - 1);
+            load8<T>(H3, (size_t)m * SCENERF_D_HIDDEN + lane * 8, h[u]);
+#pragma unroll
+            for (int j = 0; j < DO; ++j) dl[u][j] = (mb + u < M) ? dlog[(size_t)m * DO + j] : 0.f;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float a = 0.f;
+        for (int u = 0; u < RU; ++u) {
+            float g[8];
 #pragma unroll
-            for (int j = 0; j < DO; ++j) {
-                a = fmaf(dl[j], w[j][e], a);
-                dw[j][e] = fmaf(dl[j], fmaxf(h[e], 0.f), dw[j][e]);
+            for (int j = 0; j < DO; ++j) db[j] += dl[u][j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < DO; ++j) {
+                    a = fmaf(dl[u][j], w[j][e], a);
+                    dw[j][e] = fmaf(dl[u][j], fmaxf(h[u][e], 0.f), dw[j][e]);
+                }
+                g[e] = h[u][e] > 0.f ? a : 0.f;
             }
-            g[e] = h[e] > 0.f ? a : 0.f;
+            if (mb + u < M) store8<T>(dH3, (size_t)(mb + u) * lddh + lane * 8, g);
         }
-        store8<T>(dH3, (size_t)m * lddh + lane * 8, g);
     }
 #pragma unroll
     for (int j = 0; j < DO; ++j)
@@ -85,41 +94,6 @@ __global__ __launch_bounds__(256) void linout_bwd_kernel(const void* __restrict_
     if (lane == 0) {
 #pragma unroll
         for (int j = 0; j < DO; ++j) unsafeAtomicAdd(db_out + j, db[j]);
-    }
-}
-
-// out[c] += sum_m D[m][c], c in [0, ncols).  Block = 256 threads over a slab of rows; a thread owns one 8-column
-// group and strides over the slab's rows with 4 independent loads in flight; one atomic per column per block.
-template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ D, int ldd, int ncols, int M, int rows_per_block,
-                                                     float* __restrict__ out) {
-    const int groups = ncols / 8;                 // 8-column groups
-    const int tpr = groups < 256 ? groups : 256;  // threads per row
-    const int rpi = 256 / tpr;                    // rows per iteration
-    const int g = threadIdx.x % tpr, rl = threadIdx.x / tpr;
-    if (rl >= rpi) return;
-    const int mb = blockIdx.x * rows_per_block;
-    const int me = mb + rows_per_block < M ? mb + rows_per_block : M;
-    for (int gg = g; gg < groups; gg += tpr) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int m = mb + rl;
-        for (; m + 3 * rpi < me; m += 4 * rpi) {
-            float v0[8], v1[8], v2[8], v3[8];
-            load8<T>(D, (size_t)m * ldd + gg * 8, v0);
-            load8<T>(D, (size_t)(m + rpi) * ldd + gg * 8, v1);
-            load8<T>(D, (size_t)(m + 2 * rpi) * ldd + gg * 8, v2);
-            load8<T>(D, (size_t)(m + 3 * rpi) * ldd + gg * 8, v3);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
-        }
-        for (; m < me; m += rpi) {
-            float v[8];
-            load8<T>(D, (size_t)m * ldd + gg * 8, v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += v[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) unsafeAtomicAdd(out + gg * 8 + e, acc[e]);
     }
 }
 
@@ -153,22 +127,14 @@ static int launch_linout_fwd(int d_out, const void* H3, const float* w, const fl
 template <typename T>
 static int launch_linout_bwd(int d_out, const void* H3, const float* w, const float* dlog, int M, void* dH3, int lddh, float* dw,
                              float* db, hipStream_t s) {
-    int grid = cdiv(M, 4 * 64);
-    if (grid > 1024) grid = 1024;
+    int grid = cdiv(M, 4 * 16);
+    if (grid > 2048) grid = 2048;
     SrfLaunchScope ps(s, "linout_bwd", 0, (double)M * (1024.0 * sizeof(T) + 4.0 * d_out));
     if (d_out == 4) linout_bwd_kernel<T, 4><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, dw, db);
     else linout_bwd_kernel<T, 2><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, dw, db);
     SRF_LAUNCH_CHECK("linout_bwd_kernel");
     return 0;
 }
-template <typename T> static int launch_colsum(const void* D, int ldd, int ncols, int M, float* out, hipStream_t s) {
-    const int rows = 128;
-    SrfLaunchScope ps(s, "colsum", 0, (double)M * ncols * sizeof(T));
-    colsum_kernel<T><<<cdiv(M, rows), 256, 0, s>>>(D, ldd, ncols, M, rows, out);
-    SRF_LAUNCH_CHECK("colsum_kernel");
-    return 0;
-}
-
 // ================================================================================================ sequencing
 static void set_segments(GemmNT& g, const scenerf_cfg* cfg, const void* Z, const uint8_t* tile_mask) {
     g.A2 = Z;

@@ -40,6 +40,16 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_SIDE = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=key)
+    return _SIDE[key]
+
+
 def _require_cuda(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise RuntimeError("%s must live on the GPU (got %s): the SceneRF hot path has no CPU fallback" % (name, t.device))
@@ -422,10 +432,25 @@ class RenderChunk(torch.autograd.Function):
                                                      _capi.ptr(g_gmeans), _capi.ptr(g_gstds), R, d_off.data_ptr(), st),
                     "sampler_backward")
         want_maps = bool(ctx.needs_input_grad[10])
+        # The gaussian head's backward (R*G rows: small grids) is independent of the radiance MLP's backward: run it
+        # on a side stream so its workgroups fill the gaps of the big GEMMs.  Both scatter into the same map-gradient
+        # accumulators with atomics; the main stream waits for the side stream before anything reads them.
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev)
+        do_head = bool(ctx.needs_input_grad[12] or want_maps)
+        if do_head:
+            if want_maps:
+                ctx.maps.grad_accumulators()   # allocate + zero on the main stream before the fork
+            ctx.mlpg.packed.grad_sink()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _mlp_backward(ccfg, cfg, ctx.maps, ctx.mlpg.packed, run_g, d_off.view(R * G, 2), want_maps)
         if ctx.needs_input_grad[11] or want_maps:
             _mlp_backward(ccfg, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps)
-        if ctx.needs_input_grad[12] or want_maps:
-            _mlp_backward(ccfg, cfg, ctx.maps, ctx.mlpg.packed, run_g, d_off.view(R * G, 2), want_maps)
+        if do_head:
+            main.wait_stream(side)
+            for t in (d_off, run_g.Z, run_g.xenc, run_g.logits):
+                t.record_stream(side)
         ctx.keep = None
         z1 = torch.zeros(1, **f32)
         return (None, None, None, None, None, None, None, None, None, None,
