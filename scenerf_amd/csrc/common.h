@@ -68,10 +68,15 @@ __device__ static inline uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ static inline float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ static inline float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-// relu on two packed bf16: zero each half whose sign bit is set
+// relu on two packed bf16 in ONE instruction: as signed 16-bit integers every negative bf16 (sign bit set) is a
+// negative int16 and every non-negative bf16 keeps its order, so max(x, 0) per half is v_pk_max_i16 (NaNs with the
+// sign bit set become 0, like fmaxf(x, 0)).
+typedef short srf_short2 __attribute__((ext_vector_type(2)));
 __device__ static inline uint32_t relu_bf16x2(uint32_t w) {
-    uint32_t neg = (w >> 15) & 0x00010001u;
-    return w & ~(neg * 0xffffu);
+    srf_short2 v = __builtin_bit_cast(srf_short2, w);
+    srf_short2 z = {0, 0};
+    v = __builtin_elementwise_max(v, z);
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> struct ActIO;

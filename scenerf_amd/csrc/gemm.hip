@@ -152,6 +152,96 @@ __device__ __forceinline__ void epi_item(const GemmNT& p, float* v, int m, int n
     else store8<T>(p.out, (size_t)m * p.ldout + n, v);
 }
 
+// ---- epilogue shared by the register-staged and the direct-to-LDS kernels ---------------------------------------
+template <typename T, typename CF>
+__device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16_t (&acc)[2][CF::TJ], char* lds, int m0, int n0, int tid) {
+    constexpr int TJ = CF::TJ, NWN = CF::NWN, BN = CF::BN, NT = CF::NT;
+    const int lane = tid & 63, wv = tid >> 6, wm = wv / NWN, wn = wv % NWN;
+    // ---- epilogue: stage 128 x 128 fp32 column passes in LDS (reusing the operand buffers), then every thread
+    // handles 8 consecutive columns of a row with 16/32-byte global accesses (the MFMA C layout gives a lane one
+    // column of 16 scattered rows: storing from it directly means 2-byte strided accesses) -------------------------
+    float* Cs = (float*)lds;
+    constexpr int NPASS = BN / 128;
+    constexpr int WCOLS = TJ * 32;  // columns owned by one wave
+#define CS_W(i, j, r) Cs[(wm * 64 + (i) * 32 + ((r) & 3) + 8 * ((r) >> 2) + 4 * (lane >> 5)) * CLD + cbase + (j) * 32 + (lane & 31)] = acc[i][j][r];
+#define CS_TILE(i, j)                                                                                               \
+    CS_W(i, j, 0) CS_W(i, j, 1) CS_W(i, j, 2) CS_W(i, j, 3) CS_W(i, j, 4) CS_W(i, j, 5) CS_W(i, j, 6) CS_W(i, j, 7) \
+    CS_W(i, j, 8) CS_W(i, j, 9) CS_W(i, j, 10) CS_W(i, j, 11) CS_W(i, j, 12) CS_W(i, j, 13) CS_W(i, j, 14) CS_W(i, j, 15)
+    int* s_tx = (int*)(lds + BM * CLD * 4);  // taps of this row tile (scatter mode): [128][4] texel, [128][4] weight
+    float* s_tw = (float*)(s_tx + BM * 4);
+    if (p.scatter_scale >= 0) {
+        for (int i = tid; i < BM * 4; i += NT) {
+            const int m = m0 + (i >> 2);
+            const size_t o = ((size_t)m * 5 + p.scatter_scale) * 4 + (i & 3);
+            s_tx[i] = m < p.M ? p.tap_texel[o] : -1;
+            s_tw[i] = m < p.M ? p.tap_weight[o] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        if ((wn * WCOLS) / 128 == pass) {
+            const int cbase = (wn * WCOLS) % 128;
+            CS_TILE(0, 0)
+            CS_TILE(0, 1)
+            CS_TILE(1, 0)
+            CS_TILE(1, 1)
+            if constexpr (TJ == 4) {
+                CS_TILE(0, 2)
+                CS_TILE(0, 3)
+                CS_TILE(1, 2)
+                CS_TILE(1, 3)
+            }
+        }
+        __syncthreads();
+        const int nb = n0 + pass * 128;
+        if (p.scatter_scale >= 0) {
+            // grid_sampler backward.  Lanes span 64 consecutive channels of one row, so each atomic instruction adds
+            // a contiguous 256-byte run of the (H,W,C) gradient map.  The taps of a row depend only on its spherical
+            // pixel; consecutive samples of a ray often share it (far samples converge), and same-address atomics
+            // serialise in L2 -- so rows of a wave's contiguous block with identical taps are summed first and
+            // scattered once.
+            constexpr int RPW = BM / (NT / 64);
+            int r = wv * RPW;
+            const int rend = min(r + RPW, p.M - m0);
+            while (r < rend) {
+                const int t0 = s_tx[r * 4], t1 = s_tx[r * 4 + 1], t2 = s_tx[r * 4 + 2], t3 = s_tx[r * 4 + 3];
+                int e = r + 1;
+                while (e < rend && s_tx[e * 4] == t0 && s_tx[e * 4 + 1] == t1 && s_tx[e * 4 + 2] == t2 && s_tx[e * 4 + 3] == t3) ++e;
+                if ((t0 & t1 & t2 & t3) >= 0 || t0 >= 0 || t1 >= 0 || t2 >= 0 || t3 >= 0) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int col = h * 64 + lane, n = nb + col;
+                        if (n < p.N) {
+                            float v = 0.f;
+                            for (int q = r; q < e; ++q) v += Cs[q * CLD + col];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const int tx = s_tx[r * 4 + t];
+                                if (tx >= 0) unsafeAtomicAdd(p.gmap + (size_t)tx * p.N + n, v * s_tw[r * 4 + t]);
+                            }
+                        }
+                    }
+                }
+                r = e;
+            }
+        } else {
+            for (int it = tid; it < BM * 16; it += NT) {
+                const int row = it >> 4, cg = it & 15;
+                const int m = m0 + row, n = nb + cg * 8;
+                if (m < p.M && n < p.N) {
+                    float v[8];
+                    const float4 lo = *(const float4*)(Cs + row * CLD + cg * 8), hi = *(const float4*)(Cs + row * CLD + cg * 8 + 4);
+                    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+                    epi_item<T>(p, v, m, n);
+                }
+            }
+        }
+        if (pass + 1 < NPASS) __syncthreads();
+    }
+#undef CS_TILE
+#undef CS_W
+}
+
 // ================================================================================================ NT
 template <typename T, typename CF>
 __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_nt_kernel(GemmNT p) {
@@ -282,89 +372,188 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_nt_kernel(GemmNT p) {
         }
     }
 
-    // ---- epilogue: stage 128 x 128 fp32 column passes in LDS (reusing the operand buffers), then every thread
-    // handles 8 consecutive columns of a row with 16/32-byte global accesses (the MFMA C layout gives a lane one
-    // column of 16 scattered rows: storing from it directly means 2-byte strided accesses) -------------------------
-    float* Cs = (float*)lds;
-    constexpr int NPASS = BN / 128;
-    constexpr int WCOLS = TJ * 32;  // columns owned by one wave
-#define CS_W(i, j, r) Cs[(wm * 64 + (i) * 32 + ((r) & 3) + 8 * ((r) >> 2) + 4 * (lane >> 5)) * CLD + cbase + (j) * 32 + (lane & 31)] = acc[i][j][r];
-#define CS_TILE(i, j)                                                                                               \
-    CS_W(i, j, 0) CS_W(i, j, 1) CS_W(i, j, 2) CS_W(i, j, 3) CS_W(i, j, 4) CS_W(i, j, 5) CS_W(i, j, 6) CS_W(i, j, 7) \
-    CS_W(i, j, 8) CS_W(i, j, 9) CS_W(i, j, 10) CS_W(i, j, 11) CS_W(i, j, 12) CS_W(i, j, 13) CS_W(i, j, 14) CS_W(i, j, 15)
-    int* s_tx = (int*)(lds + BM * CLD * 4);  // taps of this row tile (scatter mode): [128][4] texel, [128][4] weight
-    float* s_tw = (float*)(s_tx + BM * 4);
-    if (p.scatter_scale >= 0) {
-        for (int i = tid; i < BM * 4; i += NT) {
-            const int m = m0 + (i >> 2);
-            const size_t o = ((size_t)m * 5 + p.scatter_scale) * 4 + (i & 3);
-            s_tx[i] = m < p.M ? p.tap_texel[o] : -1;
-            s_tw[i] = m < p.M ? p.tap_weight[o] : 0.f;
+    nt_epilogue<T, CF>(p, acc, lds, m0, n0, tid);
+}
+
+// ================================================================================================ NT, direct-to-LDS
+// bf16 hidden-layer variant of gemm_nt (tile 128 x 256, 8 waves, two workgroups per CU) whose operand tiles go
+// HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write pass: the ds_write path moves only
+// ~80 B/clk/CU and was the busiest LDS resource of the register-staged kernel).
+//   * LDS image of a stage: 384 rows (128 of A, then 256 of W) x 64 B (32 bf16 of K), unpadded, because a wave's
+//     glds writes 64 lanes x 16 B = 16 whole rows contiguously.  Bank conflicts are removed by an XOR swizzle of the
+//     16-byte slot inside a row, slot' = slot ^ ((row >> 2) & 3), applied on the per-lane GLOBAL source address
+//     (the LDS destination of a glds is always lane-linear) and again on the fragment read.
+//   * 3 stages, prefetch distance 2, ONE raw s_barrier per chunk, counted s_waitcnt vmcnt(3): the three loads a
+//     wave issued for chunk c+1 stay in flight across the barrier while chunk c is consumed.
+//   * ReLU on the A operand is applied to the fragment registers (8 VALU per k-step).
+#define G_ROWB 64
+#define G_STAGE ((BM + 256) * G_ROWB)      // 24576 B
+#define G_NSTAGE 3
+struct CfgG {
+    static constexpr int TJ = 2, NWN = 4, BN = 256, NT = 512, OCC = 4;
+    static constexpr int LDS_LOOP = G_NSTAGE * G_STAGE + MAX_CHUNKS * 16 + 16;
+    static constexpr int LDS_EPI = BM * CLD * 4 + BM * 4 * 8;
+    static constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
+};
+
+// One 1-KiB LDS-DMA piece: lane l's 16 bytes at *g land at LDS byte (lds_wave_base + 16 l).  Issued from inline asm on
+// purpose: through the builtin hipcc models the LDS write and puts s_waitcnt vmcnt(0) in front of every later ds_read,
+// which serialises the pipeline; an asm load is invisible to its counters, so the ONLY waits are the counted
+// s_waitcnt vmcnt(N) written in the loop below (cdna_hip_programming.md §5.7).  M0 (the DMA's LDS base) is saved and
+// restored inside the same statement; the s_nop covers the M0-write -> DMA-read hazard.
+__device__ static inline void glds16(const void* g, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(lds_wave_base)
+                 : "memory");
+}
+
+__global__ __launch_bounds__(512, 4) void gemm_nt_glds_kernel(GemmNT p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef bf16_t T;
+    constexpr int ES = 2, BK = 32, TJ = 2, NWN = 4, BN = 256;
+    int4* chunks = (int4*)(lds + G_NSTAGE * G_STAGE);  // {src, a_col, w_col, kc | shift << 16}
+    int* s_n_ptr = (int*)(lds + G_NSTAGE * G_STAGE + MAX_CHUNKS * 16);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv / NWN, wn = wv % NWN;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lin / tiles_n) * BM, n0 = (lin % tiles_n) * BN;
+
+    unsigned mask = 0xffffffffu;
+    if (p.tile_mask) mask = p.tile_mask[m0 / SCENERF_TILE_ROWS];
+    if (p.skip_bit >= 0 && !((mask >> p.skip_bit) & 1u)) return;
+
+    if (tid == 0) {
+        int n = 0;
+        for (int k0 = 0; k0 < p.K1;) {
+            const int kc = chunk_len<ES>(p.K1 - k0, BK);
+            chunks[n++] = make_int4(0, k0, k0, kc | (pieces_shift(kc * ES / 16) << 16));
+            k0 += kc;
         }
-    }
+        int wbase = p.K1;
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-        if ((wn * WCOLS) / 128 == pass) {
-            const int cbase = (wn * WCOLS) % 128;
-            CS_TILE(0, 0)
-            CS_TILE(0, 1)
-            CS_TILE(1, 0)
-            CS_TILE(1, 1)
-            if constexpr (TJ == 4) {
-                CS_TILE(0, 2)
-                CS_TILE(0, 3)
-                CS_TILE(1, 2)
-                CS_TILE(1, 3)
-            }
-        }
-        __syncthreads();
-        const int nb = n0 + pass * 128;
-        if (p.scatter_scale >= 0) {
-            // grid_sampler backward.  Lanes span 64 consecutive channels of one row, so each atomic instruction adds
-            // a contiguous 256-byte run of the (H,W,C) gradient map.  The taps of a row depend only on its spherical
-            // pixel; consecutive samples of a ray often share it (far samples converge), and same-address atomics
-            // serialise in L2 -- so rows of a wave's contiguous block with identical taps are summed first and
-            // scattered once.
-            constexpr int RPW = BM / (NT / 64);
-            int r = wv * RPW;
-            const int rend = min(r + RPW, p.M - m0);
-            while (r < rend) {
-                const int t0 = s_tx[r * 4], t1 = s_tx[r * 4 + 1], t2 = s_tx[r * 4 + 2], t3 = s_tx[r * 4 + 3];
-                int e = r + 1;
-                while (e < rend && s_tx[e * 4] == t0 && s_tx[e * 4 + 1] == t1 && s_tx[e * 4 + 2] == t2 && s_tx[e * 4 + 3] == t3) ++e;
-                if ((t0 & t1 & t2 & t3) >= 0 || t0 >= 0 || t1 >= 0 || t2 >= 0 || t3 >= 0) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int col = h * 64 + lane, n = nb + col;
-                        if (n < p.N) {
-                            float v = 0.f;
-                            for (int q = r; q < e; ++q) v += Cs[q * CLD + col];
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                const int tx = s_tx[r * 4 + t];
-                                if (tx >= 0) unsafeAtomicAdd(p.gmap + (size_t)tx * p.N + n, v * s_tw[r * 4 + t]);
-                            }
-                        }
-                    }
-                }
-                r = e;
-            }
-        } else {
-            for (int it = tid; it < BM * 16; it += NT) {
-                const int row = it >> 4, cg = it & 15;
-                const int m = m0 + row, n = nb + cg * 8;
-                if (m < p.M && n < p.N) {
-                    float v[8];
-                    const float4 lo = *(const float4*)(Cs + row * CLD + cg * 8), hi = *(const float4*)(Cs + row * CLD + cg * 8 + 4);
-                    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-                    epi_item<T>(p, v, m, n);
+        for (int s = 0; s < GEMM_MAX_SEG; ++s) {
+            if (s < p.nseg && ((mask >> s) & 1u)) {
+                for (int k0 = 0; k0 < p.seg_len[s];) {
+                    const int kc = chunk_len<ES>(p.seg_len[s] - k0, BK);
+                    chunks[n++] = make_int4(1, p.seg_off[s] + k0, wbase + k0, kc | (pieces_shift(kc * ES / 16) << 16));
+                    k0 += kc;
                 }
             }
+            if (s < p.nseg) wbase += p.seg_len[s];
         }
-        if (pass + 1 < NPASS) __syncthreads();
+        *s_n_ptr = n;
     }
-#undef CS_TILE
-#undef CS_W
+    __syncthreads();
+    const int nch = *s_n_ptr;
+
+    f32x16_t acc[2][TJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- per-lane constants, computed once: the loop body must stay lean -- a first version recomputed row / swizzle
+    // / 64-bit address math per chunk and measured 16 VALU + 9 SALU instructions per MFMA (issue-bound at 27 % MFMA).
+    // LDS fragment offsets (swizzled) for the two k-steps of a 64-byte row chunk:
+    int offA[2][2], offB[TJ][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int slot = kk * 2 + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wm * 64 + i * 32 + (lane & 31);
+            offA[i][kk] = r * G_ROWB + ((slot ^ ((r >> 2) & 3)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int r = wn * TJ * 32 + j * 32 + (lane & 31);
+            offB[j][kk] = BM * G_ROWB + r * G_ROWB + ((slot ^ ((r >> 2) & 3)) << 4);
+        }
+    }
+    // This wave's three 1-KiB LDS-DMA pieces of a stage: piece i = wv + 8u covers image rows [16 i, 16 i + 16); u = 0
+    // is always an A piece (rows 0..127), u = 1, 2 are W pieces.  Lane -> (row 16 i + lane/4, physical slot lane & 3);
+    // it fetches logical slot = physical ^ ((row >> 2) & 3).  Row pointers are chunk-invariant; a chunk only adds its
+    // (wave-uniform) column offset.
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;
+    const char *pA1, *pA2, *pW[2];
+    int lsl[3];
+    {
+        const int R = 16 * wv + (lane >> 2);
+        lsl[0] = (lane & 3) ^ ((R >> 2) & 3);
+        const int gm = min(m0 + R, p.M - 1);
+        pA1 = (const char*)p.A1 + (size_t)gm * p.lda1 * ES;
+        pA2 = (const char*)p.A2 + (size_t)gm * p.lda2 * ES;
+#pragma unroll
+        for (int u = 1; u < 3; ++u) {
+            const int Rw = 16 * (wv + 8 * u) + (lane >> 2);
+            lsl[u] = (lane & 3) ^ ((Rw >> 2) & 3);
+            const int gn = min(n0 + Rw - BM, p.N - 1);
+            pW[u - 1] = (const char*)p.W + (size_t)gn * p.ldw * ES;
+        }
+    }
+    auto issue = [&](int c, const int stage) {
+        const int4 ch = chunks[c];
+        const int ppr = 1 << (ch.w >> 16);
+        const char* ga = (ch.x == 0 ? pA1 : pA2) + (size_t)ch.y * ES;
+        const size_t wcol = (size_t)ch.z * ES;
+        const unsigned sb = lds0 + stage * G_STAGE + wvu * 1024;
+        // tail chunks (< 4 pieces per row) keep every lane inside the chunk's columns (duplicates land in unused slots)
+        glds16(ga + (min(lsl[0], ppr - 1) << 4), __builtin_amdgcn_readfirstlane(sb));
+        glds16(pW[0] + wcol + (min(lsl[1], ppr - 1) << 4), __builtin_amdgcn_readfirstlane(sb + 8 * 1024));
+        glds16(pW[1] + wcol + (min(lsl[2], ppr - 1) << 4), __builtin_amdgcn_readfirstlane(sb + 16 * 1024));
+    };
+    auto compute = [&](int c, const int stage) {
+        const char* S = lds + stage * G_STAGE;
+        const int ks = (chunks[c].w & 0xffff) >> 4;
+        const bool relu = chunks[c].x == 0 && p.relu1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk < ks) {
+                uint4 a[2], b[TJ];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = *(const uint4*)(S + offA[i][kk]);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) b[j] = *(const uint4*)(S + offB[j][kk]);
+                if (relu) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) a[i] = relu16B<T>(a[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i]),
+                                                                            __builtin_bit_cast(bf16x8_t, b[j]), acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    issue(0, 0);
+    issue(nch > 1 ? 1 : 0, 1);
+    // unrolled by the 3 stages so every stage index (LDS immediate offsets, DMA bases) is a compile-time constant
+    for (int c0 = 0; c0 < nch; c0 += G_NSTAGE) {
+#pragma unroll
+        for (int st = 0; st < G_NSTAGE; ++st) {
+            const int c = c0 + st;
+            if (c < nch) {
+                // chunk c has landed once at most the 3 loads of chunk c+1 are outstanding; the barrier then (a)
+                // publishes every wave's pieces of chunk c and (b) guarantees all waves finished reading the stage
+                // the next prefetch overwrites (chunk c-1)
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                issue(c + 2 < nch ? c + 2 : nch - 1, (st + 2) % G_NSTAGE);
+                compute(c, st);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (redundant) prefetches must land before LDS is reused
+    __syncthreads();
+    nt_epilogue<T, CfgG>(p, acc, lds, m0, n0, tid);
 }
 
 // ================================================================================================ TN
@@ -592,6 +781,21 @@ template <typename T, typename CF> static int launch_nt_t(const GemmNT& p, hipSt
     return 0;
 }
 
+static int launch_nt_glds(const GemmNT& p, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CfgG::LDS));
+        attr_done = true;
+    }
+    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, CfgG::BN));
+    double flops = 0;
+    if (srf_prof_on()) flops = nt_issued_flops(p, s);
+    SrfLaunchScope ps(s, p.name, flops, 0);
+    gemm_nt_glds_kernel<<<grid, CfgG::NT, CfgG::LDS, s>>>(p);
+    SRF_LAUNCH_CHECK(p.name);
+    return 0;
+}
+
 int launch_gemm_nt(int precision, const GemmNT& p, hipStream_t s) {
     SRF_CHECK(p.W && p.M > 0 && p.N > 0, "%s: bad operands", p.name);
     SRF_CHECK(p.K1 % 16 == 0 && p.N % 8 == 0, "%s: K1=%d must be a multiple of 16, N=%d of 8", p.name, p.K1, p.N);
@@ -604,7 +808,8 @@ int launch_gemm_nt(int precision, const GemmNT& p, hipStream_t s) {
     // (measured 466 TF/s vs 330 for the 128 x 512 single-workgroup tile and 377 for 128 x 128 at K = 512: with two
     // resident workgroups one's epilogue / LDS refill overlaps the other's MFMAs)
     const bool big = (p.N % 256 == 0) && cdiv(p.M, BM) >= 192;
-    if (p.force_tile == 3 || (p.force_tile == 0 && big)) return precision ? launch_nt_t<bf16_t, CfgM>(p, s) : launch_nt_t<float, CfgM>(p, s);
+    if (precision && (p.force_tile == 4 || (p.force_tile == 0 && big))) return launch_nt_glds(p, s);
+    if (p.force_tile == 3 || p.force_tile == 4 || (p.force_tile == 0 && big)) return precision ? launch_nt_t<bf16_t, CfgM>(p, s) : launch_nt_t<float, CfgM>(p, s);
     if (p.force_tile == 2 && p.N == 512) return precision ? launch_nt_t<bf16_t, CfgW>(p, s) : launch_nt_t<float, CfgW>(p, s);
     return precision ? launch_nt_t<bf16_t, CfgS>(p, s) : launch_nt_t<float, CfgS>(p, s);
 }

@@ -64,7 +64,7 @@ def dv(t, dtype=None):
 # ------------------------------------------------------------------------------------------------ GEMM building blocks
 @pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("M,N,K,tile", [(300, 136, 80, 1), (128, 128, 64, 1), (517, 512, 560, 1), (256, 80, 1536, 1),
-                                        (517, 512, 560, 2), (130, 512, 48, 2), (1000, 512, 512, 2), (517, 512, 560, 3), (300, 256, 80, 3)])
+                                        (517, 512, 560, 2), (130, 512, 48, 2), (1000, 512, 512, 2), (517, 512, 560, 3), (300, 256, 80, 3), (517, 512, 560, 4), (300, 256, 80, 4), (1000, 512, 2992, 4)])
 def test_gemm_nt_matches_fp64(prec, M, N, K, tile):
     lib = _capi.load()
     gen = torch.Generator().manual_seed(M * 7 + N * 3 + K)

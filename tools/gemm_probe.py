@@ -41,7 +41,7 @@ def time_tn(M, N, K, prec=1, iters=20):
 
 if __name__ == "__main__":
     M = 153600
-    for (N, K, tile) in [(512, 512, 2), (512, 1024, 2), (512, 512, 1), (512, 1024, 1), (512, 512, 3), (512, 1024, 3), (512, 1536, 3)]:
+    for (N, K, tile) in [(512, 512, 3), (512, 1024, 3), (512, 1536, 3), (512, 512, 4), (512, 1024, 4), (512, 1536, 4)]:
         us, tf = time_nt(M, N, K, tile)
         print("NT bf16 M=%d N=%d K=%d tile=%d: %8.1f us  %7.1f TF/s" % (M, N, K, tile, us, tf))
     for (N, K) in [(512, 512), (1536, 80)]:
