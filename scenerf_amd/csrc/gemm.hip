@@ -14,6 +14,8 @@
 // ds_read_b128 fragment reads); the next chunk is prefetched global->VGPR while the MFMAs of the current one run.
 // Both element types use the same fragment indexing: lane l holds k = (l>>5)*8 .. +8 of row (l&31); for fp32 the
 // 8 values feed 8 back-to-back 32x32x2 MFMAs (any bijective k-order is valid as long as A and B agree).
+#include <stdlib.h>
+
 #include <vector>
 
 #include "gemm.h"
@@ -79,13 +81,18 @@ template <> __device__ inline uint4 relu16B<float>(uint4 v) {
 // one 16-element k-step on a (64 x TJ*32) wave tile
 template <typename T, int TJ, int RB> struct WaveMma;
 template <int TJ, int RB> struct WaveMma<bf16_t, TJ, RB> {
-    __device__ static inline void step(f32x16_t (&acc)[2][TJ], const char* As, const char* Ws, int kk, int lane, int wm, int wn) {
+    __device__ static inline void step(f32x16_t (&acc)[2][TJ], const char* As, const char* Ws, int kk, int lane, int wm, int wn,
+                                       bool relu_b = false) {
         const int koff = (kk * 16 + (lane >> 5) * 8) * 2;
         uint4 a[2], b[TJ];
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[i] = *(const uint4*)(As + (wm * 64 + i * 32 + (lane & 31)) * RB + koff);
 #pragma unroll
         for (int j = 0; j < TJ; ++j) b[j] = *(const uint4*)(Ws + (wn * TJ * 32 + j * 32 + (lane & 31)) * RB + koff);
+        if (relu_b) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) b[j] = relu16B<bf16_t>(b[j]);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -95,7 +102,8 @@ template <int TJ, int RB> struct WaveMma<bf16_t, TJ, RB> {
     }
 };
 template <int TJ, int RB> struct WaveMma<float, TJ, RB> {
-    __device__ static inline void step(f32x16_t (&acc)[2][TJ], const char* As, const char* Ws, int kk, int lane, int wm, int wn) {
+    __device__ static inline void step(f32x16_t (&acc)[2][TJ], const char* As, const char* Ws, int kk, int lane, int wm, int wn,
+                                       bool = false) {
         const int koff = (kk * 16 + (lane >> 5) * 8) * 4;
         float a[2][8], b[TJ][8];
 #pragma unroll
@@ -567,30 +575,35 @@ template <typename T> struct TnStage;
 template <> struct TnStage<bf16_t> {
     static constexpr int MC = 64;  // contraction rows per chunk
     uint4 r[8];
-    // load() only issues the global loads (clamped indices, no consumer) so the wait lands in store()
-    __device__ inline void load(const GemmTN& p, int tid, int mc, int n0, int k0) {
-        // lanes walk the m-blocks first: the transposed 16-byte LDS writes of 8 consecutive lanes then fill 128
-        // contiguous bytes of one row (conflict-free) while each global load still covers 8 rows x 128 B
+    // per-lane source pointer of row 0 of this thread's 8x8 block column (chunk-invariant), set once by init()
+    const char* src;
+    size_t ld;
+    int mrow;   // first row of the block inside a chunk
+    __device__ inline void init(const GemmTN& p, int tid, int n0, int k0) {
         const int op = tid >> 7, b = tid & 127, mb = b & 7, nb = b >> 3;
         const char* base = (const char*)(op == 0 ? p.D : p.A);
-        const size_t ld = (size_t)(op == 0 ? p.ldd : p.lda) * 2;
+        ld = (size_t)(op == 0 ? p.ldd : p.lda) * 2;
         const int lim = (op == 0 ? p.N : p.K) - 8;
         const int col = min((op == 0 ? n0 : k0) + nb * 8, lim);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int m = min(mc + mb * 8 + j, p.M - 1);
-            r[j] = *(const uint4*)(base + (size_t)m * ld + (size_t)col * 2);
-        }
+        mrow = mb * 8;
+        src = base + (size_t)col * 2;
     }
+    // load() only issues the global loads (nothing consumes them) so the wait lands in store().  Branch-free on
+    // purpose: loads inside a conditional block make hipcc wait vmcnt(0) at the join (measured 188 -> 225 us).
+    __device__ inline void load(const GemmTN& p, int tid, int mc, int n0, int k0) {
+        const int m0 = mc + mrow;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = *(const uint4*)(src + (size_t)min(m0 + j, p.M - 1) * ld);
+    }
+    // 8x8 bf16 transpose in registers: output word q of column c packs rows 2q, 2q+1 -> one v_perm_b32 each
+    // (v_perm_b32 D = bytes of {S0,S1}; selector values 0-3 pick S1's bytes, 4-7 pick S0's)
     __device__ inline void store(const GemmTN& p, char* stage, int tid, int mc, int n0, int k0) {
         const int op = tid >> 7, b = tid & 127, mb = b & 7, nb = b >> 3;
         char* tile = stage + op * TN_TILE;
         const bool cok = (op == 0 ? n0 : k0) + nb * 8 < (op == 0 ? p.N : p.K);
-        const bool relu = op == 1 && p.relu_a;
+        if (!cok || mc + MC > p.M) {   // only edge tiles pay for zero-filling (VALU only: safe to branch around)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            uint4 v = (cok && mc + mb * 8 + j < p.M) ? r[j] : zero4();
-            r[j] = relu ? relu16B<bf16_t>(v) : v;
+            for (int j = 0; j < 8; ++j) r[j] = (cok && mc + mb * 8 + j < p.M) ? r[j] : zero4();
         }
         const uint32_t* w = (const uint32_t*)r;  // w[j*4 + q] = row j, column pair q
 #pragma unroll
@@ -598,8 +611,8 @@ template <> struct TnStage<bf16_t> {
             uint32_t o[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                uint32_t a = w[(2 * q) * 4 + (c >> 1)], bb = w[(2 * q + 1) * 4 + (c >> 1)];
-                o[q] = (c & 1) ? ((a >> 16) | (bb & 0xffff0000u)) : ((a & 0xffffu) | (bb << 16));
+                const uint32_t a = w[(2 * q) * 4 + (c >> 1)], bb = w[(2 * q + 1) * 4 + (c >> 1)];
+                o[q] = __builtin_amdgcn_perm(bb, a, (c & 1) ? 0x07060302u : 0x05040100u);
             }
             *(uint4*)(tile + (nb * 8 + c) * TN_RB + mb * 16) = make_uint4(o[0], o[1], o[2], o[3]);
         }
@@ -618,6 +631,7 @@ template <> struct TnStage<bf16_t> {
 template <> struct TnStage<float> {
     static constexpr int MC = 32;
     float4 r[2][4];
+    __device__ inline void init(const GemmTN&, int, int, int) {}
     __device__ inline void load(const GemmTN& p, int tid, int mc, int n0, int k0) {
         const int mb = tid & 7, nb = tid >> 3;
 #pragma unroll
@@ -676,6 +690,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
     const int mbeg = (lin / (tiles_n * tiles_k)) * rows_per_slice;
     const int mend = (mbeg + rows_per_slice < p.M) ? mbeg + rows_per_slice : p.M;
     const bool do_colsum = p.colsum != nullptr && k0 == 0 && tid < 128;
+    const bool relu_b = sizeof(T) == 2 && p.relu_a;   // bf16: ReLU of the activation operand on its fragments
 
     auto next_valid = [&](int m) {
         if (p.tile_mask && p.skip_bit >= 0) {
@@ -694,6 +709,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
     float csum = 0.f;
 
     TnStage<T> st;
+    st.init(p, tid, n0, k0);
     int c = next_valid(mbeg);
     if (c >= mend) return;  // uniform
     st.load(p, tid, c, n0, k0);
@@ -706,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
         const char* Dt = lds + buf * TN_STAGE;
         const char* At = Dt + TN_TILE;
 #pragma unroll
-        for (int kk = 0; kk < MC / 16; ++kk) WaveMma<T, 2, TN_RB>::step(acc, Dt, At, kk, lane, wm, wn);
+        for (int kk = 0; kk < MC / 16; ++kk) WaveMma<T, 2, TN_RB>::step(acc, Dt, At, kk, lane, wm, wn, relu_b);
         if (do_colsum) csum += TnStage<T>::rowsum(Dt, tid);  // bias gradient: column sums of D (staged rows are zero-padded)
         if (nx < mend) st.store(p, lds + (buf ^ 1) * TN_STAGE, tid, nx, n0, k0);
         __syncthreads();
@@ -823,7 +839,13 @@ template <typename T> static int launch_tn_t(const GemmTN& p, hipStream_t s) {
     constexpr int MC = TnStage<T>::MC;
     int tiles = cdiv(p.N, 128) * cdiv(p.K, 128);
     int chunks = cdiv(p.M, MC);
-    int slices = 1024 / tiles;
+    static int target = 0;
+    if (!target) {
+        const char* e = getenv("SRF_TN_WG_TARGET");   // tuning knob: workgroups per launch the M-split aims for
+        target = e ? atoi(e) : 512;   // 256 CUs x 2 resident workgroups: one full wave of workgroups, no tail (measured best)
+        if (target < 1) target = 512;
+    }
+    int slices = target / tiles;
     if (slices < 1) slices = 1;
     if (slices > chunks) slices = chunks;
     int cps = cdiv(chunks, slices);  // chunks per slice

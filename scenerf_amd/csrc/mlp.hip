@@ -127,8 +127,8 @@ static int launch_linout_fwd(int d_out, const void* H3, const float* w, const fl
 template <typename T>
 static int launch_linout_bwd(int d_out, const void* H3, const float* w, const float* dlog, int M, void* dH3, int lddh, float* dw,
                              float* db, hipStream_t s) {
-    int grid = cdiv(M, 4 * 16);
-    if (grid > 2048) grid = 2048;
+    int grid = cdiv(M, 4 * 64);   // few, long-running blocks: every block ends with d_out*512 atomics
+    if (grid > 512) grid = 512;
     SrfLaunchScope ps(s, "linout_bwd", 0, (double)M * (1024.0 * sizeof(T) + 4.0 * d_out));
     if (d_out == 4) linout_bwd_kernel<T, 4><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, dw, db);
     else linout_bwd_kernel<T, 2><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, dw, db);
