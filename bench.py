@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=96, help="rays of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-rays", type=int, default=64, help="rays of the bounded CPU-baseline sample")
+    ap.add_argument("--no-eager-baseline", action="store_true")
     ap.add_argument("--kernels-json", default="", help="write the per-kernel table here")
     return ap.parse_args()
 
@@ -67,36 +68,60 @@ def make_model(args, dev):
     return m
 
 
-def cpu_baseline(args):
-    """The oracle (port of the reference's eager path) on the host cores, bounded sample, fwd+bwd."""
+def _oracle_setup(args, dev):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import scenerf_oracle as orc
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     U, P = sample_split(args.samples)
     cfg = orc.OracleConfig.kitti(n_pts_uni=U, n_pts_per_gaussian=P)
     mlp, mlpg = synth.mlp_state(1, 4), synth.mlp_state(2, 2, out_scale=4.0)
-    for d in (mlp, mlpg):
-        for v in d.values():
-            v.requires_grad_(True)
-    maps = synth.feature_maps(1500, 452, 3)
-    for v in maps.values():
-        v.requires_grad_(True)
-    K, T = synth.kitti_cam_K(), synth.rel_pose(1.0, 0.0)
+    mlp = {k: v.to(dev).requires_grad_(True) for k, v in mlp.items()}
+    mlpg = {k: v.to(dev).requires_grad_(True) for k, v in mlpg.items()}
+    maps = {k: v.to(dev).requires_grad_(True) for k, v in synth.feature_maps(1500, 452, 3).items()}
+    K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
 
     def run(R, seed):
-        pix = synth.stride2_pixels((1220, 370), R, seed)
+        pix = synth.stride2_pixels((1220, 370), R, seed).to(dev)
         nu, ng = synth.sampling_noise(R, U, 4 * P, seed + 1)
-        t0 = time.perf_counter()
-        out = orc.render_chunk(cfg, mlp, mlpg, K, T, maps, pix, nu, ng)
+        out = orc.render_chunk(cfg, mlp, mlpg, K, T, maps, pix, nu.to(dev), ng.to(dev))
         orc.training_proxy_loss(out).backward()
-        return time.perf_counter() - t0
+        for d in (mlp, mlpg, maps):
+            for v in d.values():
+                v.grad = None
+    return run
 
+
+def cpu_baseline(args):
+    """The oracle (port of the reference's eager path) on the host cores, bounded sample, fwd+bwd."""
+    cores = os.cpu_count() or 1
+    threads = min(cores, 32)   # torch's CPU kernels stop scaling (and regress) beyond a few dozen threads
+    torch.set_num_threads(threads)
+    run = _oracle_setup(args, "cpu")
     run(8, 50)  # warm-up (allocators, thread pool)
     R = args.cpu_rays
-    best = min(run(R, 60), run(R, 70))
-    return {"value": R / best, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "%d rays x %d samples fwd+bwd, full KITTI maps, best of 2 (%.1f s)" % (R, args.samples, best)}
+    t0 = time.perf_counter()
+    run(R, 60)
+    best = time.perf_counter() - t0
+    return {"value": round(R / best, 2), "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": "%d rays x %d samples fwd+bwd on %d of %d host threads, full KITTI maps (%.1f s)" % (
+                R, args.samples, threads, cores, best)}
+
+
+def eager_gpu_baseline(args, dev):
+    """The same eager-PyTorch port of the reference run on THIS GPU through PyTorch-ROCm: the closest available
+    stand-in for "the reference on one GPU" (the reference itself is not on the GPU box).  Extra information next
+    to cpu_baseline, not the optimisation target."""
+    run = _oracle_setup(args, dev)
+    R = args.rays
+    run(R, 50)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for i in range(n):
+        run(R, 60 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(R / dt, 1), "unit": "rays/s", "kind": "eager PyTorch-ROCm port of the reference hot path, fp32",
+            "ms_per_step": round(dt * 1e3, 2), "sample": "%d rays x %d samples fwd+bwd, 3 steps" % (R, args.samples)}
 
 
 def main():
@@ -193,7 +218,13 @@ def main():
             with open(args.kernels_json, "w") as f:
                 json.dump(kernels, f, indent=1)
 
-    cpu = None
+    cpu = eager = None
+    if rank == 0 and world == 1 and not args.no_eager_baseline:
+        try:
+            eager = eager_gpu_baseline(args, dev)
+        except Exception as e:  # never let the side measurement break the bench line
+            eager = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
@@ -209,7 +240,7 @@ def main():
                                    "gradients, grad all-reduce (N>1), fused AdamW on both MLPs" % (args.samples, U, P, R),
                        "rays_per_gpu": R, "samples_per_ray": args.samples, "parallelism": "dp%d" % world,
                        "precision": args.precision},
-            "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -97,14 +97,14 @@ def ray_directions(pixels: torch.Tensor, inv_K: torch.Tensor):
 
 def to_frame(pts: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     """utils.py:161-166 / 268-279: homogeneous 4x4 transform of (M,3) points."""
-    h = torch.cat([pts, torch.ones(pts.shape[0], 1, dtype=pts.dtype)], dim=1).float()
+    h = torch.cat([pts, torch.ones(pts.shape[0], 1, dtype=pts.dtype, device=pts.device)], dim=1).float()
     return (T @ h.T).T[:, :3]
 
 
 def uniform_distances(n_rays: int, U: int, D: float, noise_u: torch.Tensor) -> torch.Tensor:
     """utils.py:75-90: linspace(0.2, D, U) + rand * (D-0.2)/U."""
     step = (D - 0.2) / U
-    base = torch.linspace(0.2, D, steps=U).reshape(1, U, 1).expand(n_rays, -1, -1)
+    base = torch.linspace(0.2, D, steps=U, device=noise_u.device).reshape(1, U, 1).expand(n_rays, -1, -1)
     return (base + noise_u * step).squeeze(-1)
 
 
@@ -118,7 +118,7 @@ def project_to_pixels(pts: torch.Tensor, K: torch.Tensor) -> torch.Tensor:
     """utils.py:298-315: K @ p, perspective divide where z>0, else (-1,-1)."""
     h = (K @ pts.T).T
     ok = h[:, 2] > 0
-    pix = torch.full((pts.shape[0], 2), -1.0)
+    pix = torch.full((pts.shape[0], 2), -1.0, device=pts.device)
     pix = torch.where(ok[:, None], h[:, :2] / h[:, 2:3], pix)
     return pix
 
@@ -127,12 +127,12 @@ def sphere_coords(pix: torch.Tensor, inv_K: torch.Tensor, cfg: OracleConfig, ret
     """spherical_mapping.py:80-115: pixel -> unit-depth cam point -> (acos, atan2) -> rounded sphere pixel."""
     v_min, v_fov, h_min, h_fov = cfg.fov
     c = (inv_K @ _homog(pix).T).T
-    c = torch.ones(pix.shape[0]).view(-1, 1) * c
+    c = torch.ones(pix.shape[0], device=pix.device).view(-1, 1) * c
     x, y, z = c[:, 0], c[:, 1], c[:, 2]
     dist = torch.linalg.norm(c, ord=2, dim=1)
     v_angle = torch.acos(-y / dist) / math.pi * 180
     h_angle = 180 - torch.atan2(z, x) / math.pi * 180
-    out = torch.zeros((pix.shape[0], 2))
+    out = torch.zeros((pix.shape[0], 2), device=pix.device)
     out[:, 0] = (h_angle - h_min) / h_fov * (cfg.sphere_W - 1)
     out[:, 1] = (v_angle - v_min) / v_fov * (cfg.sphere_H - 1)
     idx = torch.round(out).long()
@@ -143,9 +143,9 @@ def sphere_coords(pix: torch.Tensor, inv_K: torch.Tensor, cfg: OracleConfig, ret
 
 def positional_encoding(x: torch.Tensor, num_freqs: int = 6) -> torch.Tensor:
     """pe.py:13-43: [x, sin(f0 x), sin(f0 x + pi/2), sin(f1 x), ...], f_k = pi 2^k, (M,3)->(M,39)."""
-    freqs = math.pi * 2.0 ** torch.arange(0, num_freqs)
+    freqs = math.pi * 2.0 ** torch.arange(0, num_freqs, device=x.device)
     f = torch.repeat_interleave(freqs, 2).view(1, -1, 1)
-    ph = torch.zeros(2 * num_freqs)
+    ph = torch.zeros(2 * num_freqs, device=x.device)
     ph[1::2] = math.pi * 0.5
     e = x.unsqueeze(1).repeat(1, num_freqs * 2, 1)
     e = torch.sin(torch.addcmul(ph.view(1, -1, 1), e, f)).view(x.shape[0], -1)
@@ -154,7 +154,7 @@ def positional_encoding(x: torch.Tensor, num_freqs: int = 6) -> torch.Tensor:
 
 def gather_features(fmap: torch.Tensor, idx: torch.Tensor, div_wh: Tuple[int, int]) -> torch.Tensor:
     """utils.py:232-247: bilinear grid_sample (align_corners=False, zeros) at idx/div*2-1. (M, C)."""
-    g = (idx / torch.tensor(div_wh).type_as(idx).reshape(1, 2)) * 2 - 1
+    g = (idx / torch.tensor(div_wh, device=idx.device).type_as(idx).reshape(1, 2)) * 2 - 1
     out = F.grid_sample(fmap.unsqueeze(0), g.reshape(1, 1, -1, 2), align_corners=False,
                         mode="bilinear", padding_mode="zeros")
     return out.reshape(out.shape[1], -1).T
