@@ -36,6 +36,27 @@ PEAK_FP32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(logical_name):
+    """HBM bytes per launch of the kernel FUNCTION that runs `logical_name`, from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/pmc_hbm.py).  PMC counters cannot be read from inside the
+    process, so this is the last profiled value of the same bench command, not a live reading; None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+    except Exception:
+        return None
+    fn = "gemm_tn_kernel" if "wgrad" in logical_name else ("gemm_nt_glds_kernel" if logical_name.startswith("gemm_") and
+                                                            not logical_name.endswith("/g") else None)
+    for k, v in d.items():
+        if fn and k.startswith(fn):
+            return {"bytes_per_launch": round(v["hbm_bytes_per_launch"]), "kernel_fn": k, "source": os.path.basename(files[-1]),
+                    "note": "average over all launches of this kernel function in a step"}
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,7 +67,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=64, help="rays of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-rays", type=int, default=1024, help="rays of the bounded CPU-baseline sample")
     ap.add_argument("--no-eager-baseline", action="store_true")
     ap.add_argument("--kernels-json", default="", help="write the per-kernel table here")
     return ap.parse_args()
@@ -201,7 +222,7 @@ def main():
             tot_f = sum(k["flops"] for k in mfma)
             tot_t = sum(k["total_ms"] for k in mfma)
             roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom["name"]),
                     "avg_launch_us": round(dom["avg_us"], 2), "flops_per_launch": dom["flops"] / dom["launches"],
                     "all_mfma_kernels_achieved": round(tot_f / (tot_t * 1e-3) / 1e12, 2),
                     "all_mfma_kernels_frac": round(tot_f / (tot_t * 1e-3) / 1e12 / peak, 4),

@@ -1,0 +1,31 @@
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM bytes per launch.
+usage: pmc_hbm.py <dir_fetch> <dir_write> <out.json>
+Correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE/WRITE_SIZE count KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of
+wide (16 B/lane) coalesced reads -> doubled.  WRITE_SIZE is taken as is (uncalibrated per the guide)."""
+import collections, csv, glob, json, re, sys
+
+def agg(d, counter):
+    tot, cnt = collections.defaultdict(float), collections.Counter()
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+            tot[k] += float(r["Counter_Value"])
+            cnt[k] += 1
+    return tot, cnt
+
+ft, fc = agg(sys.argv[1], "FETCH_SIZE")
+wt, wc = agg(sys.argv[2], "WRITE_SIZE")
+out = {}
+for k in sorted(set(ft) | set(wt)):
+    if "at::" in k or "rocsolver" in k or "rocclr" in k:
+        continue
+    n = max(fc.get(k, 0), wc.get(k, 0), 1)
+    fetch = ft.get(k, 0.0) * 1024 * 2 / max(fc.get(k, 1), 1)
+    write = wt.get(k, 0.0) * 1024 / max(wc.get(k, 1), 1)
+    out[k] = {"launches": n, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+              "hbm_bytes_per_launch": fetch + write}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
+    print("%-60s n=%4d fetch %8.1f MB  write %8.1f MB" % (k[:60], v["launches"], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6))
