@@ -151,7 +151,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())   # (modulo only matters for the 1-GPU gloo self-test)
     torch.cuda.set_device(dev)
     _capi.load()
     torch.manual_seed(42 + rank)  # train_kitti.py:11 seed_everything(42), decorrelated per rank

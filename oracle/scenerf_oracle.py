@@ -271,10 +271,14 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
     viewdir = (T_source2infer[:3, :3] @ dirs.T).T                                  # utils.py:170
 
     # uniform samples (utils.py:112-173)
-    dist_u = uniform_distances(R, U, D, noise_u)
-    pts_u_src = dist_u.unsqueeze(-1) * unit.reshape(R, 1, 3)
-    z_u = pts_u_src[:, :, 2]
-    pts_u = to_frame(pts_u_src.reshape(-1, 3), T_source2infer).reshape(R, U, 3)
+    if U > 0:
+        dist_u = uniform_distances(R, U, D, noise_u)
+        pts_u_src = dist_u.unsqueeze(-1) * unit.reshape(R, 1, 3)
+        z_u = pts_u_src[:, :, 2]
+        pts_u = to_frame(pts_u_src.reshape(-1, 3), T_source2infer).reshape(R, U, 3)
+    else:  # the reference would sample 0 uniform points and use the gaussian samples only (scenerf.py:647-650)
+        dist_u = z_u = torch.zeros(R, 0, device=pixels.device)
+        pts_u = torch.zeros(R, 0, 3, device=pixels.device)
 
     # gaussian heads (scenerf.py:549-596)
     anchors = gaussian_anchor_distances(cfg).type_as(cam_K).reshape(1, G, 1).expand(R, -1, 1)

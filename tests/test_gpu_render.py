@@ -141,3 +141,50 @@ def test_larger_chunk_against_oracle_bf16_and_fp32():
         print(precision, "depth frac", fd, "color frac", fc,
               "max rel depth err", float(((out["depth"].cpu() - ref["depth"].detach()).abs() / ref["depth"].detach().abs()).max()))
         assert fd >= 0.97 and fc >= 0.97
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+EDGE_CASES = [
+    # name, ctor overrides, R, chunk, pose
+    ("single_ray", dict(), 1, 1, (2.0, 0.0)),
+    ("ragged_chunks", dict(), 37, 16, (1.0, -10.0)),                       # 16 + 16 + 5 rays: last chunk ragged
+    ("n96_odd_rows", dict(n_pts_uni=64, n_pts_per_gaussian=8), 7, 7, (5.0, 10.0)),   # M = 672 = 5.25 tiles of 128
+    ("gaussians_only", dict(n_pts_uni=0, n_pts_per_gaussian=16), 9, 9, (2.0, 0.0)),  # U = 0 branch, scenerf.py:647-650
+    ("two_gaussians", dict(n_gaussians=2, n_pts_per_gaussian=16), 6, 6, (2.0, 10.0)),
+    ("behind_camera", dict(), 12, 12, (-30.0, 170.0)),                     # most samples project with z<=0 -> pix (-1,-1)
+    ("n512_inference_sampling", dict(n_pts_uni=256, n_pts_per_gaussian=64), 3, 3, (2.0, 0.0)),
+]
+
+
+@pytest.mark.parametrize("name,over,R,chunk,pose", EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
+def test_edge_cases_against_oracle_fp32(name, over, R, chunk, pose):
+    from scenerf_amd import synth
+    kw = dict(sphere_W=376, sphere_H=114)
+    kw.update(over)
+    ocfg = orc.OracleConfig.kitti(**kw)
+    mlp, mlpg = synth.mlp_state(21, 4), synth.mlp_state(22, 2, out_scale=4.0)
+    maps = synth.feature_maps(376, 114, 23, smooth=True)
+    pix = synth.stride2_pixels((1220, 370), R, 24)
+    U, GP = ocfg.n_pts_uni, ocfg.n_gaussians * ocfg.n_pts_per_gaussian
+    nu, ng = synth.sampling_noise(R, U, GP, 25)
+    K, T = synth.kitti_cam_K(), synth.rel_pose(*pose)
+    ref = orc.render_rays_batch(ocfg, mlp, mlpg, K, T, maps, pix, nu, ng, ray_batch_size=chunk) if U > 0 else None
+    if U == 0:   # the oracle's uniform branch needs U > 0 tensors: run it chunk by chunk with empty uniform noise
+        ref = orc.render_rays_batch(ocfg, mlp, mlpg, K, T, maps, pix, torch.zeros(R, 0, 1), ng, ray_batch_size=chunk)
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="fp32", **kw).to(DEV)
+    m.mlp.load_state_dict(mlp)
+    m.mlp_gaussian.load_state_dict(mlpg)
+    x = {k: v.to(DEV).requires_grad_(True) for k, v in maps.items()}
+    out = m.render_rays_batch(K.to(DEV), T.to(DEV), x, sampled_pixels=pix.to(DEV), ray_batch_size=chunk,
+                              noise=(nu.to(DEV), ng.to(DEV)))
+    for k in OUT_KEYS:
+        got, want = out[k].detach().cpu(), ref[k].detach()
+        assert got.shape == want.shape, (k, got.shape, want.shape)
+        assert torch.isfinite(got).all(), k
+        if k in ("loss_kl", "som_vars", "closest_pts_to_depths", "weights_at_depth"):
+            continue   # threshold / argmin outputs: covered by the stage tests with identical inputs
+        fr, _ = frac_within(got, want, 5e-4, 5e-4)
+        assert fr >= (0.9 if R >= 10 else 0.6), "%s: %.2f of rays within tolerance" % (k, fr)
+    (out["depth"].sum() + out["color"].sum() + out["loss_kl"].sum()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.mlp.parameters())
+    assert all(torch.isfinite(v.grad).all() for v in x.values())
