@@ -147,7 +147,8 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
 
 /* autograd of ResnetFC.forward w.r.t. parameters and the gathered features; the feature gradient is
  * scattered straight into the (H,W,C) fp32 map-gradient accumulators (grid_sampler_2d_backward).
- * d_logits [M][d_out] fp32.  scratch: dH act [M][2048], dN act [M][512]. */
+ * d_logits [M][d_out] fp32.  scratch: dH act [M][2048], dN act [3][M][512] (one per block: the weight-gradient GEMMs
+ * run on an internal side stream, forked from / joined into `stream`, while the dgrad chain proceeds). */
 int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const scenerf_mlp_grads* g,
                              const void* Z, const float* xenc, const uint8_t* tile_mask,
                              const int32_t* tap_texel, const float* tap_weight, int M,

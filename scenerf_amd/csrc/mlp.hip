@@ -1,6 +1,8 @@
 // ResnetFC forward / backward as a sequence of MFMA GEMM launches with fused prologues/epilogues
 // (reference scenerf/models/resnetfc.py:133-164 and its autograd), plus the small memory-bound kernels
 // around them: lin_out (512 -> 4|2), bias-gradient column sums and an fp32->bf16 row conversion.
+#include <stdlib.h>
+
 #include "gemm.h"
 
 
@@ -135,6 +137,37 @@ static int launch_linout_bwd(int d_out, const void* H3, const float* w, const fl
     SRF_LAUNCH_CHECK("linout_bwd_kernel");
     return 0;
 }
+// ---- internal fork/join: weight-gradient GEMMs run on a side stream next to the dgrad chain -------------------
+// The wgrad of a layer only needs that layer's incoming gradient, not the rest of the backward chain, so it can overlap
+// the next dgrad GEMM: two kernels in flight hide each other's tails, epilogues and launch gaps.  The side stream is
+// created once per caller stream; every call forks from and joins back into the caller's stream with events, so from
+// the outside all work is still ordered on `stream` (and the pattern is hipGraph-capturable).
+#include <map>
+struct SideCtx {
+    hipStream_t side = nullptr;
+    hipEvent_t ev[16];
+    int next = 0;
+};
+static SideCtx* side_ctx(hipStream_t main) {
+    static std::map<hipStream_t, SideCtx*> g_map;
+    auto it = g_map.find(main);
+    if (it != g_map.end()) return it->second;
+    SideCtx* c = new SideCtx();
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    for (int i = 0; i < 16; ++i) {
+        if (hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
+    }
+    g_map[main] = c;
+    return c;
+}
+static int order_after(SideCtx* c, hipStream_t from, hipStream_t to) {  // everything enqueued later on `to` waits for `from`'s past
+    hipEvent_t e = c->ev[c->next];
+    c->next = (c->next + 1) & 15;
+    SRF_HIP(hipEventRecord(e, from));
+    SRF_HIP(hipStreamWaitEvent(to, e, 0));
+    return 0;
+}
+
 // ================================================================================================ sequencing
 static void set_segments(GemmNT& g, const scenerf_cfg* cfg, const void* Z, const uint8_t* tile_mask) {
     g.A2 = Z;
@@ -241,20 +274,27 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     for (int i = 0, off = 0; i < 5; ++i) { kSegOff[i] = off; off += cfg->map_C[i]; }
     auto dHcol = [&](int b) { return (void*)((char*)dH + (size_t)b * SCENERF_D_HIDDEN * es); };
 
+    static const bool overlap = getenv("SRF_NO_WGRAD_OVERLAP") == nullptr;
+    SideCtx* sc_ = overlap ? side_ctx(s) : nullptr;
+    hipStream_t s2 = sc_ ? sc_->side : s;   // weight-gradient stream (== s when overlap is off)
+    auto fork = [&]() -> int { return sc_ ? order_after(sc_, s, s2) : 0; };
+    auto dNb = [&](int b) { return (void*)((char*)dN + (size_t)b * M * SCENERF_D_HIDDEN * es); };  // dN: [3][M][512]
+
     // lin_out backward -> dH3, dw_out, db_out
     if (prec) {
         if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, s)) return e;
     } else {
         if (int e = launch_linout_bwd<float>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, s)) return e;
     }
+    if (int e = fork()) return e;
     for (int b = 2; b >= 0; --b) {
-        {   // dW1_b += dH_{b+1}^T relu(N_b)
+        {   // [side] dW1_b += dH_{b+1}^T relu(N_b)
             GemmTN t;
             t.name = head ? "gemm_wgrad_fc1/g" : "gemm_wgrad_fc1";
             t.D = dHcol(b + 1); t.ldd = LDH; t.A = a->Nn[b]; t.lda = SCENERF_D_HIDDEN; t.relu_a = 1;
             t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc1[b]; t.ldo = SCENERF_D_HIDDEN;
             t.colsum = g_->b_fc1[b];  // fc_1.b.bias gradient = column sums of dH_{b+1}
-            if (int e = launch_gemm_tn(prec, t, s)) return e;
+            if (int e = launch_gemm_tn(prec, t, s2)) return e;
         }
         {   // dN_b = (dH_{b+1} @ W1_b) * [N_b > 0]
             GemmNT g;
@@ -263,21 +303,22 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             g.W = w->w_fc1_t[b]; g.ldw = SCENERF_D_HIDDEN;
             g.M = M; g.N = SCENERF_D_HIDDEN;
             g.maskp = a->Nn[b]; g.ldmask = SCENERF_D_HIDDEN;
-            g.out = dN; g.ldout = SCENERF_D_HIDDEN;
+            g.out = dNb(b); g.ldout = SCENERF_D_HIDDEN;
             if (int e = launch_gemm_nt(prec, g, s)) return e;
         }
-        {   // dW0_b += dN_b^T relu(H_b);  db0_b = column sums of dN_b
+        if (int e = fork()) return e;
+        {   // [side] dW0_b += dN_b^T relu(H_b);  db0_b = column sums of dN_b
             GemmTN t;
             t.name = head ? "gemm_wgrad_fc0/g" : "gemm_wgrad_fc0";
-            t.D = dN; t.ldd = SCENERF_D_HIDDEN; t.A = a->H[b]; t.lda = SCENERF_D_HIDDEN; t.relu_a = 1;
+            t.D = dNb(b); t.ldd = SCENERF_D_HIDDEN; t.A = a->H[b]; t.lda = SCENERF_D_HIDDEN; t.relu_a = 1;
             t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc0[b]; t.ldo = SCENERF_D_HIDDEN;
             t.colsum = g_->b_fc0[b];
-            if (int e = launch_gemm_tn(prec, t, s)) return e;
+            if (int e = launch_gemm_tn(prec, t, s2)) return e;
         }
         {   // dH_b = dH_{b+1} + (dN_b @ W0_b) * [H_b > 0]
             GemmNT g;
             g.name = head ? "gemm_dgrad_fc0/g" : "gemm_dgrad_fc0";
-            g.A1 = dN; g.lda1 = SCENERF_D_HIDDEN; g.K1 = SCENERF_D_HIDDEN;
+            g.A1 = dNb(b); g.lda1 = SCENERF_D_HIDDEN; g.K1 = SCENERF_D_HIDDEN;
             g.W = w->w_fc0_t[b]; g.ldw = SCENERF_D_HIDDEN;
             g.M = M; g.N = SCENERF_D_HIDDEN;
             g.maskp = a->H[b]; g.ldmask = SCENERF_D_HIDDEN;
@@ -285,8 +326,9 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             g.out = dHcol(b); g.ldout = LDH;
             if (int e = launch_gemm_nt(prec, g, s)) return e;
         }
+        if (int e = fork()) return e;
     }
-    // dWz[:, slice_s] += dH[:, 0:1536]^T Z[:, slice_s]   (row-tiles without scale s skipped)
+    // [side] dWz[:, slice_s] += dH[:, 0:1536]^T Z[:, slice_s]   (row-tiles without scale s skipped)
     for (int sc = 0; sc < 5; ++sc) {
         GemmTN t;
         t.name = head ? "gemm_wgrad_linz/g" : "gemm_wgrad_linz";
@@ -295,9 +337,9 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         t.M = M; t.N = 3 * SCENERF_D_HIDDEN; t.K = cfg->map_C[sc];
         t.tile_mask = tile_mask; t.skip_bit = sc;
         t.out = g_->w_z + kSegOff[sc]; t.ldo = SCENERF_D_LATENT;
-        if (int e = launch_gemm_tn(prec, t, s)) return e;
+        if (int e = launch_gemm_tn(prec, t, s2)) return e;
     }
-    // dWin += dH0^T xenc   (bf16 mode: the hi part of the split encoding kept in h0pre is bf16(xenc))
+    // [side] dWin += dH0^T xenc   (bf16 mode: the hi part of the split encoding kept in h0pre is bf16(xenc))
     {
         GemmTN t;
         t.name = head ? "gemm_wgrad_lin_in/g" : "gemm_wgrad_lin_in";
@@ -309,12 +351,12 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         }
         t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_XENC; t.out = g_->w_in; t.ldo = SCENERF_D_XENC;
         t.colsum = g_->b_in;  // lin_in.bias gradient = column sums of dH_0
-        if (int e = launch_gemm_tn(prec, t, s)) return e;
+        if (int e = launch_gemm_tn(prec, t, s2)) return e;
     }
     // lin_z.b.bias is added at the same place as lin_in.bias (b=0) / fc_1.(b-1).bias: same column sums of dH_b
-    SRF_HIP(hipMemcpyAsync(g_->b_z, g_->b_in, SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s));
-    SRF_HIP(hipMemcpyAsync(g_->b_z + SCENERF_D_HIDDEN, g_->b_fc1[0], SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s));
-    SRF_HIP(hipMemcpyAsync(g_->b_z + 2 * SCENERF_D_HIDDEN, g_->b_fc1[1], SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s));
+    SRF_HIP(hipMemcpyAsync(g_->b_z, g_->b_in, SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s2));
+    SRF_HIP(hipMemcpyAsync(g_->b_z + SCENERF_D_HIDDEN, g_->b_fc1[0], SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s2));
+    SRF_HIP(hipMemcpyAsync(g_->b_z + 2 * SCENERF_D_HIDDEN, g_->b_fc1[1], SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s2));
     // dZ[:, slice_s] = dH[:, 0:1536] @ Wz[:, slice_s], scattered straight into the (H,W,C) map gradients
     if (gmaps_hwc) {
         for (int sc = 0; sc < 5; ++sc) {
@@ -328,6 +370,9 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             g.gmap = gmaps_hwc[sc]; g.tap_texel = tap_texel; g.tap_weight = tap_weight; g.scatter_scale = sc;
             if (int e = launch_gemm_nt(prec, g, s)) return e;
         }
+    }
+    if (sc_) {  // join: the caller's stream continues only after the weight-gradient stream has drained
+        if (int e = order_after(sc_, s2, s)) return e;
     }
     return 0;
 }

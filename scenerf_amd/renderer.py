@@ -313,7 +313,7 @@ def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: 
     act = _act_dtype(cfg.precision_code)
     dev = d_logits.device
     dH = torch.empty((run.M, 4 * D_H), dtype=act, device=dev)
-    dN = torch.empty((run.M, D_H), dtype=act, device=dev)
+    dN = torch.empty((3, run.M, D_H), dtype=act, device=dev)
     g = pk.grad_sink()
     gm = C.byref(maps.gmap_ptr_array()) if want_map_grads else None
     _capi.check(lib.scenerf_hip_mlp_backward(C.byref(ccfg), C.byref(pk.c), C.byref(g), run.Z.data_ptr(), run.xenc.data_ptr(),

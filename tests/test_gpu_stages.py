@@ -433,7 +433,7 @@ def test_mlp_forward_backward(case, precision, which):
     (ref * dl).sum().backward()
     gsink = pk.grad_sink()
     dH = torch.empty((M, 2048), dtype=act, device=DEV)
-    dN = torch.empty((M, 512), dtype=act, device=DEV)
+    dN = torch.empty((3, M, 512), dtype=act, device=DEV)
     tex = torch.full((M, 5, 4), -1, dtype=torch.int32, device=DEV)
     tw = torch.zeros((M, 5, 4), device=DEV)
     _capi.check(lib.scenerf_hip_mlp_backward(C.byref(cc), C.byref(pk.c), C.byref(gsink), run.Z.data_ptr(), run.xenc.data_ptr(),
