@@ -1,0 +1,151 @@
+"""Caller side of the boundary: the reference's ``forward / training_step`` loss assembly around ``render_rays_batch``
+(reference scenerf/models/scenerf.py:119-390, scenerf_bf.py for the indoor weights), in stock PyTorch.
+
+This is NOT part of the accelerated hot path ("next"); it exists so a Lightning ``Trainer`` can call
+``training_step`` on ``scenerf_amd.model.SceneRF`` exactly as it calls the reference.  Differences from the reference,
+none of which change a loss value:
+  * boolean-mask indexing (a device->host sync each) is replaced by masked means: mean over valid == sum(m*x)/sum(m);
+  * the metric-only second render (scenerf.py:193-198) runs under ``no_grad`` (its graph is never back-propagated);
+  * depth metrics are computed on the device with the same formulas as loss/depth_metrics.py (no ``.cpu().numpy()``).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+
+def sample_pix_features(pix: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
+    """utils.py:250-266: bilinear sample of img (C,H,W) at pixel coords (B,2) -> (C,B)."""
+    pix = pix.float()
+    g = torch.stack([(pix[:, 0] / (img.shape[2] - 1) - 0.5) * 2, (pix[:, 1] / (img.shape[1] - 1) - 0.5) * 2], dim=1)
+    out = F.grid_sample(img.unsqueeze(0), g.unsqueeze(0).unsqueeze(2).float(), align_corners=False, mode="bilinear",
+                        padding_mode="zeros")
+    return out.reshape(img.shape[0], -1)
+
+
+def depth_errors(gt: torch.Tensor, pred: torch.Tensor, min_depth: float = 1e-3, max_depth: float = 80.0):
+    """loss/depth_metrics.py:3-24 on device: abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3."""
+    pred = pred.clamp(min=min_depth, max=max_depth)
+    thresh = torch.maximum(gt / pred, pred / gt)
+    a1, a2, a3 = [(thresh < 1.25 ** k).float().mean() for k in (1, 2, 3)]
+    rmse = torch.sqrt(((gt - pred) ** 2).mean())
+    rmse_log = torch.sqrt(((torch.log(gt) - torch.log(pred)) ** 2).mean())
+    abs_rel = (torch.abs(gt - pred) / gt).mean()
+    sq_rel = (((gt - pred) ** 2) / gt).mean()
+    return abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3
+
+
+class TrainingMixin:
+    """forward / step / training_step / validation_step for SceneRF (KITTI) and SceneRFBundleFusion."""
+
+    reproj_weight = 1.0        # scenerf_bf.py:215 uses 5.0
+    dist2closest_weight = 0.01  # scenerf_bf.py:238 uses 0.1
+
+    def compute_reprojection_loss(self, pix_source, sampled_color_source, depth_rendered, img_target, inv_K, cam_K,
+                                  T_source2target):
+        """scenerf.py:349-386: min(L1 reprojection, L1 identity + 1e-5 noise) over pixels whose target point has z > 0."""
+        homo = torch.cat([pix_source, torch.ones_like(pix_source[:, :1])], dim=1)
+        cam_src = depth_rendered.reshape(-1, 1) * (inv_K @ homo.T).T
+        h = torch.cat([cam_src, torch.ones_like(cam_src[:, :1])], dim=1)
+        cam_tgt = (T_source2target @ h.T).T[:, :3]
+        hp = (cam_K @ cam_tgt.T).T
+        valid = cam_tgt[:, 2] > 0
+        pix_tgt = torch.where((hp[:, 2] > 0)[:, None], hp[:, :2] / hp[:, 2:3], torch.full_like(hp[:, :2], -1.0))
+        col_tgt = sample_pix_features(pix_tgt, img_target)
+        col_id = sample_pix_features(pix_source, img_target)
+        l_rep = torch.abs(col_tgt - sampled_color_source).mean(0)
+        l_id = torch.abs(col_id - sampled_color_source).mean(0)
+        l_id = l_id + torch.randn(l_id.shape, device=l_id.device) * 0.00001
+        loss = torch.minimum(l_rep, l_id)
+        m = valid.float()
+        return (loss * m).sum() / m.sum().clamp(min=1.0)   # == loss[valid].mean()
+
+    def process_single_source(self, n_rays, x_rgb, cam_K, inv_K, img_source, img_target, T_source2target, T_source2infer,
+                              T_cam2velo, step_type) -> Dict[str, torch.Tensor]:
+        """scenerf.py:243-320."""
+        dev = cam_K.device
+        xs = torch.arange(0, self.img_size[0], 2, device=dev, dtype=cam_K.dtype)
+        ys = torch.arange(0, self.img_size[1], 2, device=dev, dtype=cam_K.dtype)
+        gx, gy = torch.meshgrid(xs, ys, indexing="ij")
+        grid = torch.stack([gx, gy], dim=2).reshape(-1, 2)
+        idx = torch.randperm(grid.shape[0])[:n_rays].to(dev)          # CPU generator like the reference (:262)
+        pix_source = grid[idx]
+        out = self.render_rays_batch(cam_K, T_source2infer, x_rgb, T_cam2velo=T_cam2velo,
+                                     ray_batch_size=pix_source.shape[0], sampled_pixels=pix_source)
+        depth, color = out["depth"], out["color"]
+        self.log(step_type + "depth/closest_pts_to_depth", out["closest_pts_to_depths"].mean().detach(), on_epoch=True, sync_dist=True)
+        self.log(step_type + "depth/weights_at_depth", out["weights_at_depth"].mean().detach(), on_epoch=True, sync_dist=True)
+        diff = torch.abs(out["gaussian_means"] - depth.unsqueeze(-1).detach())
+        min_diff, gi = torch.min(diff, dim=1)
+        min_stds = torch.gather(out["gaussian_stds"], 1, gi.unsqueeze(-1))
+        min_som_vars = torch.gather(out["som_vars"], 1, gi.unsqueeze(-1))
+        self.log(step_type + "_som/dist_2_closest_gaussian", min_diff.mean().detach(), on_epoch=True, sync_dist=True)
+        self.log(step_type + "_som/closest_std", min_stds.mean().detach(), on_epoch=True, sync_dist=True)
+        col_src = sample_pix_features(pix_source, img_source)
+        loss_color = torch.abs(color - col_src.T)
+        loss_rep = self.compute_reprojection_loss(pix_source, col_src, depth, img_target, inv_K, cam_K, T_source2target)
+        return dict(loss_kl=out["loss_kl"], loss_dist2closest_gauss=min_diff, loss_reprojection=loss_rep, loss_color=loss_color,
+                    min_som_vars=min_som_vars, min_stds=min_stds)
+
+    def evaluate_depth(self, step_type, gt_depth, pred_depth):
+        """scenerf.py:322-346 (metrics computed on device)."""
+        names = ["abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3"]
+        vals = depth_errors(gt_depth.reshape(-1).detach().float(), pred_depth.reshape(-1).detach().float())
+        for n, v in zip(names, vals):
+            self.log(step_type + "depth/" + n, v, on_epoch=True, sync_dist=True)
+
+    def forward(self, batch, step_type):
+        """scenerf.py:119-241.  ``self.net_rgb`` (stock encoder) must be set by the caller."""
+        img_input = batch["img_inputs"]
+        bs = img_input.shape[0]
+        T_cam2velo = torch.inverse(batch["T_velo_2_cam"][0]) if "T_velo_2_cam" in batch else None
+        cam_K0 = batch["cam_K"][0]
+        pix, pix_sphere, _ = self.spherical_mapping.from_pixels(inv_K=torch.inverse(cam_K0))
+        x_rgbs = self.net_rgb(img_input, pix=pix, pix_sphere=pix_sphere)
+        tot = dict(rep=0.0, col=0.0, kl=0.0, somv=0.0, stds=0.0, d2c=0.0)
+        for i in range(bs):
+            x_rgb = {k: x_rgbs[k][i] for k in x_rgbs}
+            cam_K = batch["cam_K"][i]
+            inv_K = torch.inverse(cam_K)
+            for sid in range(len(batch["img_sources"][i])):
+                T_s2i = batch["T_source2infers"][i][sid]
+                ret = self.process_single_source(self.n_rays, x_rgb=x_rgb, cam_K=cam_K, inv_K=inv_K,
+                                                 img_source=batch["img_sources"][i][sid], img_target=batch["img_targets"][i][sid],
+                                                 T_source2target=batch["T_source2targets"][i][sid], T_source2infer=T_s2i,
+                                                 T_cam2velo=T_cam2velo, step_type=step_type)
+                tot["somv"] = tot["somv"] + ret["min_som_vars"].mean()
+                tot["kl"] = tot["kl"] + ret["loss_kl"].mean()
+                tot["d2c"] = tot["d2c"] + ret["loss_dist2closest_gauss"].mean()
+                tot["stds"] = tot["stds"] + ret["min_stds"].mean()
+                tot["rep"] = tot["rep"] + ret["loss_reprojection"].mean()
+                tot["col"] = tot["col"] + ret["loss_color"].mean()
+                if "loc2d_with_depths" in batch:   # depth metrics on the lidar pixels, scenerf.py:190-201
+                    gt_pix = batch["loc2d_with_depths"][i][sid].float()
+                    with torch.no_grad():
+                        r = self.render_rays_batch(cam_K, T_s2i, x_rgb, ray_batch_size=gt_pix.shape[0], sampled_pixels=gt_pix)
+                    self.evaluate_depth(step_type, batch["lidar_depths"][i][sid], r["depth"])
+        total = 0.0
+        if self.use_reprojection:
+            total = total + tot["rep"] / bs * self.reproj_weight
+            self.log(step_type + "/loss_reprojection", (tot["rep"] / bs).detach(), on_epoch=True, sync_dist=True)
+        if self.use_color:
+            total = total + tot["col"] / bs
+            self.log(step_type + "/loss_color", (tot["col"] / bs).detach(), on_epoch=True, sync_dist=True)
+        total = total + tot["kl"] / bs
+        self.log(step_type + "/loss_som_kl", (tot["kl"] / bs).detach(), on_epoch=True, sync_dist=True)
+        self.log(step_type + "/min_som_vars", (tot["somv"] / bs).detach(), on_epoch=True, sync_dist=True)
+        total = total + tot["d2c"] / bs * self.dist2closest_weight
+        self.log(step_type + "/loss_dist2closest_gauss", (tot["d2c"] / bs).detach(), on_epoch=True, sync_dist=True)
+        self.log(step_type + "/total_loss", total.detach(), on_epoch=True, sync_dist=True)
+        return {"total_loss": total}
+
+    def step(self, batch, step_type):
+        return self.forward(batch, step_type)["total_loss"]
+
+    def training_step(self, batch, batch_idx):
+        return self.step(batch, "train")
+
+    def validation_step(self, batch, batch_idx):
+        self.step(batch, "val")

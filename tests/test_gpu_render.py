@@ -188,3 +188,86 @@ def test_edge_cases_against_oracle_fp32(name, over, R, chunk, pose):
     (out["depth"].sum() + out["color"].sum() + out["loss_kl"].sum()).backward()
     assert all(torch.isfinite(p.grad).all() for p in m.mlp.parameters())
     assert all(torch.isfinite(v.grad).all() for v in x.values())
+
+
+# ------------------------------------------------------------------------------------------------ caller side
+class _StubEncoder(torch.nn.Module):
+    """Stands in for the stock EfficientNet-B7 U-Net: fixed maps times a learnable gain (so gradients must arrive)."""
+
+    def __init__(self, maps):
+        super().__init__()
+        self.gain = torch.nn.Parameter(torch.ones(()))
+        self.maps = {k: v.to(DEV) for k, v in maps.items()}
+
+    def forward(self, img, pix=None, pix_sphere=None):
+        assert pix.shape == (img.shape[2] * img.shape[3], 2) and pix_sphere.dtype == torch.int64
+        return {k: (self.gain * v).unsqueeze(0).expand(img.shape[0], -1, -1, -1) for k, v in self.maps.items()}
+
+
+def test_training_step_through_the_boundary():
+    """Lightning-style call: training_step(batch) -> scalar loss; gradients reach both MLPs and the encoder."""
+    from scenerf_amd import synth
+    torch.manual_seed(0)
+    maps = synth.feature_maps(376, 114, 31, smooth=True)
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, sphere_W=376, sphere_H=114, n_rays=96,
+                net_rgb=_StubEncoder(maps), precision="bf16").to(DEV)
+    m.mlp.load_state_dict(synth.mlp_state(32, 4))
+    m.mlp_gaussian.load_state_dict(synth.mlp_state(33, 2, out_scale=4.0))
+    g = torch.Generator().manual_seed(1)
+    img = lambda: torch.rand(3, 370, 1220, generator=g).to(DEV)
+    lidar_pix = torch.stack([torch.randint(0, 1220, (50,), generator=g), torch.randint(0, 370, (50,), generator=g)], 1).to(DEV)
+    batch = {
+        "img_inputs": torch.rand(1, 3, 370, 1220, generator=g).to(DEV),
+        "cam_K": synth.kitti_cam_K().unsqueeze(0).to(DEV),
+        "T_velo_2_cam": torch.eye(4).unsqueeze(0).to(DEV),
+        "T_source2infers": [[synth.rel_pose(2.0, 0.0).to(DEV)]],
+        "T_source2targets": [[synth.rel_pose(1.0, 5.0).to(DEV)]],
+        "img_sources": [[img()]], "img_targets": [[img()]],
+        "loc2d_with_depths": [[lidar_pix]], "lidar_depths": [[(torch.rand(50, generator=g) * 40 + 2).to(DEV)]],
+    }
+    loss = m.training_step(batch, 0)
+    assert loss.ndim == 0 and torch.isfinite(loss)
+    loss.backward()
+    assert torch.isfinite(m.net_rgb.gain.grad) and float(m.net_rgb.gain.grad.abs()) > 0
+    for p in list(m.mlp.parameters()) + list(m.mlp_gaussian.parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    opt, sched = m.configure_optimizers()
+    opt[0].step()
+    with torch.no_grad():
+        m.validation_step(batch, 0)
+
+
+def test_optional_output_gradients_match_oracle():
+    """weights / alphas / densities / depth_volumes are differentiable outputs like in the reference."""
+    from scenerf_amd import synth
+    kw = dict(sphere_W=376, sphere_H=114)
+    R = 32
+    ocfg = orc.OracleConfig.kitti(**kw)
+    mlp, mlpg = synth.mlp_state(41, 4), synth.mlp_state(42, 2, out_scale=4.0)
+    maps = synth.feature_maps(376, 114, 43, smooth=True)
+    pix = synth.stride2_pixels((1220, 370), R, 44)
+    nu, ng = synth.sampling_noise(R, 32, 32, 45)
+    K, T = synth.kitti_cam_K(), synth.rel_pose(2.0, 5.0)
+    gen = torch.Generator().manual_seed(3)
+    cw, ca, cd, cz = [torch.randn(R, 64, generator=gen) for _ in range(4)]
+    po = {k: v.clone().requires_grad_(True) for k, v in mlp.items()}
+    pg = {k: v.clone().requires_grad_(True) for k, v in mlpg.items()}
+    ref = orc.render_chunk(ocfg, po, pg, K, T, maps, pix, nu, ng)
+    ((ref["weights"] * cw).sum() + (ref["alphas"] * ca).sum() + (ref["densities"] * cd).sum() + (ref["depth_volumes"] * cz).sum()).backward()
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="fp32", **kw).to(DEV)
+    m.mlp.load_state_dict(mlp)
+    m.mlp_gaussian.load_state_dict(mlpg)
+    out = m.render_rays_batch(K.to(DEV), T.to(DEV), {k: v.to(DEV) for k, v in maps.items()}, sampled_pixels=pix.to(DEV),
+                              ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
+    ((out["weights"] * cw.to(DEV)).sum() + (out["alphas"] * ca.to(DEV)).sum() + (out["densities"] * cd.to(DEV)).sum()
+     + (out["depth_volumes"] * cz.to(DEV)).sum()).backward()
+    for name in ("lin_out.weight", "blocks.1.fc_0.weight", "lin_z.0.weight", "lin_in.weight"):
+        got = dict(m.mlp.named_parameters())[name].grad.cpu()
+        want = po[name].grad
+        rel = float((got - want).norm() / want.norm())
+        assert rel < 2e-2, "mlp.%s rel %.3e" % (name, rel)
+    for name in ("lin_out.weight", "blocks.2.fc_1.weight"):
+        got = dict(m.mlp_gaussian.named_parameters())[name].grad.cpu()
+        want = pg[name].grad
+        rel = float((got - want).norm() / max(float(want.norm()), 1e-12))
+        assert rel < 2e-2, "mlp_gaussian.%s rel %.3e" % (name, rel)
