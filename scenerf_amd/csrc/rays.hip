@@ -341,8 +341,13 @@ __device__ static inline float wave_excl_suffix_sum(float v, int lane) {
     return lane == 63 ? 0.f : ex;
 }
 
-// One wave per ray, C consecutive samples per lane (64*C >= N): per-ray state lives in VGPRs, the in-ray
-// transmittance product is a lane-local product + a 6-step wave scan.  4 rays (waves) per 256-thread block.
+// wave-wide inclusive->total helpers
+__device__ static inline float wave_total_prod_from_excl(float excl, float own) { return __shfl(excl * own, 63, WAVE); }
+
+// One wave per ray; the ray's N samples are processed in C = ceil(N/64) segments of 64, lane l owning sample 64 c + l of
+// segment c, so every global access of a segment is one fully coalesced 256-byte (fp32) / 1-KiB (float4 logits) run.
+// Per-ray state lives in VGPRs; the in-ray transmittance product is a 6-step __shfl_up scan per segment with the
+// running product carried across segments (wave-uniform).  4 rays (waves) per 256-thread block.
 template <int C>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ dist,
                                                             const float* __restrict__ zv, int R, int N,
@@ -354,42 +359,45 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     const size_t base = (size_t)r * N;
-    float d[C], z[C], sg[C], al[C], w[C], cr[C], cg[C], cb[C];
-    const int i0 = lane * C;
+    float z[C], w[C];
+    float4 lg[C];
+    float d[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        int i = i0 + c;
-        bool ok = i < N;
-        float4 lg = ok ? *(const float4*)(logits + (base + i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float dd = ok ? dist[base + i] : 0.f;
+    for (int c = 0; c < C; ++c) {   // issue all loads first
+        const int i = c * 64 + lane;
+        const bool ok = i < N;
+        lg[c] = ok ? *(const float4*)(logits + (base + i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float dd = ok ? dist[base + i] : 0.f;
         d[c] = dd < 0.f ? 0.f : dd;  // scenerf.py:707
         z[c] = ok ? zv[base + i] : 0.f;
-        sg[c] = softplus_m1(lg.w);
-        cr[c] = sigmoidf(lg.x);
-        cg[c] = sigmoidf(lg.y);
-        cb[c] = sigmoidf(lg.z);
     }
-    float prev = __shfl_up(d[C - 1], 1, WAVE);  // last sample of the previous lane
-    float lp = 1.f;                              // lane-local product of (1 - alpha + 1e-10)
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        int i = i0 + c;
-        float before = (c == 0) ? prev : d[c - 1];
-        float delta = (i == 0) ? d[c] : d[c] - before;  // scenerf.py:708-710
-        float a = (i < N) ? 1.f - expf(-delta * sg[c]) : 0.f;
-        al[c] = a;
-        lp *= (1.f - a + 1e-10f);
-    }
-    float Tr = wave_excl_prod(lp, lane);  // cumprod, scenerf.py:718-721
+    float carryT = 1.f, carry_d = 0.f;
     float sd = 0.f, sr = 0.f, sgc = 0.f, sb = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        w[c] = al[c] * Tr;  // scenerf.py:723
-        Tr *= (1.f - al[c] + 1e-10f);
+        const int i = c * 64 + lane;
+        const bool ok = i < N;
+        const float sg = softplus_m1(lg[c].w);
+        const float cr = sigmoidf(lg[c].x), cg = sigmoidf(lg[c].y), cb = sigmoidf(lg[c].z);
+        float before = __shfl_up(d[c], 1, WAVE);
+        if (lane == 0) before = carry_d;
+        const float delta = (i == 0) ? d[c] : d[c] - before;             // scenerf.py:708-710
+        const float a = ok ? 1.f - expf(-delta * sg) : 0.f;
+        const float sfac = 1.f - a + 1e-10f;
+        const float excl = wave_excl_prod(sfac, lane);                   // cumprod, scenerf.py:718-721
+        const float Ti = carryT * excl;
+        w[c] = a * Ti;                                                   // scenerf.py:723
+        carryT *= wave_total_prod_from_excl(excl, sfac);
+        carry_d = __shfl(d[c], 63, WAVE);
         sd += w[c] * z[c];
-        sr += w[c] * cr[c];
-        sgc += w[c] * cg[c];
-        sb += w[c] * cb[c];
+        sr += w[c] * cr;
+        sgc += w[c] * cg;
+        sb += w[c] * cb;
+        if (ok) {
+            densities[base + i] = sg;
+            alphas[base + i] = a;
+            weights[base + i] = w[c];
+        }
     }
     sd = wave_sum(sd);
     sr = wave_sum(sr);
@@ -401,27 +409,18 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     float bw = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        int i = i0 + c;
+        const int i = c * 64 + lane;
         if (i < N) {
-            float a = fabsf(sd - z[c]);
+            const float a = fabsf(sd - z[c]);
             if (a < best) { best = a; bi = i; bw = w[c]; }
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        float ob = __shfl_xor(best, o, WAVE);
-        int oi = __shfl_xor(bi, o, WAVE);
-        float ow = __shfl_xor(bw, o, WAVE);
+        const float ob = __shfl_xor(best, o, WAVE);
+        const int oi = __shfl_xor(bi, o, WAVE);
+        const float ow = __shfl_xor(bw, o, WAVE);
         if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; bw = ow; }
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        int i = i0 + c;
-        if (i < N) {
-            densities[base + i] = sg[c];
-            alphas[base + i] = al[c];
-            weights[base + i] = w[c];
-        }
     }
     if (lane == 0) {
         depth[r] = sd;
@@ -434,8 +433,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     }
 }
 
-// backward: recompute sigma/alpha/T/w in-wave (nothing but the inputs is re-read), reverse scan for the
-// transmittance term.  dL/dalpha_i = gw_i T_i - (sum_{j>i} gw_j w_j) / (1 - alpha_i + 1e-10).
+// backward: recompute sigma/alpha/T/w in-wave (nothing but the inputs is re-read), then walk the segments in reverse
+// with a carried suffix sum.  dL/dalpha_i = gw_i T_i - (sum_{j>i} gw_j w_j) / (1 - alpha_i + 1e-10).
 template <int C>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ dist,
                                                             const float* __restrict__ zv, int R, int N,
@@ -448,14 +447,13 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     const size_t base = (size_t)r * N;
-    const int i0 = lane * C;
     float d[C], z[C], sg[C], al[C], w[C], cr[C], cg[C], cb[C], dl[C], Ti[C], o3[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        int i = i0 + c;
-        bool ok = i < N;
-        float4 lg = ok ? *(const float4*)(logits + (base + i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float dd = ok ? dist[base + i] : 0.f;
+        const int i = c * 64 + lane;
+        const bool ok = i < N;
+        const float4 lg = ok ? *(const float4*)(logits + (base + i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float dd = ok ? dist[base + i] : 0.f;
         d[c] = dd < 0.f ? 0.f : dd;
         z[c] = ok ? zv[base + i] : 0.f;
         o3[c] = lg.w;
@@ -464,49 +462,51 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
         cg[c] = sigmoidf(lg.y);
         cb[c] = sigmoidf(lg.z);
     }
-    float prev = __shfl_up(d[C - 1], 1, WAVE);
-    float lp = 1.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        int i = i0 + c;
-        float before = (c == 0) ? prev : d[c - 1];
-        dl[c] = (i == 0) ? d[c] : d[c] - before;
-        al[c] = (i < N) ? 1.f - expf(-dl[c] * sg[c]) : 0.f;
-        lp *= (1.f - al[c] + 1e-10f);
-    }
-    float Tr = wave_excl_prod(lp, lane);
     const float gd = g_depth[r];
     const float gcr = g_color[3 * r], gcg = g_color[3 * r + 1], gcb = g_color[3 * r + 2];
+    float carryT = 1.f, carry_d = 0.f;
     float gw[C];
-    float lsum = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        int i = i0 + c;
-        Ti[c] = Tr;
-        w[c] = al[c] * Tr;
-        Tr *= (1.f - al[c] + 1e-10f);
+        const int i = c * 64 + lane;
+        const bool ok = i < N;
+        float before = __shfl_up(d[c], 1, WAVE);
+        if (lane == 0) before = carry_d;
+        dl[c] = (i == 0) ? d[c] : d[c] - before;
+        al[c] = ok ? 1.f - expf(-dl[c] * sg[c]) : 0.f;
+        const float sfac = 1.f - al[c] + 1e-10f;
+        const float excl = wave_excl_prod(sfac, lane);
+        Ti[c] = carryT * excl;
+        w[c] = al[c] * Ti[c];
+        carryT *= wave_total_prod_from_excl(excl, sfac);
+        carry_d = __shfl(d[c], 63, WAVE);
         float g = gd * z[c] + gcr * cr[c] + gcg * cg[c] + gcb * cb[c];
-        if (g_weights && i < N) g += g_weights[base + i];
-        gw[c] = (i < N) ? g : 0.f;
-        lsum += gw[c] * w[c];
+        if (g_weights && ok) g += g_weights[base + i];
+        gw[c] = ok ? g : 0.f;
     }
-    float S = wave_excl_suffix_sum(lsum, lane);  // sum over later lanes
-    float gdelta[C];
-    // walk this lane's samples backwards so S always holds sum_{j>i} gw_j w_j
+    float carryS = 0.f;        // sum of gw*w over all later segments
+    float next_first = 0.f;    // gdelta of the first sample of the next segment (i + 1 for lane 63)
 #pragma unroll
     for (int c = C - 1; c >= 0; --c) {
-        int i = i0 + c;
-        float s_i = 1.f - al[c] + 1e-10f;
+        const int i = c * 64 + lane;
+        const bool ok = i < N;
+        const float v = gw[c] * w[c];
+        const float S = carryS + wave_excl_suffix_sum(v, lane);
+        carryS += wave_sum(v);
+        const float s_i = 1.f - al[c] + 1e-10f;
         float ga = gw[c] * Ti[c] - S / s_i;
-        if (g_alphas && i < N) ga += g_alphas[base + i];
-        float one_m = expf(-dl[c] * sg[c]);  // = 1 - alpha
+        if (g_alphas && ok) ga += g_alphas[base + i];
+        const float one_m = expf(-dl[c] * sg[c]);  // = 1 - alpha
         float gs = ga * dl[c] * one_m;
-        if (g_dens && i < N) gs += g_dens[base + i];
-        gdelta[c] = (i < N) ? ga * sg[c] * one_m : 0.f;
-        S += gw[c] * w[c];
-        if (i < N) {
-            float y = o3[c] - 1.f;
-            float dsig = y > 20.f ? 1.f : sigmoidf(y);  // softplus'
+        if (g_dens && ok) gs += g_dens[base + i];
+        const float gdelta = ok ? ga * sg[c] * one_m : 0.f;
+        // delta_i = d_i - d_{i-1}  =>  dL/dd_i = gdelta_i - gdelta_{i+1}
+        float after = __shfl_down(gdelta, 1, WAVE);
+        if (lane == 63) after = next_first;
+        next_first = __shfl(gdelta, 0, WAVE);
+        if (ok) {
+            const float y = o3[c] - 1.f;
+            const float dsig = y > 20.f ? 1.f : sigmoidf(y);  // softplus'
             float4 o;
             o.x = gcr * w[c] * cr[c] * (1.f - cr[c]);
             o.y = gcg * w[c] * cg[c] * (1.f - cg[c]);
@@ -516,16 +516,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
             float gz = gd * w[c];
             if (g_zvol) gz += g_zvol[base + i];
             d_z[base + i] = gz;
+            d_dist[base + i] = gdelta - ((i + 1 < N) ? after : 0.f);
         }
-    }
-    // delta_i = d_i - d_{i-1}  =>  dL/dd_i = gdelta_i - gdelta_{i+1}
-    float next = __shfl_down(gdelta[0], 1, WAVE);
-    if (lane == 63) next = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        int i = i0 + c;
-        float after = (c == C - 1) ? next : gdelta[c + 1];
-        if (i < N) d_dist[base + i] = gdelta[c] - ((i + 1 < N) ? after : 0.f);
     }
 }
 
