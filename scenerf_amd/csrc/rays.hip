@@ -724,20 +724,59 @@ __global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ layout changes
-// in [A][B] (fp32) -> out [B][A] (TO). 32x32 tiles through LDS.
+// in [A][B] (fp32) -> out [B][A] (TO).  64x64 tiles through LDS, 16-byte global accesses on both sides: float4 reads
+// along B, and 4 (fp32) / 8 (bf16) consecutive A-elements per store.  LDS row stride 65 floats: the column reads of the
+// write phase are conflict-free.
 template <typename TO>
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, TO* __restrict__ out, int A, int B) {
-    __shared__ float tile[32][33];
-    int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx over B, by over A
-    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int k = ty; k < 32; k += 8) {
-        int a = by + k, b = bx + tx;
-        tile[k][tx] = (a < A && b < B) ? in[(size_t)a * B + b] : 0.f;
+    __shared__ float tile[64][65];
+    const int b0 = blockIdx.x * 64, a0 = blockIdx.y * 64;
+    const int t = threadIdx.x;
+    const bool vec_in = (B & 3) == 0;
+    // read: 64 rows (a) x 16 float4 (b)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = t + i * 256;
+        const int ar = q >> 4, bq = (q & 15) * 4;
+        const int a = a0 + ar, bb = b0 + bq;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a < A) {
+            if (vec_in && bb + 3 < B) {
+                const float4 f = *(const float4*)(in + (size_t)a * B + bb);
+                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (bb + e < B) v[e] = in[(size_t)a * B + bb + e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[ar][bq + e] = v[e];
     }
     __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
-        int b = bx + k, a = by + tx;
-        if (a < A && b < B) ActIO<TO>::st(out, (size_t)b * A + a, tile[tx][k]);
+    // write: 64 rows (b) x (64 / VN) vectors of VN consecutive a
+    constexpr int VN = 16 / (int)sizeof(TO);
+    constexpr int VPR = 64 / VN;                // vectors per output row
+    const bool vec_out = (A % VN) == 0;
+    for (int q = t; q < 64 * VPR; q += 256) {
+        const int br = q / VPR, aq = (q % VPR) * VN;
+        const int bb = b0 + br, a = a0 + aq;
+        if (bb >= B) continue;
+        float v[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) v[e] = tile[aq + e][br];
+        if (vec_out && a + VN - 1 < A) {
+            if constexpr (sizeof(TO) == 2) {
+                *(uint4*)((bf16_t*)out + (size_t)bb * A + a) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                                            pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+            } else {
+                *(float4*)((float*)out + (size_t)bb * A + a) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VN; ++e)
+                if (a + e < A) ActIO<TO>::st(out, (size_t)bb * A + a + e, v[e]);
+        }
     }
 }
 
@@ -782,7 +821,7 @@ int scenerf_hip_maps_chw_to_hwc(const float* chw, void* hwc, int C, int H, int W
     SRF_CHECK(chw && hwc && C > 0 && H > 0 && W > 0, "maps_chw_to_hwc: bad args");
     hipStream_t s = as_stream(stream);
     int A = C, B = H * W;
-    dim3 grid(cdiv(B, 32), cdiv(A, 32));
+    dim3 grid(cdiv(B, 64), cdiv(A, 64));
     SrfLaunchScope ps(s, "maps_chw_to_hwc", 0, (double)A * B * (4 + (precision ? 2 : 4)));
     if (precision)
         transpose_kernel<bf16_t><<<grid, 256, 0, s>>>(chw, (bf16_t*)hwc, A, B);
@@ -796,7 +835,7 @@ int scenerf_hip_grads_hwc_to_chw(const float* hwc, float* chw, int C, int H, int
     SRF_CHECK(chw && hwc && C > 0 && H > 0 && W > 0, "grads_hwc_to_chw: bad args");
     hipStream_t s = as_stream(stream);
     int A = H * W, B = C;
-    dim3 grid(cdiv(B, 32), cdiv(A, 32));
+    dim3 grid(cdiv(B, 64), cdiv(A, 64));
     SrfLaunchScope ps(s, "grads_hwc_to_chw", 0, (double)A * B * 8);
     transpose_kernel<float><<<grid, 256, 0, s>>>(hwc, chw, A, B);
     SRF_LAUNCH_CHECK("transpose_kernel");
