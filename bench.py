@@ -160,7 +160,8 @@ def main():
     model = make_model(args, dev)
     params = list(model.mlp.parameters()) + list(model.mlp_gaussian.parameters())
     opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, fused=True)
-    bucket = sdist.GradBucket(params) if world > 1 else None
+    # N > 1: each MLP's packed gradient sink is all-reduced (RCCL) right before it is handed to autograd: 2 x 21.7 MB
+    model.grad_sync = sdist.allreduce_mean_ if world > 1 else None
     maps = {k: v.to(dev).requires_grad_(True) for k, v in synth.feature_maps(1500, 452, 3 + rank).items()}
     K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
     pix = synth.stride2_pixels((1220, 370), R, 100 + rank).to(dev)
@@ -171,8 +172,6 @@ def main():
         out = model.render_rays_batch(K, T, maps, T_cam2velo=None, sampled_pixels=pix, ray_batch_size=R)
         loss = out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
         loss.backward()
-        if bucket is not None:
-            bucket.allreduce_mean()
         opt.step()
         opt.zero_grad(set_to_none=True)
         return loss

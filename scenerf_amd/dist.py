@@ -36,6 +36,14 @@ def shard_rays(n_rays_total: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def allreduce_mean_(flat: torch.Tensor) -> None:
+    """In-place mean over ranks of a flat gradient buffer (no-op for a single process).  Installed as
+    ``model.grad_sync``: the renderer calls it once per MLP on the packed fp32 gradient sink (21.7 MB)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+
+
 class GradBucket:
     """Flat fp32 bucket over a fixed parameter list; ``allreduce_mean`` averages .grad across ranks in one call."""
 

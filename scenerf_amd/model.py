@@ -179,6 +179,8 @@ class SceneRF(TrainingMixin, _Base):
             som_sigma=float(som_sigma), gauss_floor=1.5 if self._VARIANT == "kitti" else 0.5,
             precision=precision, device_rng=device_rng, **fov)
         self.render_cfg.validate()
+        # optional data-parallel hook (scenerf_amd.dist.allreduce_mean_): called on each MLP's packed gradient buffer
+        self.grad_sync = None
 
     # ---- the hot path ---------------------------------------------------------------------------------------
     def render_rays_batch(self, cam_K, T_source2infer, x_rgb: Dict[str, torch.Tensor], depth_window=100,
@@ -194,7 +196,8 @@ class SceneRF(TrainingMixin, _Base):
         cfg = self.render_cfg
         cfg.som_sigma = float(self.ray_som.som_sigma)
         inv_K = torch.inverse(cam_K)
-        sess = RenderSession(cfg, x_rgb, self.mlp.ordered_params(), self.mlp_gaussian.ordered_params())
+        sess = RenderSession(cfg, x_rgb, self.mlp.ordered_params(), self.mlp_gaussian.ordered_params(),
+                             grad_sync=self.grad_sync)
         outs = []
         n = sampled_pixels.shape[0]
         for s in range(0, n, ray_batch_size):

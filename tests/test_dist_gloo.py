@@ -37,6 +37,9 @@ def _worker(rank, world, port, out):
     local = [p.grad.clone() for p in lin.parameters()]
     bucket = sdist.GradBucket(lin.parameters())
     bucket.allreduce_mean()
+    flat = torch.full((5,), float(rank + 1))
+    sdist.allreduce_mean_(flat)                       # the hook bench.py installs as model.grad_sync
+    assert torch.allclose(flat, torch.full((5,), (1 + world) / 2.0))
     torch.save(dict(local=local, reduced=[p.grad.clone() for p in lin.parameters()], shard=(b, e)), out % rank)
     dist.destroy_process_group()
 
