@@ -271,3 +271,51 @@ def test_optional_output_gradients_match_oracle():
         want = pg[name].grad
         rel = float((got - want).norm() / max(float(want.norm()), 1e-12))
         assert rel < 2e-2, "mlp_gaussian.%s rel %.3e" % (name, rel)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE full size
+def test_full_size_config2_properties_and_subset_parity():
+    """BASELINE.json configs[1] at full size (KITTI 1500x452 sphere, R=1200, N=128): size-independent properties of the
+    renderer, plus exact-input parity on a subset -- rays are independent, so the first 40 rays of the full-size GPU run
+    must equal the CPU oracle run on just those 40 rays with the same pixels / noise."""
+    from scenerf_amd import synth
+    R, U, P = 1200, 64, 16
+    N = U + 4 * P
+    kw = dict(n_pts_uni=U, n_pts_per_gaussian=P)
+    mlp, mlpg = synth.mlp_state(51, 4), synth.mlp_state(52, 2, out_scale=4.0)
+    maps = synth.feature_maps(1500, 452, 53, smooth=True)
+    pix = synth.stride2_pixels((1220, 370), R, 54)
+    nu, ng = synth.sampling_noise(R, U, 4 * P, 55)
+    K, T = synth.kitti_cam_K(), synth.rel_pose(1.0, 0.0)
+    outs = {}
+    for precision in ("fp32", "bf16"):
+        m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision=precision, **kw).to(DEV)
+        m.mlp.load_state_dict(mlp)
+        m.mlp_gaussian.load_state_dict(mlpg)
+        with torch.no_grad():
+            o = m.render_rays_batch(K.to(DEV), T.to(DEV), {k: v.to(DEV) for k, v in maps.items()}, sampled_pixels=pix.to(DEV),
+                                    ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
+        outs[precision] = {k: v.cpu() for k, v in o.items()}
+    o = outs["fp32"]
+    w, a, z, dep = o["weights"], o["alphas"], o["depth_volumes"], o["depth"]
+    assert w.shape == (R, N)
+    assert bool((a >= 0).all()) and bool((a <= 1).all()) and bool((w >= 0).all())
+    assert bool((w.sum(1) <= 1 + 1e-4).all())                                   # transmittance is a sub-probability
+    assert bool((z[:, 1:] >= z[:, :-1] - 1e-6).all())                           # samples sorted along the ray
+    assert bool((dep >= 0).all()) and bool((dep <= z.max(dim=1).values + 1e-3).all())   # depth is a convex-ish combination
+    T_acc = torch.cumprod(1 - a + 1e-10, dim=1)
+    torch.testing.assert_close(w[:, 1:], a[:, 1:] * T_acc[:, :-1], rtol=1e-4, atol=1e-6)   # w_i = a_i * prod_{j<i}(1-a_j)
+    torch.testing.assert_close(dep, (w * z).sum(1), rtol=1e-4, atol=1e-4)
+    assert bool((o["gaussian_means"] >= 1.5).all()) and bool((o["gaussian_stds"] >= 1.5).all())   # relu(.) + 1.5 floors
+    assert bool((o["densities"] >= 0).all()) and bool((o["color"] >= 0).all()) and bool((o["color"] <= 1 + 1e-4).all())
+    # bf16 operands vs fp32 operands at full size
+    rel = ((outs["bf16"]["depth"] - dep).abs() / dep.abs().clamp(min=1e-3))
+    assert float(rel.median()) < 5e-3 and float(rel.quantile(0.99)) < 5e-2, (float(rel.median()), float(rel.max()))
+    assert float((outs["bf16"]["color"] - o["color"]).abs().max()) < 5e-2
+    # subset parity against the oracle (CPU) on identical inputs
+    S = 40
+    ocfg = orc.OracleConfig.kitti(**kw)
+    ref = orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix[:S], nu[:S], ng[:S])
+    for k in ("depth", "color", "weights", "alphas", "densities", "gaussian_means", "gaussian_stds", "depth_volumes"):
+        fr, _ = frac_within(o[k][:S], ref[k].detach(), 5e-4, 5e-4)
+        assert fr >= 0.95, "%s: %.3f of the subset rays within tolerance" % (k, fr)
