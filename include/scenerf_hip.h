@@ -81,6 +81,21 @@ typedef struct scenerf_mlp_weights {
     const void* w_z_t[SCENERF_N_SCALES]; /* T: [C_s][1536] = (cat_b lin_z.b.weight[:, slice_s])^T */
 } scenerf_mlp_weights;
 
+/* Raw ResnetFC parameters exactly as the reference's nn.Linear modules hold them (fp32, row-major [out][in]). */
+typedef struct scenerf_mlp_params {
+    int32_t d_out;
+    const float* lin_in_w;          /* [512][42] */
+    const float* lin_in_b;          /* [512] */
+    const float* lin_out_w;         /* [d_out][512] */
+    const float* lin_out_b;         /* [d_out] */
+    const float* fc0_w[3];          /* blocks.b.fc_0.weight [512][512] */
+    const float* fc0_b[3];
+    const float* fc1_w[3];          /* blocks.b.fc_1.weight [512][512] */
+    const float* fc1_b[3];
+    const float* linz_w[3];         /* lin_z.b.weight [512][2480] */
+    const float* linz_b[3];
+} scenerf_mlp_params;
+
 /* Gradients of the packed operands (fp32, accumulated with atomics: zero them first). */
 typedef struct scenerf_mlp_grads {
     float* w_in;                    /* [512][48] */
@@ -141,6 +156,11 @@ int scenerf_hip_gather_features(const scenerf_cfg* cfg, const void* const maps_h
                                 float* tap_weight /*[M][5][4]*/, scenerf_stream_t stream);
 
 /* ---- radiance MLP ---------------------------------------------------------------------------------------- */
+/* Fill the packed operand buffers of `dst` (caller-allocated, sizes as documented in scenerf_mlp_weights; b_fc0 / w_out /
+ * b_out / b_in may simply alias the parameters) from the raw nn.Linear parameters: casts, concatenations along K, the
+ * transposed dgrad copies and the split-bf16 lin_in, in two launches.  resnetfc.py:88-118. */
+int scenerf_hip_mlp_pack(const scenerf_cfg* cfg, const scenerf_mlp_params* params, const scenerf_mlp_weights* dst,
+                         scenerf_stream_t stream);
 /* ResnetFC.forward, resnetfc.py:133-164.  Z/xenc as produced above.  Writes acts (kept for backward). */
 int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const float* xenc,
                             const uint8_t* tile_mask, int M, const scenerf_mlp_acts* acts, scenerf_stream_t stream);

@@ -50,6 +50,14 @@ class MlpWeights(C.Structure):
     ]
 
 
+class MlpParams(C.Structure):
+    _fields_ = [
+        ("d_out", C.c_int32),
+        ("lin_in_w", vp), ("lin_in_b", vp), ("lin_out_w", vp), ("lin_out_b", vp),
+        ("fc0_w", vp * 3), ("fc0_b", vp * 3), ("fc1_w", vp * 3), ("fc1_b", vp * 3), ("linz_w", vp * 3), ("linz_b", vp * 3),
+    ]
+
+
 class MlpGrads(C.Structure):
     _fields_ = [
         ("w_in", vp), ("b_in", vp),
@@ -77,6 +85,7 @@ _PROTOS = {
     "scenerf_hip_ray_setup": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "scenerf_hip_encode_points": (C.c_int, [C.POINTER(Cfg), vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "scenerf_hip_gather_features": (C.c_int, [C.POINTER(Cfg), C.POINTER(vp * N_SCALES), vp, i32, vp, vp, vp, vp, vp]),
+    "scenerf_hip_mlp_pack": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpParams), C.POINTER(MlpWeights), vp]),
     "scenerf_hip_mlp_forward": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpWeights), vp, vp, vp, i32, C.POINTER(MlpActs), vp]),
     "scenerf_hip_mlp_backward": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpWeights), C.POINTER(MlpGrads), vp, vp, vp, vp, vp,
                                            i32, C.POINTER(MlpActs), vp, vp, vp, C.POINTER(vp * N_SCALES), vp]),

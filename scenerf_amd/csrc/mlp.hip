@@ -400,3 +400,128 @@ int scenerf_hip_test_gemm_tn(int precision, const void* D, const void* A, int M,
 }
 
 }  // extern "C"
+
+// ================================================================================================ operand packing
+// nn.Linear parameters (fp32, reference layout) -> MFMA operand layout of scenerf_mlp_weights, in TWO launches
+// (previously ~60 small torch kernels per MLP per step: concatenations, casts, transposes).
+struct PackJob {
+    const float* src;
+    void* dst;
+    int rows, cols;        // destination region
+    int src_ld, dst_ld;
+    int transpose;         // dst[r][c] = src[c][r]
+    int mode;              // 0: cast, 1: bf16 hi part, 2: bf16 lo part (x - hi)
+    int valid_cols;        // non-transposed: columns >= valid_cols are zero (padding)
+    int dst_f32;           // destination element type: 1 = fp32, 0 = act type of the launch
+    int tile0;             // index of this job's first 64x64 tile
+};
+#define PACK_MAX_JOBS 40
+struct PackTable {
+    PackJob job[PACK_MAX_JOBS];
+    int njobs;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(PackTable tab) {
+    __shared__ float tile[64][65];
+    int j = 0;
+    while (j + 1 < tab.njobs && (int)blockIdx.x >= tab.job[j + 1].tile0) ++j;
+    const PackJob J = tab.job[j];
+    const int t = blockIdx.x - J.tile0;
+    const int tiles_c = (J.cols + 63) / 64;
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (J.transpose) {
+        // read src rows c0.. (coalesced along src columns = dst rows), write dst rows r0.. (coalesced along dst columns)
+        for (int k = ty; k < 64; k += 4) {
+            const int sc = r0 + tx, sr = c0 + k;   // src[sr][sc] -> dst[sc][sr]
+            tile[k][tx] = (sr < J.cols && sc < J.rows) ? J.src[(size_t)sr * J.src_ld + sc] : 0.f;
+        }
+        __syncthreads();
+    }
+    for (int k = ty; k < 64; k += 4) {
+        const int r = r0 + k, c = c0 + tx;
+        if (r >= J.rows || c >= J.cols) continue;
+        float v;
+        if (J.transpose) v = tile[tx][k];
+        else v = (c < J.valid_cols) ? J.src[(size_t)r * J.src_ld + c] : 0.f;
+        if (J.mode) {
+            const float hi = bf16_to_f32(f32_to_bf16(v));
+            v = (J.mode == 1) ? hi : v - hi;
+        }
+        if (J.dst_f32) ((float*)J.dst)[(size_t)r * J.dst_ld + c] = v;
+        else ActIO<T>::st(J.dst, (size_t)r * J.dst_ld + c, v);
+    }
+}
+
+// b_h[0] = lin_z.0.bias (+ lin_in.bias when lin_in is fused), b_h[1] = fc_1.0.bias + lin_z.1.bias, ...
+__global__ void pack_bias_kernel(const float* a0, const float* c0, const float* a1, const float* z1, const float* a2, const float* z2,
+                                 const float* a3, float* o0, float* o1, float* o2, float* o3) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= SCENERF_D_HIDDEN) return;
+    o0[i] = a0[i] + (c0 ? c0[i] : 0.f);
+    o1[i] = a1[i] + z1[i];
+    o2[i] = a2[i] + z2[i];
+    o3[i] = a3[i];
+}
+
+extern "C" int scenerf_hip_mlp_pack(const scenerf_cfg* cfg, const scenerf_mlp_params* P, const scenerf_mlp_weights* W,
+                                    scenerf_stream_t stream) {
+    SRF_CHECK(cfg && P && W, "mlp_pack: NULL argument");
+    SRF_CHECK(P->d_out == 4 || P->d_out == 2, "mlp_pack: d_out must be 4 or 2");
+    const int prec = cfg->precision;
+    hipStream_t s = as_stream(stream);
+    const int H = SCENERF_D_HIDDEN, L = SCENERF_D_LATENT, X = SCENERF_D_XENC;
+    const size_t es = prec ? 2 : 4;
+    PackTable tab;
+    tab.njobs = 0;
+    int tiles = 0;
+    auto add = [&](const float* src, void* dst, int rows, int cols, int src_ld, int dst_ld, int transpose, int mode, int valid_cols,
+                   int dst_f32) {
+        if (tab.njobs >= PACK_MAX_JOBS) { ++tab.njobs; return; }
+        PackJob& J = tab.job[tab.njobs++];
+        J.src = src; J.dst = dst; J.rows = rows; J.cols = cols; J.src_ld = src_ld; J.dst_ld = dst_ld;
+        J.transpose = transpose; J.mode = mode; J.valid_cols = valid_cols; J.dst_f32 = dst_f32; J.tile0 = tiles;
+        tiles += cdiv(rows, 64) * cdiv(cols, 64);
+    };
+    auto at = [&](const void* base, size_t elem_off) { return (void*)((char*)base + elem_off * es); };
+    for (int i = 0; i < 3; ++i) SRF_CHECK(P->fc0_w[i] && P->fc1_w[i] && P->linz_w[i] && P->fc1_b[i] && P->linz_b[i], "mlp_pack: NULL parameter");
+    SRF_CHECK(P->lin_in_w && P->lin_in_b && W->w_in && W->w_h[0] && W->b_h[0], "mlp_pack: NULL parameter");
+    // lin_in: fp32 copy zero-padded 42 -> 48 (used by the fp32 path and by nothing else in bf16 mode)
+    add(P->lin_in_w, (void*)W->w_in, H, X, 42, X, 0, 0, 42, 1);
+    // first hidden GEMM
+    if (prec) {
+        const int ld0 = 3 * X + L;
+        add(P->lin_in_w, at(W->w_h[0], 0), H, X, 42, ld0, 0, 1, 42, 0);        // w_hi  (against x_hi)
+        add(P->lin_in_w, at(W->w_h[0], X), H, X, 42, ld0, 0, 1, 42, 0);        // w_hi  (against x_lo)
+        add(P->lin_in_w, at(W->w_h[0], 2 * X), H, X, 42, ld0, 0, 2, 42, 0);    // w_lo  (against x_hi)
+        add(P->linz_w[0], at(W->w_h[0], 3 * X), H, L, L, ld0, 0, 0, L, 0);
+    } else {
+        add(P->linz_w[0], (void*)W->w_h[0], H, L, L, L, 0, 0, L, 0);
+    }
+    for (int b = 0; b < 3; ++b) {
+        const int ld = b < 2 ? H + L : H;
+        add(P->fc1_w[b], (void*)W->w_h[b + 1], H, H, H, ld, 0, 0, H, 0);
+        if (b < 2) add(P->linz_w[b + 1], at(W->w_h[b + 1], H), H, L, L, ld, 0, 0, L, 0);
+        add(P->fc0_w[b], (void*)W->w_fc0[b], H, H, H, H, 0, 0, H, 0);
+        add(P->fc0_w[b], (void*)W->w_fc0_t[b], H, H, H, H, 1, 0, H, 0);
+        add(P->fc1_w[b], (void*)W->w_fc1_t[b], H, H, H, H, 1, 0, H, 0);
+    }
+    int off = 0;
+    for (int sc = 0; sc < 5; ++sc) {   // w_z_t[s][c][b*512 + n] = lin_z.b.weight[n][off_s + c]
+        for (int b = 0; b < 3; ++b)
+            add(P->linz_w[b] + off, at(W->w_z_t[sc], (size_t)b * H), cfg->map_C[sc], H, L, 3 * H, 1, 0, H, 0);
+        off += cfg->map_C[sc];
+    }
+    SRF_CHECK(tab.njobs <= PACK_MAX_JOBS, "mlp_pack: job table overflow");
+    {
+        SrfLaunchScope ps(s, "mlp_pack", 0, 0);
+        if (prec) pack_kernel<bf16_t><<<tiles, 256, 0, s>>>(tab);
+        else pack_kernel<float><<<tiles, 256, 0, s>>>(tab);
+        SRF_LAUNCH_CHECK("pack_kernel");
+    }
+    pack_bias_kernel<<<2, 256, 0, s>>>(P->linz_b[0], prec ? P->lin_in_b : nullptr, P->fc1_b[0], P->linz_b[1], P->fc1_b[1], P->linz_b[2],
+                                       P->fc1_b[2], (float*)W->b_h[0], (float*)W->b_h[1], (float*)W->b_h[2], (float*)W->b_h[3]);
+    SRF_LAUNCH_CHECK("pack_bias_kernel");
+    return 0;
+}

@@ -146,51 +146,45 @@ class PackedMLP:
         self.d_out = d_out
         self.prec = prec
         self.device = dev
-        w_in = torch.zeros((D_H, D_X), dtype=torch.float32, device=dev)
-        w_in[:, :42] = p["lin_in.weight"]
-        self.w_in, self.b_in = w_in, p["lin_in.bias"]
-        fc0 = [p["blocks.%d.fc_0.weight" % b] for b in range(3)]
-        fc1 = [p["blocks.%d.fc_1.weight" % b] for b in range(3)]
-        lz = [p["lin_z.%d.weight" % b] for b in range(3)]
-        if prec:
-            # bf16 mode: lin_in rides in the first hidden GEMM as [w_hi | w_hi | w_lo] against [x_hi | x_lo | x_hi]
-            w_hi = w_in.to(torch.bfloat16)
-            w_lo = (w_in - w_hi.float()).to(torch.bfloat16)
-            first = torch.cat([w_hi, w_hi, w_lo, lz[0].to(act)], dim=1).contiguous()
-            first_bias = (p["lin_in.bias"] + p["lin_z.0.bias"]).contiguous()
-        else:
-            first, first_bias = lz[0].to(act).contiguous(), p["lin_z.0.bias"]
-        self.w_h = [first,
-                    torch.cat([fc1[0], lz[1]], dim=1).to(act).contiguous(),
-                    torch.cat([fc1[1], lz[2]], dim=1).to(act).contiguous(),
-                    fc1[2].to(act).contiguous()]
-        self.b_h = [first_bias,
-                    (p["blocks.0.fc_1.bias"] + p["lin_z.1.bias"]).contiguous(),
-                    (p["blocks.1.fc_1.bias"] + p["lin_z.2.bias"]).contiguous(),
-                    p["blocks.2.fc_1.bias"]]
-        self.w_fc0 = [w.to(act).contiguous() for w in fc0]
-        self.b_fc0 = [p["blocks.%d.fc_0.bias" % b] for b in range(3)]
-        self.w_out, self.b_out = p["lin_out.weight"], p["lin_out.bias"]
-        self.w_fc0_t = [w.t().contiguous().to(act) for w in fc0]
-        self.w_fc1_t = [w.t().contiguous().to(act) for w in fc1]
-        wz_cat = torch.cat(lz, dim=0)  # [1536][2480]
-        self.w_z_t = []
-        off = 0
-        for c in FEAT_CHANNELS:
-            self.w_z_t.append(wz_cat[:, off:off + c].t().contiguous().to(act))
-            off += c
+        self.params = p   # keep the fp32 parameters alive: several operand pointers alias them
+        # one act-typed and one fp32 buffer hold every packed operand; scenerf_hip_mlp_pack fills them in two launches
+        first_cols = (3 * D_X + D_L) if prec else D_L
+        act_sizes = [("w_h0", D_H * first_cols), ("w_h1", D_H * (D_H + D_L)), ("w_h2", D_H * (D_H + D_L)), ("w_h3", D_H * D_H)]
+        for b in range(3):
+            act_sizes += [("w_fc0.%d" % b, D_H * D_H), ("w_fc0_t.%d" % b, D_H * D_H), ("w_fc1_t.%d" % b, D_H * D_H)]
+        for i, c in enumerate(FEAT_CHANNELS):
+            act_sizes.append(("w_z_t.%d" % i, c * 3 * D_H))
+        tot = sum(((n + 7) // 8) * 8 for _, n in act_sizes)
+        self.act_buf = torch.empty(tot, dtype=act, device=dev)
+        av, off = {}, 0
+        for name, n in act_sizes:
+            av[name] = self.act_buf[off:off + n]
+            off += ((n + 7) // 8) * 8
+        self.f32_buf = torch.empty(D_H * D_X + 4 * D_H, dtype=torch.float32, device=dev)
+        w_in = self.f32_buf[:D_H * D_X]
+        b_h = [self.f32_buf[D_H * D_X + i * D_H: D_H * D_X + (i + 1) * D_H] for i in range(4)]
         s = _capi.MlpWeights()
         s.d_out = d_out
-        s.w_in, s.b_in = self.w_in.data_ptr(), self.b_in.data_ptr()
+        s.w_in, s.b_in = w_in.data_ptr(), p["lin_in.bias"].data_ptr()
         for i in range(4):
-            s.w_h[i], s.b_h[i] = self.w_h[i].data_ptr(), self.b_h[i].data_ptr()
+            s.w_h[i], s.b_h[i] = av["w_h%d" % i].data_ptr(), b_h[i].data_ptr()
         for i in range(3):
-            s.w_fc0[i], s.b_fc0[i] = self.w_fc0[i].data_ptr(), self.b_fc0[i].data_ptr()
-            s.w_fc0_t[i], s.w_fc1_t[i] = self.w_fc0_t[i].data_ptr(), self.w_fc1_t[i].data_ptr()
-        s.w_out, s.b_out = self.w_out.data_ptr(), self.b_out.data_ptr()
+            s.w_fc0[i], s.b_fc0[i] = av["w_fc0.%d" % i].data_ptr(), p["blocks.%d.fc_0.bias" % i].data_ptr()
+            s.w_fc0_t[i], s.w_fc1_t[i] = av["w_fc0_t.%d" % i].data_ptr(), av["w_fc1_t.%d" % i].data_ptr()
+        s.w_out, s.b_out = p["lin_out.weight"].data_ptr(), p["lin_out.bias"].data_ptr()
         for i in range(5):
-            s.w_z_t[i] = self.w_z_t[i].data_ptr()
+            s.w_z_t[i] = av["w_z_t.%d" % i].data_ptr()
         self.c = s
+        raw = _capi.MlpParams()
+        raw.d_out = d_out
+        raw.lin_in_w, raw.lin_in_b = p["lin_in.weight"].data_ptr(), p["lin_in.bias"].data_ptr()
+        raw.lin_out_w, raw.lin_out_b = p["lin_out.weight"].data_ptr(), p["lin_out.bias"].data_ptr()
+        for i in range(3):
+            raw.fc0_w[i], raw.fc0_b[i] = p["blocks.%d.fc_0.weight" % i].data_ptr(), p["blocks.%d.fc_0.bias" % i].data_ptr()
+            raw.fc1_w[i], raw.fc1_b[i] = p["blocks.%d.fc_1.weight" % i].data_ptr(), p["blocks.%d.fc_1.bias" % i].data_ptr()
+            raw.linz_w[i], raw.linz_b[i] = p["lin_z.%d.weight" % i].data_ptr(), p["lin_z.%d.bias" % i].data_ptr()
+        ccfg = cfg.to_c()
+        _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(raw), C.byref(s), _stream()), "mlp_pack")
         # gradient sink (flat fp32 buffer carved into the scenerf_mlp_grads fields), allocated on first backward
         self.gflat: Optional[torch.Tensor] = None
         self.gviews: Dict[str, torch.Tensor] = {}
