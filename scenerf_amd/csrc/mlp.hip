@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void linout_fwd_kernel(const void* __restrict_
 template <typename T, int DO>
 __global__ __launch_bounds__(256) void linout_bwd_kernel(const void* __restrict__ H3, const float* __restrict__ w_out,
                                                          const float* __restrict__ dlog, int M, void* __restrict__ dH3, int lddh,
-                                                         float* __restrict__ dw_out, float* __restrict__ db_out) {
+                                                         float* __restrict__ partial) {
     __shared__ float s_dw[4][DO][SCENERF_D_HIDDEN];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wave = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
@@ -88,15 +88,40 @@ __global__ __launch_bounds__(256) void linout_bwd_kernel(const void* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) s_dw[wv][j][lane * 8 + e] = dw[j][e];
     __syncthreads();
+    // per-block partial sums go to scratch (no atomics: with ~1000 blocks adding into the same 2048 addresses the
+    // same-address atomics serialised and dominated the kernel); linout_reduce_kernel folds them afterwards
+    float* part = partial + (size_t)blockIdx.x * (DO * SCENERF_D_HIDDEN + 8);
     for (int i = threadIdx.x; i < DO * SCENERF_D_HIDDEN; i += 256) {
         int j = i / SCENERF_D_HIDDEN, k = i - j * SCENERF_D_HIDDEN;
-        float v = s_dw[0][j][k] + s_dw[1][j][k] + s_dw[2][j][k] + s_dw[3][j][k];
-        unsafeAtomicAdd(dw_out + i, v);
+        part[i] = s_dw[0][j][k] + s_dw[1][j][k] + s_dw[2][j][k] + s_dw[3][j][k];
     }
+    __shared__ float s_db[4][DO];
     if (lane == 0) {
 #pragma unroll
-        for (int j = 0; j < DO; ++j) unsafeAtomicAdd(db_out + j, db[j]);
+        for (int j = 0; j < DO; ++j) s_db[wv][j] = db[j];
     }
+    __syncthreads();
+    if (threadIdx.x < DO) part[DO * SCENERF_D_HIDDEN + threadIdx.x] = s_db[0][threadIdx.x] + s_db[1][threadIdx.x] + s_db[2][threadIdx.x] + s_db[3][threadIdx.x];
+}
+
+// dw_out[i] += sum over blocks of the partials (one thread per output element; plain read-modify-write, stream-ordered)
+template <int DO>
+__global__ void linout_reduce_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ dw_out, float* __restrict__ db_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stride = DO * SCENERF_D_HIDDEN + 8;
+    if (i >= DO * SCENERF_D_HIDDEN + DO) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblocks; b += 4) {
+        a0 += partial[(size_t)b * stride + i];
+        a1 += partial[(size_t)(b + 1) * stride + i];
+        a2 += partial[(size_t)(b + 2) * stride + i];
+        a3 += partial[(size_t)(b + 3) * stride + i];
+    }
+    for (; b < nblocks; ++b) a0 += partial[(size_t)b * stride + i];
+    const float v = (a0 + a1) + (a2 + a3);
+    if (i < DO * SCENERF_D_HIDDEN) dw_out[i] += v;
+    else db_out[i - DO * SCENERF_D_HIDDEN] += v;
 }
 
 // bf16 mode: lin_in runs inside the first hidden GEMM as three extra K-segments.  x = hi + lo with hi = bf16(x),
@@ -128,15 +153,22 @@ static int launch_linout_fwd(int d_out, const void* H3, const float* w, const fl
 }
 template <typename T>
 static int launch_linout_bwd(int d_out, const void* H3, const float* w, const float* dlog, int M, void* dH3, int lddh, float* dw,
-                             float* db, hipStream_t s) {
-    int grid = cdiv(M, 4 * 64);   // few, long-running blocks: every block ends with d_out*512 atomics
-    if (grid > 512) grid = 512;
-    SrfLaunchScope ps(s, "linout_bwd", 0, (double)M * (1024.0 * sizeof(T) + 4.0 * d_out));
-    if (d_out == 4) linout_bwd_kernel<T, 4><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, dw, db);
-    else linout_bwd_kernel<T, 2><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, dw, db);
-    SRF_LAUNCH_CHECK("linout_bwd_kernel");
+                             float* db, float* scratch, hipStream_t s) {
+    int grid = cdiv(M, 128);   // 32 rows per wave
+    if (grid > 2048) grid = 2048;
+    {
+        SrfLaunchScope ps(s, "linout_bwd", 0, (double)M * (1024.0 * sizeof(T) + 4.0 * d_out));
+        if (d_out == 4) linout_bwd_kernel<T, 4><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, scratch);
+        else linout_bwd_kernel<T, 2><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, scratch);
+        SRF_LAUNCH_CHECK("linout_bwd_kernel");
+    }
+    const int n = d_out * SCENERF_D_HIDDEN + d_out;
+    if (d_out == 4) linout_reduce_kernel<4><<<cdiv(n, 256), 256, 0, s>>>(scratch, grid, dw, db);
+    else linout_reduce_kernel<2><<<cdiv(n, 256), 256, 0, s>>>(scratch, grid, dw, db);
+    SRF_LAUNCH_CHECK("linout_reduce_kernel");
     return 0;
 }
+
 // ---- internal fork/join: weight-gradient GEMMs run on a side stream next to the dgrad chain -------------------
 // The wgrad of a layer only needs that layer's incoming gradient, not the rest of the backward chain, so it can overlap
 // the next dgrad GEMM: two kernels in flight hide each other's tails, epilogues and launch gaps.  The side stream is
@@ -265,6 +297,12 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
                              void* dN, float* const gmaps_hwc[SCENERF_N_SCALES], scenerf_stream_t stream) {
     SRF_CHECK(cfg && w && g_ && Z && xenc && tile_mask && a && d_logits && dH && dN && M > 0, "mlp_backward: NULL argument");
     SRF_CHECK(!gmaps_hwc || (tap_texel && tap_weight), "mlp_backward: taps missing");
+    // the dN scratch ([3][M][512] act) doubles as the lin_out partial-sum buffer before the block loop starts
+    {
+        const size_t blocks = (size_t)(cdiv(M, 128) > 2048 ? 2048 : cdiv(M, 128));
+        SRF_CHECK((size_t)3 * M * SCENERF_D_HIDDEN * (cfg->precision ? 2 : 4) >= blocks * (4 * SCENERF_D_HIDDEN + 8) * 4,
+                  "mlp_backward: dN scratch too small for the lin_out partial sums");
+    }
     const int prec = cfg->precision;
     const bool head = w->d_out == 2;
     const size_t es = prec ? 2 : 4;
@@ -283,9 +321,9 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
 
     // lin_out backward -> dH3, dw_out, db_out
     if (prec) {
-        if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, s)) return e;
+        if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, (float*)dN, s)) return e;
     } else {
-        if (int e = launch_linout_bwd<float>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, s)) return e;
+        if (int e = launch_linout_bwd<float>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, (float*)dN, s)) return e;
     }
     if (int e = fork()) return e;
     for (int b = 2; b >= 0; --b) {
