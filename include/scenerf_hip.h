@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SCENERF_HIP_ABI_VERSION 1
+#define SCENERF_HIP_ABI_VERSION 2
 #define SCENERF_N_SCALES 5          /* feature maps "1_1","1_2","1_4","1_8","1_16" */
 #define SCENERF_D_LATENT 2480       /* 80+160+320+640+1280 (resnetfc d_latent, scenerf.py:100-114) */
 #define SCENERF_D_HIDDEN 512
@@ -79,7 +79,13 @@ typedef struct scenerf_mlp_weights {
     const void* w_fc0_t[3];         /* T: [512][512] = fc_0.weight^T */
     const void* w_fc1_t[3];         /* T: [512][512] = fc_1.weight^T */
     const void* w_z_t[SCENERF_N_SCALES]; /* T: [C_s][1536] = (cat_b lin_z.b.weight[:, slice_s])^T */
+    /* bf16 mode only (NULL otherwise, or NULL to disable the fused forward kernel): the seven forward operands
+     * w_h[0], w_fc0[0], w_h[1], w_fc0[1], w_h[2], w_fc0[2], w_h[3] re-tiled for streaming -- per 16 columns of K one
+     * contiguous 16 KiB block [512 rows][32 B] holding the exact LDS image (16-byte halves of row r swapped when
+     * (r >> 3) & 1).  SCENERF_W_STREAM_BLOCKS blocks in all. */
+    const void* w_stream;
 } scenerf_mlp_weights;
+#define SCENERF_W_STREAM_BLOCKS ((3 * SCENERF_D_XENC + SCENERF_D_LATENT) / 16 + 2 * ((SCENERF_D_HIDDEN + SCENERF_D_LATENT) / 16) + 4 * (SCENERF_D_HIDDEN / 16))
 
 /* Raw ResnetFC parameters exactly as the reference's nn.Linear modules hold them (fp32, row-major [out][in]). */
 typedef struct scenerf_mlp_params {

@@ -21,7 +21,8 @@ D_LATENT = 2480
 D_HIDDEN = 512
 D_XENC = 48
 TILE_ROWS = 128
-ABI_VERSION = 1
+W_STREAM_BLOCKS = (3 * D_XENC + D_LATENT) // 16 + 2 * ((512 + D_LATENT) // 16) + 4 * (512 // 16)   # scenerf_hip.h
+ABI_VERSION = 2
 
 vp = C.c_void_p
 
@@ -47,6 +48,7 @@ class MlpWeights(C.Structure):
         ("w_fc0", vp * 3), ("b_fc0", vp * 3),
         ("w_out", vp), ("b_out", vp),
         ("w_fc0_t", vp * 3), ("w_fc1_t", vp * 3), ("w_z_t", vp * N_SCALES),
+        ("w_stream", vp),
     ]
 
 

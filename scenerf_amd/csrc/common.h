@@ -63,8 +63,12 @@ __host__ __device__ static inline bf16_t f32_to_bf16(float f) {
     uint32_t r = 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)((u + r) >> 16);
 }
+// two floats -> packed bf16 pair, round-to-nearest-even: ONE v_cvt_pk_bf16_f32 on gfx950 (same rounding as f32_to_bf16)
+typedef __attribute__((ext_vector_type(2))) __bf16 srf_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float srf_f32x2;
 __device__ static inline uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    srf_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, srf_bf16x2));
 }
 __device__ static inline float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ static inline float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }

@@ -58,3 +58,8 @@ struct GemmTN {
 
 int launch_gemm_nt(int precision, const GemmNT& p, hipStream_t s);
 int launch_gemm_tn(int precision, const GemmTN& p, hipStream_t s);
+
+// fused.hip: whole ResnetFC trunk (lin_in + lin_z + 3 residual blocks) for bf16 operands in one kernel; writes relu(H_b),
+// relu(N_b) (what the backward pass consumes) to a->H / a->Nn.  a->h0pre must hold the split encoding [M][144].
+int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const uint8_t* tile_mask, int M,
+                         const scenerf_mlp_acts* a, hipStream_t s);

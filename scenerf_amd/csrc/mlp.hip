@@ -252,6 +252,13 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
             split_xenc_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(xenc, x3, M);
             SRF_LAUNCH_CHECK("split_xenc_kernel");
         }
+        // rows from which the whole trunk runs as ONE fused kernel (fused.hip); read per call so a test can compare paths
+        const char* fenv = getenv("SRF_FUSED_MIN_M");
+        const int fused_min_m = fenv ? atoi(fenv) : (1 << 30);
+        if (M >= fused_min_m && w->w_stream) {
+            if (int e = launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s)) return e;
+            return launch_linout_fwd<bf16_t>(w->d_out, a->H[3], w->w_out, w->b_out, M, a->logits, s);
+        }
         GemmNT g;
         g.name = head ? "gemm_fwd_in_linz0/g" : "gemm_fwd_in_linz0";
         g.A1 = x3; g.lda1 = 3 * SCENERF_D_XENC; g.K1 = 3 * SCENERF_D_XENC;
@@ -503,6 +510,25 @@ __global__ void pack_bias_kernel(const float* a0, const float* c0, const float* 
     o3[i] = a3[i];
 }
 
+// w_stream (scenerf_hip.h): the seven forward operands re-tiled into 16 KiB blocks [512 rows][32 B] per 16 columns of K, the
+// two 16-byte halves of row r swapped when (r >> 3) & 1 -- the LDS image fused.hip's fragment reads expect, so a streaming
+// piece (1 KiB per wave) is contiguous in memory.  One thread per 16-byte half row.
+struct StreamSrc {
+    const bf16_t* W[7];
+    int ld[7];
+    int block0[8];   // first block of each operand; block0[7] = total
+};
+__global__ __launch_bounds__(256) void pack_stream_kernel(StreamSrc t, uint4* __restrict__ dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int blk = idx >> 10;
+    if (blk >= t.block0[7]) return;
+    int l = 0;
+    while (blk >= t.block0[l + 1]) ++l;
+    const int r = (idx & 1023) >> 1, ps = idx & 1;
+    const int k = (blk - t.block0[l]) * 16 + 8 * (ps ^ ((r >> 3) & 1));
+    dst[idx] = *(const uint4*)(t.W[l] + (size_t)r * t.ld[l] + k);
+}
+
 extern "C" int scenerf_hip_mlp_pack(const scenerf_cfg* cfg, const scenerf_mlp_params* P, const scenerf_mlp_weights* W,
                                     scenerf_stream_t stream) {
     SRF_CHECK(cfg && P && W, "mlp_pack: NULL argument");
@@ -557,6 +583,23 @@ extern "C" int scenerf_hip_mlp_pack(const scenerf_cfg* cfg, const scenerf_mlp_pa
         if (prec) pack_kernel<bf16_t><<<tiles, 256, 0, s>>>(tab);
         else pack_kernel<float><<<tiles, 256, 0, s>>>(tab);
         SRF_LAUNCH_CHECK("pack_kernel");
+    }
+    if (prec && W->w_stream) {
+        StreamSrc t;
+        const void* ops[7] = {W->w_h[0], W->w_fc0[0], W->w_h[1], W->w_fc0[1], W->w_h[2], W->w_fc0[2], W->w_h[3]};
+        const int lds_[7] = {3 * X + L, H, H + L, H, H + L, H, H};
+        int nb = 0;
+        for (int i = 0; i < 7; ++i) {
+            t.W[i] = (const bf16_t*)ops[i];
+            t.ld[i] = lds_[i];
+            t.block0[i] = nb;
+            nb += lds_[i] / 16;
+        }
+        t.block0[7] = nb;
+        SRF_CHECK(nb == SCENERF_W_STREAM_BLOCKS, "mlp_pack: stream block count");
+        SrfLaunchScope ps(s, "mlp_pack_stream", 0, (double)nb * 32768);
+        pack_stream_kernel<<<nb * 4, 256, 0, s>>>(t, (uint4*)W->w_stream);
+        SRF_LAUNCH_CHECK("pack_stream_kernel");
     }
     pack_bias_kernel<<<2, 256, 0, s>>>(P->linz_b[0], prec ? P->lin_in_b : nullptr, P->fc1_b[0], P->linz_b[1], P->fc1_b[1], P->linz_b[2],
                                        P->fc1_b[2], (float*)W->b_h[0], (float*)W->b_h[1], (float*)W->b_h[2], (float*)W->b_h[3]);

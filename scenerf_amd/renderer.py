@@ -154,6 +154,8 @@ class PackedMLP:
             act_sizes += [("w_fc0.%d" % b, D_H * D_H), ("w_fc0_t.%d" % b, D_H * D_H), ("w_fc1_t.%d" % b, D_H * D_H)]
         for i, c in enumerate(FEAT_CHANNELS):
             act_sizes.append(("w_z_t.%d" % i, c * 3 * D_H))
+        if prec:   # forward operands re-tiled in 16 KiB streaming blocks for the fused trunk kernel (scenerf_hip.h)
+            act_sizes.append(("w_stream", _capi.W_STREAM_BLOCKS * 8192))
         tot = sum(((n + 7) // 8) * 8 for _, n in act_sizes)
         self.act_buf = torch.empty(tot, dtype=act, device=dev)
         av, off = {}, 0
@@ -174,6 +176,7 @@ class PackedMLP:
         s.w_out, s.b_out = p["lin_out.weight"].data_ptr(), p["lin_out.bias"].data_ptr()
         for i in range(5):
             s.w_z_t[i] = av["w_z_t.%d" % i].data_ptr()
+        s.w_stream = av["w_stream"].data_ptr() if prec else None
         self.c = s
         raw = _capi.MlpParams()
         raw.d_out = d_out

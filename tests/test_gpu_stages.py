@@ -454,3 +454,67 @@ def test_mlp_forward_backward(case, precision, which):
         assert rel <= gtol, "%s: relative L2 grad error %.3e" % (n, rel)
         assert e <= 4 * gtol * max(s, 1e-6), "%s: grad err %.3e vs scale %.3e" % (n, e, s)
     print("worst grad errors:", sorted(worst.items(), key=lambda kv: -kv[1][0])[:3])
+
+
+@pytest.mark.parametrize("M", [64, 5000, 40000])
+def test_mlp_forward_fused_matches_layer_path(case, M):
+    """fused.hip (one kernel for the whole trunk, residual stream in fp32 registers) against the per-layer GEMM path on the
+    same packed weights: saved activations are relu(H_b) / relu(N_b) -- what the backward pass consumes -- and must agree
+    with the layer path's within bf16 rounding of the residual stream; logits against the fp32 oracle must be at least
+    as close as the layer path's.  Tiles use different scale masks (skipped K segments)."""
+    import os
+    from scenerf_amd.renderer import _MlpRun
+    lib = _capi.load()
+    rcfg, xin0, state, d_out, pk = _mlp_case(case, "bf16", "mlp")
+    cc = rcfg.to_c()
+    gen = torch.Generator().manual_seed(M)
+    z = torch.randn(M, 2480, generator=gen) * 0.5
+    xe = torch.zeros((M, 48))
+    xe[:, :42] = torch.randn(M, 42, generator=gen).clamp(-1, 1)
+    ntile = (M + 127) // 128
+    masks = torch.tensor([7, 31, 1, 5, 0, 24, 3], dtype=torch.uint8)[torch.arange(ntile) % 7]
+    seg = [0]
+    for c, _, _ in rcfg.map_shapes():
+        seg.append(seg[-1] + c)
+    for t in range(ntile):
+        for s_ in range(5):
+            if not (int(masks[t]) >> s_) & 1:
+                z[t * 128:(t + 1) * 128, seg[s_]:seg[s_ + 1]] = 0
+    runs = {}
+    for name, env in (("layers", str(1 << 30)), ("fused", "0")):
+        os.environ["SRF_FUSED_MIN_M"] = env
+        run = _MlpRun(M, d_out, 1, torch.device(DEV))
+        run.Z.zero_()
+        run.Z[:M] = dv(z, torch.bfloat16)
+        run.xenc.copy_(dv(xe))
+        run.tile_mask.zero_()
+        run.tile_mask[:ntile] = dv(masks)
+        _capi.check(lib.scenerf_hip_mlp_forward(C.byref(cc), C.byref(pk.c), run.Z.data_ptr(), run.xenc.data_ptr(), run.tile_mask.data_ptr(),
+                                                M, C.byref(run.c), _st()), "mlp_forward")
+        torch.cuda.synchronize()
+        runs[name] = run
+    os.environ.pop("SRF_FUSED_MIN_M")
+    a, b = runs["layers"], runs["fused"]
+    xin = torch.cat([run.Z[:M].float().cpu(), xe[:, :42]], dim=1)
+    keep = {}
+    ref = orc.resnetfc_forward(state, xin, keep=keep)
+    for i in range(4):
+        want = torch.relu(a.H[i].float())
+        got = b.H[i].float()
+        assert float((got < 0).sum()) == 0
+        scale = float(want.abs().max())
+        e = float((got - want).abs().max())
+        e_or = float((got.cpu() - torch.relu(keep["h%d" % i])).abs().max())
+        e_or_layers = float((want.cpu() - torch.relu(keep["h%d" % i])).abs().max())
+        print("H%d: fused vs layers %.3e, fused vs oracle %.3e, layers vs oracle %.3e (scale %.2f)" % (i, e, e_or, e_or_layers, scale))
+        assert e <= 3e-2 * max(scale, 1.0)
+        assert e_or <= max(1.25 * e_or_layers, 1e-2 * max(scale, 1.0))
+    for i in range(3):
+        want = torch.relu(a.Nn[i].float())
+        got = b.Nn[i].float()
+        e = float((got - want).abs().max())
+        assert e <= 3e-2 * max(float(want.abs().max()), 1.0), "N%d err %.3e" % (i, e)
+    el = float((a.logits.cpu() - ref).abs().max())
+    ef = float((b.logits.cpu() - ref).abs().max())
+    print("logits err: layers %.3e fused %.3e" % (el, ef))
+    assert ef <= max(1.25 * el, 1e-2 * max(float(ref.abs().max()), 1.0))
