@@ -29,13 +29,26 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_f;
 #define F_NST 5                           // ring depth
 #define F_BIAS (F_ABUF + F_NST * F_STAGE) // 2 KiB: the next layer's bias
 #define F_LDS (F_BIAS + 2048)             // 159744 of 163840
-#define F_MAXRUN 24
 
 // 16 bytes per lane, global -> LDS, no VGPR round trip: source = uniform base (SGPR pair) + 32-bit per-lane offset, destination
 // = M0 (wave-uniform LDS address) + 16 * lane
 __device__ static inline void f_glds16(const void* sbase, unsigned voff, unsigned lds_wave_base) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_wave_base)
+                 : "memory");
+}
+
+// four consecutive 1 KiB pieces with ONE M0 setup: the instruction offset advances the global and the LDS address alike
+__device__ static inline void f_glds16x4(const void* sbase, unsigned voff, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_wave_base)
                  : "memory");
@@ -52,65 +65,90 @@ struct FusedArgs {
     const void* X3;      // [M][144] bf16 split encoding
     const void* Z;       // [Mpad][2480] bf16
     const uint8_t* tile_mask;
-    const int4* runs;    // [32][F_MAXRUN] per tile mask: header {number of chunks}, run descriptors, terminator (w == 0)
+    const int* desc;     // [32][F_MAXCH] per tile mask: header {number of chunks}, chunk descriptors, zero padding
     int M;
 };
 
-typedef int run_t __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) run_t* run_ptr;   // constant address space: descriptor reads are s_load
+// One 32-bit descriptor per 16-wide K chunk (host-built per tile mask, read with scalar loads one step ahead):
+//   [0:9] w_stream block   [10:17] A column / 16   [18:19] src (0 = resident A buffer, 1 = X3, 2 = Z)   [20:22] layer
+//   [23] last chunk of its layer   [24] first chunk of its layer   [25:27] ring stage (chunk index mod 5)
+typedef const __attribute__((address_space(4))) int* desc_ptr;   // constant address space: descriptor reads are s_load
+#define FD_Z(d) ((d) & 1023)
+#define FD_Y(d) ((((d) >> 10) & 255) * F_BK)
+#define FD_SRC(d) (((d) >> 18) & 3)
+#define FD_LAYER(d) (((d) >> 20) & 7)
+#define FD_END(d) (((d) >> 23) & 1)
+#define FD_BEGIN(d) (((d) >> 24) & 1)
+#define FD_STAGE(d) (((d) >> 25) & 7)
+#define F_MAXCH 704     // 666 chunks with all five scales + header + zero padding (the pipeline reads a few entries past the end)
 
-// A run = consecutive 16-wide K chunks of one layer with one operand source:
-//   x = layer | src << 8 (0 = resident A buffer, 1 = X3, 2 = Z) | last_run_of_layer << 16 | first_run_of_layer << 17
-//   y = first A column (elements), z = first w_stream block, w = number of chunks (0 terminates the list)
-// A cursor walks the chunk sequence in scalar registers; a new descriptor is loaded once per run (~20 per workgroup).
-struct Cursor {
-    run_ptr next;        // descriptor after the current run
-    int meta, y, z, n;   // current chunk: A column, block; n = chunks left in the run including this one; n == 0: end
-    bool fresh;          // first chunk of its run
-    __device__ void start(run_ptr runs) {
-        const run_t r = runs[0];
-        next = runs + 1;
-        meta = r.x; y = r.y; z = r.z; n = r.w; fresh = true;
-    }
-    __device__ void advance() {
-        if (n > 1) { y += F_BK; z += 1; n -= 1; fresh = false; }
-        else if (n == 1) {
-            const run_t r = *next;
-            ++next;
-            meta = r.x; y = r.y; z = r.z; n = r.w; fresh = true;
-        }
-    }
-    __device__ bool valid() const { return n > 0; }
-    __device__ int src() const { return (meta >> 8) & 0xff; }
-    __device__ int layer() const { return meta & 0xff; }
-    __device__ bool layer_end() const { return n == 1 && ((meta >> 16) & 1); }
-    __device__ bool layer_begin() const { return fresh && ((meta >> 17) & 1); }
-};
+#define F_THREADS 768   // 8 consumer waves (fragments + MFMA + epilogue) and 4 producer waves (one per SIMD: the weight stream)
 
-template <int ORDER>
-__global__ __launch_bounds__(512, 2) void mlp_fwd_fused_kernel(FusedArgs p) {
+__global__ __launch_bounds__(F_THREADS) void mlp_fwd_fused_kernel(FusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Abuf = lds;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 2, wn = wv & 3;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
     const int m0 = blockIdx.x * F_BM;
     const unsigned mask = __builtin_amdgcn_readfirstlane((unsigned)p.tile_mask[m0 / SCENERF_TILE_ROWS] & 31u);
-    run_ptr runs = (run_ptr)(uintptr_t)(p.runs + mask * F_MAXRUN);
-    const int nch = runs[0].x;   // entry 0: header (total number of chunks); the runs follow
-    ++runs;
-
-    // ---- per-lane constants --------------------------------------------------------------------------------------
-    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    desc_ptr D = (desc_ptr)(uintptr_t)(p.desc + mask * F_MAXCH);
+    const int nch = D[0];   // entry 0: header (total number of chunks); the descriptors follow
+    ++D;
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
-    // glds pieces are 1 KiB.  W: contiguous in w_stream (already the LDS image); wave w fetches bytes [1024 w, +1024) and
-    // [1024 (w + 8), +1024) of the 16 KiB block.  Streamed A (X3 / Z rows): piece = 32 rows x 32 B; lane -> (row lane / 2,
-    // physical 16-byte slot lane & 1) fetching the logical slot physical ^ ((row >> 3) & 1) (swizzle on the SOURCE address);
-    // waves 0 and 1.  Bias of the next layer: 2 pieces, waves 2 and 3.
-    const unsigned wlane = wv * 1024 + lane * 16;
-    const int prow = lane >> 1;
-    const int pls = ((lane & 1) ^ ((lane >> 4) & 1)) << 4;
-    const int gm_a = min(m0 + 32 * (wv & 1) + prow, p.M - 1);
-    const unsigned ox3 = (unsigned)gm_a * (3 * SCENERF_D_XENC * 2) + pls;       // < 4 GiB: M * 4960 B fits 32 bits up to 865k rows
-    const unsigned oz = (unsigned)gm_a * (SCENERF_D_LATENT * 2) + pls;
+    const unsigned ring0 = lds0 + F_ABUF;
+
+    // Pipeline, one raw barrier per 16-wide K chunk (+ two per layer end).  In step c the consumers hold chunk c's fragments in
+    // registers (read in step c-1), read chunk c+1's (landed) while their MFMAs of chunk c run; chunks c+2, c+3 are in flight
+    // and the producers issue chunk c+4 into the stage chunk c-1 occupied (every consumer finished reading that one before its
+    // MFMAs of c-1, i.e. before this barrier).  Ring: 5 stages.  Loads are counted by the waves that issue them: only the
+    // producers wait on vmcnt, and the consumers' activation stores never enter those counts.
+    if (wvu >= 8) {
+        // ================================================================================ producers
+        // glds pieces are 1 KiB.  W: contiguous in w_stream (already the LDS image); producer q fetches bytes [4096 q, +4096)
+        // of the 16 KiB block, four pieces behind one M0 setup.  Streamed A (X3 / Z rows): piece = 32 rows x 32 B; lane -> (row lane / 2, physical 16-byte slot
+        // lane & 1) fetching the logical slot physical ^ ((row >> 3) & 1) (swizzle on the SOURCE address); producers 0 and 1.
+        // Bias of a layer (2 KiB, with the layer's first chunk): producers 2 and 3.
+        const int q = wvu - 8;
+        const unsigned wlane = q * 4096 + lane * 16;
+        const int prow = lane >> 1;
+        const int pls = ((lane & 1) ^ ((lane >> 4) & 1)) << 4;
+        const int gm_a = min(m0 + 32 * (q & 1) + prow, p.M - 1);
+        const unsigned ox3 = (unsigned)gm_a * (3 * SCENERF_D_XENC * 2) + pls;   // < 4 GiB: M * 4960 B fits 32 bits up to 865k rows
+        const unsigned oz = (unsigned)gm_a * (SCENERF_D_LATENT * 2) + pls;
+        auto issue = [&](const int d) {
+            const int src = FD_SRC(d);
+            const unsigned sb = ring0 + FD_STAGE(d) * F_STAGE;
+            f_glds16x4((const char*)p.Wst + (size_t)FD_Z(d) * F_WSTG, wlane, __builtin_amdgcn_readfirstlane(sb + q * 4096));
+            if (src != 0 && q < 2)
+                f_glds16((const char*)(src == 1 ? p.X3 : p.Z) + (size_t)FD_Y(d) * 2, src == 1 ? ox3 : oz,
+                         __builtin_amdgcn_readfirstlane(sb + F_WSTG + q * 1024));
+            if (FD_BEGIN(d) && q >= 2)   // the bias this layer's accumulators start from (read at the previous layer's end)
+                f_glds16((const char*)p.layer[FD_LAYER(d)].bias + (q - 2) * 1024, lane * 16,
+                         __builtin_amdgcn_readfirstlane(lds0 + F_BIAS + (q - 2) * 1024));
+        };
+#pragma unroll 1
+        for (int c = 0; c < F_NST - 1 && c < nch; ++c) issue(D[c]);   // (chunk 0 carries layer 0's bias)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int steps = (nch + 1) & ~1;   // the consumers run their ping-pong in pairs
+        int d_iss = D[F_NST - 1], d_cur = D[0];   // chunk c + 4 (to issue), chunk c (layer ends: the epilogue has two more barriers)
+#pragma unroll 1
+        for (int c = 0; c < steps; ++c) {
+            const int d_iss_n = D[c + F_NST], d_cur_n = D[c + 1];   // next step's descriptors (the table is zero-padded)
+            // chunk c+1 has landed once at most the loads of chunks c+2, c+3 (>= 4 per producer each) are outstanding
+            if (c + F_NST - 1 < nch) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail
+            __builtin_amdgcn_s_barrier();
+            if (c + F_NST - 1 < nch) issue(d_iss);   // into the stage chunk c - 1 occupied
+            if (FD_END(d_cur)) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+            d_iss = d_iss_n;
+            d_cur = d_cur_n;
+        }
+        return;
+    }
+
+    // ==================================================================================== consumers
+    const int wm = wv >> 2, wn = wv & 3;
     // fragment offsets inside a stage: W tile j adds j * 1024 (the swizzle term does not depend on j)
     const int ra = wm * 32 + (lane & 31);           // this lane's activation row inside the 64-row block
     const int offW = (wn * 128 + (lane & 31)) * 32 + (((lane >> 5) ^ ((lane >> 3) & 1)) << 4);
@@ -119,8 +157,11 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_fused_kernel(FusedArgs p) {
     const int axor = ra & 15;
 
     // transposed accumulator tile j: lane holds activation row m = wm*32 + (lane & 31) and outputs n = wn*128 + 32 j + 8 q +
-    // 4 (lane >> 5) + e in register r = 4 q + e.  The accumulators start from the layer's bias (LDS copy).
-    f32x16_f acc[4], h[4];
+    // 4 (lane >> 5) + e in register r = 4 q + e.  The accumulators start from the layer's bias (LDS copy).  The residual stream h
+    // is kept as packed bf16 pairs (elements 2i, 2i+1 of tile j in hp[j][i]): it is rounded to bf16 at every block, exactly where
+    // the layer path rounds it when it writes H_b -- and it is what the A buffer receives before the relu.
+    f32x16_f acc[4];
+    uint32_t hp[4][8];
     auto init_acc = [&]() {
         const char* bb = lds + F_BIAS + (wn * 128 + 4 * (lane >> 5)) * 4;
 #pragma unroll
@@ -134,27 +175,14 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_fused_kernel(FusedArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h[j][r] = 0.f;
+        for (int i = 0; i < 8; ++i) hp[j][i] = 0u;
 
-    const unsigned ring0 = lds0 + F_ABUF;
-    auto issue = [&](const Cursor& cu, unsigned sb) {
-        const int src = cu.src();
-        const char* g = (const char*)p.Wst + (size_t)cu.z * F_WSTG;
-        f_glds16(g, wlane, __builtin_amdgcn_readfirstlane(sb + wvu * 1024));
-        f_glds16(g + 8192, wlane, __builtin_amdgcn_readfirstlane(sb + (wvu + 8) * 1024));
-        if (src != 0 && wvu < 2)
-            f_glds16((const char*)(src == 1 ? p.X3 : p.Z) + (size_t)cu.y * 2, src == 1 ? ox3 : oz,
-                     __builtin_amdgcn_readfirstlane(sb + F_WSTG + wvu * 1024));
-        if (cu.layer_begin() && (wvu & 6) == 2)   // the bias this layer's accumulators start from (read at the previous layer's end)
-            f_glds16((const char*)p.layer[cu.layer()].bias + (wvu - 2) * 1024, lane * 16,
-                     __builtin_amdgcn_readfirstlane(lds0 + F_BIAS + (wvu - 2) * 1024));
-    };
     struct Frags { uint4 a, b[4]; };
     // fragments of one chunk: W from its ring stage; the activation operand from the resident A buffer or the stage
-    auto load_frags = [&](Frags& f, const Cursor& cu, int stage) {
-        const char* S = lds + F_ABUF + stage * F_STAGE;
-        const int kslot = (cu.y >> 3) + (lane >> 5);
-        const char* pa = cu.src() == 0 ? Abuf + abase + ((kslot ^ axor) << 4) : S + offA2;
+    auto load_frags = [&](Frags& f, const int d) {
+        const char* S = lds + F_ABUF + FD_STAGE(d) * F_STAGE;
+        const int kslot = (FD_Y(d) >> 3) + (lane >> 5);
+        const char* pa = FD_SRC(d) == 0 ? Abuf + abase + ((kslot ^ axor) << 4) : S + offA2;
         f.a = *(const uint4*)pa;
 #pragma unroll
         for (int j = 0; j < 4; ++j) f.b[j] = *(const uint4*)(S + offW + j * 1024);
@@ -164,8 +192,8 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_fused_kernel(FusedArgs p) {
         for (int j = 0; j < 4; ++j)   // C^T tile: rows = outputs n, cols = activation rows m
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_f, f.b[j]), __builtin_bit_cast(bf16x8_f, f.a), acc[j], 0, 0, 0);
     };
-    // saved activation: the A buffer of the finished layer is streamed to HBM one 16-byte piece per thread per iteration of
-    // the NEXT layer (8 in all), so that the counted vmcnt waits of the weight pipeline never sit behind a burst of stores
+    // saved activation: the A buffer of the finished layer is streamed to HBM one 16-byte piece per consumer thread per step of
+    // the NEXT layer (8 in all)
     char* save_ptr = nullptr;
     int save_i = 8;
     auto save_piece = [&]() {   // rows 8 i .. 8 i + 7 of the block: thread t moves bytes [16 t, +16) of that 8 KiB slab
@@ -182,104 +210,81 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_fused_kernel(FusedArgs p) {
         int wbase = ra * F_AROW + 8 * (lane >> 5);
         asm volatile("" : "+v"(wbase));   // keep the 16 swizzled addresses out of loop-invariant registers
         while (save_i < 8) save_piece();  // (only if a layer had fewer than 8 chunks)
-        __syncthreads();   // every wave has finished reading the A buffer for this layer
-        auto put = [&](int j, int q, const float* v) {
-            const int slot = wn * 16 + j * 4 + q;
-            uint2 pk;   // relu after rounding (the rounding keeps the sign): one v_pk_max_i16 per pair
-            pk.x = relu_bf16x2(pack_bf16x2(v[0], v[1]));
-            pk.y = relu_bf16x2(pack_bf16x2(v[2], v[3]));
-            *(uint2*)(Abuf + wbase + ((slot ^ axor) << 4)) = pk;   // four consecutive outputs: one 8-byte LDS write
-        };
-        // residual layers (the first one too: h starts at 0): h += acc, out = h ; fc_0 layers: out = acc.  Branch-free with a uniform
-        // 0/1 factor (exact) -- two code versions of this block cost ~140 spilled registers at the join
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // every consumer has finished reading the A buffer for this layer
+        // residual layers (the first one too: h starts at 0): out = h + acc, h = bf16(out) ; fc_0 layers: out = acc.  Branch-free
+        // with a uniform 0/1 factor (exact)
         const bool is_res = L.kind != 1;
         const float resf = is_res ? 1.f : 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float v[4];
+                uint32_t pk[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = acc[j][4 * q + e];   // bias included: the accumulators start from it
-                    h[j][4 * q + e] = __builtin_fmaf(t, resf, h[j][4 * q + e]);
-                    v[e] = is_res ? h[j][4 * q + e] : t;
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 2 * q + e;   // elements 2i, 2i+1
+                    const float v0 = __builtin_fmaf(bf16lo(hp[j][i]), resf, acc[j][2 * i]);      // bias included in acc
+                    const float v1 = __builtin_fmaf(bf16hi(hp[j][i]), resf, acc[j][2 * i + 1]);
+                    pk[e] = pack_bf16x2(v0, v1);
+                    hp[j][i] = is_res ? pk[e] : hp[j][i];
                 }
-                put(j, q, v);
+                const int slot = wn * 16 + j * 4 + q;
+                uint2 o;   // relu after rounding (the rounding keeps the sign): one v_pk_max_i16 per pair
+                o.x = relu_bf16x2(pk[0]);
+                o.y = relu_bf16x2(pk[1]);
+                *(uint2*)(Abuf + wbase + ((slot ^ axor) << 4)) = o;   // four consecutive outputs: one 8-byte LDS write
             }
         asm volatile("" ::: "memory");   // bias reads go straight into the (now dead) accumulators, not into 64 temporaries
         init_acc();        // next layer's bias (its DMA was issued with that layer's first chunk, which has landed)
-        __syncthreads();   // A buffer complete: the next layer may read it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // A buffer complete: the next layer may read it
         save_ptr = (char*)L.save;
         save_i = 0;
     };
 
-    // Software pipeline, one raw barrier per chunk.  In iteration c: chunk c's fragments are already in registers (read in
-    // iteration c-1), chunk c+1 has landed and is read into the other fragment set while the MFMAs of chunk c run, chunks
-    // c+2, c+3 are in flight and chunk c+4 is issued into the stage chunk c-1 occupied (every wave finished reading that one
-    // before its MFMAs of c-1, i.e. before this barrier).  Ring: 5 stages.
-    Cursor ci, cn;   // issue cursor (chunk c+4), fragment cursor (chunk c+1)
-    ci.start(runs);
-    cn.start(runs);
-    if ((wvu & 6) == 2)
-        f_glds16((const char*)p.layer[0].bias + (wvu - 2) * 1024, lane * 16, __builtin_amdgcn_readfirstlane(lds0 + F_BIAS + (wvu - 2) * 1024));
-    ci.fresh = false;   // (layer 0's bias is fetched right here)
-#pragma unroll 1
-    for (int c = 0; c < F_NST - 1 && ci.valid(); ++c) { issue(ci, ring0 + c * F_STAGE); ci.advance(); }
     Frags f0, f1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();    // producers: bias(0) and chunks 0..3 have landed
     init_acc();
-    load_frags(f0, cn, 0);
-    bool cur_end = cn.layer_end();   // properties of chunk c
-    int cur_layer = cn.layer();
-    cn.advance();
-    int st = 0;                      // ring stage of chunk c
-    const bool late_mfma = ORDER == 1 ? true : ORDER == 2 ? wvu < 4 : false;
+    int d_cur = D[0], d_nxt = D[1];  // chunk c (in registers), chunk c + 1 (fragments read during step c)
+    load_frags(f0, d_cur);
+    int c = 0;
     auto step = [&](Frags& cur, Frags& nxt) {
-        // chunk c+1 has landed once at most the loads of chunks c+2, c+3 (>= 2 per wave each) are outstanding (a store or a bias
-        // piece issued in between can only make this wait longer, never shorter than needed)
-        if (ci.valid()) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: fewer than two chunks behind chunk c+1
+        const int d_nxt_n = D[c + 2];    // next step's descriptor (the table is zero-padded)
         __builtin_amdgcn_s_barrier();
-        const int stp = st == 0 ? F_NST - 1 : st - 1;         // stage of chunk c - 1 == stage of chunk c + 4
-        const int stn = st == F_NST - 1 ? 0 : st + 1;         // stage of chunk c + 1
-        if (!late_mfma) mfmas(cur);
-        if (ci.valid()) { issue(ci, ring0 + stp * F_STAGE); ci.advance(); }
+        load_frags(nxt, d_nxt);          // (past the end: a harmless in-bounds read)
+        mfmas(cur);
         if (save_i < 8) save_piece();
-        load_frags(nxt, cn, stn);        // (past the end: a harmless in-bounds read)
-        if (late_mfma) mfmas(cur);
-        if (cur_end) {
-            epilogue(cur_layer);
+        if (FD_END(d_cur)) {
+            epilogue(FD_LAYER(d_cur));
             // the next layer starts with the resident operand: its first activation fragment must see the A buffer just written
-            const int kslot = (cn.y >> 3) + (lane >> 5);
+            const int kslot = (FD_Y(d_nxt) >> 3) + (lane >> 5);
             nxt.a = *(const uint4*)(Abuf + abase + ((kslot ^ axor) << 4));
         }
-        st = stn;
-        cur_end = cn.layer_end();
-        cur_layer = cn.layer();
-        cn.advance();
+        d_cur = d_nxt;
+        d_nxt = d_nxt_n;
+        ++c;
     };
 #pragma unroll 1
-    for (int c = 0; c < nch; c += 2) {   // (an odd count runs one phantom step: its MFMAs land in dead accumulators)
+    while (c < nch) {   // (an odd count runs one phantom step: its MFMAs land in dead accumulators)
         step(f0, f1);
         step(f1, f0);
     }
     while (save_i < 8) save_piece();
 }
 
-// run lists for the 32 possible scale masks, built once per segment layout and kept on the device
+// chunk descriptors for the 32 possible scale masks, built once per segment layout and kept on the device
 struct FusedTable {
     int seg_len[5] = {-1, -1, -1, -1, -1};
-    int4* d_runs = nullptr;
+    int* d_desc = nullptr;
 };
 static FusedTable g_table;
 
-static int fused_table_get(const scenerf_cfg* cfg, hipStream_t s, const int4** runs) {
-    bool same = g_table.d_runs != nullptr;
+static int fused_table_get(const scenerf_cfg* cfg, hipStream_t s, const int** desc) {
+    bool same = g_table.d_desc != nullptr;
     for (int i = 0; i < 5; ++i) same = same && g_table.seg_len[i] == cfg->map_C[i];
     if (!same) {
-        std::vector<int4> tab((size_t)32 * F_MAXRUN, make_int4(0, 0, 0, 0));
+        std::vector<int> tab((size_t)32 * F_MAXCH, 0);
         int seg_off[5], off = 0;
         for (int i = 0; i < 5; ++i) { seg_off[i] = off; off += cfg->map_C[i]; }
         SRF_CHECK(off == SCENERF_D_LATENT, "fused mlp: map channels do not add up to the latent width");
@@ -288,14 +293,18 @@ static int fused_table_get(const scenerf_cfg* cfg, hipStream_t s, const int4** r
                                 SCENERF_D_HIDDEN + SCENERF_D_LATENT, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN};
         int layer_block0[7], nb = 0;
         for (int i = 0; i < 7; ++i) { layer_block0[i] = nb; nb += layer_k[i] / F_BK; }
+        SRF_CHECK(nb < 1024, "fused mlp: w_stream block index does not fit the descriptor");
         for (int mask = 0; mask < 32; ++mask) {
-            int4* ru = tab.data() + (size_t)mask * F_MAXRUN + 1;   // entry 0 is the header
+            int* ch = tab.data() + (size_t)mask * F_MAXCH + 1;   // entry 0 is the header
             int n = 0;
             bool ok = true;
             auto seg = [&](int layer, int src, int a0, int w0, int len) {
-                if (len % F_BK) ok = false;
-                if (n >= F_MAXRUN - 2) { ok = false; return; }
-                ru[n++] = make_int4(layer | (src << 8), a0, layer_block0[layer] + w0 / F_BK, len / F_BK);
+                if (len % F_BK || a0 % F_BK) ok = false;
+                for (int k = 0; k + F_BK <= len; k += F_BK) {
+                    if (n >= F_MAXCH - 10) { ok = false; return; }
+                    ch[n] = (layer_block0[layer] + (w0 + k) / F_BK) | (((a0 + k) / F_BK) << 10) | (src << 18) | (layer << 20) | ((n % F_NST) << 25);
+                    ++n;
+                }
             };
             auto zsegs = [&](int layer, int wbase) {
                 for (int i = 0; i < 5; ++i) {
@@ -311,21 +320,20 @@ static int fused_table_get(const scenerf_cfg* cfg, hipStream_t s, const int4** r
                 seg(2 + 2 * b, 0, 0, 0, SCENERF_D_HIDDEN);
                 if (b < 2) zsegs(2 + 2 * b, SCENERF_D_HIDDEN);
             }
-            SRF_CHECK(ok, "fused mlp: segment lengths must be multiples of 16 and fit the run table");
-            int total = 0;
-            for (int i = 0; i < n; ++i) total += ru[i].w;
-            ru[-1] = make_int4(total, 0, 0, 0);
+            SRF_CHECK(ok, "fused mlp: segment lengths must be multiples of 16 and fit the descriptor table");
             for (int i = 0; i < n; ++i) {
-                if (i + 1 == n || (ru[i + 1].x & 0xff) != (ru[i].x & 0xff)) ru[i].x |= 1 << 16;
-                if (i == 0 || (ru[i - 1].x & 0xff) != (ru[i].x & 0xff)) ru[i].x |= 1 << 17;
+                if (i + 1 == n || FD_LAYER(ch[i + 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 23;
+                if (i == 0 || FD_LAYER(ch[i - 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 24;
             }
+            for (int i = n; i < n + 8; ++i) ch[i] = (i % F_NST) << 25;   // padding: in-bounds no-ops
+            ch[-1] = n;
         }
-        if (!g_table.d_runs) SRF_HIP(hipMalloc((void**)&g_table.d_runs, tab.size() * sizeof(int4)));
+        if (!g_table.d_desc) SRF_HIP(hipMalloc((void**)&g_table.d_desc, tab.size() * sizeof(int)));
         SRF_HIP(hipStreamSynchronize(s));
-        SRF_HIP(hipMemcpy(g_table.d_runs, tab.data(), tab.size() * sizeof(int4), hipMemcpyHostToDevice));
+        SRF_HIP(hipMemcpy(g_table.d_desc, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
         for (int i = 0; i < 5; ++i) g_table.seg_len[i] = cfg->map_C[i];
     }
-    *runs = g_table.d_runs;
+    *desc = g_table.d_desc;
     return 0;
 }
 
@@ -333,9 +341,7 @@ int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
                          const scenerf_mlp_acts* a, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        SRF_HIP(hipFuncSetAttribute((const void*)mlp_fwd_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
-        SRF_HIP(hipFuncSetAttribute((const void*)mlp_fwd_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
-        SRF_HIP(hipFuncSetAttribute((const void*)mlp_fwd_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+        SRF_HIP(hipFuncSetAttribute((const void*)mlp_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         attr_done = true;
     }
     FusedArgs p;
@@ -348,16 +354,13 @@ int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
     p.X3 = a->h0pre;
     p.Z = Z;
     p.tile_mask = tile_mask;
-    if (int e = fused_table_get(cfg, s, &p.runs)) return e;
+    if (int e = fused_table_get(cfg, s, &p.desc)) return e;
     p.M = M;
     // dense-equivalent FLOPs of the trunk (profile mode refines nothing here: reported as the dense count of the layers
     // without the skipped segments is not known on the host without a sync; use the always-present part as a lower bound)
     const double flops = 2.0 * M * 512.0 * (144.0 + 6 * 512.0);
-    const int order = getenv("SRF_FUSED_ORDER") ? atoi(getenv("SRF_FUSED_ORDER")) : 0;
     SrfLaunchScope ps(s, "mlp_fwd_fused", flops, 0);
-    if (order == 1) mlp_fwd_fused_kernel<1><<<cdiv(M, F_BM), 512, F_LDS, s>>>(p);
-    else if (order == 2) mlp_fwd_fused_kernel<2><<<cdiv(M, F_BM), 512, F_LDS, s>>>(p);
-    else mlp_fwd_fused_kernel<0><<<cdiv(M, F_BM), 512, F_LDS, s>>>(p);
+    mlp_fwd_fused_kernel<<<cdiv(M, F_BM), F_THREADS, F_LDS, s>>>(p);
     SRF_LAUNCH_CHECK("mlp_fwd_fused_kernel");
     return 0;
 }

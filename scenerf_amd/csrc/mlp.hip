@@ -254,7 +254,7 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
         }
         // rows from which the whole trunk runs as ONE fused kernel (fused.hip); read per call so a test can compare paths
         const char* fenv = getenv("SRF_FUSED_MIN_M");
-        const int fused_min_m = fenv ? atoi(fenv) : (1 << 30);
+        const int fused_min_m = fenv ? atoi(fenv) : 4096;
         if (M >= fused_min_m && w->w_stream) {
             if (int e = launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s)) return e;
             return launch_linout_fwd<bf16_t>(w->d_out, a->H[3], w->w_out, w->b_out, M, a->logits, s);
