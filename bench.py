@@ -48,8 +48,12 @@ def pmc_traffic(logical_name):
         d = json.load(open(files[-1]))
     except Exception:
         return None
-    fn = "gemm_tn_kernel" if "wgrad" in logical_name else ("gemm_nt_glds_kernel" if logical_name.startswith("gemm_") and
-                                                            not logical_name.endswith("/g") else None)
+    if logical_name.startswith("mlp_fwd_fused"):
+        fn = "mlp_fwd_fused_kernel"
+    elif "wgrad" in logical_name:
+        fn = "gemm_tn_kernel"
+    else:
+        fn = "gemm_nt_glds_kernel" if logical_name.startswith("gemm_") and not logical_name.endswith("/g") else None
     for k, v in d.items():
         if fn and k.startswith(fn):
             return {"bytes_per_launch": round(v["hbm_bytes_per_launch"]), "kernel_fn": k, "source": os.path.basename(files[-1]),

@@ -79,13 +79,14 @@ typedef struct scenerf_mlp_weights {
     const void* w_fc0_t[3];         /* T: [512][512] = fc_0.weight^T */
     const void* w_fc1_t[3];         /* T: [512][512] = fc_1.weight^T */
     const void* w_z_t[SCENERF_N_SCALES]; /* T: [C_s][1536] = (cat_b lin_z.b.weight[:, slice_s])^T */
-    /* bf16 mode only (NULL otherwise, or NULL to disable the fused forward kernel): the seven forward operands
-     * w_h[0], w_fc0[0], w_h[1], w_fc0[1], w_h[2], w_fc0[2], w_h[3] re-tiled for streaming -- per 16 columns of K one
+    /* bf16 mode only (NULL otherwise, or NULL to disable the fused kernels): the seven forward operands
+     * w_h[0], w_fc0[0], w_h[1], w_fc0[1], w_h[2], w_fc0[2], w_h[3], then the six dgrad operands w_fc1_t[2], w_fc0_t[2],
+     * w_fc1_t[1], w_fc0_t[1], w_fc1_t[0], w_fc0_t[0], re-tiled for streaming -- per 16 columns of K one
      * contiguous 16 KiB block [512 rows][32 B] holding the exact LDS image (16-byte halves of row r swapped when
      * (r >> 3) & 1).  SCENERF_W_STREAM_BLOCKS blocks in all. */
     const void* w_stream;
 } scenerf_mlp_weights;
-#define SCENERF_W_STREAM_BLOCKS ((3 * SCENERF_D_XENC + SCENERF_D_LATENT) / 16 + 2 * ((SCENERF_D_HIDDEN + SCENERF_D_LATENT) / 16) + 4 * (SCENERF_D_HIDDEN / 16))
+#define SCENERF_W_STREAM_BLOCKS ((3 * SCENERF_D_XENC + SCENERF_D_LATENT) / 16 + 2 * ((SCENERF_D_HIDDEN + SCENERF_D_LATENT) / 16) + 10 * (SCENERF_D_HIDDEN / 16))
 
 /* Raw ResnetFC parameters exactly as the reference's nn.Linear modules hold them (fp32, row-major [out][in]). */
 typedef struct scenerf_mlp_params {
@@ -123,6 +124,9 @@ typedef struct scenerf_mlp_acts {
     void* Nn[3];                    /* T [M][512] */
     float* h0pre;                   /* [M][512] fp32 scratch: lin_in output (fp32 mode) / split-bf16 encoding [M][144] (bf16 mode) */
     float* logits;                  /* fp32 [M][d_out] */
+    uint8_t* sign_bits;             /* bf16 mode, may be NULL: [7][Mpad][64] -- bit n of row m = (saved activation [m][n] > 0) for
+                                     * H0, N0, H1, N1, H2, N2, H3; written by the fused forward kernel, gates the fused backward
+                                     * chain (Mpad = M rounded up to SCENERF_TILE_ROWS).  NULL disables the fused backward. */
 } scenerf_mlp_acts;
 
 int scenerf_hip_abi_version(void);

@@ -21,7 +21,7 @@ D_LATENT = 2480
 D_HIDDEN = 512
 D_XENC = 48
 TILE_ROWS = 128
-W_STREAM_BLOCKS = (3 * D_XENC + D_LATENT) // 16 + 2 * ((512 + D_LATENT) // 16) + 4 * (512 // 16)   # scenerf_hip.h
+W_STREAM_BLOCKS = (3 * D_XENC + D_LATENT) // 16 + 2 * ((512 + D_LATENT) // 16) + 10 * (512 // 16)   # scenerf_hip.h
 ABI_VERSION = 2
 
 vp = C.c_void_p
@@ -70,7 +70,7 @@ class MlpGrads(C.Structure):
 
 
 class MlpActs(C.Structure):
-    _fields_ = [("H", vp * 4), ("Nn", vp * 3), ("h0pre", vp), ("logits", vp)]
+    _fields_ = [("H", vp * 4), ("Nn", vp * 3), ("h0pre", vp), ("logits", vp), ("sign_bits", vp)]
 
 
 class ProfRec(C.Structure):

@@ -63,3 +63,7 @@ int launch_gemm_tn(int precision, const GemmTN& p, hipStream_t s);
 // relu(N_b) (what the backward pass consumes) to a->H / a->Nn.  a->h0pre must hold the split encoding [M][144].
 int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const uint8_t* tile_mask, int M,
                          const scenerf_mlp_acts* a, hipStream_t s);
+// backward dgrad chain of the three residual blocks in one kernel (bf16): reads dH column block 3, writes dH column blocks 2..0 and
+// dN [3][M][512]; sign gates come from the saved activations a->Nn / a->H.
+int launch_mlp_bwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, int M, const scenerf_mlp_acts* a, void* dH, void* dN,
+                         hipStream_t s);

@@ -104,24 +104,26 @@ __global__ __launch_bounds__(256) void linout_bwd_kernel(const void* __restrict_
     if (threadIdx.x < DO) part[DO * SCENERF_D_HIDDEN + threadIdx.x] = s_db[0][threadIdx.x] + s_db[1][threadIdx.x] + s_db[2][threadIdx.x] + s_db[3][threadIdx.x];
 }
 
-// dw_out[i] += sum over blocks of the partials (one thread per output element; plain read-modify-write, stream-ordered)
+// dw_out[i] += sum over blocks of the partials.  grid.y slices of the block range run in parallel (a single thread per output
+// walking ~1200 partials was latency-bound: 107 us), each adding its share with one atomic per output.
 template <int DO>
 __global__ void linout_reduce_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ dw_out, float* __restrict__ db_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = DO * SCENERF_D_HIDDEN + 8;
     if (i >= DO * SCENERF_D_HIDDEN + DO) return;
+    const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int b = 0;
-    for (; b + 3 < nblocks; b += 4) {
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
         a0 += partial[(size_t)b * stride + i];
         a1 += partial[(size_t)(b + 1) * stride + i];
         a2 += partial[(size_t)(b + 2) * stride + i];
         a3 += partial[(size_t)(b + 3) * stride + i];
     }
-    for (; b < nblocks; ++b) a0 += partial[(size_t)b * stride + i];
+    for (; b < b1; ++b) a0 += partial[(size_t)b * stride + i];
     const float v = (a0 + a1) + (a2 + a3);
-    if (i < DO * SCENERF_D_HIDDEN) dw_out[i] += v;
-    else db_out[i - DO * SCENERF_D_HIDDEN] += v;
+    if (b1 > b0) unsafeAtomicAdd(i < DO * SCENERF_D_HIDDEN ? dw_out + i : db_out + (i - DO * SCENERF_D_HIDDEN), v);
 }
 
 // bf16 mode: lin_in runs inside the first hidden GEMM as three extra K-segments.  x = hi + lo with hi = bf16(x),
@@ -163,8 +165,9 @@ static int launch_linout_bwd(int d_out, const void* H3, const float* w, const fl
         SRF_LAUNCH_CHECK("linout_bwd_kernel");
     }
     const int n = d_out * SCENERF_D_HIDDEN + d_out;
-    if (d_out == 4) linout_reduce_kernel<4><<<cdiv(n, 256), 256, 0, s>>>(scratch, grid, dw, db);
-    else linout_reduce_kernel<2><<<cdiv(n, 256), 256, 0, s>>>(scratch, grid, dw, db);
+    const dim3 rgrid(cdiv(n, 256), grid >= 64 ? 32 : 1);
+    if (d_out == 4) linout_reduce_kernel<4><<<rgrid, 256, 0, s>>>(scratch, grid, dw, db);
+    else linout_reduce_kernel<2><<<rgrid, 256, 0, s>>>(scratch, grid, dw, db);
     SRF_LAUNCH_CHECK("linout_reduce_kernel");
     return 0;
 }
@@ -333,6 +336,14 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         if (int e = launch_linout_bwd<float>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, (float*)dN, s)) return e;
     }
     if (int e = fork()) return e;
+    // bf16, enough rows: the whole dgrad chain (6 GEMMs) runs as ONE kernel (fused.hip); the weight-gradient GEMMs below then
+    // only consume dH / dN
+    const char* fenv = getenv("SRF_FUSED_MIN_M");
+    const bool fused_chain = prec && w->w_stream && a->sign_bits && M >= (fenv ? atoi(fenv) : 4096) && !getenv("SRF_NO_FUSED_BWD");
+    if (fused_chain) {
+        if (int e = launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
+        if (int e = fork()) return e;
+    }
     for (int b = 2; b >= 0; --b) {
         {   // [side] dW1_b += dH_{b+1}^T relu(N_b)
             GemmTN t;
@@ -342,7 +353,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             t.colsum = g_->b_fc1[b];  // fc_1.b.bias gradient = column sums of dH_{b+1}
             if (int e = launch_gemm_tn(prec, t, s2)) return e;
         }
-        {   // dN_b = (dH_{b+1} @ W1_b) * [N_b > 0]
+        if (!fused_chain) {   // dN_b = (dH_{b+1} @ W1_b) * [N_b > 0]
             GemmNT g;
             g.name = head ? "gemm_dgrad_fc1/g" : "gemm_dgrad_fc1";
             g.A1 = dHcol(b + 1); g.lda1 = LDH; g.K1 = SCENERF_D_HIDDEN;
@@ -361,7 +372,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             t.colsum = g_->b_fc0[b];
             if (int e = launch_gemm_tn(prec, t, s2)) return e;
         }
-        {   // dH_b = dH_{b+1} + (dN_b @ W0_b) * [H_b > 0]
+        if (!fused_chain) {   // dH_b = dH_{b+1} + (dN_b @ W0_b) * [H_b > 0]
             GemmNT g;
             g.name = head ? "gemm_dgrad_fc0/g" : "gemm_dgrad_fc0";
             g.A1 = dNb(b); g.lda1 = SCENERF_D_HIDDEN; g.K1 = SCENERF_D_HIDDEN;
@@ -513,15 +524,16 @@ __global__ void pack_bias_kernel(const float* a0, const float* c0, const float* 
 // w_stream (scenerf_hip.h): the seven forward operands re-tiled into 16 KiB blocks [512 rows][32 B] per 16 columns of K, the
 // two 16-byte halves of row r swapped when (r >> 3) & 1 -- the LDS image fused.hip's fragment reads expect, so a streaming
 // piece (1 KiB per wave) is contiguous in memory.  One thread per 16-byte half row.
+#define STREAM_OPS 13
 struct StreamSrc {
-    const bf16_t* W[7];
-    int ld[7];
-    int block0[8];   // first block of each operand; block0[7] = total
+    const bf16_t* W[STREAM_OPS];
+    int ld[STREAM_OPS];
+    int block0[STREAM_OPS + 1];   // first block of each operand; the last entry = total
 };
 __global__ __launch_bounds__(256) void pack_stream_kernel(StreamSrc t, uint4* __restrict__ dst) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int blk = idx >> 10;
-    if (blk >= t.block0[7]) return;
+    if (blk >= t.block0[STREAM_OPS]) return;
     int l = 0;
     while (blk >= t.block0[l + 1]) ++l;
     const int r = (idx & 1023) >> 1, ps = idx & 1;
@@ -586,16 +598,17 @@ extern "C" int scenerf_hip_mlp_pack(const scenerf_cfg* cfg, const scenerf_mlp_pa
     }
     if (prec && W->w_stream) {
         StreamSrc t;
-        const void* ops[7] = {W->w_h[0], W->w_fc0[0], W->w_h[1], W->w_fc0[1], W->w_h[2], W->w_fc0[2], W->w_h[3]};
-        const int lds_[7] = {3 * X + L, H, H + L, H, H + L, H, H};
+        const void* ops[STREAM_OPS] = {W->w_h[0], W->w_fc0[0], W->w_h[1], W->w_fc0[1], W->w_h[2], W->w_fc0[2], W->w_h[3],
+                                       W->w_fc1_t[2], W->w_fc0_t[2], W->w_fc1_t[1], W->w_fc0_t[1], W->w_fc1_t[0], W->w_fc0_t[0]};
+        const int lds_[STREAM_OPS] = {3 * X + L, H, H + L, H, H + L, H, H, H, H, H, H, H, H};
         int nb = 0;
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < STREAM_OPS; ++i) {
             t.W[i] = (const bf16_t*)ops[i];
             t.ld[i] = lds_[i];
             t.block0[i] = nb;
             nb += lds_[i] / 16;
         }
-        t.block0[7] = nb;
+        t.block0[STREAM_OPS] = nb;
         SRF_CHECK(nb == SCENERF_W_STREAM_BLOCKS, "mlp_pack: stream block count");
         SrfLaunchScope ps(s, "mlp_pack_stream", 0, (double)nb * 32768);
         pack_stream_kernel<<<nb * 4, 256, 0, s>>>(t, (uint4*)W->w_stream);

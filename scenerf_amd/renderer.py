@@ -291,6 +291,9 @@ class _MlpRun:
             a.Nn[i] = self.Nn[i].data_ptr()
         a.h0pre = self.h0pre.data_ptr()
         a.logits = self.logits.data_ptr()
+        # sign bits of the seven saved activations (fused forward -> fused backward chain, scenerf_hip.h)
+        self.sign_bits = torch.empty((7, self.Mpad, 64), dtype=torch.uint8, device=dev) if prec else None
+        a.sign_bits = self.sign_bits.data_ptr() if prec else None
         self.c = a
 
 

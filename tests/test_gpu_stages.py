@@ -518,3 +518,58 @@ def test_mlp_forward_fused_matches_layer_path(case, M):
     ef = float((b.logits.cpu() - ref).abs().max())
     print("logits err: layers %.3e fused %.3e" % (el, ef))
     assert ef <= max(1.25 * el, 1e-2 * max(float(ref.abs().max()), 1.0))
+
+
+@pytest.mark.parametrize("M", [4096 + 37, 40000])
+def test_mlp_backward_fused_matches_layer_path(case, M):
+    """fused.hip MODE 1 (the six dgrad GEMMs of the residual blocks in one kernel, sign gates rebuilt from the saved activations by
+    the producer waves) against the per-layer dgrad GEMMs on the same forward state: dH column blocks 0..2, dN and every parameter
+    gradient.  Both paths round dH / dN to bf16 at the same places; only the accumulation order inside a K = 512 product differs."""
+    import os
+    from scenerf_amd.renderer import MLP_PARAM_NAMES, _MlpRun
+    lib = _capi.load()
+    rcfg, xin0, state, d_out, pk = _mlp_case(case, "bf16", "mlp")
+    cc = rcfg.to_c()
+    gen = torch.Generator().manual_seed(M + 1)
+    run = _MlpRun(M, d_out, 1, torch.device(DEV))
+    run.Z.copy_(dv(torch.randn(run.Z.shape, generator=gen) * 0.5, torch.bfloat16))
+    xe = torch.zeros((M, 48))
+    xe[:, :42] = torch.randn(M, 42, generator=gen).clamp(-1, 1)
+    run.xenc.copy_(dv(xe))
+    run.tile_mask.fill_(31)
+    _capi.check(lib.scenerf_hip_mlp_forward(C.byref(cc), C.byref(pk.c), run.Z.data_ptr(), run.xenc.data_ptr(), run.tile_mask.data_ptr(), M,
+                                            C.byref(run.c), _st()), "mlp_forward")
+    dl = dv(torch.randn(M, d_out, generator=gen))
+    tex = torch.full((M, 5, 4), -1, dtype=torch.int32, device=DEV)
+    tw = torch.zeros((M, 5, 4), device=DEV)
+    res = {}
+    for name in ("layers", "fused"):
+        if name == "layers":
+            os.environ["SRF_NO_FUSED_BWD"] = "1"
+        else:
+            os.environ.pop("SRF_NO_FUSED_BWD", None)
+        gs = pk.grad_sink()
+        pk.gflat.zero_()
+        dH = torch.zeros((M, 2048), dtype=torch.bfloat16, device=DEV)
+        dN = torch.zeros((3, M, 512), dtype=torch.bfloat16, device=DEV)
+        _capi.check(lib.scenerf_hip_mlp_backward(C.byref(cc), C.byref(pk.c), C.byref(gs), run.Z.data_ptr(), run.xenc.data_ptr(),
+                                                 run.tile_mask.data_ptr(), tex.data_ptr(), tw.data_ptr(), M, C.byref(run.c),
+                                                 dl.data_ptr(), dH.data_ptr(), dN.data_ptr(), None, _st()), "mlp_backward")
+        torch.cuda.synchronize()
+        res[name] = (dH.float().cpu(), dN.float().cpu(), [g.clone().cpu() for g in pk.unpack_grads()])
+    os.environ.pop("SRF_NO_FUSED_BWD", None)
+    (dHa, dNa, ga), (dHb, dNb, gb) = res["layers"], res["fused"]
+    assert torch.equal(dHa[:, 1536:], dHb[:, 1536:])          # lin_out's backward is shared
+    bad = []
+    for b in (2, 1, 0):   # chain order
+        for nm, x, y in (("dN%d" % b, dNa[b], dNb[b]), ("dH%d" % b, dHa[:, 512 * b:512 * (b + 1)], dHb[:, 512 * b:512 * (b + 1)])):
+            rel = float((x - y).norm() / max(float(x.norm()), 1e-20))
+            # the gate must be identical: an element is zero in one path iff it is zero in the other (up to exact-zero products)
+            zero_mismatch = float(((x == 0) != (y == 0)).float().mean())
+            print("%s: rel L2 %.3e, zero-pattern mismatch %.2e" % (nm, rel, zero_mismatch))
+            if rel > 1.5e-2 or zero_mismatch > 1e-3:
+                bad.append(nm)
+    assert not bad, bad
+    for n, x, y in zip(MLP_PARAM_NAMES, ga, gb):
+        rel = float((x - y).norm() / max(float(x.norm()), 1e-20))
+        assert rel <= 1.5e-2, "%s: relative L2 difference %.3e" % (n, rel)
