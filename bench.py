@@ -49,13 +49,23 @@ def pmc_traffic(logical_name):
     except Exception:
         return None
     if logical_name.startswith("mlp_fwd_fused"):
-        fn = "mlp_fwd_fused_kernel"
+        fn = "mlp_fused_kernel<0>"
+    elif logical_name.startswith("mlp_bwd_fused"):
+        fn = "mlp_fused_kernel<1>"
     elif "wgrad" in logical_name:
         fn = "gemm_tn_kernel"
     else:
         fn = "gemm_nt_glds_kernel" if logical_name.startswith("gemm_") and not logical_name.endswith("/g") else None
+    if not fn:
+        return None
+    # the dominant launch of a logical kernel is the largest grid of its function (main MLP, not the 4-point gaussian head)
+    sized = [(int(k.split("@grid=")[1]), k, v) for k, v in d.items() if k.startswith(fn) and "@grid=" in k]
+    if sized and logical_name.startswith("mlp_"):
+        _, k, v = max(sized)
+        return {"bytes_per_launch": round(v["hbm_bytes_per_launch"]), "kernel_fn": k, "source": os.path.basename(files[-1]),
+                "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, average over the launches of this grid size"}
     for k, v in d.items():
-        if fn and k.startswith(fn):
+        if k.startswith(fn) and "@grid=" not in k:
             return {"bytes_per_launch": round(v["hbm_bytes_per_launch"]), "kernel_fn": k, "source": os.path.basename(files[-1]),
                     "note": "average over all launches of this kernel function in a step"}
     return None

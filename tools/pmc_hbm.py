@@ -11,8 +11,9 @@ def agg(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
-            tot[k] += float(r["Counter_Value"])
-            cnt[k] += 1
+            for key in (k, k + " @grid=" + r["Grid_Size"]):   # per kernel function, and per (function, launch size)
+                tot[key] += float(r["Counter_Value"])
+                cnt[key] += 1
     return tot, cnt
 
 ft, fc = agg(sys.argv[1], "FETCH_SIZE")
@@ -27,5 +28,5 @@ for k in sorted(set(ft) | set(wt)):
     out[k] = {"launches": n, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
               "hbm_bytes_per_launch": fetch + write}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
+for k, v in sorted(((k, v) for k, v in out.items() if "@grid" not in k), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
     print("%-60s n=%4d fetch %8.1f MB  write %8.1f MB" % (k[:60], v["launches"], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6))
