@@ -127,6 +127,11 @@ def load() -> C.CDLL:
     return lib
 
 
+def fused_min_rows() -> int:
+    """Row count from which libscenerf_hip.so runs the ResnetFC trunk as one fused kernel (bf16; mlp.hip reads the same variable)."""
+    return int(os.environ.get("SRF_FUSED_MIN_M", "4096"))
+
+
 def check(code: int, what: str) -> None:
     if code != 0:
         msg = load().scenerf_hip_last_error()

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(F_THREADS) void mlp_fused_kernel(FusedArgs p) {
     int save_i = 8;
     auto save_piece = [&]() {   // rows 8 i .. 8 i + 7 of the block: thread t moves slot t & 63 of row 8 i + t / 64
         const int row = 8 * save_i + (tid >> 6), slot = tid & 63;
-        if (m0 + row < p.M) {
+        if (save_ptr && m0 + row < p.M) {   // (inference: only the last layer has a destination)
             const uint4 v = *(const uint4*)(Abuf + row * F_AROW + ((slot ^ (row & 15)) << 4));
             *(uint4*)(save_ptr + (size_t)(m0 + row) * save_ld2 + slot * 16) = v;
             if (MODE == 0 && sign_ptr) {

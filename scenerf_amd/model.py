@@ -183,6 +183,16 @@ class SceneRF(TrainingMixin, _Base):
         self.grad_sync = None
 
     # ---- the hot path ---------------------------------------------------------------------------------------
+    def _inv_K(self, cam_K: torch.Tensor) -> torch.Tensor:
+        """torch.inverse(cam_K) as the reference computes it (scenerf.py:400), cached per intrinsics tensor: rocSOLVER's LU is ~8
+        tiny launches and is not stream-capturable.  The cache key is the tensor OBJECT and its version counter (never the address:
+        a new tensor may reuse it), so a loop that passes the same K tensor pays once and anything else recomputes."""
+        hit = getattr(self, "_inv_K_cache", None)
+        if hit is None or hit[0] is not cam_K or hit[1] != cam_K._version:
+            hit = (cam_K, cam_K._version, torch.inverse(cam_K))
+            object.__setattr__(self, "_inv_K_cache", hit)
+        return hit[2]
+
     def render_rays_batch(self, cam_K, T_source2infer, x_rgb: Dict[str, torch.Tensor], depth_window=100,
                           T_cam2velo=None, sampled_pixels=None, ray_batch_size=128, noise=None):
         """scenerf.py:392-471.  ``depth_window`` / ``T_cam2velo`` are accepted and unused, as in the reference.
@@ -195,7 +205,7 @@ class SceneRF(TrainingMixin, _Base):
         self.ray_som  # noqa: B018  (attribute kept for parity with the reference module tree)
         cfg = self.render_cfg
         cfg.som_sigma = float(self.ray_som.som_sigma)
-        inv_K = torch.inverse(cam_K)
+        inv_K = self._inv_K(cam_K)
         sess = RenderSession(cfg, x_rgb, self.mlp.ordered_params(), self.mlp_gaussian.ordered_params(),
                              grad_sync=self.grad_sync)
         outs = []

@@ -270,8 +270,11 @@ class PackMLP(torch.autograd.Function):
 class _MlpRun:
     """Buffers of one ResnetFC evaluation over M rows (kept for backward when grad is enabled)."""
 
-    def __init__(self, M: int, d_out: int, prec: int, dev):
+    def __init__(self, M: int, d_out: int, prec: int, dev, keep_acts: bool = True):
         act = _act_dtype(prec)
+        # inference (no_grad) on the fused bf16 path: nothing but H3 (lin_out's input) is ever read again, so the six other
+        # activations and the sign bits are neither allocated nor written (NULL in scenerf_mlp_acts)
+        lean = (not keep_acts) and prec == 1 and M >= _capi.fused_min_rows()
         self.M = M
         self.Mpad = (M + _capi.TILE_ROWS - 1) // _capi.TILE_ROWS * _capi.TILE_ROWS
         self.sphere_idx = torch.empty((M, 2), dtype=torch.int32, device=dev)
@@ -280,28 +283,29 @@ class _MlpRun:
         self.tile_mask = torch.empty((self.Mpad // _capi.TILE_ROWS,), dtype=torch.uint8, device=dev)
         self.tap_texel = torch.empty((M, 5, 4), dtype=torch.int32, device=dev)
         self.tap_weight = torch.empty((M, 5, 4), dtype=torch.float32, device=dev)
-        self.H = [torch.empty((M, D_H), dtype=act, device=dev) for _ in range(4)]
-        self.Nn = [torch.empty((M, D_H), dtype=act, device=dev) for _ in range(3)]
-        self.h0pre = torch.empty((M, D_H), dtype=torch.float32, device=dev)
+        self.H = [None if (lean and i < 3) else torch.empty((M, D_H), dtype=act, device=dev) for i in range(4)]
+        self.Nn = [None if lean else torch.empty((M, D_H), dtype=act, device=dev) for _ in range(3)]
+        # fp32 lin_in output (fp32 mode) or the split-bf16 encoding [M][144] (bf16 mode)
+        self.h0pre = torch.empty((M, D_H) if prec == 0 else (M, 3 * D_X // 2), dtype=torch.float32, device=dev)
         self.logits = torch.empty((M, d_out), dtype=torch.float32, device=dev)
         a = _capi.MlpActs()
         for i in range(4):
-            a.H[i] = self.H[i].data_ptr()
+            a.H[i] = self.H[i].data_ptr() if self.H[i] is not None else None
         for i in range(3):
-            a.Nn[i] = self.Nn[i].data_ptr()
+            a.Nn[i] = self.Nn[i].data_ptr() if self.Nn[i] is not None else None
         a.h0pre = self.h0pre.data_ptr()
         a.logits = self.logits.data_ptr()
         # sign bits of the seven saved activations (fused forward -> fused backward chain, scenerf_hip.h)
-        self.sign_bits = torch.empty((7, self.Mpad, 64), dtype=torch.uint8, device=dev) if prec else None
-        a.sign_bits = self.sign_bits.data_ptr() if prec else None
+        self.sign_bits = torch.empty((7, self.Mpad, 64), dtype=torch.uint8, device=dev) if (prec and not lean) else None
+        a.sign_bits = self.sign_bits.data_ptr() if self.sign_bits is not None else None
         self.c = a
 
 
 def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dist_ray_stride, ppr, unit_dir, viewdir,
-              K, inv_K, T, M) -> _MlpRun:
+              K, inv_K, T, M, keep_acts: bool = True) -> _MlpRun:
     lib = _capi.load()
     st = _stream()
-    run = _MlpRun(M, pk.d_out, cfg.precision_code, dist.device)
+    run = _MlpRun(M, pk.d_out, cfg.precision_code, dist.device, keep_acts=keep_acts)
     _capi.check(lib.scenerf_hip_encode_points(C.byref(ccfg), dist.data_ptr(), dist_ray_stride, ppr, unit_dir.data_ptr(),
                                               viewdir.data_ptr(), K.data_ptr(), inv_K.data_ptr(), T.data_ptr(), M, None,
                                               run.sphere_idx.data_ptr(), run.xenc.data_ptr(), st), "encode_points")
@@ -356,7 +360,9 @@ class RenderChunk(torch.autograd.Function):
                                               _capi.ptr(noise_u), R, unit_dir.data_ptr(), viewdir.data_ptr(),
                                               _capi.ptr(dist_u), st), "ray_setup")
         # gaussian head on the G anchors per ray (scenerf.py:549-596)
-        run_g = _mlp_eval(ccfg, cfg, maps, mlpg.packed, anchors, 0, G, unit_dir, viewdir, K, iK, T, R * G)
+        # (grad mode is off inside Function.forward: whether a backward can follow is what needs_input_grad says)
+        keep = any(ctx.needs_input_grad)
+        run_g = _mlp_eval(ccfg, cfg, maps, mlpg.packed, anchors, 0, G, unit_dir, viewdir, K, iK, T, R * G, keep)
         gmeans = torch.empty((R, G), **f32)
         gstds = torch.empty((R, G), **f32)
         dist_s = torch.empty((R, N), **f32)
@@ -367,7 +373,7 @@ class RenderChunk(torch.autograd.Function):
                                                          gmeans.data_ptr(), gstds.data_ptr(), dist_s.data_ptr(), z_s.data_ptr(),
                                                          perm.data_ptr(), st), "gaussian_sample_sort")
         # radiance MLP on the sorted samples (scenerf.py:661-665)
-        run_m = _mlp_eval(ccfg, cfg, maps, mlp.packed, dist_s, N, N, unit_dir, viewdir, K, iK, T, R * N)
+        run_m = _mlp_eval(ccfg, cfg, maps, mlp.packed, dist_s, N, N, unit_dir, viewdir, K, iK, T, R * N, keep)
         dens = torch.empty((R, N), **f32)
         alphas = torch.empty((R, N), **f32)
         weights = torch.empty((R, N), **f32)

@@ -319,3 +319,43 @@ def test_full_size_config2_properties_and_subset_parity():
     for k in ("depth", "color", "weights", "alphas", "densities", "gaussian_means", "gaussian_stds", "depth_volumes"):
         fr, _ = frac_within(o[k][:S], ref[k].detach(), 5e-4, 5e-4)
         assert fr >= 0.95, "%s: %.3f of the subset rays within tolerance" % (k, fr)
+
+
+@pytest.mark.gpu
+def test_inference_chunk_replays_as_a_graph():
+    """Config C5's mechanics (static chunk, no_grad, hipGraph): with the sampling noise supplied, one chunk of
+    render_rays_batch is launch-only (no host sync, no rocSOLVER after the first call, allocations inside the graph pool), so it
+    captures into a graph whose replay reproduces the eager outputs bit for bit -- on the lean fused-inference path (only H3 is
+    written; the other activations and the sign bits are NULL)."""
+    from scenerf_amd import synth
+    kw = dict(sphere_W=376, sphere_H=114, n_pts_uni=32, n_pts_per_gaussian=8)
+    R = 512   # x 64 samples = 32768 rows >= 4096: fused kernel
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="bf16", **kw).to(DEV).eval()
+    m.mlp.load_state_dict(synth.mlp_state(21, 4))
+    m.mlp_gaussian.load_state_dict(synth.mlp_state(22, 2, out_scale=4.0))
+    maps = {k: v.to(DEV) for k, v in synth.feature_maps(376, 114, 23, smooth=True).items()}
+    K, T = synth.kitti_cam_K().to(DEV), synth.rel_pose(2.0, 10.0).to(DEV)
+    pix = synth.stride2_pixels((1220, 370), R, 24).to(DEV)
+    nu, ng = synth.sampling_noise(R, 32, 32, 25)
+    nu, ng = nu.to(DEV), ng.to(DEV)
+    with torch.no_grad():
+        ref = m.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=R, noise=(nu, ng))
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=R, noise=(nu, ng))
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = m.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=R, noise=(nu, ng))
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+    for k in OUT_KEYS:
+        assert torch.equal(ref[k], out[k]), k
+    # and the lean path agrees with the training-mode forward (all activations saved) on the same inputs
+    maps_g = {k: v.clone().requires_grad_(True) for k, v in maps.items()}
+    full = m.render_rays_batch(K, T, maps_g, sampled_pixels=pix, ray_batch_size=R, noise=(nu, ng))
+    for k in ("depth", "color", "loss_kl"):
+        assert torch.equal(ref[k], full[k].detach()), k

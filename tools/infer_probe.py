@@ -22,3 +22,41 @@ for (U, P, nrays, chunk) in [(32, 8, 50468, 4000), (32, 8, 112850, 8192), (64, 1
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("N=%d rays=%d chunk=%d: %.1f ms  %.0f rays/s  (%.1f Msamples/s) peak mem %.1f GB" % (
         U + 4 * P, nrays, chunk, dt * 1e3, nrays / dt, nrays * (U + 4 * P) / dt / 1e6, torch.cuda.max_memory_allocated() / 2**30))
+
+# ---- config C5 with a captured graph: one static 4096-ray chunk (N = 512) replayed over the frame --------------------
+# ("chunk 4096 rays static (pad tail), no_grad, hipGraph").  The sampling noise is drawn outside the graph
+# and copied into static buffers; everything inside render_rays_batch is launch-only (no host sync, no allocation outside
+# the graph's private pool), so the ~60 launches of a chunk replay as one graph launch.
+if "--graph" in sys.argv:
+    U, P, chunk, nrays = 256, 64, 4096, 32768
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, n_pts_uni=U, n_pts_per_gaussian=P, precision="bf16",
+                device_rng=True).to(dev).eval()
+    m.mlp.load_state_dict(synth.mlp_state(1, 4)); m.mlp_gaussian.load_state_dict(synth.mlp_state(2, 2, out_scale=4.0))
+    pix_all = synth.stride2_pixels((1220, 370), nrays, 7).to(dev)
+    s_pix = pix_all[:chunk].clone()
+    s_nu = torch.rand(chunk, U, 1, device=dev)
+    s_ng = torch.randn(chunk, 4 * P, device=dev)
+    with torch.no_grad():
+        ref = m.render_rays_batch(K, T, maps, sampled_pixels=s_pix, ray_batch_size=chunk, noise=(s_nu, s_ng))   # warm-up (tables, attributes)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m.render_rays_batch(K, T, maps, sampled_pixels=s_pix, ray_batch_size=chunk, noise=(s_nu, s_ng))
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(g):
+            s_out = m.render_rays_batch(K, T, maps, sampled_pixels=s_pix, ray_batch_size=chunk, noise=(s_nu, s_ng))
+        g.replay()
+        torch.cuda.synchronize()
+        same = all(torch.equal(ref[k], s_out[k]) for k in ("depth", "color"))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        depth = []
+        for s in range(0, nrays, chunk):
+            s_pix.copy_(pix_all[s:s + chunk])
+            s_nu.uniform_()
+            s_ng.normal_()
+            g.replay()
+            depth.append(s_out["depth"].clone())
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("C5 graph replay N=512 chunk=%d rays=%d: %.1f ms  %.0f rays/s ; replay == eager: %s" % (chunk, nrays, dt * 1e3, nrays / dt, same))
