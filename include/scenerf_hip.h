@@ -120,7 +120,7 @@ typedef struct scenerf_mlp_grads {
 /* Saved activations of one ResnetFC evaluation over M rows (caller-allocated).
  * act = T.  H[b] is the residual stream after adding lin_z.b (b<3) / the final one (b=3); N[b] = fc_0 output. */
 typedef struct scenerf_mlp_acts {
-    void* H[4];                     /* T [M][512]; H[0..2] and Nn may be NULL for inference when the fused bf16 kernel runs (>= 4096 rows) */
+    void* H[4];                     /* T [M][512]; H and Nn may be NULL for inference when the fused bf16 kernel runs (>= 4096 rows) */
     void* Nn[3];                    /* T [M][512] */
     float* h0pre;                   /* scratch: fp32 mode [M][512] fp32 lin_in output ; bf16 mode the split-bf16 encoding [M][144] bf16 */
     float* logits;                  /* fp32 [M][d_out] */

@@ -82,6 +82,11 @@ struct FusedArgs {
     const uint8_t* tile_mask;
     const int* desc;     // [32][F_MAXCH] per tile mask: header {number of chunks}, chunk descriptors, zero padding
     int M;
+    // forward: lin_out fused behind the last layer (resnetfc.py:162-163): logits[m][j] = relu(H3[m]) . w_out[j] + b_out[j]
+    const float* w_out;  // [d_out][512] fp32
+    const float* b_out;
+    float* logits;       // [M][d_out]
+    int d_out;
 };
 
 // One 32-bit descriptor per 16-wide K chunk (host-built per tile mask, read with scalar loads one step ahead):
@@ -359,6 +364,36 @@ __global__ __launch_bounds__(F_THREADS) void mlp_fused_kernel(FusedArgs p) {
         step(f1, f0);
     }
     while (save_i < 8) save_piece();
+    if (MODE == 0 && p.logits) {
+        // lin_out on the rectified H3 tile still resident in the A buffer (every consumer is past the last epilogue's second
+        // barrier): 8 threads per row, 64 columns each, fp32 weights from L1, butterfly over the 8 partial sums
+        const int row = tid >> 3, part = tid & 7;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int s8 = 0; s8 < 8; ++s8) {
+            const int slot = part * 8 + s8;
+            const uint4 v = *(const uint4*)(Abuf + row * F_AROW + ((slot ^ (row & 15)) << 4));
+            const float f[8] = {bf16lo(v.x), bf16hi(v.x), bf16lo(v.y), bf16hi(v.y), bf16lo(v.z), bf16hi(v.z), bf16lo(v.w), bf16hi(v.w)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < p.d_out) {
+                    const float4 w0 = *(const float4*)(p.w_out + j * SCENERF_D_HIDDEN + slot * 8);
+                    const float4 w1 = *(const float4*)(p.w_out + j * SCENERF_D_HIDDEN + slot * 8 + 4);
+                    o[j] = fmaf(f[0], w0.x, o[j]); o[j] = fmaf(f[1], w0.y, o[j]); o[j] = fmaf(f[2], w0.z, o[j]); o[j] = fmaf(f[3], w0.w, o[j]);
+                    o[j] = fmaf(f[4], w1.x, o[j]); o[j] = fmaf(f[5], w1.y, o[j]); o[j] = fmaf(f[6], w1.z, o[j]); o[j] = fmaf(f[7], w1.w, o[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] += __shfl_xor(o[j], 1);
+            o[j] += __shfl_xor(o[j], 2);
+            o[j] += __shfl_xor(o[j], 4);
+        }
+        if (part == 0 && m0 + row < p.M) {
+            for (int j = 0; j < p.d_out; ++j) p.logits[(size_t)(m0 + row) * p.d_out + j] = o[j] + p.b_out[j];
+        }
+    }
 }
 
 // chunk descriptors for the 32 possible scale masks, built once per segment layout and kept on the device
@@ -458,6 +493,10 @@ int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
     p.tile_mask = tile_mask;
     if (int e = fused_table_get(cfg, s, &p.desc)) return e;
     p.M = M;
+    p.w_out = w->w_out;
+    p.b_out = w->b_out;
+    p.logits = a->logits;
+    p.d_out = w->d_out;
     // FLOPs actually issued (profile mode only; synchronises to read the scale-activity mask): a 128-row tile skips the K
     // segments of the scales it does not touch in the three lin_z products
     double flops = 0;

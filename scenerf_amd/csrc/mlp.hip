@@ -258,11 +258,8 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
         // rows from which the whole trunk runs as ONE fused kernel (fused.hip); read per call so a test can compare paths
         const char* fenv = getenv("SRF_FUSED_MIN_M");
         const int fused_min_m = fenv ? atoi(fenv) : 4096;
+        if (M >= fused_min_m && w->w_stream) return launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s);   // lin_out included
         SRF_CHECK(a->H[3], "mlp_forward: acts->H[3] is NULL");
-        if (M >= fused_min_m && w->w_stream) {
-            if (int e = launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s)) return e;
-            return launch_linout_fwd<bf16_t>(w->d_out, a->H[3], w->w_out, w->b_out, M, a->logits, s);
-        }
         SRF_CHECK(a->H[0] && a->H[1] && a->H[2] && a->Nn[0] && a->Nn[1] && a->Nn[2],
                   "mlp_forward: the per-layer path needs every activation buffer (NULL entries are for fused-kernel inference only)");
         GemmNT g;

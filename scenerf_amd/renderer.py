@@ -272,8 +272,8 @@ class _MlpRun:
 
     def __init__(self, M: int, d_out: int, prec: int, dev, keep_acts: bool = True):
         act = _act_dtype(prec)
-        # inference (no_grad) on the fused bf16 path: nothing but H3 (lin_out's input) is ever read again, so the six other
-        # activations and the sign bits are neither allocated nor written (NULL in scenerf_mlp_acts)
+        # inference (no_grad) on the fused bf16 path: lin_out runs inside the kernel, so no activation is ever read again: neither
+        # they nor the sign bits are allocated or written (NULL in scenerf_mlp_acts)
         lean = (not keep_acts) and prec == 1 and M >= _capi.fused_min_rows()
         self.M = M
         self.Mpad = (M + _capi.TILE_ROWS - 1) // _capi.TILE_ROWS * _capi.TILE_ROWS
@@ -283,7 +283,7 @@ class _MlpRun:
         self.tile_mask = torch.empty((self.Mpad // _capi.TILE_ROWS,), dtype=torch.uint8, device=dev)
         self.tap_texel = torch.empty((M, 5, 4), dtype=torch.int32, device=dev)
         self.tap_weight = torch.empty((M, 5, 4), dtype=torch.float32, device=dev)
-        self.H = [None if (lean and i < 3) else torch.empty((M, D_H), dtype=act, device=dev) for i in range(4)]
+        self.H = [None if lean else torch.empty((M, D_H), dtype=act, device=dev) for i in range(4)]
         self.Nn = [None if lean else torch.empty((M, D_H), dtype=act, device=dev) for _ in range(3)]
         # fp32 lin_in output (fp32 mode) or the split-bf16 encoding [M][144] (bf16 mode)
         self.h0pre = torch.empty((M, D_H) if prec == 0 else (M, 3 * D_X // 2), dtype=torch.float32, device=dev)
