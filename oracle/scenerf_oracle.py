@@ -173,9 +173,12 @@ def point_inputs(pts: torch.Tensor, viewdir_rows: torch.Tensor, x_rgb: Dict[str,
 
 
 # ----------------------------------------------------------------------------- MLP
-def resnetfc_forward(p: Dict[str, torch.Tensor], zx: torch.Tensor, d_latent: int = 2480, n_blocks: int = 3,
+def resnetfc_forward(p: Dict[str, torch.Tensor], zx: torch.Tensor, d_latent: int = 2480, n_blocks: Optional[int] = None,
                      keep: Optional[dict] = None) -> torch.Tensor:
-    """resnetfc.py:133-164 (+ block :54-63): lin_in; per block: += lin_z(z); x + fc_1(relu(fc_0(relu(x)))); lin_out(relu)."""
+    """resnetfc.py:133-164 (+ block :54-63): lin_in; per block: += lin_z(z); x + fc_1(relu(fc_0(relu(x)))); lin_out(relu).
+    ``n_blocks`` defaults to what the state dict holds (3 for SceneRF; 1 for the 4-layer plumbing config of BASELINE configs[0])."""
+    if n_blocks is None:
+        n_blocks = sum(1 for k in p if k.startswith("blocks.") and k.endswith(".fc_0.weight"))
     z, x = zx[..., :d_latent], zx[..., d_latent:]
     h = F.linear(x, p["lin_in.weight"], p["lin_in.bias"])
     for b in range(n_blocks):

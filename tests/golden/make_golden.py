@@ -93,6 +93,12 @@ CASES = {
     "bf_small_n96": dict(variant="bf", ctor=dict(som_sigma=0.02, std=0.1, add_fov_hor=14, add_fov_ver=11,
                          sphere_W=240, sphere_H=180, n_pts_uni=64, n_pts_per_gaussian=8, max_sample_depth=12),
                          R=16, chunk=16, pose=(0.4, 10.0), seed=404, smooth=True),
+    # BASELINE.json configs[0] ("4k rays x 64 samples, 4-layer 128-wide MLP, CPU forward only"): both MLPs replaced by
+    # ResnetFC(d_in=42, n_blocks=1, d_hidden=128) = lin_in + (lin_z.0, fc_0, fc_1) + lin_out.  Forward only; the (R, N)
+    # outputs are stored as digests to keep the fixture small.
+    "c1_plumbing_r4096_n64": dict(variant="kitti", ctor=dict(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8,
+                                  sphere_W=376, sphere_H=114), R=4096, chunk=1024, pose=(2.0, -10.0), seed=505, smooth=True,
+                                  mlp=dict(n_blocks=1, d_hidden=128), forward_only=True),
 }
 
 OUT_KEYS = ["depth", "color", "gaussian_means", "gaussian_stds", "weights_at_depth", "closest_pts_to_depths",
@@ -118,8 +124,13 @@ def run_case(name, spec):
         K = synth.bundlefusion_cam_K()
     model = Model(**spec["ctor"])
     seed = spec["seed"]
-    model.mlp.load_state_dict(synth.mlp_state(seed + 1, 4))
-    model.mlp_gaussian.load_state_dict(synth.mlp_state(seed + 2, 2, out_scale=4.0))
+    mk = spec.get("mlp", {})
+    if mk:
+        from scenerf.models.resnetfc import ResnetFC
+        model.mlp = ResnetFC(d_in=42, d_out=4, d_latent=2480, **mk)
+        model.mlp_gaussian = ResnetFC(d_in=42, d_out=2, d_latent=2480, **mk)
+    model.mlp.load_state_dict(synth.mlp_state(seed + 1, 4, **mk))
+    model.mlp_gaussian.load_state_dict(synth.mlp_state(seed + 2, 2, out_scale=4.0, **mk))
     W, H = model.out_img_W, model.out_img_H
     x_rgb = synth.feature_maps(W, H, seed + 3, smooth=spec["smooth"])
     for v in x_rgb.values():
@@ -135,16 +146,30 @@ def run_case(name, spec):
             kwargs["T_cam2velo"] = torch.eye(4)
         out = model.render_rays_batch(K, T, x_rgb, **kwargs)
     loss = out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
-    loss.backward()
+    fwd_only = spec.get("forward_only", False)
+    if not fwd_only:
+        loss.backward()
 
-    blob = {"cam_K": K.numpy(), "T_source2infer": T.numpy(), "pixels": pix.numpy(),
-            "noise_u": noise_u.numpy(), "noise_g": noise_g.numpy(),
+    blob = {"cam_K": K.numpy(), "T_source2infer": T.numpy(),
             "meta": np.array(repr(dict(variant=spec["variant"], ctor=spec["ctor"], R=R, chunk=spec["chunk"],
                                        seed=seed, smooth=spec["smooth"], sphere_W=W, sphere_H=H,
-                                       img_size=tuple(model.img_size))))}
+                                       img_size=tuple(model.img_size), mlp=mk, forward_only=fwd_only)))}
+    if not fwd_only:   # (the big forward-only case regenerates pixels and noise from the seeds: golden_util.Golden)
+        blob.update({"pixels": pix.numpy(), "noise_u": noise_u.numpy(), "noise_g": noise_g.numpy()})
     for k in OUT_KEYS:
-        blob["out/" + k] = out[k].detach().numpy()
+        o = out[k].detach()
+        if fwd_only and o.dim() == 2 and o.shape[1] > 8:     # (R, N) outputs of the big forward-only case: digest
+            for kk, vv in grad_digest(o).items():
+                blob["outdigest/%s/%s" % (k, kk)] = vv
+        else:
+            blob["out/" + k] = o.numpy()
     blob["loss"] = np.float64(loss.item())
+    if fwd_only:
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print("%-28s loss=%.6f  depth[0:3]=%s  -> %s (%.1f KB, forward only)" % (
+            name, loss.item(), out["depth"][:3].detach().numpy(), os.path.basename(path), os.path.getsize(path) / 1024))
+        return
     for mod_name, mod in (("mlp", model.mlp), ("mlp_gaussian", model.mlp_gaussian)):
         for pn, p in mod.named_parameters():
             d = grad_digest(p.grad)

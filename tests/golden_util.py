@@ -23,16 +23,28 @@ class Golden:
         self.seed = self.meta["seed"]
         self.cam_K = torch.from_numpy(self.z["cam_K"])
         self.T = torch.from_numpy(self.z["T_source2infer"])
-        self.pixels = torch.from_numpy(self.z["pixels"])
-        self.noise_u = torch.from_numpy(self.z["noise_u"])
-        self.noise_g = torch.from_numpy(self.z["noise_g"])
         self.chunk = self.meta["chunk"]
+        if "pixels" in self.z.files:
+            self.pixels = torch.from_numpy(self.z["pixels"])
+            self.noise_u = torch.from_numpy(self.z["noise_u"])
+            self.noise_g = torch.from_numpy(self.z["noise_g"])
+        else:   # big forward-only case: inputs are regenerated from the seeds exactly as make_golden.py drew them
+            c = self.ctor
+            U, G, P = c.get("n_pts_uni", 32), c.get("n_gaussians", 4), c.get("n_pts_per_gaussian", 8)
+            self.pixels = synth.stride2_pixels(tuple(self.meta["img_size"]), self.meta["R"], self.seed + 4)
+            self.noise_u, self.noise_g = synth.sampling_noise(self.meta["R"], U, G * P, self.seed + 5)
 
     def out(self, key):
         return torch.from_numpy(self.z["out/" + key])
 
     def mlp_states(self):
-        return synth.mlp_state(self.seed + 1, 4), synth.mlp_state(self.seed + 2, 2, out_scale=4.0)
+        mk = self.meta.get("mlp", {})   # non-default ResnetFC shape (BASELINE configs[0]: n_blocks=1, d_hidden=128)
+        return synth.mlp_state(self.seed + 1, 4, **mk), synth.mlp_state(self.seed + 2, 2, out_scale=4.0, **mk)
+
+    def out_digest(self, key):
+        p = "outdigest/%s/" % key
+        return dict(norm=float(self.z[p + "norm"]), sum=float(self.z[p + "sum"]),
+                    idx=torch.from_numpy(self.z[p + "idx"]), val=torch.from_numpy(self.z[p + "val"]))
 
     def feature_maps(self):
         return synth.feature_maps(self.meta["sphere_W"], self.meta["sphere_H"], self.seed + 3,

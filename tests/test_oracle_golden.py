@@ -57,3 +57,27 @@ def test_sort_is_a_permutation_and_sorted():
     assert torch.equal(torch.sort(perm, dim=1).values, torch.arange(perm.shape[1]).expand_as(perm))
     d = out["_dist_sorted"]
     assert bool((d[:, 1:] >= d[:, :-1]).all())
+
+
+def test_oracle_matches_reference_on_the_plumbing_config():
+    """BASELINE.json configs[0]: 4k rays x 64 samples through a 4-layer 128-wide ResnetFC (n_blocks=1), CPU forward only.  The golden
+    vector was produced by the reference's own render_rays_batch with its mlp / mlp_gaussian swapped for that shape."""
+    g = Golden("c1_plumbing_r4096_n64")
+    assert g.meta["mlp"] == dict(n_blocks=1, d_hidden=128) and g.meta["R"] == 4096
+    cfg = _cfg(g)
+    mlp, mlpg = g.mlp_states()
+    assert mlp["lin_in.weight"].shape == (128, 42) and "blocks.1.fc_0.weight" not in mlp
+    with torch.no_grad():
+        out = orc.render_rays_batch(cfg, mlp, mlpg, g.cam_K, g.T, g.feature_maps(), g.pixels, g.noise_u, g.noise_g,
+                                    ray_batch_size=g.chunk)
+    for k in OUT_KEYS:
+        if ("out/" + k) in g.z.files:
+            ref = g.out(k)
+            assert out[k].shape == ref.shape, k
+            torch.testing.assert_close(out[k], ref, rtol=2e-5, atol=2e-6, msg=lambda m: "%s: %s" % (k, m))
+        else:
+            d = g.out_digest(k)
+            flat = out[k].reshape(-1)
+            assert abs(float(flat.double().norm()) - d["norm"]) <= 2e-5 * d["norm"] + 1e-9, k
+            torch.testing.assert_close(flat[d["idx"]], d["val"], rtol=2e-5, atol=2e-6, msg=lambda m: "%s: %s" % (k, m))
+    assert abs(orc.training_proxy_loss(out).item() - float(g.z["loss"])) < 1e-4 * abs(float(g.z["loss"]))
