@@ -359,3 +359,67 @@ def test_inference_chunk_replays_as_a_graph():
     full = m.render_rays_batch(K, T, maps_g, sampled_pixels=pix, ray_batch_size=R, noise=(nu, ng))
     for k in ("depth", "color", "loss_kl"):
         assert torch.equal(ref[k], full[k].detach()), k
+
+
+@pytest.mark.gpu
+def test_full_size_config3_bundlefusion_fused_vs_layers_and_subset_parity():
+    """BASELINE.json configs[3] at full size (BundleFusion 640x480, sphere 960x720 from the CLI, R=1080, N=96, D=12, std 0.1,
+    floors +0.5), a different scale-activity pattern and K-segment mix than KITTI for the fused kernels.  (1) fp32 forward: the first 24 rays equal the CPU oracle run on just those rays (rays are independent).
+    (2) bf16 training step on the fused kernels vs the same step on the per-layer kernels (SRF_FUSED_MIN_M): outputs within bf16
+    rounding, every parameter / feature-map gradient within 2e-2 relative L2 (the dgrad chain itself is bit-identical; the
+    forward's residual stream is rounded at the same places but accumulated in a different order)."""
+    import os
+    from scenerf_amd import synth
+    R, U, P = 1080, 64, 8
+    kw = dict(som_sigma=0.02, std=0.1, add_fov_hor=14, add_fov_ver=11, sphere_W=960, sphere_H=720, n_pts_uni=U, n_pts_per_gaussian=P,
+              max_sample_depth=12)
+    mlp, mlpg = synth.mlp_state(61, 4), synth.mlp_state(62, 2, out_scale=0.5)
+    maps = synth.feature_maps(960, 720, 63, smooth=True)
+    pix = synth.stride2_pixels((640, 480), R, 64)
+    nu, ng = synth.sampling_noise(R, U, 4 * P, 65)
+    K, T = synth.bundlefusion_cam_K(), synth.rel_pose(0.3, 8.0)
+
+    def run(precision, grad):
+        m = SceneRFBundleFusion(precision=precision, **kw).to(DEV)
+        m.mlp.load_state_dict(mlp)
+        m.mlp_gaussian.load_state_dict(mlpg)
+        x = {k: v.to(DEV).requires_grad_(grad) for k, v in maps.items()}
+        with torch.set_grad_enabled(grad):
+            o = m.render_rays_batch(K.to(DEV), T.to(DEV), x, sampled_pixels=pix.to(DEV), ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
+        grads = None
+        if grad:
+            (o["depth"].mean() + o["color"].mean() + o["loss_kl"].mean() + o["gaussian_means"].mean()).backward()
+            grads = {"mlp." + n: p.grad.cpu() for n, p in m.mlp.named_parameters()}
+            grads.update({"mlpg." + n: p.grad.cpu() for n, p in m.mlp_gaussian.named_parameters()})
+            grads.update({"map." + k: (v.grad.cpu() if v.grad is not None else torch.zeros_like(v).cpu()) for k, v in x.items()})
+        return {k: v.detach().cpu() for k, v in o.items()}, grads
+
+    # (1) fp32 subset parity
+    o32, _ = run("fp32", False)
+    S = 24
+    ocfg = orc.OracleConfig.bundlefusion(**{k: v for k, v in kw.items()})
+    ref = orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix[:S], nu[:S], ng[:S])
+    for k in ("depth", "color", "weights", "alphas", "gaussian_means", "gaussian_stds", "depth_volumes"):
+        fr, _ = frac_within(o32[k][:S], ref[k].detach(), 5e-4, 5e-4)
+        assert fr >= 0.9, "%s: %.3f of the subset rays within tolerance" % (k, fr)
+    assert bool((o32["gaussian_means"] >= 0.5).all()) and bool((o32["gaussian_stds"] >= 0.5).all())   # scenerf_bf.py:606-608
+    # (2) fused vs per-layer kernels, bf16, forward + backward
+    os.environ["SRF_FUSED_MIN_M"] = str(1 << 30)
+    try:
+        ol, gl = run("bf16", True)
+    finally:
+        os.environ.pop("SRF_FUSED_MIN_M")
+    of, gf = run("bf16", True)
+    rel = (of["depth"] - ol["depth"]).abs() / ol["depth"].abs().clamp(min=1e-3)
+    assert float(rel.median()) < 2e-3 and float(rel.quantile(0.99)) < 3e-2, (float(rel.median()), float(rel.max()))
+    assert float((of["color"] - ol["color"]).abs().max()) < 3e-2
+    touched = 0
+    for n in gl:
+        a, b = gl[n].double(), gf[n].double()
+        if float(a.norm()) == 0.0:
+            assert float(b.norm()) == 0.0, n          # (scales no ray reaches get exactly zero gradient on both paths)
+            continue
+        touched += n.startswith("map.")
+        r = float((a - b).norm() / a.norm())
+        assert r <= 2e-2, "%s: fused vs layers relative L2 %.3e" % (n, r)
+    assert touched >= 2, "at least the two finest pyramid scales receive gradient (quirk Q1 keeps the coarse ones out of range)"
