@@ -25,7 +25,14 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = os.environ.get("SRF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":   # bind the communicator to this rank's GPU up front (no device guessing in barrier())
+            torch.cuda.set_device(local % torch.cuda.device_count())
+            kw["device_id"] = torch.device("cuda", local % torch.cuda.device_count())
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        except TypeError:       # older torch without device_id
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 

@@ -210,6 +210,7 @@ class SceneRF(TrainingMixin, _Base):
                              grad_sync=self.grad_sync)
         outs = []
         n = sampled_pixels.shape[0]
+        sess.mlpg.single_chunk = n <= ray_batch_size   # training (scenerf.py:262-275): lets the head's gradient all-reduce start early
         for s in range(0, n, ray_batch_size):
             e = min(s + ray_batch_size, n)
             nu = noise[0][s:e] if noise is not None else None

@@ -244,6 +244,8 @@ class MlpHolder:
     def __init__(self, grad_sync=None):
         self.packed: Optional[PackedMLP] = None
         self.grad_sync = grad_sync   # callable(flat fp32 tensor) -> None, e.g. an all-reduce-mean (see dist.py)
+        self.synced = False          # the sink was already reduced (early, on the side stream: RenderChunk.backward)
+        self.single_chunk = False    # set by render_rays_batch when the whole call is one chunk
 
 
 class PackMLP(torch.autograd.Function):
@@ -258,8 +260,9 @@ class PackMLP(torch.autograd.Function):
         pk: PackedMLP = ctx.holder.packed
         # data-parallel hook: reduce the packed fp32 gradient sink in ONE collective (21.7 MB per MLP) before it is
         # carved into per-parameter views -- no flatten/unflatten copies, one large message per MLP over xGMI
-        if ctx.holder.grad_sync is not None and pk.gflat is not None:
+        if ctx.holder.grad_sync is not None and pk.gflat is not None and not ctx.holder.synced:
             ctx.holder.grad_sync(pk.gflat)
+        ctx.holder.synced = False
         grads = pk.unpack_grads()
         grads = [g if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(grads)]
         pk.gflat, pk.gc, pk.gviews = None, None, {}
@@ -456,6 +459,12 @@ class RenderChunk(torch.autograd.Function):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 _mlp_backward(ccfg, cfg, ctx.maps, ctx.mlpg.packed, run_g, d_off.view(R * G, 2), want_maps)
+                # data parallel, one chunk per step (training): the head's parameter gradients are final here, ~2 ms before the
+                # radiance MLP's -- reduce them now, on the side stream, under the main backward (half of the step's all-reduce
+                # volume leaves the critical path).  Every rank takes this branch in the same order: head first, main MLP later.
+                if ctx.mlpg.single_chunk and ctx.mlpg.grad_sync is not None and ctx.needs_input_grad[12]:
+                    ctx.mlpg.grad_sync(ctx.mlpg.packed.gflat)
+                    ctx.mlpg.synced = True
         if ctx.needs_input_grad[11] or want_maps:
             _mlp_backward(ccfg, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps)
         if do_head:

@@ -1,0 +1,55 @@
+"""Worker of tests/test_gpu_dp.py: one data-parallel rank (launched by torch.distributed.run, gloo backend so that two ranks can
+share the single GPU of the test box).  Each rank renders its own ray shard with model.grad_sync installed, then repeats the
+step without it and checks: synced gradient == mean over ranks of the local gradients (gathered through the process group)."""
+import os, sys
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scenerf_amd import dist as sdist, synth   # noqa: E402
+from scenerf_amd.model import SceneRF          # noqa: E402
+
+
+def main():
+    rank, world, local = sdist.init_from_env("gloo")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    kw = dict(sphere_W=376, sphere_H=114, n_pts_uni=32, n_pts_per_gaussian=8)
+    R_total = 256                                # 128 rays x 64 samples per rank = 8192 rows: fused kernels
+    b, e = sdist.shard_rays(R_total, rank, world)
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="bf16", **kw).to(dev)
+    m.mlp.load_state_dict(synth.mlp_state(71, 4))
+    m.mlp_gaussian.load_state_dict(synth.mlp_state(72, 2, out_scale=4.0))
+    maps = {k: v.to(dev) for k, v in synth.feature_maps(376, 114, 73, smooth=True).items()}
+    K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(2.0, 10.0).to(dev)
+    pix = synth.stride2_pixels((1220, 370), R_total, 74)[b:e].to(dev)
+    nu, ng = synth.sampling_noise(R_total, 32, 32, 75)
+    nu, ng = nu[b:e].to(dev), ng[b:e].to(dev)
+
+    def grads(sync):
+        m.grad_sync = sdist.allreduce_mean_ if sync else None
+        for p in m.parameters():
+            p.grad = None
+        out = m.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=pix.shape[0], noise=(nu, ng))
+        (out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()).backward()
+        torch.cuda.synchronize()
+        return torch.cat([p.grad.reshape(-1) for p in list(m.mlp.parameters()) + list(m.mlp_gaussian.parameters())]).cpu()
+
+    g_sync = grads(True)
+    g_local = grads(False)
+    mean = g_local.clone()
+    dist.all_reduce(mean)
+    mean /= world
+    others = [torch.empty_like(g_sync) for _ in range(world)]
+    dist.all_gather(others, g_sync)
+    same_on_all_ranks = all(torch.equal(others[0], o) for o in others)
+    # atomics make the local gradients reproducible only to rounding, so compare in relative L2
+    rel = float((g_sync - mean).norm() / mean.norm())
+    differs = float((g_local - mean).norm() / mean.norm())   # sanity: the shards really have different gradients
+    if rank == 0:
+        print("DP_RESULT same=%s rel=%.3e local_vs_mean=%.3e" % (same_on_all_ranks, rel, differs))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

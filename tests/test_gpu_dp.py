@@ -1,0 +1,24 @@
+"""Data-parallel gradient path on a GPU: two ranks over gloo on the one GPU of the test box.  Covers what the CPU gloo
+test cannot: the renderer's packed gradient sinks, the head's early all-reduce on the side stream, and the `synced` hand-off."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.gpu
+def test_two_ranks_average_their_gradients():
+    env = dict(os.environ, SRF_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(HERE, "dp_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r"DP_RESULT same=(\w+) rel=([\d.e+-]+) local_vs_mean=([\d.e+-]+)", r.stdout)
+    assert m, r.stdout[-2000:]
+    assert m.group(1) == "True"                 # every rank ends up with the same gradient
+    assert float(m.group(2)) < 1e-3             # ... which is the mean of the per-rank gradients
+    assert float(m.group(3)) > 1e-2             # (and the shards' own gradients do differ)
