@@ -67,3 +67,8 @@ int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
 // dN [3][M][512]; sign gates come from the saved activations a->Nn / a->H.
 int launch_mlp_bwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, int M, const scenerf_mlp_acts* a, void* dH, void* dN,
                          hipStream_t s);
+// wgrad.hip: bf16 weight-gradient GEMM on transposing LDS reads (256 x 256 output tiles, wave-specialised); launch_gemm_tn uses it
+// for the shapes it fits
+bool wgrad_tr_applicable(const GemmTN& p);
+int launch_wgrad_tr(const GemmTN& p, hipStream_t s);
+int launch_wgrad_tr_batch(const GemmTN* probs, int count, hipStream_t s);   // same (M, N, K) for all: one launch, one atomic flush

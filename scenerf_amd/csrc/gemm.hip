@@ -865,5 +865,6 @@ template <typename T> static int launch_tn_t(const GemmTN& p, hipStream_t s) {
 int launch_gemm_tn(int precision, const GemmTN& p, hipStream_t s) {
     SRF_CHECK(p.D && p.A && p.out && p.M > 0 && p.N > 0 && p.K > 0, "%s: bad operands", p.name);
     SRF_CHECK(p.N % 8 == 0 && p.K % 8 == 0, "%s: N=%d and K=%d must be multiples of 8", p.name, p.N, p.K);
+    if (precision && wgrad_tr_applicable(p)) return launch_wgrad_tr(p, s);
     return precision ? launch_tn_t<bf16_t>(p, s) : launch_tn_t<float>(p, s);
 }

@@ -344,6 +344,8 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         if (int e = launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
         if (int e = fork()) return e;
     }
+    GemmTN wg[6];   // the six fc weight gradients: batched into one launch when the chain kernel already produced every dH / dN
+    int nwg = 0;
     for (int b = 2; b >= 0; --b) {
         {   // [side] dW1_b += dH_{b+1}^T relu(N_b)
             GemmTN t;
@@ -351,7 +353,8 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             t.D = dHcol(b + 1); t.ldd = LDH; t.A = a->Nn[b]; t.lda = SCENERF_D_HIDDEN; t.relu_a = 1;
             t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc1[b]; t.ldo = SCENERF_D_HIDDEN;
             t.colsum = g_->b_fc1[b];  // fc_1.b.bias gradient = column sums of dH_{b+1}
-            if (int e = launch_gemm_tn(prec, t, s2)) return e;
+            if (fused_chain && wgrad_tr_applicable(t)) { t.name = "gemm_wgrad_fc"; wg[nwg++] = t; }
+            else if (int e = launch_gemm_tn(prec, t, s2)) return e;
         }
         if (!fused_chain) {   // dN_b = (dH_{b+1} @ W1_b) * [N_b > 0]
             GemmNT g;
@@ -370,7 +373,8 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             t.D = dNb(b); t.ldd = SCENERF_D_HIDDEN; t.A = a->H[b]; t.lda = SCENERF_D_HIDDEN; t.relu_a = 1;
             t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc0[b]; t.ldo = SCENERF_D_HIDDEN;
             t.colsum = g_->b_fc0[b];
-            if (int e = launch_gemm_tn(prec, t, s2)) return e;
+            if (fused_chain && wgrad_tr_applicable(t)) { t.name = "gemm_wgrad_fc"; wg[nwg++] = t; }
+            else if (int e = launch_gemm_tn(prec, t, s2)) return e;
         }
         if (!fused_chain) {   // dH_b = dH_{b+1} + (dN_b @ W0_b) * [H_b > 0]
             GemmNT g;
@@ -384,6 +388,9 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             if (int e = launch_gemm_nt(prec, g, s)) return e;
         }
         if (int e = fork()) return e;
+    }
+    if (nwg) {
+        if (int e = launch_wgrad_tr_batch(wg, nwg, s2)) return e;
     }
     // [side] dWz[:, slice_s] += dH[:, 0:1536]^T Z[:, slice_s]   (row-tiles without scale s skipped)
     for (int sc = 0; sc < 5; ++sc) {

@@ -1,0 +1,269 @@
+// Weight-gradient GEMM for gfx950, bf16 operands:  out[n][k] += sum_m D[m][n] * act(A[m][k])   (contraction over the ROWS of two
+// row-major activation matrices; resnetfc.py's fc_0 / fc_1 weights: dW = dOut^T relu(In)).
+//
+// Both MFMA operands are "transposed" accesses (lane = column, 8 consecutive rows per lane).  The first wgrad kernel
+// (gemm_tn_kernel, gemm.hip) transposes 8x8 blocks in registers with v_perm on the way into LDS; this one stages nothing in
+// registers: row-major [16 rows][256 columns] tiles of D and A go straight from global memory into LDS (global_load_lds, one
+// 1-KiB piece = two rows), and the fragments come out with gfx950's transposing LDS read, ds_read_b64_tr_b16: within a group
+// of 16 lanes, lane 4r + c supplies the address of 4 consecutive columns of row r, and lane i receives rows 0..3 of column i
+// (probed on hardware: tools/ubench/tr_read_probe.hip) -- two of them give a lane its 8 consecutive rows.  Rows are 512 B in
+// LDS; the 64-byte chunk index is XORed with (row & 3) on the DMA's source side, which makes the four rows of a transposing
+// read hit four different bank quarters.
+//
+// Same wave specialisation as fused.hip: 8 consumer waves (2 x 4 over a 256 x 256 output tile, wave tile 128 x 64, 128 fp32
+// accumulators per lane) and 4 producer waves (one per SIMD) streaming through an 8-stage ring with a counted vmcnt; one raw
+// s_barrier per 16 rows.  The M range is split over workgroups; partial tiles are added with fp32 atomics.  ReLU is applied
+// to the fragments (v_pk_max_i16); the bias gradient (column sums of D) is accumulated from the D fragments by the workgroups
+// of the first k tile.
+#include "gemm.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_w;
+typedef __attribute__((ext_vector_type(16))) float f32x16_w;
+typedef unsigned u32x2_w __attribute__((ext_vector_type(2)));
+
+#define W_TILE 256                 // output tile: 256 (n) x 256 (k)
+#define W_BM 16                    // rows per step (one MFMA k-step)
+#define W_ROW 512                  // LDS row: 256 bf16
+#define W_HALF (W_BM * W_ROW)      // 8192: one operand's part of a stage
+#define W_STAGE (2 * W_HALF)       // 16384
+#define W_NST 8
+#define W_LDS (W_NST * W_STAGE)    // 131072
+#define W_THREADS 768
+
+#define W_MAXPROB 8
+struct WgradProblem {
+    const char* D;       // [M][ldd] bf16
+    const char* A;       // [M][lda] bf16
+    float* out;          // [N][ldo] fp32, atomically accumulated
+    float* colsum;       // optional [N]: += sum_m D[m][n]
+    int ldd2, lda2;      // row strides in BYTES
+    int ldo, relu_a;
+};
+struct WgradArgs {
+    WgradProblem prob[W_MAXPROB];   // same M, N, K for all (the six fc_0 / fc_1 weight gradients of a backward pass share one launch:
+    int nprob;                      // one atomic flush per workgroup for all of them instead of one per GEMM)
+    int M, rows_per_split, splits, tiles_n, tiles_k;
+    const char* zero;    // >= 1 KiB of zeros (rows past M)
+};
+
+__device__ static inline void w_glds16(const void* sbase, unsigned voff, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_wave_base)
+                 : "memory");
+}
+// same, 64-bit per-lane address (tail rows: some lanes read the zero page)
+__device__ static inline void w_glds16v(const void* vaddr, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(vaddr), "s"(lds_wave_base)
+                 : "memory");
+}
+__device__ static inline u32x2_w w_tr_read(unsigned addr) {
+    u32x2_w v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the tiles of one
+    // M split -- which read the same rows of D and of A -- are given ids that land on the same XCD, back to back: every row slab
+    // then comes from HBM once and from that L2 for the other tiles
+    const int ntile = p.tiles_n * p.tiles_k;
+    int tile, split, pi;
+    {
+        const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+        tile = j % ntile;
+        const int u = (j / ntile) * 8 + xcd;   // (problem, split) unit
+        pi = u % p.nprob;
+        split = u / p.nprob;
+    }
+    if (split >= p.splits) return;
+    const WgradProblem& P = p.prob[pi];
+    const int n0 = (tile % p.tiles_n) * W_TILE, k0 = (tile / p.tiles_n) * W_TILE;
+    const int first_k_tile = tile / p.tiles_n == 0;
+    const int mb = split * p.rows_per_split;
+    const int me = min(p.M, mb + p.rows_per_split);
+    const int steps = (me - mb + W_BM - 1) / W_BM;
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;
+    if (steps <= 0) return;
+
+    if (wvu >= 8) {
+        // ================================================================================ producers
+        // a piece = two 512-byte rows of one operand's tile; producer q moves pieces 2q, 2q+1 of D and of A.  Lane L: row 2 piece +
+        // L / 32 of the stage, physical 16-byte slot L & 31 of that row, fetching logical chunk (slot / 4) ^ (row & 3)
+        const int q = wvu - 8;
+        unsigned offD[2], offA[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = 2 * (2 * q + u) + (lane >> 5);
+            const int chunk = ((lane & 31) >> 2) ^ (row & 3);
+            offD[u] = (unsigned)row * P.ldd2 + n0 * 2 + chunk * 64 + (lane & 3) * 16;
+            offA[u] = (unsigned)row * P.lda2 + k0 * 2 + chunk * 64 + (lane & 3) * 16;
+        }
+        auto issue = [&](int c) {
+            const int m = mb + c * W_BM;
+            const unsigned sb = lds0 + (c % W_NST) * W_STAGE;
+            if (m + W_BM <= p.M) {
+                const char* dD = P.D + (size_t)m * P.ldd2;
+                const char* dA = P.A + (size_t)m * P.lda2;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    w_glds16(dD, offD[u], __builtin_amdgcn_readfirstlane(sb + (2 * q + u) * 1024));
+                    w_glds16(dA, offA[u], __builtin_amdgcn_readfirstlane(sb + W_HALF + (2 * q + u) * 1024));
+                }
+            } else {   // the last rows of the matrix: rows past M come from the zero page
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int row = 2 * (2 * q + u) + (lane >> 5);
+                    const bool ok = m + row < p.M;
+                    const char* gD = ok ? P.D + (size_t)m * P.ldd2 + offD[u] : p.zero + (lane & 31) * 16;
+                    const char* gA = ok ? P.A + (size_t)m * P.lda2 + offA[u] : p.zero + (lane & 31) * 16;
+                    w_glds16v(gD, __builtin_amdgcn_readfirstlane(sb + (2 * q + u) * 1024));
+                    w_glds16v(gA, __builtin_amdgcn_readfirstlane(sb + W_HALF + (2 * q + u) * 1024));
+                }
+            }
+        };
+#pragma unroll 1
+        for (int c = 0; c < W_NST - 1 && c < steps; ++c) issue(c);
+#pragma unroll 1
+        for (int c = 0; c < steps; ++c) {
+            // chunk c has landed once at most the loads of chunks c+1 .. c+6 (4 per producer each) are outstanding
+            if (c + W_NST - 2 < steps) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail
+            __builtin_amdgcn_s_barrier();
+            if (c + W_NST - 1 < steps) issue(c + W_NST - 1);   // into the stage the consumers read in step c - 1
+        }
+        return;
+    }
+
+    // ==================================================================================== consumers
+    const int wn = wv >> 2, wk = wv & 3;   // wave tile: n in [128 wn, +128), k in [64 wk, +64)
+    // transposing-read addresses: lane l = 16 g + 4 r + c supplies (row 8 (g >> 1) + r [+ 4 for the second half], 4 columns at
+    // 16 (g & 1) + 4 c of the 32-column tile) and receives rows 0..3 [4..7] of column l & 15 (+ 16 (g & 1)): lane l & 31 = column
+    const int g = lane >> 4, r = (lane >> 2) & 3, cq = lane & 3;
+    const int rowoff = (8 * (g >> 1) + r) * W_ROW;
+    const int inchunk = (16 * (g & 1) + 4 * cq) * 2;
+    unsigned adD[4], adA[2];   // per 32-column tile: byte offset inside a stage of the first read (second: + 4 rows)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) adD[i] = rowoff + (((wn * 4 + i) ^ r) << 6) + inchunk;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) adA[j] = W_HALF + rowoff + (((wk * 2 + j) ^ r) << 6) + inchunk;
+
+    f32x16_w acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of D for column n0 + 128 wn + 32 i + (lane & 31), this lane's 8 rows
+    const bool do_cs = P.colsum != nullptr && first_k_tile && wk == 0;
+    const bool relu_a = P.relu_a != 0;
+
+#pragma unroll 1
+    for (int c = 0; c < steps; ++c) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned S = lds0 + (c % W_NST) * W_STAGE;
+        u32x2_w fa[4][2], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = w_tr_read(S + adD[i]);
+            fa[i][1] = w_tr_read(S + adD[i] + 4 * W_ROW);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fb[j][0] = w_tr_read(S + adA[j]);
+            fb[j][1] = w_tr_read(S + adA[j] + 4 * W_ROW);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        uint4 A4[4], B4[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A4[i] = make_uint4(fa[i][0][0], fa[i][0][1], fa[i][1][0], fa[i][1][1]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            B4[j] = make_uint4(fb[j][0][0], fb[j][0][1], fb[j][1][0], fb[j][1][1]);
+            if (relu_a) {
+                B4[j].x = relu_bf16x2(B4[j].x); B4[j].y = relu_bf16x2(B4[j].y);
+                B4[j].z = relu_bf16x2(B4[j].z); B4[j].w = relu_bf16x2(B4[j].w);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, A4[i]), __builtin_bit_cast(bf16x8_w, B4[j]),
+                                                                    acc[i][j], 0, 0, 0);
+        if (do_cs) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                cs[i] += (bf16lo(A4[i].x) + bf16hi(A4[i].x)) + (bf16lo(A4[i].y) + bf16hi(A4[i].y)) + (bf16lo(A4[i].z) + bf16hi(A4[i].z)) +
+                         (bf16lo(A4[i].w) + bf16hi(A4[i].w));
+        }
+    }
+    // ---- partial tile -> out (fp32 atomics; C tile layout: row (e & 3) + 8 (e >> 2) + 4 (lane >> 5), column lane & 31)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* o = P.out + (size_t)(n0 + wn * 128 + i * 32 + 4 * (lane >> 5)) * P.ldo + k0 + wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) unsafeAtomicAdd(o + (size_t)((e & 3) + 8 * (e >> 2)) * P.ldo, acc[i][j][e]);
+        }
+    if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = cs[i] + __shfl_xor(cs[i], 32);   // the two lane halves hold rows 0..7 and 8..15 of the same column
+            if (lane < 32) unsafeAtomicAdd(P.colsum + n0 + wn * 128 + i * 32 + lane, t);
+        }
+    }
+}
+
+// Used by launch_gemm_tn for the shapes it fits (bf16, N and K multiples of 256, no tile skipping, enough rows).
+bool wgrad_tr_applicable(const GemmTN& p) {
+    static const bool off = getenv("SRF_NO_WGRAD_TR") != nullptr;
+    return !off && p.N % W_TILE == 0 && p.K % W_TILE == 0 && !p.tile_mask && p.M >= 32768 && p.ldd % 8 == 0 && p.lda % 8 == 0;
+}
+
+// `count` problems of identical shape (M, N, K) in one launch
+int launch_wgrad_tr_batch(const GemmTN* probs, int count, hipStream_t s) {
+    static bool attr_done = false;
+    static char* zero = nullptr;
+    if (!attr_done) {
+        SRF_HIP(hipFuncSetAttribute((const void*)wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
+        SRF_HIP(hipMalloc((void**)&zero, 1024));
+        SRF_HIP(hipMemset(zero, 0, 1024));
+        attr_done = true;
+    }
+    SRF_CHECK(count >= 1 && count <= W_MAXPROB, "wgrad batch: 1..%d problems", W_MAXPROB);
+    const GemmTN& p0 = probs[0];
+    WgradArgs a;
+    for (int i = 0; i < count; ++i) {
+        const GemmTN& p = probs[i];
+        SRF_CHECK(p.M == p0.M && p.N == p0.N && p.K == p0.K && wgrad_tr_applicable(p), "wgrad batch: problems must share one applicable shape");
+        a.prob[i] = {(const char*)p.D, (const char*)p.A, p.out, p.colsum, p.ldd * 2, p.lda * 2, p.ldo, p.relu_a};
+    }
+    a.nprob = count;
+    a.M = p0.M;
+    a.zero = zero;
+    const int tiles = (p0.N / W_TILE) * (p0.K / W_TILE);
+    static const int wg_target = getenv("SRF_WGRAD_TR_WGS") ? atoi(getenv("SRF_WGRAD_TR_WGS")) : 256;   // one workgroup per CU (128 KiB of LDS)
+    int splits = wg_target / (tiles * count) > 1 ? wg_target / (tiles * count) : 1;
+    int rows = cdiv(cdiv(p0.M, splits), W_BM) * W_BM;
+    splits = cdiv(p0.M, rows);
+    a.rows_per_split = rows;
+    a.splits = splits;
+    a.tiles_n = p0.N / W_TILE;
+    a.tiles_k = p0.K / W_TILE;
+    SrfLaunchScope ps(s, p0.name, 2.0 * p0.M * (double)p0.N * p0.K * count, 0);
+    wgrad_tr_kernel<<<tiles * cdiv(splits * count, 8) * 8, W_THREADS, W_LDS, s>>>(a);
+    SRF_LAUNCH_CHECK("wgrad_tr_kernel");
+    return 0;
+}
+
+int launch_wgrad_tr(const GemmTN& p, hipStream_t s) { return launch_wgrad_tr_batch(&p, 1, s); }

@@ -82,7 +82,7 @@ def test_gemm_nt_matches_fp64(prec, M, N, K, tile):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(300, 136, 80), (1000, 512, 48), (4099, 256, 160)])
+@pytest.mark.parametrize("M,N,K", [(300, 136, 80), (1000, 512, 48), (4099, 256, 160), (33000, 256, 512), (40007, 512, 256)])
 def test_gemm_tn_matches_fp64(prec, M, N, K):
     lib = _capi.load()
     gen = torch.Generator().manual_seed(M + N * 5 + K * 11)
