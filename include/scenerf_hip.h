@@ -35,6 +35,8 @@ extern "C" {
 #define SCENERF_N_SCALES 5          /* feature maps "1_1","1_2","1_4","1_8","1_16" */
 #define SCENERF_D_LATENT 2480       /* 80+160+320+640+1280 (resnetfc d_latent, scenerf.py:100-114) */
 #define SCENERF_D_HIDDEN 512
+#define SCENERF_Z_DENSE_COLS 256    /* columns [0, 256) of the gathered features Z are always defined (zeros where a row tile misses
+                                       the scale); the columns of an untouched (tile, scale) pair beyond that are left unwritten */
 #define SCENERF_D_XENC 48           /* PE(39) + viewdir(3), zero-padded to a multiple of 16 */
 #define SCENERF_TILE_ROWS 128       /* granularity of the scale-activity mask (Q1 sparsity) */
 #define SCENERF_MAX_GAUSSIANS 8

@@ -344,7 +344,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         if (int e = launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
         if (int e = fork()) return e;
     }
-    GemmTN wg[6];   // the six fc weight gradients: batched into one launch when the chain kernel already produced every dH / dN
+    GemmTN wg[8];   // the six fc weight gradients (+ lin_z, below): batched into one launch when the chain kernel already produced every dH / dN
     int nwg = 0;
     for (int b = 2; b >= 0; --b) {
         {   // [side] dW1_b += dH_{b+1}^T relu(N_b)
@@ -389,18 +389,34 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         }
         if (int e = fork()) return e;
     }
+    // lin_z: dWz[:, slice_s] += dH[:, 0:1536]^T Z[:, slice_s].  In the batched launch the first 256 columns of Z -- the two finest
+    // scales, which (nearly) every row block touches, and the head of the third -- ride along as a seventh problem without row
+    // skipping (the gather writes exact zeros there for the row tiles that miss a scale: SCENERF_Z_DENSE_COLS); the per-scale
+    // launches below then start at that column
+    int linz_done = 0;
+    if (nwg && SCENERF_Z_DENSE_COLS % 256 == 0) {
+        GemmTN t;
+        t.name = "gemm_wgrad_fc";
+        t.D = dH; t.ldd = LDH;
+        t.A = Z; t.lda = SCENERF_D_LATENT;
+        t.M = M; t.N = 3 * SCENERF_D_HIDDEN; t.K = SCENERF_Z_DENSE_COLS;
+        t.out = g_->w_z; t.ldo = SCENERF_D_LATENT;
+        if (wgrad_tr_applicable(t)) { wg[nwg++] = t; linz_done = SCENERF_Z_DENSE_COLS; }
+    }
     if (nwg) {
         if (int e = launch_wgrad_tr_batch(wg, nwg, s2)) return e;
     }
-    // [side] dWz[:, slice_s] += dH[:, 0:1536]^T Z[:, slice_s]   (row-tiles without scale s skipped)
+    // [side] the remaining (scale, column) ranges, row-tiles without scale s skipped
     for (int sc = 0; sc < 5; ++sc) {
+        const int c0 = kSegOff[sc] > linz_done ? kSegOff[sc] : linz_done, c1 = kSegOff[sc] + cfg->map_C[sc];
+        if (c1 <= c0) continue;
         GemmTN t;
         t.name = head ? "gemm_wgrad_linz/g" : "gemm_wgrad_linz";
         t.D = dH; t.ldd = LDH;
-        t.A = (const char*)Z + (size_t)kSegOff[sc] * es; t.lda = SCENERF_D_LATENT;
-        t.M = M; t.N = 3 * SCENERF_D_HIDDEN; t.K = cfg->map_C[sc];
+        t.A = (const char*)Z + (size_t)c0 * es; t.lda = SCENERF_D_LATENT;
+        t.M = M; t.N = 3 * SCENERF_D_HIDDEN; t.K = c1 - c0;
         t.tile_mask = tile_mask; t.skip_bit = sc;
-        t.out = g_->w_z + kSegOff[sc]; t.ldo = SCENERF_D_LATENT;
+        t.out = g_->w_z + c0; t.ldo = SCENERF_D_LATENT;
         if (int e = launch_gemm_tn(prec, t, s2)) return e;
     }
     // [side] dWin += dH0^T xenc   (bf16 mode: the hi part of the split encoding kept in h0pre is bf16(xenc))

@@ -215,7 +215,23 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
     if (tid == 0) tile_mask[tile] = (uint8_t)mask;
     constexpr int VN = Vec16<T>::N;
     for (int s = 0; s < 5; ++s) {
-        if (!(mask & (1u << s))) continue;
+        if (!(mask & (1u << s))) {
+            // a scale this tile does not touch: its columns are normally never read (every consumer skips them by tile_mask) and stay
+            // unwritten -- except the first SCENERF_Z_DENSE_COLS columns, which the batched lin_z weight gradient reads for every row
+            // (mlp.hip): those get exact zeros
+            const int c1 = min(gc.off[s] + gc.C[s], SCENERF_Z_DENSE_COLS);
+            const int nzc = (c1 - gc.off[s]) / VN;
+            if (nzc > 0) {
+                float z[VN];
+#pragma unroll
+                for (int e = 0; e < VN; ++e) z[e] = 0.f;
+                for (int it = tid; it < SCENERF_TILE_ROWS * nzc; it += 256) {
+                    const int row = it / nzc, ch = it - row * nzc;
+                    Vec16<T>::store(Z + ((size_t)tile * SCENERF_TILE_ROWS + row) * SCENERF_D_LATENT + gc.off[s] + ch * VN, z);
+                }
+            }
+            continue;
+        }
         const int C = gc.C[s];
         const int chunks = C / VN;
         const T* map = (const T*)maps.p[s];

@@ -39,10 +39,15 @@ struct WgradProblem {
     int ldd2, lda2;      // row strides in BYTES
     int ldo, relu_a;
 };
+#define W_MAXWG 512
 struct WgradArgs {
-    WgradProblem prob[W_MAXPROB];   // same M, N, K for all (the six fc_0 / fc_1 weight gradients of a backward pass share one launch:
-    int nprob;                      // one atomic flush per workgroup for all of them instead of one per GEMM)
-    int M, rows_per_split, splits, tiles_n, tiles_k;
+    WgradProblem prob[W_MAXPROB];   // same M for all; N and K (multiples of 256) may differ.  The weight gradients of a backward pass
+                                    // share one launch: one atomic flush per workgroup for all of them instead of one per GEMM
+    unsigned short tiles_n[W_MAXPROB];
+    // workgroup id -> problem (bits 12..15) | tile (bits 6..11) | split (bits 0..5); 0xffff = idle.  Host-built so that the tiles
+    // of one (problem, split) get ids on the same XCD, back to back
+    unsigned short map[W_MAXWG];
+    int M, rows_per_split;
     const char* zero;    // >= 1 KiB of zeros (rows past M)
 };
 
@@ -74,19 +79,16 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
     // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the tiles of one
     // M split -- which read the same rows of D and of A -- are given ids that land on the same XCD, back to back: every row slab
     // then comes from HBM once and from that L2 for the other tiles
-    const int ntile = p.tiles_n * p.tiles_k;
-    int tile, split, pi;
-    {
-        const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-        tile = j % ntile;
-        const int u = (j / ntile) * 8 + xcd;   // (problem, split) unit
-        pi = u % p.nprob;
-        split = u / p.nprob;
-    }
-    if (split >= p.splits) return;
+    // XCD-aware placement (host-built map): consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so
+    // the tiles of one M split -- which read the same rows of D and of A -- get ids that land on the same XCD, back to back: every
+    // row slab then comes from HBM once and from that L2 for the other tiles
+    const unsigned code = p.map[blockIdx.x];
+    if (code == 0xffffu) return;
+    const int pi = code >> 12, tile = (code >> 6) & 63, split = code & 63;
     const WgradProblem& P = p.prob[pi];
-    const int n0 = (tile % p.tiles_n) * W_TILE, k0 = (tile / p.tiles_n) * W_TILE;
-    const int first_k_tile = tile / p.tiles_n == 0;
+    const int tn = p.tiles_n[pi];
+    const int n0 = (tile % tn) * W_TILE, k0 = (tile / tn) * W_TILE;
+    const int first_k_tile = tile / tn == 0;
     const int mb = split * p.rows_per_split;
     const int me = min(p.M, mb + p.rows_per_split);
     const int steps = (me - mb + W_BM - 1) / W_BM;
@@ -230,7 +232,7 @@ bool wgrad_tr_applicable(const GemmTN& p) {
     return !off && p.N % W_TILE == 0 && p.K % W_TILE == 0 && !p.tile_mask && p.M >= 32768 && p.ldd % 8 == 0 && p.lda % 8 == 0;
 }
 
-// `count` problems of identical shape (M, N, K) in one launch
+// `count` problems over the same M rows (N, K multiples of 256, possibly different) in one launch
 int launch_wgrad_tr_batch(const GemmTN* probs, int count, hipStream_t s) {
     static bool attr_done = false;
     static char* zero = nullptr;
@@ -243,25 +245,41 @@ int launch_wgrad_tr_batch(const GemmTN* probs, int count, hipStream_t s) {
     SRF_CHECK(count >= 1 && count <= W_MAXPROB, "wgrad batch: 1..%d problems", W_MAXPROB);
     const GemmTN& p0 = probs[0];
     WgradArgs a;
+    int tile_units = 0;
+    double flops = 0;
     for (int i = 0; i < count; ++i) {
         const GemmTN& p = probs[i];
-        SRF_CHECK(p.M == p0.M && p.N == p0.N && p.K == p0.K && wgrad_tr_applicable(p), "wgrad batch: problems must share one applicable shape");
+        SRF_CHECK(p.M == p0.M && wgrad_tr_applicable(p), "wgrad batch: problems must share M and fit the kernel");
         a.prob[i] = {(const char*)p.D, (const char*)p.A, p.out, p.colsum, p.ldd * 2, p.lda * 2, p.ldo, p.relu_a};
+        a.tiles_n[i] = (unsigned short)(p.N / W_TILE);
+        SRF_CHECK((p.N / W_TILE) * (p.K / W_TILE) <= 64, "wgrad batch: at most 64 tiles per problem");
+        tile_units += (p.N / W_TILE) * (p.K / W_TILE);
+        flops += 2.0 * p.M * (double)p.N * p.K;
     }
-    a.nprob = count;
     a.M = p0.M;
     a.zero = zero;
-    const int tiles = (p0.N / W_TILE) * (p0.K / W_TILE);
     static const int wg_target = getenv("SRF_WGRAD_TR_WGS") ? atoi(getenv("SRF_WGRAD_TR_WGS")) : 256;   // one workgroup per CU (128 KiB of LDS)
-    int splits = wg_target / (tiles * count) > 1 ? wg_target / (tiles * count) : 1;
+    int splits = wg_target / tile_units > 1 ? wg_target / tile_units : 1;
+    if (splits > 64) splits = 64;
     int rows = cdiv(cdiv(p0.M, splits), W_BM) * W_BM;
     splits = cdiv(p0.M, rows);
     a.rows_per_split = rows;
-    a.splits = splits;
-    a.tiles_n = p0.N / W_TILE;
-    a.tiles_k = p0.K / W_TILE;
-    SrfLaunchScope ps(s, p0.name, 2.0 * p0.M * (double)p0.N * p0.K * count, 0);
-    wgrad_tr_kernel<<<tiles * cdiv(splits * count, 8) * 8, W_THREADS, W_LDS, s>>>(a);
+    // groups (problem, split) dealt round-robin to the 8 XCDs; each XCD's workgroups = its groups' tiles, in order
+    int len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < W_MAXWG; ++i) a.map[i] = 0xffff;
+    int g = 0, grid = 0;
+    for (int sp = 0; sp < splits; ++sp)
+        for (int i = 0; i < count; ++i, ++g) {
+            const int x = g & 7, nt = (probs[i].N / W_TILE) * (probs[i].K / W_TILE);
+            for (int t = 0; t < nt; ++t) {
+                const int b = (len[x]++) * 8 + x;
+                SRF_CHECK(b < W_MAXWG, "wgrad batch: workgroup map overflow");
+                a.map[b] = (unsigned short)((i << 12) | (t << 6) | sp);
+                if (b + 1 > grid) grid = b + 1;
+            }
+        }
+    SrfLaunchScope ps(s, p0.name, flops, 0);
+    wgrad_tr_kernel<<<grid, W_THREADS, W_LDS, s>>>(a);
     SRF_LAUNCH_CHECK("wgrad_tr_kernel");
     return 0;
 }
