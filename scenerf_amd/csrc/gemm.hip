@@ -692,9 +692,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
     const bool do_colsum = p.colsum != nullptr && k0 == 0 && tid < 128;
     const bool relu_b = sizeof(T) == 2 && p.relu_a;   // bf16: ReLU of the activation operand on its fragments
 
+    // next row block of a tile that touches the scale: whole inactive tiles are skipped at once, eight at a time where the range
+    // allows (a launch for a scale no ray reaches used to spend ~40 us walking the mask in MC-row steps)
     auto next_valid = [&](int m) {
         if (p.tile_mask && p.skip_bit >= 0) {
-            while (m < mend && !((p.tile_mask[m / SCENERF_TILE_ROWS] >> p.skip_bit) & 1u)) m += MC;
+            const uint64_t bit8 = 0x0101010101010101ull << p.skip_bit;
+            while (m < mend) {
+                const int t = m / SCENERF_TILE_ROWS;
+                if ((t & 7) == 0 && (t + 8) * SCENERF_TILE_ROWS <= mend && !(*(const uint64_t*)(p.tile_mask + t) & bit8)) {
+                    m = (t + 8) * SCENERF_TILE_ROWS;
+                    continue;
+                }
+                if ((p.tile_mask[t] >> p.skip_bit) & 1u) break;
+                m = (t + 1) * SCENERF_TILE_ROWS;
+            }
         }
         return m;
     };
