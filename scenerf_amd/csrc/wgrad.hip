@@ -22,12 +22,15 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_w;
 typedef unsigned u32x2_w __attribute__((ext_vector_type(2)));
 
 #define W_TILE 256                 // output tile: 256 (n) x 256 (k)
-#define W_BM 16                    // rows per step (one MFMA k-step)
+#ifndef W_BM
+#define W_BM 32                    // rows per step (W_BM / 16 MFMA k-steps)
+#endif
 #define W_ROW 512                  // LDS row: 256 bf16
-#define W_HALF (W_BM * W_ROW)      // 8192: one operand's part of a stage
-#define W_STAGE (2 * W_HALF)       // 16384
-#define W_NST 8
+#define W_HALF (W_BM * W_ROW)      // one operand's part of a stage
+#define W_STAGE (2 * W_HALF)
+#define W_NST (8 * 16 / W_BM)      // ring depth: 128 KiB in all
 #define W_LDS (W_NST * W_STAGE)    // 131072
+#define W_PPP (W_BM / 8)           // pieces per producer per operand per stage (a piece = two rows; four producers)
 #define W_THREADS 768
 
 #define W_MAXPROB 8
@@ -100,10 +103,10 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
         // a piece = two 512-byte rows of one operand's tile; producer q moves pieces 2q, 2q+1 of D and of A.  Lane L: row 2 piece +
         // L / 32 of the stage, physical 16-byte slot L & 31 of that row, fetching logical chunk (slot / 4) ^ (row & 3)
         const int q = wvu - 8;
-        unsigned offD[2], offA[2];
+        unsigned offD[W_PPP], offA[W_PPP];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row = 2 * (2 * q + u) + (lane >> 5);
+        for (int u = 0; u < W_PPP; ++u) {
+            const int row = 2 * (W_PPP * q + u) + (lane >> 5);
             const int chunk = ((lane & 31) >> 2) ^ (row & 3);
             offD[u] = (unsigned)row * P.ldd2 + n0 * 2 + chunk * 64 + (lane & 3) * 16;
             offA[u] = (unsigned)row * P.lda2 + k0 * 2 + chunk * 64 + (lane & 3) * 16;
@@ -115,19 +118,19 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
                 const char* dD = P.D + (size_t)m * P.ldd2;
                 const char* dA = P.A + (size_t)m * P.lda2;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    w_glds16(dD, offD[u], __builtin_amdgcn_readfirstlane(sb + (2 * q + u) * 1024));
-                    w_glds16(dA, offA[u], __builtin_amdgcn_readfirstlane(sb + W_HALF + (2 * q + u) * 1024));
+                for (int u = 0; u < W_PPP; ++u) {
+                    w_glds16(dD, offD[u], __builtin_amdgcn_readfirstlane(sb + (W_PPP * q + u) * 1024));
+                    w_glds16(dA, offA[u], __builtin_amdgcn_readfirstlane(sb + W_HALF + (W_PPP * q + u) * 1024));
                 }
             } else {   // the last rows of the matrix: rows past M come from the zero page
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int row = 2 * (2 * q + u) + (lane >> 5);
+                for (int u = 0; u < W_PPP; ++u) {
+                    const int row = 2 * (W_PPP * q + u) + (lane >> 5);
                     const bool ok = m + row < p.M;
                     const char* gD = ok ? P.D + (size_t)m * P.ldd2 + offD[u] : p.zero + (lane & 31) * 16;
                     const char* gA = ok ? P.A + (size_t)m * P.lda2 + offA[u] : p.zero + (lane & 31) * 16;
-                    w_glds16v(gD, __builtin_amdgcn_readfirstlane(sb + (2 * q + u) * 1024));
-                    w_glds16v(gA, __builtin_amdgcn_readfirstlane(sb + W_HALF + (2 * q + u) * 1024));
+                    w_glds16v(gD, __builtin_amdgcn_readfirstlane(sb + (W_PPP * q + u) * 1024));
+                    w_glds16v(gA, __builtin_amdgcn_readfirstlane(sb + W_HALF + (W_PPP * q + u) * 1024));
                 }
             }
         };
@@ -135,8 +138,12 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
         for (int c = 0; c < W_NST - 1 && c < steps; ++c) issue(c);
 #pragma unroll 1
         for (int c = 0; c < steps; ++c) {
-            // chunk c has landed once at most the loads of chunks c+1 .. c+6 (4 per producer each) are outstanding
-            if (c + W_NST - 2 < steps) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            // chunk c has landed once at most the loads of chunks c+1 .. c+W_NST-2 (2 W_PPP per producer each) are outstanding
+            static_assert((W_NST - 2) * 2 * W_PPP == 24 || (W_NST - 2) * 2 * W_PPP == 16, "update the counted wait");
+            if (c + W_NST - 2 < steps) {
+                if ((W_NST - 2) * 2 * W_PPP == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail
             __builtin_amdgcn_s_barrier();
             if (c + W_NST - 1 < steps) issue(c + W_NST - 1);   // into the stage the consumers read in step c - 1
@@ -172,40 +179,44 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
     for (int c = 0; c < steps; ++c) {
         __builtin_amdgcn_s_barrier();
         const unsigned S = lds0 + (c % W_NST) * W_STAGE;
-        u32x2_w fa[4][2], fb[2][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fa[i][0] = w_tr_read(S + adD[i]);
-            fa[i][1] = w_tr_read(S + adD[i] + 4 * W_ROW);
-        }
+        for (int ks = 0; ks < W_BM / 16; ++ks) {
+            const unsigned Sk = S + ks * 16 * W_ROW;
+            u32x2_w fa[4][2], fb[2][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            fb[j][0] = w_tr_read(S + adA[j]);
-            fb[j][1] = w_tr_read(S + adA[j] + 4 * W_ROW);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        uint4 A4[4], B4[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) A4[i] = make_uint4(fa[i][0][0], fa[i][0][1], fa[i][1][0], fa[i][1][1]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            B4[j] = make_uint4(fb[j][0][0], fb[j][0][1], fb[j][1][0], fb[j][1][1]);
-            if (relu_a) {
-                B4[j].x = relu_bf16x2(B4[j].x); B4[j].y = relu_bf16x2(B4[j].y);
-                B4[j].z = relu_bf16x2(B4[j].z); B4[j].w = relu_bf16x2(B4[j].w);
+            for (int i = 0; i < 4; ++i) {
+                fa[i][0] = w_tr_read(Sk + adD[i]);
+                fa[i][1] = w_tr_read(Sk + adD[i] + 4 * W_ROW);
             }
-        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 2; ++j) {
+                fb[j][0] = w_tr_read(Sk + adA[j]);
+                fb[j][1] = w_tr_read(Sk + adA[j] + 4 * W_ROW);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            uint4 A4[4], B4[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, A4[i]), __builtin_bit_cast(bf16x8_w, B4[j]),
-                                                                    acc[i][j], 0, 0, 0);
-        if (do_cs) {
+            for (int i = 0; i < 4; ++i) A4[i] = make_uint4(fa[i][0][0], fa[i][0][1], fa[i][1][0], fa[i][1][1]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                B4[j] = make_uint4(fb[j][0][0], fb[j][0][1], fb[j][1][0], fb[j][1][1]);
+                if (relu_a) {
+                    B4[j].x = relu_bf16x2(B4[j].x); B4[j].y = relu_bf16x2(B4[j].y);
+                    B4[j].z = relu_bf16x2(B4[j].z); B4[j].w = relu_bf16x2(B4[j].w);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                cs[i] += (bf16lo(A4[i].x) + bf16hi(A4[i].x)) + (bf16lo(A4[i].y) + bf16hi(A4[i].y)) + (bf16lo(A4[i].z) + bf16hi(A4[i].z)) +
-                         (bf16lo(A4[i].w) + bf16hi(A4[i].w));
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, A4[i]), __builtin_bit_cast(bf16x8_w, B4[j]),
+                                                                        acc[i][j], 0, 0, 0);
+            if (do_cs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    cs[i] += (bf16lo(A4[i].x) + bf16hi(A4[i].x)) + (bf16lo(A4[i].y) + bf16hi(A4[i].y)) + (bf16lo(A4[i].z) + bf16hi(A4[i].z)) +
+                             (bf16lo(A4[i].w) + bf16hi(A4[i].w));
+            }
         }
     }
     // ---- partial tile -> out (fp32 atomics; C tile layout: row (e & 3) + 8 (e >> 2) + 4 (lane >> 5), column lane & 31)
@@ -261,7 +272,7 @@ int launch_wgrad_tr_batch(const GemmTN* probs, int count, hipStream_t s) {
     static const int wg_target = getenv("SRF_WGRAD_TR_WGS") ? atoi(getenv("SRF_WGRAD_TR_WGS")) : 256;   // one workgroup per CU (128 KiB of LDS)
     int splits = wg_target / tile_units > 1 ? wg_target / tile_units : 1;
     if (splits > 64) splits = 64;
-    int rows = cdiv(cdiv(p0.M, splits), W_BM) * W_BM;
+    int rows = cdiv(cdiv(p0.M, splits), W_BM) * W_BM;   // (a multiple of the step)
     splits = cdiv(p0.M, rows);
     a.rows_per_split = rows;
     // groups (problem, split) dealt round-robin to the 8 XCDs; each XCD's workgroups = its groups' tiles, in order
