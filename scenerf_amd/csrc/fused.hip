@@ -257,14 +257,12 @@ __global__ __launch_bounds__(F_THREADS) void mlp_fused_kernel(FusedArgs p) {
             if (MODE == 0 && sign_ptr) {
                 // the backward chain's gates: 8 sign bits per piece (the values are rectified: positive == non-zero; min(x, 1) per
                 // half gives the bit), one byte store -- 64 consecutive bytes per row
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                uint32_t bits = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t t = pk_min_u16(w[e], 0x00010001u);
-                    bits |= ((t | (t >> 15)) & 3u) << (2 * e);
-                }
-                sign_ptr[(size_t)(m0 + row) * 64 + slot] = (uint8_t)bits;
+                // min(x, 1) per half -> 0x000b000a per word; the four words interleave into 0x00BB00AA (b = odd, a = even elements)
+                uint32_t u = pk_min_u16(v.x, 0x00010001u);
+                u |= pk_min_u16(v.y, 0x00010001u) << 2;
+                u |= pk_min_u16(v.z, 0x00010001u) << 4;
+                u |= pk_min_u16(v.w, 0x00010001u) << 6;
+                sign_ptr[(size_t)(m0 + row) * 64 + slot] = (uint8_t)(u | (u >> 15));
             }
         }
         ++save_i;
@@ -366,7 +364,12 @@ __global__ __launch_bounds__(F_THREADS) void mlp_fused_kernel(FusedArgs p) {
     while (save_i < 8) save_piece();
     if (MODE == 0 && p.logits) {
         // lin_out on the rectified H3 tile still resident in the A buffer (every consumer is past the last epilogue's second
-        // barrier): 8 threads per row, 64 columns each, fp32 weights from L1, butterfly over the 8 partial sums
+        // barrier).  w_out (fp32, <= 8 KiB) is first copied into the now idle ring -- 512 threads re-reading their slices from
+        // global memory cost ~8 us per workgroup -- then 8 threads per row take 64 columns each and a butterfly adds the partials.
+        float* wl = (float*)(lds + F_ABUF);
+        if (tid < p.d_out * (SCENERF_D_HIDDEN / 4)) *(float4*)(wl + tid * 4) = *(const float4*)(p.w_out + tid * 4);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // (the producer waves have left or are leaving: ended waves do not count)
         const int row = tid >> 3, part = tid & 7;
         float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
@@ -377,8 +380,8 @@ __global__ __launch_bounds__(F_THREADS) void mlp_fused_kernel(FusedArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j < p.d_out) {
-                    const float4 w0 = *(const float4*)(p.w_out + j * SCENERF_D_HIDDEN + slot * 8);
-                    const float4 w1 = *(const float4*)(p.w_out + j * SCENERF_D_HIDDEN + slot * 8 + 4);
+                    const float4 w0 = *(const float4*)(wl + j * SCENERF_D_HIDDEN + slot * 8);
+                    const float4 w1 = *(const float4*)(wl + j * SCENERF_D_HIDDEN + slot * 8 + 4);
                     o[j] = fmaf(f[0], w0.x, o[j]); o[j] = fmaf(f[1], w0.y, o[j]); o[j] = fmaf(f[2], w0.z, o[j]); o[j] = fmaf(f[3], w0.w, o[j]);
                     o[j] = fmaf(f[4], w1.x, o[j]); o[j] = fmaf(f[5], w1.y, o[j]); o[j] = fmaf(f[6], w1.z, o[j]); o[j] = fmaf(f[7], w1.w, o[j]);
                 }
@@ -485,8 +488,8 @@ int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
     p.layer[0] = {w->b_h[0], a->H[0], sign(0), 0, H};
     for (int b = 0; b < 3; ++b) {
         p.layer[1 + 2 * b] = {w->b_fc0[b], a->Nn[b], sign(1 + 2 * b), 1, H};
-        p.layer[2 + 2 * b] = {w->b_h[b + 1], a->H[b + 1], sign(2 + 2 * b), 2, H};
-    }
+        p.layer[2 + 2 * b] = {w->b_h[b + 1], a->H[b + 1], b < 2 ? sign(2 + 2 * b) : nullptr, 2, H};   // (H3's sign is not used: lin_out's
+    }                                                                                                     //  backward reads H3 itself)
     p.Wst = w->w_stream;
     p.X3 = a->h0pre;
     p.Z = Z;
