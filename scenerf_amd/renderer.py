@@ -341,6 +341,7 @@ class RenderChunk(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg: RenderConfig, maps: MapHolder, mlp: MlpHolder, mlpg: MlpHolder, pixels, cam_K, inv_K, T_s2i,
                 noise_u, noise_g, tok_maps, tok_mlp, tok_mlpg):
+        ctx.set_materialize_grads(False)   # outputs nobody differentiates arrive as None, not as freshly filled zero tensors
         lib = _capi.load()
         st = _stream()
         ccfg = cfg.to_c()
