@@ -176,6 +176,7 @@ def main():
     opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, fused=True)
     # N > 1: each MLP's packed gradient sink is all-reduced (RCCL) right before it is handed to autograd: 2 x 21.7 MB
     model.grad_sync = sdist.allreduce_mean_ if world > 1 else None
+    model.grad_sync_async = sdist.allreduce_mean_async if world > 1 else None   # radiance MLP: started before the feature scatter
     maps = {k: v.to(dev).requires_grad_(True) for k, v in synth.feature_maps(1500, 452, 3 + rank).items()}
     K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
     pix = synth.stride2_pixels((1220, 370), R, 100 + rank).to(dev)

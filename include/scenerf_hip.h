@@ -188,6 +188,13 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
                              float* const gmaps_hwc[SCENERF_N_SCALES] /* may be NULL: skip map grads */,
                              scenerf_stream_t stream);
 
+/* The feature-gradient part of scenerf_hip_mlp_backward on its own: call scenerf_hip_mlp_backward with gmaps_hwc = NULL, start the
+ * gradient all-reduce of the (now final) parameter gradients, then scatter the feature gradients from the same dH while the
+ * collective is in flight (data-parallel training).  dH as written by scenerf_hip_mlp_backward. */
+int scenerf_hip_mlp_feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const uint8_t* tile_mask,
+                                  const int32_t* tap_texel, const float* tap_weight, int M, const void* dH,
+                                  float* const gmaps_hwc[SCENERF_N_SCALES], scenerf_stream_t stream);
+
 /* ---- probabilistic depth sampler ------------------------------------------------------------------------- */
 /* scenerf.py:585-596 (means/stds from the gaussian head), utils.py:186-229 (reparameterised samples,
  * clamp at 0.1), scenerf.py:636-659 (merge with the uniform samples, argsort, gathers).  perm is the

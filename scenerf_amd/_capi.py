@@ -91,6 +91,8 @@ _PROTOS = {
     "scenerf_hip_mlp_forward": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpWeights), vp, vp, vp, i32, C.POINTER(MlpActs), vp]),
     "scenerf_hip_mlp_backward": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpWeights), C.POINTER(MlpGrads), vp, vp, vp, vp, vp,
                                            i32, C.POINTER(MlpActs), vp, vp, vp, C.POINTER(vp * N_SCALES), vp]),
+    "scenerf_hip_mlp_feature_grads": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpWeights), vp, vp, vp, i32, vp,
+                                                C.POINTER(vp * N_SCALES), vp]),
     "scenerf_hip_gaussian_sample_sort": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_composite_forward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_composite_backward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

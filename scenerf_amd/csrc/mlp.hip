@@ -217,7 +217,32 @@ static void set_segments(GemmNT& g, const scenerf_cfg* cfg, const void* Z, const
     g.tile_mask = tile_mask;
 }
 
+// dZ[:, slice_s] = dH[:, 0:1536] @ Wz[:, slice_s], scattered straight into the (H,W,C) map gradients (grid_sampler_2d_backward)
+static int feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const uint8_t* tile_mask, const int32_t* tap_texel,
+                         const float* tap_weight, int M, const void* dH, float* const gmaps_hwc[SCENERF_N_SCALES], hipStream_t s) {
+    const bool head = w->d_out == 2;
+    for (int sc = 0; sc < 5; ++sc) {
+        if (!gmaps_hwc[sc]) continue;
+        GemmNT g;
+        g.name = head ? "gemm_dfeat_scatter/g" : "gemm_dfeat_scatter";
+        g.A1 = dH; g.lda1 = 4 * SCENERF_D_HIDDEN; g.K1 = 3 * SCENERF_D_HIDDEN;
+        g.W = w->w_z_t[sc]; g.ldw = 3 * SCENERF_D_HIDDEN;
+        g.M = M; g.N = cfg->map_C[sc];
+        g.tile_mask = tile_mask; g.skip_bit = sc;
+        g.gmap = gmaps_hwc[sc]; g.tap_texel = tap_texel; g.tap_weight = tap_weight; g.scatter_scale = sc;
+        if (int e = launch_gemm_nt(cfg->precision, g, s)) return e;
+    }
+    return 0;
+}
+
 extern "C" {
+
+int scenerf_hip_mlp_feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const uint8_t* tile_mask,
+                                  const int32_t* tap_texel, const float* tap_weight, int M, const void* dH,
+                                  float* const gmaps_hwc[SCENERF_N_SCALES], scenerf_stream_t stream) {
+    SRF_CHECK(cfg && w && tile_mask && tap_texel && tap_weight && dH && gmaps_hwc && M > 0, "mlp_feature_grads: NULL argument");
+    return feature_grads(cfg, w, tile_mask, tap_texel, tap_weight, M, dH, gmaps_hwc, as_stream(stream));
+}
 
 int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const float* xenc,
                             const uint8_t* tile_mask, int M, const scenerf_mlp_acts* a, scenerf_stream_t stream) {
@@ -437,19 +462,8 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     SRF_HIP(hipMemcpyAsync(g_->b_z, g_->b_in, SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s2));
     SRF_HIP(hipMemcpyAsync(g_->b_z + SCENERF_D_HIDDEN, g_->b_fc1[0], SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s2));
     SRF_HIP(hipMemcpyAsync(g_->b_z + 2 * SCENERF_D_HIDDEN, g_->b_fc1[1], SCENERF_D_HIDDEN * sizeof(float), hipMemcpyDeviceToDevice, s2));
-    // dZ[:, slice_s] = dH[:, 0:1536] @ Wz[:, slice_s], scattered straight into the (H,W,C) map gradients
     if (gmaps_hwc) {
-        for (int sc = 0; sc < 5; ++sc) {
-            if (!gmaps_hwc[sc]) continue;
-            GemmNT g;
-            g.name = head ? "gemm_dfeat_scatter/g" : "gemm_dfeat_scatter";
-            g.A1 = dH; g.lda1 = LDH; g.K1 = 3 * SCENERF_D_HIDDEN;
-            g.W = w->w_z_t[sc]; g.ldw = 3 * SCENERF_D_HIDDEN;
-            g.M = M; g.N = cfg->map_C[sc];
-            g.tile_mask = tile_mask; g.skip_bit = sc;
-            g.gmap = gmaps_hwc[sc]; g.tap_texel = tap_texel; g.tap_weight = tap_weight; g.scatter_scale = sc;
-            if (int e = launch_gemm_nt(prec, g, s)) return e;
-        }
+        if (int e = feature_grads(cfg, w, tile_mask, tap_texel, tap_weight, M, dH, gmaps_hwc, s)) return e;
     }
     if (sc_) {  // join: the caller's stream continues only after the weight-gradient stream has drained
         if (int e = order_after(sc_, s2, s)) return e;

@@ -51,6 +51,20 @@ def allreduce_mean_(flat: torch.Tensor) -> None:
         flat.div_(dist.get_world_size())
 
 
+def allreduce_mean_async(flat: torch.Tensor):
+    """Start the same reduction without blocking the calling stream; returns ``finish()`` -- call it (on the stream that will read
+    ``flat``) before the gradients are used -- or None for a single process.  Installed as ``model.grad_sync_async``."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return None
+    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    world = dist.get_world_size()
+
+    def finish():
+        work.wait()          # the current stream waits for the collective
+        flat.div_(world)
+    return finish
+
+
 class GradBucket:
     """Flat fp32 bucket over a fixed parameter list; ``allreduce_mean`` averages .grad across ranks in one call."""
 

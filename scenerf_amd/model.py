@@ -181,6 +181,9 @@ class SceneRF(TrainingMixin, _Base):
         self.render_cfg.validate()
         # optional data-parallel hook (scenerf_amd.dist.allreduce_mean_): called on each MLP's packed gradient buffer
         self.grad_sync = None
+        # optional early form of the same hook (scenerf_amd.dist.allreduce_mean_async): the radiance MLP's collective then starts
+        # before the feature-gradient scatter of a single-chunk (training) step instead of after it
+        self.grad_sync_async = None
 
     # ---- the hot path ---------------------------------------------------------------------------------------
     def _inv_K(self, cam_K: torch.Tensor) -> torch.Tensor:
@@ -207,7 +210,7 @@ class SceneRF(TrainingMixin, _Base):
         cfg.som_sigma = float(self.ray_som.som_sigma)
         inv_K = self._inv_K(cam_K)
         sess = RenderSession(cfg, x_rgb, self.mlp.ordered_params(), self.mlp_gaussian.ordered_params(),
-                             grad_sync=self.grad_sync)
+                             grad_sync=self.grad_sync, grad_sync_async=self.grad_sync_async)
         outs = []
         n = sampled_pixels.shape[0]
         sess.mlpg.single_chunk = n <= ray_batch_size   # training (scenerf.py:262-275): lets the head's gradient all-reduce start early

@@ -241,9 +241,11 @@ class PackedMLP:
 
 
 class MlpHolder:
-    def __init__(self, grad_sync=None):
+    def __init__(self, grad_sync=None, grad_sync_async=None):
         self.packed: Optional[PackedMLP] = None
         self.grad_sync = grad_sync   # callable(flat fp32 tensor) -> None, e.g. an all-reduce-mean (see dist.py)
+        self.grad_sync_async = grad_sync_async   # callable(flat) -> finisher() or None: same collective, started early (dist.py)
+        self.pending = None          # finisher of a collective in flight on the sink
         self.synced = False          # the sink was already reduced (early, on the side stream: RenderChunk.backward)
         self.single_chunk = False    # set by render_rays_batch when the whole call is one chunk
 
@@ -260,7 +262,10 @@ class PackMLP(torch.autograd.Function):
         pk: PackedMLP = ctx.holder.packed
         # data-parallel hook: reduce the packed fp32 gradient sink in ONE collective (21.7 MB per MLP) before it is
         # carved into per-parameter views -- no flatten/unflatten copies, one large message per MLP over xGMI
-        if ctx.holder.grad_sync is not None and pk.gflat is not None and not ctx.holder.synced:
+        if ctx.holder.pending is not None:      # started in RenderChunk.backward, overlapped with the feature-gradient scatter
+            ctx.holder.pending()
+            ctx.holder.pending = None
+        elif ctx.holder.grad_sync is not None and pk.gflat is not None and not ctx.holder.synced:
             ctx.holder.grad_sync(pk.gflat)
         ctx.holder.synced = False
         grads = pk.unpack_grads()
@@ -320,7 +325,11 @@ def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dis
     return run
 
 
-def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: _MlpRun, d_logits, want_map_grads: bool):
+def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: _MlpRun, d_logits, want_map_grads: bool,
+                  sync_async=None):
+    """``sync_async`` (data parallel, scenerf_amd.dist.allreduce_mean_async): the parameter gradients are final once the weight-
+    gradient GEMMs are queued, so their all-reduce is started there and the feature-gradient GEMM + scatter (0.5 ms) runs while
+    the collective is in flight; returns the collective's finisher (or None)."""
     lib = _capi.load()
     act = _act_dtype(cfg.precision_code)
     dev = d_logits.device
@@ -328,10 +337,17 @@ def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: 
     dN = torch.empty((3, run.M, D_H), dtype=act, device=dev)
     g = pk.grad_sink()
     gm = C.byref(maps.gmap_ptr_array()) if want_map_grads else None
+    split = sync_async is not None and gm is not None
     _capi.check(lib.scenerf_hip_mlp_backward(C.byref(ccfg), C.byref(pk.c), C.byref(g), run.Z.data_ptr(), run.xenc.data_ptr(),
                                              run.tile_mask.data_ptr(), run.tap_texel.data_ptr(), run.tap_weight.data_ptr(),
-                                             run.M, C.byref(run.c), d_logits.data_ptr(), dH.data_ptr(), dN.data_ptr(), gm,
-                                             _stream()), "mlp_backward")
+                                             run.M, C.byref(run.c), d_logits.data_ptr(), dH.data_ptr(), dN.data_ptr(),
+                                             None if split else gm, _stream()), "mlp_backward")
+    finish = sync_async(pk.gflat) if sync_async is not None else None
+    if split:
+        _capi.check(lib.scenerf_hip_mlp_feature_grads(C.byref(ccfg), C.byref(pk.c), run.tile_mask.data_ptr(), run.tap_texel.data_ptr(),
+                                                      run.tap_weight.data_ptr(), run.M, dH.data_ptr(), gm, _stream()),
+                    "mlp_feature_grads")
+    return finish
 
 
 # ------------------------------------------------------------------------------------------------ one chunk of rays
@@ -467,7 +483,8 @@ class RenderChunk(torch.autograd.Function):
                     ctx.mlpg.grad_sync(ctx.mlpg.packed.gflat)
                     ctx.mlpg.synced = True
         if ctx.needs_input_grad[11] or want_maps:
-            _mlp_backward(ccfg, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps)
+            early = ctx.mlp.grad_sync_async if (ctx.mlpg.single_chunk and ctx.needs_input_grad[11]) else None
+            ctx.mlp.pending = _mlp_backward(ccfg, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps, sync_async=early)
         if do_head:
             main.wait_stream(side)
             for t in (d_off, run_g.Z, run_g.xenc, run_g.logits):
@@ -484,16 +501,18 @@ class RenderSession:
     """Per-call state of ``render_rays_batch``: converted maps + packed MLPs, shared by all chunks."""
 
     def __init__(self, cfg: RenderConfig, x_rgb: Dict[str, torch.Tensor], mlp_params: Sequence[torch.Tensor],
-                 mlpg_params: Sequence[torch.Tensor], grad_sync=None):
+                 mlpg_params: Sequence[torch.Tensor], grad_sync=None, grad_sync_async=None):
         _capi.load()
         cfg.validate()
         self.cfg = cfg
         chw = [x_rgb["1_%d" % s] for s in (1, 2, 4, 8, 16)]
-        self.maps = MapHolder(cfg)
-        self.tok_maps = PrepareMaps.apply(self.maps, *chw)
-        self.mlp, self.mlpg = MlpHolder(grad_sync), MlpHolder(grad_sync)
+        # autograd runs ready nodes newest-first: the MLP tokens are created BEFORE the map token so that in backward the map
+        # transposes (PrepareMaps.backward) are queued before PackMLP.backward waits for a gradient all-reduce in flight
+        self.mlp, self.mlpg = MlpHolder(grad_sync, grad_sync_async), MlpHolder(grad_sync)
         self.tok_mlp = PackMLP.apply(self.mlp, 4, cfg, *mlp_params)
         self.tok_mlpg = PackMLP.apply(self.mlpg, 2, cfg, *mlpg_params)
+        self.maps = MapHolder(cfg)
+        self.tok_maps = PrepareMaps.apply(self.maps, *chw)
 
     def draw_noise(self, R: int, device):
         """The reference's in-path RNG calls, same generators and order (SURVEY §5 RNG row)."""

@@ -20,7 +20,7 @@ def main():
     m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="bf16", **kw).to(dev)
     m.mlp.load_state_dict(synth.mlp_state(71, 4))
     m.mlp_gaussian.load_state_dict(synth.mlp_state(72, 2, out_scale=4.0))
-    maps = {k: v.to(dev) for k, v in synth.feature_maps(376, 114, 73, smooth=True).items()}
+    maps = {k: v.to(dev).requires_grad_(True) for k, v in synth.feature_maps(376, 114, 73, smooth=True).items()}   # (split path)
     K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(2.0, 10.0).to(dev)
     pix = synth.stride2_pixels((1220, 370), R_total, 74)[b:e].to(dev)
     nu, ng = synth.sampling_noise(R_total, 32, 32, 75)
@@ -28,7 +28,8 @@ def main():
 
     def grads(sync):
         m.grad_sync = sdist.allreduce_mean_ if sync else None
-        for p in m.parameters():
+        m.grad_sync_async = sdist.allreduce_mean_async if sync else None
+        for p in list(m.parameters()) + list(maps.values()):
             p.grad = None
         out = m.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=pix.shape[0], noise=(nu, ng))
         (out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()).backward()
