@@ -224,6 +224,14 @@ def test_gather_features(case, precision):
                 torch.testing.assert_close(Zc[rows, off:off + c], r, rtol=tol, atol=tol)
             else:
                 assert float(r.abs().max()) == 0.0, "tile %d scale %d skipped but the oracle has non-zero features" % (t, s)
+                # columns below SCENERF_Z_DENSE_COLS are always defined (exact zeros: the batched lin_z weight gradient reads them for
+                # every row); beyond that an untouched (tile, scale) pair is left unwritten (the NaN fill survives)
+                dense = max(0, min(off + c, 256) - off)
+                full = slice(t * 128, (t + 1) * 128)
+                if dense:
+                    assert float(Zc[full, off:off + dense].abs().max()) == 0.0
+                if dense < c:
+                    assert bool(torch.isnan(Zc[full, off + dense:off + c]).all())
         off += c
     # taps are a faithful description of the gather: re-applying them on the CHW map reproduces the oracle
     key = "1_1"
