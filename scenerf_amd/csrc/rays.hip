@@ -740,20 +740,20 @@ __global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ layout changes
-// in [A][B] (fp32) -> out [B][A] (TO).  64x64 tiles through LDS, 16-byte global accesses on both sides: float4 reads
-// along B, and 4 (fp32) / 8 (bf16) consecutive A-elements per store.  LDS row stride 65 floats: the column reads of the
-// write phase are conflict-free.
-template <typename TO>
+// in [A][B] (fp32) -> out [B][A] (TO).  RA x RB tiles through LDS, 16-byte global accesses on both sides: float4 reads along B,
+// and 4 (fp32) / 8 (bf16) consecutive A-elements per store.  The extent along the CHANNEL axis is 80 when the channel count is a
+// multiple of 80 (the encoder's are 80 * 2^k: with 64-wide tiles every second tile of the 80-channel map was 3/4 empty), 64
+// otherwise.  Odd LDS row stride: the column reads of the write phase are conflict-free.
+template <typename TO, int RA, int RB>
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, TO* __restrict__ out, int A, int B) {
-    __shared__ float tile[64][65];
-    const int b0 = blockIdx.x * 64, a0 = blockIdx.y * 64;
+    __shared__ float tile[RA][RB + 1];
+    const int b0 = blockIdx.x * RB, a0 = blockIdx.y * RA;
     const int t = threadIdx.x;
     const bool vec_in = (B & 3) == 0;
-    // read: 64 rows (a) x 16 float4 (b)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = t + i * 256;
-        const int ar = q >> 4, bq = (q & 15) * 4;
+    // read: RA rows (a) x RB/4 float4 (b)
+    constexpr int QB = RB / 4;
+    for (int q = t; q < RA * QB; q += 256) {
+        const int ar = q / QB, bq = (q % QB) * 4;
         const int a = a0 + ar, bb = b0 + bq;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (a < A) {
@@ -770,11 +770,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
         for (int e = 0; e < 4; ++e) tile[ar][bq + e] = v[e];
     }
     __syncthreads();
-    // write: 64 rows (b) x (64 / VN) vectors of VN consecutive a
+    // write: RB rows (b) x (RA / VN) vectors of VN consecutive a
     constexpr int VN = 16 / (int)sizeof(TO);
-    constexpr int VPR = 64 / VN;                // vectors per output row
+    constexpr int VPR = RA / VN;                // vectors per output row
     const bool vec_out = (A % VN) == 0;
-    for (int q = t; q < 64 * VPR; q += 256) {
+    for (int q = t; q < RB * VPR; q += 256) {
         const int br = q / VPR, aq = (q % VPR) * VN;
         const int bb = b0 + br, a = a0 + aq;
         if (bb >= B) continue;
@@ -793,6 +793,18 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
             for (int e = 0; e < VN; ++e)
                 if (a + e < A) ActIO<TO>::st(out, (size_t)bb * A + a + e, v[e]);
         }
+    }
+}
+
+// channels_are_a: the channel axis is A (CHW -> HWC) or B (HWC -> CHW)
+template <typename TO>
+static void launch_transpose(const float* in, TO* out, int A, int B, bool channels_are_a, hipStream_t s) {
+    const int C = channels_are_a ? A : B;
+    if (C % 80 == 0) {
+        if (channels_are_a) transpose_kernel<TO, 80, 64><<<dim3(cdiv(B, 64), cdiv(A, 80)), 256, 0, s>>>(in, out, A, B);
+        else transpose_kernel<TO, 64, 80><<<dim3(cdiv(B, 80), cdiv(A, 64)), 256, 0, s>>>(in, out, A, B);
+    } else {
+        transpose_kernel<TO, 64, 64><<<dim3(cdiv(B, 64), cdiv(A, 64)), 256, 0, s>>>(in, out, A, B);
     }
 }
 
@@ -837,12 +849,9 @@ int scenerf_hip_maps_chw_to_hwc(const float* chw, void* hwc, int C, int H, int W
     SRF_CHECK(chw && hwc && C > 0 && H > 0 && W > 0, "maps_chw_to_hwc: bad args");
     hipStream_t s = as_stream(stream);
     int A = C, B = H * W;
-    dim3 grid(cdiv(B, 64), cdiv(A, 64));
     SrfLaunchScope ps(s, "maps_chw_to_hwc", 0, (double)A * B * (4 + (precision ? 2 : 4)));
-    if (precision)
-        transpose_kernel<bf16_t><<<grid, 256, 0, s>>>(chw, (bf16_t*)hwc, A, B);
-    else
-        transpose_kernel<float><<<grid, 256, 0, s>>>(chw, (float*)hwc, A, B);
+    if (precision) launch_transpose<bf16_t>(chw, (bf16_t*)hwc, A, B, true, s);
+    else launch_transpose<float>(chw, (float*)hwc, A, B, true, s);
     SRF_LAUNCH_CHECK("transpose_kernel");
     return 0;
 }
@@ -851,9 +860,8 @@ int scenerf_hip_grads_hwc_to_chw(const float* hwc, float* chw, int C, int H, int
     SRF_CHECK(chw && hwc && C > 0 && H > 0 && W > 0, "grads_hwc_to_chw: bad args");
     hipStream_t s = as_stream(stream);
     int A = H * W, B = C;
-    dim3 grid(cdiv(B, 64), cdiv(A, 64));
     SrfLaunchScope ps(s, "grads_hwc_to_chw", 0, (double)A * B * 8);
-    transpose_kernel<float><<<grid, 256, 0, s>>>(hwc, chw, A, B);
+    launch_transpose<float>(hwc, chw, A, B, false, s);
     SRF_LAUNCH_CHECK("transpose_kernel");
     return 0;
 }
