@@ -214,6 +214,8 @@ def main():
 
     roof = roof_c = None
     kernels = []
+    # everything below is rank-0-only side measurement: no collective may be issued from here on (the other ranks are done)
+    model.grad_sync = model.grad_sync_async = None
     if rank == 0 and not args.no_roofline:
         lib = _capi.load()
         torch.cuda.synchronize()
