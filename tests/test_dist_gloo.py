@@ -40,6 +40,11 @@ def _worker(rank, world, port, out):
     flat = torch.full((5,), float(rank + 1))
     sdist.allreduce_mean_(flat)                       # the hook bench.py installs as model.grad_sync
     assert torch.allclose(flat, torch.full((5,), (1 + world) / 2.0))
+    flat2 = torch.full((5,), float(10 * (rank + 1)))
+    finish = sdist.allreduce_mean_async(flat2)        # ... and its early form (model.grad_sync_async): start now, finish later
+    assert callable(finish)
+    finish()
+    assert torch.allclose(flat2, torch.full((5,), 10 * (1 + world) / 2.0))
     torch.save(dict(local=local, reduced=[p.grad.clone() for p in lin.parameters()], shard=(b, e)), out % rank)
     dist.destroy_process_group()
 
