@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SCENERF_HIP_ABI_VERSION 2
+#define SCENERF_HIP_ABI_VERSION 3
 #define SCENERF_N_SCALES 5          /* feature maps "1_1","1_2","1_4","1_8","1_16" */
 #define SCENERF_D_LATENT 2480       /* 80+160+320+640+1280 (resnetfc d_latent, scenerf.py:100-114) */
 #define SCENERF_D_HIDDEN 512
@@ -62,6 +62,10 @@ typedef struct scenerf_cfg {
     int32_t map_H[SCENERF_N_SCALES], map_W[SCENERF_N_SCALES]; /* round(H/s), round(W/s): unet2d_sphere.py:139 */
     int32_t div_H[SCENERF_N_SCALES], div_W[SCENERF_N_SCALES]; /* H//s, W//s: scenerf.py:525 */
     int32_t precision;              /* 0 fp32, 1 bf16 operands */
+    int32_t map_chw[SCENERF_N_SCALES]; /* 1: scale s is NOT converted -- gather_features reads the caller's fp32 (C,H,W) map and the
+                                          feature gradient is scattered into an fp32 (C,H,W) buffer (slow per access, meant for the coarse
+                                          scales that quirk Q1 keeps out of range for all but <= 1/s^2 of the sphere) ; 0: (H,W,C) act copy
+                                          and (H,W,C) fp32 gradient accumulator */
 } scenerf_cfg;
 
 /* Packed ResnetFC operands (built by the host from the nn.Linear parameters).

@@ -22,7 +22,7 @@ D_HIDDEN = 512
 D_XENC = 48
 TILE_ROWS = 128
 W_STREAM_BLOCKS = (3 * D_XENC + D_LATENT) // 16 + 2 * ((512 + D_LATENT) // 16) + 10 * (512 // 16)   # scenerf_hip.h
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 vp = C.c_void_p
 
@@ -37,6 +37,7 @@ class Cfg(C.Structure):
         ("map_C", C.c_int32 * N_SCALES), ("map_H", C.c_int32 * N_SCALES), ("map_W", C.c_int32 * N_SCALES),
         ("div_H", C.c_int32 * N_SCALES), ("div_W", C.c_int32 * N_SCALES),
         ("precision", C.c_int32),
+        ("map_chw", C.c_int32 * N_SCALES),
     ]
 
 

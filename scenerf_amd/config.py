@@ -39,6 +39,14 @@ class RenderConfig:
     kl_std_floor: float = 1.5    # ray_som_kl.py:83
     precision: str = "bf16"      # "bf16": bf16 GEMM operands / fp32 accumulate; "fp32": fp32 MFMA everywhere
     device_rng: bool = False     # False: gaussian noise drawn on CPU like the reference (utils.py:208-211)
+    # pyramid levels (indices into FEAT_SCALES) that are NOT converted to (H,W,C): the gather reads the caller's fp32 (C,H,W) map
+    # and the feature gradient lands in a (C,H,W) buffer directly.  Quirk Q1 (full-resolution sample index against a down-scaled
+    # divisor, scenerf.py:522-525) keeps scale 1/s in range for at most 1/s^2 of the sphere (KITTI geometry: 0.14 % of the samples
+    # at 1/4, none at 1/8 and 1/16), so for the two coarsest levels the per-image conversion, the accumulator transpose and the
+    # half-precision copy cost more than the (rare to absent) strided accesses.  Measured at KITTI: (3, 4) saves 45 us per step;
+    # adding level 2 saves 80 us more in conversions but its 0.14 % of samples cluster in a few row tiles whose 1280 strided
+    # cache-line reads per sample stretch the gather by 100 us.
+    direct_scales: Tuple[int, ...] = (3, 4)
 
     # ---- derived -----------------------------------------------------------------------------------------
     @property
@@ -92,6 +100,8 @@ class RenderConfig:
             c.map_C[i], c.map_H[i], c.map_W[i] = ch, h, w
             c.div_H[i], c.div_W[i] = self.sphere_H // s, self.sphere_W // s   # scenerf.py:525
         c.precision = self.precision_code
+        for i in range(5):
+            c.map_chw[i] = 1 if i in self.direct_scales else 0
         return c
 
     @staticmethod

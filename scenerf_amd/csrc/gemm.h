@@ -34,6 +34,7 @@ struct GemmNT {
     // scatter epilogue (grid_sampler backward): out is ignored; v * tap_weight is atomically added to
     // gmap[texel][n] for the 4 taps of row m at scale `scatter_scale`
     float* gmap = nullptr;
+    long gmap_st = 0, gmap_sc = 1;   // element strides of gmap per texel / per channel: (N, 1) for (H,W,C) [gmap_st == 0 means N], (1, H*W) for (C,H,W)
     const int32_t* tap_texel = nullptr;
     const float* tap_weight = nullptr;
     int scatter_scale = -1;

@@ -209,6 +209,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16_t (&acc)[2][
             // serialise in L2 -- so rows of a wave's contiguous block with identical taps are summed first and
             // scattered once.
             constexpr int RPW = BM / (NT / 64);
+            const size_t gst = p.gmap_st ? (size_t)p.gmap_st : (size_t)p.N;
             int r = wv * RPW;
             const int rend = min(r + RPW, p.M - m0);
             while (r < rend) {
@@ -225,7 +226,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16_t (&acc)[2][
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
                                 const int tx = s_tx[r * 4 + t];
-                                if (tx >= 0) unsafeAtomicAdd(p.gmap + (size_t)tx * p.N + n, v * s_tw[r * 4 + t]);
+                                if (tx >= 0) unsafeAtomicAdd(p.gmap + (size_t)tx * gst + (size_t)n * p.gmap_sc, v * s_tw[r * 4 + t]);
                             }
                         }
                     }

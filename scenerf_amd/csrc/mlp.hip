@@ -230,6 +230,7 @@ static int feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
         g.M = M; g.N = cfg->map_C[sc];
         g.tile_mask = tile_mask; g.skip_bit = sc;
         g.gmap = gmaps_hwc[sc]; g.tap_texel = tap_texel; g.tap_weight = tap_weight; g.scatter_scale = sc;
+        if (cfg->map_chw[sc]) { g.gmap_st = 1; g.gmap_sc = (long)cfg->map_H[sc] * cfg->map_W[sc]; }   // (C,H,W) gradient buffer
         if (int e = launch_gemm_nt(cfg->precision, g, s)) return e;
     }
     return 0;

@@ -122,6 +122,7 @@ __global__ void encode_points_kernel(const float* __restrict__ dist, int dist_ra
 // ------------------------------------------------------------------------------------------------ gather
 struct GatherConsts {
     int C[5], Hm[5], Wm[5], Hd[5], Wd[5], off[5];
+    int chw[5];   // scale read from the caller's fp32 (C,H,W) map instead of an (H,W,C) copy (scenerf_cfg.map_chw)
 };
 
 template <typename T> struct Vec16;  // 16-byte vector of T
@@ -158,9 +159,13 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
     __shared__ int s_tex[SCENERF_TILE_ROWS][5][4];
     __shared__ float s_w[SCENERF_TILE_ROWS][5][4];
     __shared__ unsigned s_mask;
+    __shared__ uint8_t s_rowbits[SCENERF_TILE_ROWS];   // per row: scales with at least one in-range tap
+    __shared__ uint8_t s_list[5][SCENERF_TILE_ROWS];   // per scale: the rows with taps, compacted (direct (C,H,W) scales)
+    __shared__ int s_cnt[5];
     const int tile = blockIdx.x;
     const int tid = threadIdx.x;
     if (tid == 0) s_mask = 0u;
+    if (tid < 5) s_cnt[tid] = 0;
     __syncthreads();
     if (tid < SCENERF_TILE_ROWS) {
         int m = tile * SCENERF_TILE_ROWS + tid;
@@ -208,6 +213,9 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
                 s_w[tid][s][t] = w[t];
             }
         }
+        s_rowbits[tid] = (uint8_t)bits;
+        for (int sc = 0; sc < 5; ++sc)
+            if (gc.chw[sc] && ((bits >> sc) & 1u)) s_list[sc][atomicAdd(&s_cnt[sc], 1)] = (uint8_t)tid;
         if (bits) atomicOr(&s_mask, bits);
     }
     __syncthreads();
@@ -234,6 +242,41 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
         }
         const int C = gc.C[s];
         const int chunks = C / VN;
+        if (gc.chw[s]) {
+            // this scale was not converted: blend straight from the caller's fp32 (C,H,W) map.  Rows without a tap (nearly all of
+            // them at the coarse scales) get their zeros from the vector loop; a row with taps spreads its C x 4 strided loads
+            // over the whole workgroup -- they are independent cache lines, so parallelism is what hides them
+            const float* chw = (const float*)maps.p[s];
+            const size_t HW = (size_t)gc.Hm[s] * gc.Wm[s];
+            {
+                float z[VN];
+#pragma unroll
+                for (int e = 0; e < VN; ++e) z[e] = 0.f;
+                for (int it = tid; it < SCENERF_TILE_ROWS * chunks; it += 256) {
+                    const int row = it / chunks, ch = it - row * chunks;
+                    if (!((s_rowbits[row] >> s) & 1u))
+                        Vec16<T>::store(Z + ((size_t)tile * SCENERF_TILE_ROWS + row) * SCENERF_D_LATENT + gc.off[s] + ch * VN, z);
+                }
+            }
+            // all (row with taps, channel) pairs of the tile in one flat loop: every load of the workgroup is independent
+            const int nv = s_cnt[s];
+            for (int idx = tid; idx < nv * C; idx += 256) {
+                const int row = s_list[s][idx / C], c = idx % C;
+                float acc = 0.f;
+                bool first = true;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int tx = s_tex[row][s][t];
+                    if (tx >= 0) {
+                        const float v = chw[(size_t)c * HW + tx], w = s_w[row][s][t];
+                        acc = first ? v * w : fmaf(v, w, acc);
+                        first = false;
+                    }
+                }
+                ActIO<T>::st(Z + ((size_t)tile * SCENERF_TILE_ROWS + row) * SCENERF_D_LATENT + gc.off[s], c, acc);
+            }
+            continue;
+        }
         const T* map = (const T*)maps.p[s];
         const int items = SCENERF_TILE_ROWS * chunks;
         for (int it = tid; it < items; it += 256) {
@@ -819,6 +862,7 @@ static GatherConsts make_gc(const scenerf_cfg* cfg) {
         gc.Hd[s] = cfg->div_H[s];
         gc.Wd[s] = cfg->div_W[s];
         gc.off[s] = off;
+        gc.chw[s] = cfg->map_chw[s];
         off += cfg->map_C[s];
     }
     return gc;

@@ -85,16 +85,21 @@ class MapHolder:
                     i, tuple(t.shape), want[i], self.cfg.sphere_W, self.cfg.sphere_H))
             src = _f32c(t)
             c, h, w = src.shape
-            dst = torch.empty((h, w, c), dtype=_act_dtype(prec), device=src.device)
-            _capi.check(lib.scenerf_hip_maps_chw_to_hwc(src.data_ptr(), dst.data_ptr(), c, h, w, prec, _stream()),
-                        "maps_chw_to_hwc")
+            if i in self.cfg.direct_scales:
+                dst = src   # read in place, (C,H,W) fp32 (RenderConfig.direct_scales)
+            else:
+                dst = torch.empty((h, w, c), dtype=_act_dtype(prec), device=src.device)
+                _capi.check(lib.scenerf_hip_maps_chw_to_hwc(src.data_ptr(), dst.data_ptr(), c, h, w, prec, _stream()),
+                            "maps_chw_to_hwc")
             self.hwc.append(dst)
             self.shapes.append((c, h, w))
 
     def grad_accumulators(self) -> List[torch.Tensor]:
         if self.gmaps is None:
             dev = self.hwc[0].device
-            self.gmaps = [torch.zeros((h, w, c), dtype=torch.float32, device=dev) for (c, h, w) in self.shapes]
+            # (H,W,C) accumulators, transposed once at the end; the direct scales accumulate in the (C,H,W) result itself
+            self.gmaps = [torch.zeros((c, h, w) if i in self.cfg.direct_scales else (h, w, c), dtype=torch.float32, device=dev)
+                          for i, (c, h, w) in enumerate(self.shapes)]
         return self.gmaps
 
     def map_ptr_array(self):
@@ -121,6 +126,9 @@ class PrepareMaps(torch.autograd.Function):
         for i, (c, h, w) in enumerate(holder.shapes):
             if not ctx.needs_input_grad[1 + i]:
                 outs.append(None)
+                continue
+            if i in holder.cfg.direct_scales:
+                outs.append(holder.gmaps[i])
                 continue
             g = torch.empty((c, h, w), dtype=torch.float32, device=holder.gmaps[i].device)
             _capi.check(lib.scenerf_hip_grads_hwc_to_chw(holder.gmaps[i].data_ptr(), g.data_ptr(), c, h, w, _stream()),

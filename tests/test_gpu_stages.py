@@ -196,12 +196,13 @@ def test_gather_features(case, precision):
     prec = rcfg.precision_code
     act = torch.bfloat16 if prec else torch.float32
     hwc = []
-    for (c, h, w), key in zip(rcfg.map_shapes(), ["1_1", "1_2", "1_4", "1_8", "1_16"]):
+    for i, ((c, h, w), key) in enumerate(zip(rcfg.map_shapes(), ["1_1", "1_2", "1_4", "1_8", "1_16"])):
         src = dv(case["maps"][key])
         dst = torch.empty((h, w, c), dtype=act, device=DEV)
         _capi.check(lib.scenerf_hip_maps_chw_to_hwc(src.data_ptr(), dst.data_ptr(), c, h, w, prec, _st()), "maps_chw_to_hwc")
         torch.testing.assert_close(dst.float().cpu(), case["maps"][key].permute(1, 2, 0).to(act).float(), rtol=0, atol=0)
-        hwc.append(dst)
+        # RenderConfig.direct_scales: the coarse levels are gathered from the fp32 (C,H,W) tensor itself (scenerf_cfg.map_chw)
+        hwc.append(src if i in rcfg.direct_scales else dst)
     idx = o["_idx"].to(torch.int32)
     M = idx.shape[0]
     Mpad = (M + 127) // 128 * 128
