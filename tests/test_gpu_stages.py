@@ -582,3 +582,72 @@ def test_mlp_backward_fused_matches_layer_path(case, M):
     for n, x, y in zip(MLP_PARAM_NAMES, ga, gb):
         rel = float((x - y).norm() / max(float(x.norm()), 1e-20))
         assert rel <= 1.5e-2, "%s: relative L2 difference %.3e" % (n, rel)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_direct_chw_scales_match_the_converted_path(case, precision):
+    """scenerf_cfg.map_chw (RenderConfig.direct_scales): a pyramid level read from the caller's fp32 (C,H,W) tensor and scattered into a
+    (C,H,W) gradient buffer must give what the (H,W,C) copy + accumulator + transpose give.  The sample indices are drawn small
+    enough to be in range of EVERY scale (quirk Q1 keeps the coarse ones out of range in the real geometry, so nothing else
+    exercises their taps)."""
+    import dataclasses
+    from scenerf_amd.renderer import MLP_PARAM_NAMES, PackedMLP
+    lib = _capi.load()
+    g = case["g"]
+    _, rcfg0 = _cfgs(g, precision)
+    prec = rcfg0.precision_code
+    act = torch.bfloat16 if prec else torch.float32
+    shapes = rcfg0.map_shapes()
+    gen = torch.Generator().manual_seed(17)
+    M = 1000
+    W16, H16 = rcfg0.sphere_W // 16, rcfg0.sphere_H // 16
+    idx = torch.stack([torch.randint(0, W16 + 2, (M,), generator=gen), torch.randint(0, H16 + 2, (M,), generator=gen)], dim=1).to(torch.int32)
+    idx[::7] = torch.tensor([rcfg0.sphere_W - 1, rcfg0.sphere_H - 1], dtype=torch.int32)   # some rows out of range of the coarse scales
+    maps = [dv(case["maps"][k]) for k in ["1_1", "1_2", "1_4", "1_8", "1_16"]]
+    params = [dv(case["mlp"][n]) for n in MLP_PARAM_NAMES]
+    dH = dv((torch.randn(M, 2048, generator=gen) * 0.1), act)
+    Mpad = (M + 127) // 128 * 128
+    res = {}
+    for name, direct in (("converted", ()), ("direct", (2, 3, 4))):
+        rcfg = dataclasses.replace(rcfg0, direct_scales=direct)
+        cc = rcfg.to_c()
+        srcs = []
+        for i, ((c, h, w), src) in enumerate(zip(shapes, maps)):
+            if i in direct:
+                srcs.append(src)
+            else:
+                dst = torch.empty((h, w, c), dtype=act, device=DEV)
+                _capi.check(lib.scenerf_hip_maps_chw_to_hwc(src.data_ptr(), dst.data_ptr(), c, h, w, prec, _st()), "maps_chw_to_hwc")
+                srcs.append(dst)
+        Z = torch.zeros((Mpad, 2480), dtype=act, device=DEV)
+        mask = torch.zeros((Mpad // 128,), dtype=torch.uint8, device=DEV)
+        tex = torch.empty((M, 5, 4), dtype=torch.int32, device=DEV)
+        tw = torch.empty((M, 5, 4), device=DEV)
+        arr = (C.c_void_p * 5)(*[t.data_ptr() for t in srcs])
+        _capi.check(lib.scenerf_hip_gather_features(C.byref(cc), C.byref(arr), dv(idx).data_ptr(), M, Z.data_ptr(), mask.data_ptr(),
+                                                    tex.data_ptr(), tw.data_ptr(), _st()), "gather_features")
+        assert int(mask.max()) == 31, "the drawn indices must reach every scale"
+        pk = PackedMLP(params, 4, rcfg)
+        gm = [torch.zeros((c, h, w) if i in direct else (h, w, c), device=DEV) for i, (c, h, w) in enumerate(shapes)]
+        garr = (C.c_void_p * 5)(*[t.data_ptr() for t in gm])
+        _capi.check(lib.scenerf_hip_mlp_feature_grads(C.byref(cc), C.byref(pk.c), mask.data_ptr(), tex.data_ptr(), tw.data_ptr(), M,
+                                                      dH.data_ptr(), C.byref(garr), _st()), "mlp_feature_grads")
+        grads = []
+        for i, (c, h, w) in enumerate(shapes):
+            if i in direct:
+                grads.append(gm[i])
+            else:
+                out = torch.empty((c, h, w), device=DEV)
+                _capi.check(lib.scenerf_hip_grads_hwc_to_chw(gm[i].data_ptr(), out.data_ptr(), c, h, w, _st()), "grads_hwc_to_chw")
+                grads.append(out)
+        torch.cuda.synchronize()
+        res[name] = (Z[:M].float().cpu(), [x.cpu() for x in grads])
+    (Za, ga), (Zb, gb) = res["converted"], res["direct"]
+    if prec == 0:
+        assert torch.equal(Za, Zb)                      # same fp32 values, same blend order
+    else:
+        torch.testing.assert_close(Zb, Za, rtol=1.2e-2, atol=1.2e-2)   # the direct path blends un-rounded fp32 map values
+    for i, (x, y) in enumerate(zip(ga, gb)):
+        assert float(x.abs().max()) > 0, "scale %d received no gradient" % i
+        rel = float((x - y).norm() / x.norm())
+        assert rel <= (1e-5 if prec == 0 else 2e-2), "scale %d: relative L2 %.3e" % (i, rel)
