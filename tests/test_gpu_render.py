@@ -423,3 +423,41 @@ def test_full_size_config3_bundlefusion_fused_vs_layers_and_subset_parity():
         r = float((a - b).norm() / a.norm())
         assert r <= 2e-2, "%s: fused vs layers relative L2 %.3e" % (n, r)
     assert touched >= 2, "at least the two finest pyramid scales receive gradient (quirk Q1 keeps the coarse ones out of range)"
+
+
+@pytest.mark.gpu
+def test_chunked_call_equals_single_chunk_on_the_fused_path():
+    """render_rays_batch in two chunks of 128 rays (8,192 rows each: fused kernels) against one chunk of 256 rays with the same pixels
+    and noise: rays are independent, so the outputs must agree to bf16-kernel reproducibility, and the gradients -- accumulated
+    across the chunks in the same packed sinks / map accumulators -- to atomic-ordering noise."""
+    from scenerf_amd import synth
+    kw = dict(sphere_W=376, sphere_H=114, n_pts_uni=32, n_pts_per_gaussian=8)
+    R = 256
+    mlp, mlpg = synth.mlp_state(81, 4), synth.mlp_state(82, 2, out_scale=4.0)
+    maps = synth.feature_maps(376, 114, 83, smooth=True)
+    pix = synth.stride2_pixels((1220, 370), R, 84).to(DEV)
+    nu, ng = synth.sampling_noise(R, 32, 32, 85)
+    nu, ng = nu.to(DEV), ng.to(DEV)
+    K, T = synth.kitti_cam_K().to(DEV), synth.rel_pose(2.0, 10.0).to(DEV)
+    res = {}
+    for chunk in (R, R // 2):
+        m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="bf16", **kw).to(DEV)
+        m.mlp.load_state_dict(mlp)
+        m.mlp_gaussian.load_state_dict(mlpg)
+        x = {k: v.to(DEV).requires_grad_(True) for k, v in maps.items()}
+        out = m.render_rays_batch(K, T, x, sampled_pixels=pix, ray_batch_size=chunk, noise=(nu, ng))
+        (out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()).backward()
+        g = {"mlp." + n: p.grad for n, p in m.mlp.named_parameters()}
+        g.update({"mlpg." + n: p.grad for n, p in m.mlp_gaussian.named_parameters()})
+        g.update({"map." + k: v.grad for k, v in x.items()})
+        res[chunk] = ({k: v.detach() for k, v in out.items()}, g)
+    (o1, g1), (o2, g2) = res[R], res[R // 2]
+    for k in ("depth", "color", "loss_kl", "gaussian_means", "weights"):
+        torch.testing.assert_close(o2[k], o1[k], rtol=1e-3, atol=1e-3, msg=lambda s_, k=k: "%s: %s" % (k, s_))
+    for n in g1:
+        a, b = g1[n].double(), g2[n].double()
+        if float(a.norm()) == 0.0:
+            assert float(b.norm()) == 0.0, n
+            continue
+        r = float((a - b).norm() / a.norm())
+        assert r <= 2e-3, "%s: chunked vs single relative L2 %.3e" % (n, r)
