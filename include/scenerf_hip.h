@@ -259,6 +259,18 @@ typedef struct scenerf_prof_rec {
 } scenerf_prof_rec;
 int scenerf_hip_profile_collect(scenerf_prof_rec* out_host, int cap);
 
+/* ---- TSDF fusion (off the render path) ------------------------------------------------- */
+/* One RGB-D frame into a voxel volume: the reference's pycuda kernel (scenerf/data/utils/fusion.py:72-145, semantics 0: truncated,
+ * normalised distance, running weighted average of distance and colour, fp32) or the CPU path next to it (fusion.py:236-325,
+ * semantics 1: metric distance, a voxel keeps the observation of smallest magnitude and its colour, float64 projection with
+ * round-half-even; needs cam_pose_inv = inverse(cam_pose) in float64, which the reference computes with numpy).  Volumes:
+ * device fp32 [X][Y][Z] C-order, tsdf initialised to 255, weight and colour to 0 (fusion.py:52-56).  color_im: device fp32
+ * [im_h][im_w] folded as floor(b*65536 + g*256 + r) (fusion.py:219-220); depth_im: device fp32 [im_h][im_w], 0 = invalid. */
+int scenerf_hip_tsdf_integrate(float* tsdf_vol, float* weight_vol, float* color_vol, const int32_t vol_dim[3],
+                               const float vol_origin[3], double voxel_size, const float cam_intr[9], const float cam_pose[16],
+                               const double cam_pose_inv[16], const float* color_im, const float* depth_im, int im_h, int im_w,
+                               float trunc_margin, float obs_weight, int semantics, scenerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
