@@ -121,10 +121,20 @@ class SphericalMapping(nn.Module):
         self.h_fov = abs(h_angle_max - h_angle_min)
         self.v_fov = abs(v_angle_max - v_angle_min)
 
+    def _full_grid(self, like: torch.Tensor) -> torch.Tensor:
+        """All (u, v) pixel coordinates of the image, built once per (device, dtype): the reference rebuilds the 451k-point meshgrid on
+        the CPU and uploads it on every step (spherical_mapping.py:84-90)."""
+        key = (like.device, like.dtype)
+        cache = self.__dict__.setdefault("_grid_cache", {})
+        if key not in cache:
+            ys, xs = torch.meshgrid(torch.arange(self.img_H, device=like.device), torch.arange(self.img_W, device=like.device),
+                                    indexing="ij")
+            cache[key] = torch.stack([xs.reshape(-1), ys.reshape(-1)], 1).to(like.dtype)
+        return cache[key]
+
     def from_pixels(self, inv_K, pix_coords=None):
         if pix_coords is None:
-            ys, xs = torch.meshgrid(torch.arange(self.img_H), torch.arange(self.img_W), indexing="ij")
-            pix_coords = torch.stack([xs.reshape(-1), ys.reshape(-1)], 1).to(inv_K)
+            pix_coords = self._full_grid(inv_K)
         homo = torch.cat([pix_coords, torch.ones_like(pix_coords[:, :1])], dim=1)
         cam = (inv_K @ homo.T).T
         dist = torch.linalg.norm(cam, ord=2, dim=1)

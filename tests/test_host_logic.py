@@ -120,3 +120,33 @@ def test_synthetic_inputs_are_deterministic():
     p = synth.stride2_pixels((1220, 370), 100, 3)
     assert p.shape == (100, 2) and float(p[:, 0].max()) <= 1218 and bool(((p % 2) == 0).all())
     assert len({(float(u), float(v)) for u, v in p}) == 100
+
+
+def test_spherical_mapping_from_pixels_matches_reference_formula_and_caches_the_grid():
+    """SphericalMapping.from_pixels (encoder-side, spherical_mapping.py:80-115): full-image call equals the explicit-coordinates call,
+    and the pixel grid is built once."""
+    import math
+    import torch
+    from scenerf_amd import synth
+    from scenerf_amd.model import SceneRF
+    m = SceneRF(som_sigma=2.0, add_fov_hor=20, add_fov_ver=8, img_size=(61, 19), sphere_W=75, sphere_H=23)
+    K = synth.kitti_cam_K().clone()
+    K[0, 0] = K[1, 1] = 36.0; K[0, 2] = 30.0; K[1, 2] = 9.0
+    inv_K = torch.inverse(K)
+    pix, sph, dist = m.spherical_mapping.from_pixels(inv_K=inv_K)
+    assert pix.shape == (61 * 19, 2) and sph.dtype == torch.long
+    grid_a = m.spherical_mapping._full_grid(inv_K)
+    pix2, sph2, dist2 = m.spherical_mapping.from_pixels(inv_K=inv_K)
+    assert m.spherical_mapping._full_grid(inv_K) is grid_a            # cached
+    assert torch.equal(sph, sph2) and torch.equal(dist, dist2)
+    # explicit coordinates, straight from the reference's formulas
+    ys, xs = torch.meshgrid(torch.arange(19), torch.arange(61), indexing="ij")
+    pc = torch.stack([xs.reshape(-1), ys.reshape(-1)], 1).float()
+    _, sph3, _ = m.spherical_mapping.from_pixels(inv_K=inv_K, pix_coords=pc)
+    assert torch.equal(sph, sph3)
+    cam = (inv_K @ torch.cat([pc, torch.ones(len(pc), 1)], 1).T).T
+    d = cam.norm(dim=1)
+    v = torch.acos(-cam[:, 1] / d) / math.pi * 180
+    sm = m.spherical_mapping
+    py = torch.round((v - sm.v_angle_min) / sm.v_fov * (sm.out_img_H - 1)).long()
+    assert torch.equal(sph[:, 1], py)
