@@ -1,5 +1,6 @@
-// Fused ResnetFC forward for gfx950 (bf16 operands): ONE kernel evaluates the whole 7-GEMM trunk (lin_in + lin_z.0, then three
-// residual blocks fc_0 / fc_1 + lin_z.b) for a block of 64 rows.  reference scenerf/models/resnetfc.py:133-164.
+// Fused ResnetFC kernels for gfx950 (bf16 operands).  MODE 0: ONE kernel evaluates the whole 7-GEMM forward trunk (lin_in + lin_z.0,
+// then three residual blocks fc_0 / fc_1 + lin_z.b) and lin_out for a block of 64 rows; MODE 1: the 6-GEMM dgrad chain of the
+// blocks in the backward pass, same pipeline (see the kernel's comment).  reference scenerf/models/resnetfc.py:41-57,133-164.
 //
 // Why: the per-layer GEMMs (gemm.hip) are HBM-limited -- a K = 512 hidden layer with bf16 activations in HBM has an
 // arithmetic intensity of only ~170 FLOP/B.  Here the 512-wide residual stream never leaves the chip:
