@@ -271,6 +271,24 @@ int scenerf_hip_tsdf_integrate(float* tsdf_vol, float* weight_vol, float* color_
                                const double cam_pose_inv[16], const float* color_im, const float* depth_im, int im_h, int im_w,
                                float trunc_margin, float obs_weight, int semantics, scenerf_stream_t stream);
 
+/* ---- image -> sphere resampling of the encoder levels --------------------------------------------------------
+ * Replaces DecoderSphere.get_sphere_feature (reference scenerf/models/unet2d_sphere.py:138-165; six calls per image).
+ * map_build  = :140-147, the scatter of `pix // scale` into the (out_w x out_h) sphere grid at round(pix_sphere / scale)
+ *              (clamped); duplicate cells: the LAST pixel wins (the reference's single-thread CPU result; undefined on its GPU
+ *              path).  pix: device fp32 [n_pix][2] (x, y); pix_sphere: device int64 [n_pix][2]; winner: device scratch
+ *              int32 [out_h*out_w]; src: device int32 [out_h][out_w] = (sy << 16 | sx) or -1 for an empty cell.  out_w / out_h
+ *              are the level's dims, round(out_img_W / scale) and round(out_img_H / scale) (Python round) -- the caller's job.
+ * forward    = :149-165 (normalise + F.grid_sample bilinear/zeros/align_corners=False + permute): x device fp32
+ *              [planes][H][W] (planes = B*C), out device fp32 [planes][out_h][out_w], written in full (empty cells = 0).
+ * backward   = the adjoint w.r.t. x in gather form: row_ptr device int32 [(H+1)*(W+1)+1], cells device int32 [n_mapped] = the
+ *              mapped cells grouped by source pixel sy*(W+1)+sx (sy <= H, sx <= W), ascending inside a group; dx device fp32 [planes][H][W], written in full. */
+int scenerf_hip_sphere_map_build(const float* pix, const int64_t* pix_sphere, int64_t n_pix, int scale, int out_w, int out_h,
+                                 int32_t* winner, int32_t* src, scenerf_stream_t stream);
+int scenerf_hip_sphere_resample_forward(const float* x, int64_t planes, int H, int W, const int32_t* src, int out_w, int out_h,
+                                        float* out, scenerf_stream_t stream);
+int scenerf_hip_sphere_resample_backward(const float* dout, int64_t planes, int H, int W, const int32_t* row_ptr, const int32_t* cells,
+                                         int out_w, int out_h, float* dx, scenerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

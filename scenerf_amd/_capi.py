@@ -95,6 +95,9 @@ _PROTOS = {
     "scenerf_hip_tsdf_integrate": (C.c_int, [vp, vp, vp, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_float * 3), C.c_double,
                                              C.POINTER(C.c_float * 9), C.POINTER(C.c_float * 16), C.POINTER(C.c_double * 16), vp, vp,
                                              i32, i32, C.c_float, C.c_float, i32, vp]),
+    "scenerf_hip_sphere_map_build": (C.c_int, [vp, vp, C.c_int64, i32, i32, i32, vp, vp, vp]),
+    "scenerf_hip_sphere_resample_forward": (C.c_int, [vp, C.c_int64, i32, i32, vp, i32, i32, vp, vp]),
+    "scenerf_hip_sphere_resample_backward": (C.c_int, [vp, C.c_int64, i32, i32, vp, vp, i32, i32, vp, vp]),
     "scenerf_hip_mlp_feature_grads": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpWeights), vp, vp, vp, i32, vp,
                                                 C.POINTER(vp * N_SCALES), vp]),
     "scenerf_hip_gaussian_sample_sort": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),

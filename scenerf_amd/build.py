@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libscenerf_hip.so")
-SOURCES = ["runtime.hip", "rays.hip", "gemm.hip", "wgrad.hip", "fused.hip", "mlp.hip", "tsdf.hip"]
+SOURCES = ["runtime.hip", "rays.hip", "gemm.hip", "wgrad.hip", "fused.hip", "mlp.hip", "tsdf.hip", "sphere.hip"]
 HEADERS = ["common.h", "gemm.h", os.path.join("..", "..", "include", "scenerf_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
