@@ -14,7 +14,8 @@ from typing import Optional
 import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libscenerf_hip.so")
+_TAG = os.environ.get("SRF_LIB_TAG", "")      # development only: a variant library built with SRF_LIB_TAG / SRF_EXTRA_FLAGS (build.py)
+LIB_PATH = os.path.join(HERE, "csrc", "libscenerf_hip%s.so" % ("_" + _TAG if _TAG else ""))
 
 N_SCALES = 5
 D_LATENT = 2480

@@ -12,11 +12,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(CSRC, "libscenerf_hip.so")
+# development knobs (kernel experiments, tools/variants.sh): extra -D flags build a separately named library next to the default one
+_TAG = os.environ.get("SRF_LIB_TAG", "")
+LIB = os.path.join(CSRC, "libscenerf_hip%s.so" % ("_" + _TAG if _TAG else ""))
 SOURCES = ["runtime.hip", "rays.hip", "gemm.hip", "wgrad.hip", "fused.hip", "mlp.hip", "tsdf.hip", "sphere.hip"]
 HEADERS = ["common.h", "gemm.h", os.path.join("..", "..", "include", "scenerf_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("SRF_EXTRA_FLAGS", "").split()
 
 
 def _hipcc() -> str:
@@ -53,7 +55,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, src.replace(".hip", (("_" + _TAG) if _TAG else "") + ".o"))
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

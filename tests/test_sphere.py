@@ -199,8 +199,12 @@ def test_hip_against_torch_grid_sample_at_kitti_size():
         ref = ref.reshape(1, C, m.out_w, m.out_h).permute(0, 1, 3, 2)
         ref.backward(dout)
         assert tuple(out.shape) == tuple(ref.shape)
-        assert (out - ref).abs().max().item() <= 2e-6, "level %d forward" % s
-        assert (x.grad - x2.grad).abs().max().item() <= 2e-5, "level %d backward" % s          # torch sums with atomics, in any order
+        # torch's GPU kernel contracts ((g + 1) * W - 1) / 2 into an fma: its sample point differs from the eager-CPU sequence (which the
+        # oracle and the HIP kernel follow bit for bit) by up to half an ulp of 2 W, and so do the bilinear weights -- 6e-5 at W = 1220.
+        tol = max(2e-6, 3.0 * w * 2.0 ** -23 * float(x.detach().abs().max()))
+        ef, eb = (out - ref).abs().max().item(), (x.grad - x2.grad).abs().max().item()
+        assert ef <= tol, "level %d forward: %g > %g" % (s, ef, tol)
+        assert eb <= 6 * tol, "level %d backward: %g > %g" % (s, eb, 6 * tol)    # up to ~6 cells per pixel; torch sums them with atomics
         lhs = (out.double() * dout.double()).sum().item(); rhs = (x.detach().double() * x.grad.double()).sum().item()
         assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs)), "level %d adjoint" % s
         g1 = x.grad.clone(); x.grad = None
