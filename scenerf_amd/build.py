@@ -15,8 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 # development knobs (kernel experiments, tools/variants.sh): extra -D flags build a separately named library next to the default one
 _TAG = os.environ.get("SRF_LIB_TAG", "")
 LIB = os.path.join(CSRC, "libscenerf_hip%s.so" % ("_" + _TAG if _TAG else ""))
-SOURCES = ["runtime.hip", "rays.hip", "gemm.hip", "wgrad.hip", "fused.hip", "mlp.hip", "tsdf.hip", "sphere.hip"]
-HEADERS = ["common.h", "gemm.h", os.path.join("..", "..", "include", "scenerf_hip.h")]
+SOURCES = ["runtime.hip", "rays.hip", "gemm.hip", "wgrad.hip", "fused.hip", "stream.hip", "mlp.hip", "tsdf.hip", "sphere.hip"]
+HEADERS = ["common.h", "gemm.h", "fused.h", os.path.join("..", "..", "include", "scenerf_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"] + os.environ.get("SRF_EXTRA_FLAGS", "").split()
 

@@ -17,19 +17,11 @@
 // One raw s_barrier per 16-element K chunk; per-chunk bookkeeping is ONE 32-bit descriptor read with a scalar load (the first
 // version spent ~45 SALU instructions per chunk per wave on cursors and was SALU-bound).  Scale segments a 128-row tile
 // does not touch are skipped (tile_mask).  Measured history in DESIGN.md §5.
-#include "gemm.h"
+#include "fused.h"
 #include <vector>
 #include <cstdio>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_f;
-typedef __attribute__((ext_vector_type(16))) float f32x16_f;
-
-#define F_BM 64
-#define F_BK 16                           // K elements per chunk (one MFMA k-step)
-#define F_AROW 1024                       // A-buffer row: 512 bf16
-#define F_ABUF (F_BM * F_AROW)            // 65536
 #define F_WSTG (512 * F_BK * 2)           // W stage: 512 output columns x 32 B
-#define F_A2STG (F_BM * F_BK * 2)         // streamed-A stage: 64 rows x 32 B
 #define F_STAGE (F_WSTG + F_A2STG)        // 18432
 #define F_NST 5                           // ring depth
 #define F_BIAS (F_ABUF + F_NST * F_STAGE) // 2 KiB: the next layer's bias
@@ -66,42 +58,6 @@ __device__ static inline uint32_t pk_min_u16(uint32_t a, uint32_t b) {   // v_pk
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(f_ushort2, a), __builtin_bit_cast(f_ushort2, b)));
 }
 
-struct FusedLayer {
-    const float* bias;   // forward: [512]
-    void* save;          // [M][save_ld] bf16: forward relu(output) (H_b or N_b); backward dN_b or the dH_b column block
-    uint8_t* sign;       // [Mpad][64] sign bits of the saved activation: forward writes its layer's, backward reads the gate of its output
-    int kind;            // forward 1: n = acc (fc_0), else h += acc ; backward 1: dN = acc*mask, else dh += acc*mask
-    int save_ld;         // row stride of `save` in elements
-};
-struct FusedArgs {
-    FusedLayer layer[7];
-    const void* Wst;     // w_stream: 16 KiB blocks, see scenerf_hip.h
-    const void* X3;      // forward: [M][144] bf16 split encoding
-    const void* Z;       // forward: [Mpad][2480] bf16
-    const void* dH3;     // backward: incoming gradient rows, [M][dH_ld] bf16 (column block 3 of the dH scratch)
-    int dH_ld;
-    const uint8_t* tile_mask;
-    const int* desc;     // [32][F_MAXCH] per tile mask: header {number of chunks}, chunk descriptors, zero padding
-    int M;
-    // forward: lin_out fused behind the last layer (resnetfc.py:162-163): logits[m][j] = relu(H3[m]) . w_out[j] + b_out[j]
-    const float* w_out;  // [d_out][512] fp32
-    const float* b_out;
-    float* logits;       // [M][d_out]
-    int d_out;
-};
-
-// One 32-bit descriptor per 16-wide K chunk (host-built per tile mask, read with scalar loads one step ahead):
-//   [0:9] w_stream block   [10:17] A column / 16   [18:19] src (0 = resident A buffer, 1 = X3, 2 = Z)   [20:22] layer
-//   [23] last chunk of its layer   [24] first chunk of its layer   [25:27] ring stage (chunk index mod 5)
-typedef const __attribute__((address_space(4))) int* desc_ptr;   // constant address space: descriptor reads are s_load
-#define FD_Z(d) ((d) & 1023)
-#define FD_Y(d) ((((d) >> 10) & 255) * F_BK)
-#define FD_SRC(d) (((d) >> 18) & 3)
-#define FD_LAYER(d) (((d) >> 20) & 7)
-#define FD_END(d) (((d) >> 23) & 1)
-#define FD_BEGIN(d) (((d) >> 24) & 1)
-#define FD_STAGE(d) (((d) >> 25) & 7)
-#define F_MAXCH 704     // 666 chunks with all five scales + header + zero padding (the pipeline reads a few entries past the end)
 
 #define F_THREADS 768   // 8 consumer waves (fragments + MFMA + epilogue) and 4 producer waves (one per SIMD: the weight stream)
 

@@ -66,6 +66,9 @@ int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
                          const scenerf_mlp_acts* a, hipStream_t s);
 // backward dgrad chain of the three residual blocks in one kernel (bf16): reads dH column block 3, writes dH column blocks 2..0 and
 // dN [3][M][512]; sign gates come from the saved activations a->Nn / a->H.
+// stream.hip: the register-streamed forward (same arguments and results as launch_mlp_fwd_fused, which it replaces by default)
+int launch_mlp_fwd_stream(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const uint8_t* tile_mask, int M,
+                          const scenerf_mlp_acts* a, hipStream_t s);
 int launch_mlp_bwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, int M, const scenerf_mlp_acts* a, void* dH, void* dN,
                          hipStream_t s);
 // wgrad.hip: bf16 weight-gradient GEMM on transposing LDS reads (256 x 256 output tiles, wave-specialised); launch_gemm_tn uses it

@@ -284,7 +284,12 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
         // rows from which the whole trunk runs as ONE fused kernel (fused.hip); read per call so a test can compare paths
         const char* fenv = getenv("SRF_FUSED_MIN_M");
         const int fused_min_m = fenv ? atoi(fenv) : 4096;
-        if (M >= fused_min_m && w->w_stream) return launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s);   // lin_out included
+        if (M >= fused_min_m && w->w_stream) {   // lin_out included
+            // two kernels with identical results: fused.hip's LDS-ring pipeline (default) and stream.hip's register-streamed one
+            const char* kv = getenv("SRF_FWD_KERNEL");
+            const bool stream = kv && kv[0] == 's';
+            return stream ? launch_mlp_fwd_stream(cfg, w, Z, tile_mask, M, a, s) : launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s);
+        }
         SRF_CHECK(a->H[3], "mlp_forward: acts->H[3] is NULL");
         SRF_CHECK(a->H[0] && a->H[1] && a->H[2] && a->Nn[0] && a->Nn[1] && a->Nn[2],
                   "mlp_forward: the per-layer path needs every activation buffer (NULL entries are for fused-kernel inference only)");

@@ -1,0 +1,458 @@
+// Register-streamed fused ResnetFC forward for gfx950 (bf16 operands): the whole 7-GEMM trunk (lin_in + lin_z.0, three residual
+// blocks fc_0 / fc_1 + lin_z.b) and lin_out for a block of 64 rows in ONE kernel.  reference scenerf/models/resnetfc.py:133-164.
+//
+// Same arithmetic, data layouts and HBM traffic as the LDS-ring kernel in fused.hip (which it replaces for the forward pass;
+// results are bit-identical), different plumbing.  What bound that kernel was the weight stream: every 64-row workgroup pulls each
+// layer's weights through L2 -> LDS DMA, only two 18-KiB chunks could be in flight (LDS holds the 64-KiB resident operand too) and
+// all twelve waves met at a barrier per 16-wide K chunk: ~850 cycles per chunk for 256 cycles of MFMA.  Here
+//   * there are 8 waves and NO weight ring in LDS: wave w owns output columns [64 w, 64 w + 64) for all 64 rows (2 x 2 MFMA
+//     32x32x16 tiles) and streams exactly ITS slice of w_stream (2 KiB per chunk: two coalesced 1-KiB global_load_dwordx4)
+//     straight into a 4-deep VGPR ring -- 64 KiB in flight per CU, nothing shared between waves, so the K loop of a hidden layer
+//     runs 32 chunks without a single barrier (tools/ubench/wreg_stream.hip: 390 cycles per chunk at 1.35 PFLOP/s for this shape);
+//   * the loads are plain C++ loads: hipcc counts vmcnt for them by itself once a scheduling barrier per step stops it from
+//     sinking them to their first use.  Therefore NO other load kind may sit in the loop (an LDS-DMA makes hipcc wait vmcnt(0)):
+//     the streamed activation operand of the lin_in / lin_z segments (X3 / Z rows, 2 KiB per chunk, shared by all waves) is
+//     register-staged -- a wave pair loads it six chunks ahead, writes it to one of eight small LDS stages two chunks ahead, and
+//     only those chunks start with a barrier; the activation / sign-bit stores are inline asm (the compiler must not see them:
+//     a pending store would turn every counted wait into vmcnt(0); hidden stores only make a counted wait more conservative);
+//   * layer ends fall on multiples of four chunks (host-padded with no-op chunks) so that the ring slot is static in the 4x
+//     unrolled loop and there is ONE epilogue site; biases of all layers and w_out sit in LDS from the start (104 KiB in all).
+#include "fused.h"
+#include <type_traits>
+#include <vector>
+#include <cstdio>
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_f;
+
+#define G_THREADS 512
+#define G_D 4                                  // weight ring depth in chunks = chunks per group of the chunk loop (8: no faster)
+#define G_NW 12                                // descriptor window: chunks c .. c + 11 (staging looks 9 ahead; 12 keeps the groups of
+                                               // four that join it inside one 64-entry block of the table)
+#define G_NSTG 8                               // streamed-operand stages (2 KiB each)
+#define G_STG F_ABUF                           // 65536
+#define G_BIAS (G_STG + G_NSTG * F_A2STG)      // 81920: 7 layers x 2 KiB
+#define G_WOUT (G_BIAS + 7 * 2048)             // 96256: w_out, <= 8 KiB
+#define G_TAB (G_WOUT + 8192)                  // 104448: this tile mask's chunk descriptors, <= 704 (+ 64 read slack)
+#define G_LDS (G_TAB + 768 * 4)                // 107520
+// descriptor bits as in fused.h except [25] = no-op chunk (padding: loads happen, MFMAs do not) and [26:28] = stage (chunk mod 8)
+#define GD_SKIP(d) (((d) >> 25) & 1)
+#define GD_STAGE(d) (((d) >> 26) & 7)
+
+__device__ static inline void g_store16(void* p, uint4 v) {
+    const u32x4_f t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(t) : "memory");
+}
+__device__ static inline void g_store1(void* p, uint32_t v) { asm volatile("global_store_byte %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+
+typedef unsigned short g_ushort2 __attribute__((ext_vector_type(2)));
+__device__ static inline uint32_t g_pk_min_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(g_ushort2, a), __builtin_bit_cast(g_ushort2, b)));
+}
+
+__global__ __launch_bounds__(G_THREADS) void mlp_stream_kernel(FusedArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* const Abuf = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const int m0 = blockIdx.x * F_BM;
+    const unsigned mask = __builtin_amdgcn_readfirstlane((unsigned)p.tile_mask[m0 / SCENERF_TILE_ROWS] & 31u);
+    desc_ptr D = (desc_ptr)(uintptr_t)(p.desc + mask * F_MAXCH);
+    const int nch = D[0];   // header: number of chunks (a multiple of 4); the descriptors follow, zero-padded
+    ++D;
+
+    // ---- one-time LDS contents: the biases of all seven layers, w_out
+    for (int i = tid; i < 7 * 128; i += G_THREADS)
+        *(float4*)(lds + G_BIAS + i * 16) = *(const float4*)(p.layer[i >> 7].bias + (i & 127) * 4);
+    if (p.logits && tid < p.d_out * (SCENERF_D_HIDDEN / 4)) *(float4*)(lds + G_WOUT + tid * 16) = *(const float4*)(p.w_out + tid * 4);
+    // the descriptors too: a scalar load per step shares lgkmcnt with the fragment reads and returns out of order, so every step
+    // would start by waiting out its latency (measured: ~2x on the whole kernel); from LDS, 64 at a time into one VGPR + v_readlane
+    int* const tab = (int*)(lds + G_TAB);
+    for (int i = tid; i < nch + G_NW + 8; i += G_THREADS) tab[i] = D[i];
+
+    // ---- weights: lane's 16 bytes of tile j of a 16-KiB w_stream block ([512 rows n][32 B], halves swapped when (n >> 3) & 1)
+    const uint4* const Wb = (const uint4*)p.Wst;
+    const int woff = (wvu * 64 + (lane & 31)) * 2 + ((lane >> 5) ^ ((lane >> 3) & 1));   // + 64 for tile 1
+    // ---- streamed operand (X3 / Z rows): the pair's two waves cover rows 0..31 / 32..63; lane -> row lane / 2, physical slot lane & 1
+    const int pr = wvu >> 1;
+    const int gm_a = min(m0 + 32 * (wvu & 1) + (lane >> 1), p.M - 1);
+    const int pls = ((lane & 1) ^ ((lane >> 4) & 1)) << 4;
+    const unsigned ox3 = (unsigned)gm_a * (3 * SCENERF_D_XENC * 2) + pls;   // < 4 GiB: M * 4960 B fits 32 bits up to 865k rows
+    const unsigned oz = (unsigned)gm_a * (SCENERF_D_LATENT * 2) + pls;
+    auto s_load = [&](const int d) -> uint4 {   // (wave-uniform d with src != 0)
+        const char* base = FD_SRC(d) == 1 ? (const char*)p.X3 : (const char*)p.Z;
+        return *(const uint4*)(base + ((FD_SRC(d) == 1 ? ox3 : oz) + (unsigned)FD_Y(d) * 2));
+    };
+    auto s_write = [&](const int d, const uint4 v) { *(uint4*)(lds + G_STG + GD_STAGE(d) * F_A2STG + (wvu & 1) * 1024 + lane * 16) = v; };
+
+    // ---- fragments.  Transposed accumulator tile (i, j): lane holds activation row m = 32 i + (lane & 31) and outputs
+    // n = 64 w + 32 j + 8 q + 4 (lane >> 5) + e in register 4 q + e.  hp: the residual stream as packed bf16 pairs.
+    f32x16_f acc[2][2];
+    uint32_t hp[2][2][8];
+    const int arow = (lane & 31) * F_AROW;
+    const int axor = lane & 15;
+    const int offA2 = (lane & 31) * 32 + (((lane >> 5) ^ ((lane >> 3) & 1)) << 4);
+    auto init_acc = [&](const int layer) __attribute__((always_inline)) {
+        const char* bb = lds + G_BIAS + layer * 2048 + (wvu * 64 + 4 * (lane >> 5)) * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b = *(const float4*)(bb + (j * 32 + q * 8) * 4);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { acc[i][j][4 * q] = b.x; acc[i][j][4 * q + 1] = b.y; acc[i][j][4 * q + 2] = b.z; acc[i][j][4 * q + 3] = b.w; }
+            }
+    };
+
+    // ---- layer output -> HBM: the A buffer of the finished layer is streamed out one 16-byte piece per thread per step of the
+    // NEXT layer (8 pieces), stores and sign bytes by inline asm
+    char* save_ptr = nullptr;
+    uint8_t* sign_ptr = nullptr;
+    int save_ld2 = 0;
+    int save_i = 8;
+    auto save_piece = [&]() __attribute__((always_inline)) {   // rows 8 i .. 8 i + 7: thread t moves slot t & 63 of row 8 i + t / 64
+        const int row = 8 * save_i + (tid >> 6), slot = tid & 63;
+        if (save_ptr && m0 + row < p.M) {
+            const uint4 v = *(const uint4*)(Abuf + row * F_AROW + ((slot ^ (row & 15)) << 4));
+            g_store16(save_ptr + (size_t)(m0 + row) * save_ld2 + slot * 16, v);
+            if (sign_ptr) {   // 8 sign bits per piece (rectified values: positive == non-zero), see fused.hip
+                uint32_t u = g_pk_min_u16(v.x, 0x00010001u);
+                u |= g_pk_min_u16(v.y, 0x00010001u) << 2;
+                u |= g_pk_min_u16(v.z, 0x00010001u) << 4;
+                u |= g_pk_min_u16(v.w, 0x00010001u) << 6;
+                g_store1(sign_ptr + (size_t)(m0 + row) * 64 + slot, (u | (u >> 15)) & 0xffu);
+            }
+        }
+        ++save_i;
+    };
+
+    // ---- layer epilogue: residual in registers, rectified output -> resident A buffer
+    auto epilogue = [&](const int layer) __attribute__((always_inline)) {
+        const FusedLayer& L = p.layer[layer];
+        while (save_i < 8) save_piece();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // every wave has finished reading the A buffer for this layer
+        const bool is_res = L.kind != 1;  // residual layers: out = h + acc, h = bf16(out) ; fc_0 layers: out = acc   (bias is in acc)
+        const float resf = is_res ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int wbase = (32 * i + (lane & 31)) * F_AROW + 8 * (lane >> 5);
+            asm volatile("" : "+v"(wbase));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t pk[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int k = 2 * q + e;
+                        const float v0 = __builtin_fmaf(bf16lo(hp[i][j][k]), resf, acc[i][j][2 * k]);
+                        const float v1 = __builtin_fmaf(bf16hi(hp[i][j][k]), resf, acc[i][j][2 * k + 1]);
+                        pk[e] = pack_bf16x2(v0, v1);
+                        hp[i][j][k] = is_res ? pk[e] : hp[i][j][k];
+                    }
+                    const int slot = wvu * 8 + j * 4 + q;
+                    uint2 o;
+                    o.x = relu_bf16x2(pk[0]);
+                    o.y = relu_bf16x2(pk[1]);
+                    *(uint2*)(Abuf + wbase + ((slot ^ axor) << 4)) = o;
+                }
+        }
+        asm volatile("" ::: "memory");
+        init_acc(layer < 6 ? layer + 1 : 6);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // A buffer complete
+        save_ptr = (char*)L.save;
+        sign_ptr = L.sign;
+        save_ld2 = L.save_ld * 2;
+        save_i = 0;
+    };
+
+    // ---- prologue: descriptor window, weight ring (chunks 0..3), streamed chunks 0..5
+    // (named scalars, not an array: hipcc turns a select chain over array elements into a dynamically indexed load and the array
+    //  moves to scratch memory)
+    int q0 = D[0], q1 = D[1], q2 = D[2], q3 = D[3], q4 = D[4], q5 = D[5], q6 = D[6], q7 = D[7], q8 = D[8], q9 = D[9], q10 = D[10], q11 = D[11];
+    // staging register of this wave's pair: all pairs stage in step 0 of a group (pair q: chunk c + 2 + q written, chunk c + 6 + q
+    // fetched) -- ONE load site, so hipcc sees eight ring loads between the fetch and the write and waits vmcnt(8), not vmcnt(0)
+    uint4 zr = {0, 0, 0, 0};
+    {   // chunks 0, 1: straight into their stages (pairs 0, 1); chunks 2..5: fetched here, written in step 0
+        const int dnow = pr == 0 ? q0 : q1;
+        if (pr < 2 && FD_SRC(dnow)) s_write(dnow, s_load(dnow));
+        const int dlat = pr == 0 ? q2 : pr == 1 ? q3 : pr == 2 ? q4 : q5;
+        if (FD_SRC(dlat)) zr = s_load(dlat);
+    }
+    // (the ring loads come AFTER the staging loads: the first staging write then has eight younger loads in front of it on every
+    // path, like in the steady state, and hipcc's counted wait there stays vmcnt(8) instead of draining the ring)
+    uint4 ring[G_D][2];
+#pragma unroll
+    for (int s = 0; s < G_D; ++s) {
+        const uint4* b = Wb + (size_t)FD_Z((s == 0 ? q0 : s == 1 ? q1 : s == 2 ? q2 : q3)) * 1024 + woff;
+        ring[s][0] = b[0];
+        ring[s][1] = b[64];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) hp[i][j][k] = 0u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();   // biases, w_out, stages 0 / 1 (a full barrier: the global loads above are waited for too)
+    init_acc(0);
+    int dv = tab[lane];                   // descriptors 64 k .. 64 k + 63 of the block the window's head (c + G_NW) is in
+    __builtin_amdgcn_sched_barrier(0);
+
+#ifdef G_DBG
+    const long long tloop = __builtin_readcyclecounter();
+    long long tepi = 0;
+#endif
+    int c = 0;
+    uint4 afr[2][2];
+    bool pre = false;                     // afr[c & 1] already holds chunk c's fragments
+    int dend = 0;                         // descriptor of the last chunk of the group just done
+    auto step = [&](auto SC) __attribute__((always_inline)) {
+        constexpr int S = decltype(SC)::value;
+        const int idx = c + G_NW;         // joins the window at the end of the step
+        if ((idx & 63) == 0) dv = tab[idx + lane];
+        const int dn = __builtin_amdgcn_readlane(dv, idx & 63);
+        const int d0 = q0;
+        if (FD_SRC(d0)) {         // streamed chunk: its stage was written two steps ago by another pair
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        // activation fragments, ping-pong over the steps: a resident-operand chunk's fragments are read one step ahead (while the
+        // previous chunk's MFMAs run), so its MFMAs can start at once; a streamed chunk's only after its barrier, a layer's first
+        // only after the epilogue
+        uint4 (&a)[2] = afr[S & 1];
+        if (!pre) {
+            if (FD_SRC(d0) == 0) {
+                const int kslot = (FD_Y(d0) >> 3) + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = *(const uint4*)(Abuf + i * 32 * F_AROW + arow + ((kslot ^ axor) << 4));
+            } else {
+                const char* St = lds + G_STG + GD_STAGE(d0) * F_A2STG + offA2;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = *(const uint4*)(St + i * 1024);
+            }
+        }
+        pre = FD_SRC(q1) == 0 && !FD_END(d0);
+        if (pre) {
+            const int kslot = (FD_Y(q1) >> 3) + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) afr[(S + 1) & 1][i] = *(const uint4*)(Abuf + i * 32 * F_AROW + arow + ((kslot ^ axor) << 4));
+        }
+#ifdef G_DBG_NOMFMA
+        acc[0][0][0] += __builtin_bit_cast(float, ring[S][0].x ^ ring[S][1].y ^ a[0].x ^ a[1].y);
+#else
+        if (!GD_SKIP(d0)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)   // C^T tile: rows = outputs n, cols = activation rows m
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_f, ring[S][j]), __builtin_bit_cast(bf16x8_f, a[i]),
+                                                                        acc[i][j], 0, 0, 0);
+        }
+#endif
+#ifndef G_DBG_NOLOAD
+        {   // refill this ring slot with chunk c + G_D
+            const uint4* b = Wb + (size_t)FD_Z(q4) * 1024 + woff;
+            ring[S][0] = b[0];
+            ring[S][1] = b[64];
+        }
+#endif
+        if (S == 0) {                     // staging: pair q writes chunk c + 2 + q (used >= 2 steps later), fetches chunk c + 6 + q
+            const int dw = pr == 0 ? q2 : pr == 1 ? q3 : pr == 2 ? q4 : q5;
+            const int dl = pr == 0 ? q6 : pr == 1 ? q7 : pr == 2 ? q8 : q9;
+            if (FD_SRC(dw)) s_write(dw, zr);
+            if (FD_SRC(dl)) zr = s_load(dl);
+        }
+        if (save_i < 8) save_piece();
+        if (S == G_D - 1) dend = d0;      // (layer ends only here: the epilogue runs after the group, at its single site)
+        q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = q6; q6 = q7; q7 = q8; q8 = q9; q9 = q10; q10 = q11; q11 = dn;
+        ++c;
+        __builtin_amdgcn_sched_barrier(0);   // nothing moves across a step: the ring loads stay where they are written
+    };
+#pragma unroll 1
+    while (c < nch) {
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+#ifdef G_DBG
+        const long long te0 = __builtin_readcyclecounter();
+#endif
+        if (FD_END(dend)) epilogue(FD_LAYER(dend));
+#ifdef G_DBG
+        tepi += __builtin_readcyclecounter() - te0;
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#ifdef G_DBG
+    if (p.dH3 && lane == 0) {
+        long long* o = (long long*)p.dH3 + ((size_t)blockIdx.x * 8 + wvu) * 2;
+        o[0] = __builtin_readcyclecounter() - tloop; o[1] = tepi;
+    }
+#endif
+    while (save_i < 8) save_piece();
+    if (p.logits) {
+        // lin_out on the rectified H3 tile still resident in the A buffer (all waves are past the last epilogue's second barrier);
+        // 8 threads per row take 64 columns each, a butterfly adds the partials
+        const float* wl = (const float*)(lds + G_WOUT);
+        const int row = tid >> 3, part = tid & 7;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int s8 = 0; s8 < 8; ++s8) {
+            const int slot = part * 8 + s8;
+            const uint4 v = *(const uint4*)(Abuf + row * F_AROW + ((slot ^ (row & 15)) << 4));
+            const float f[8] = {bf16lo(v.x), bf16hi(v.x), bf16lo(v.y), bf16hi(v.y), bf16lo(v.z), bf16hi(v.z), bf16lo(v.w), bf16hi(v.w)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < p.d_out) {
+                    const float4 w0 = *(const float4*)(wl + j * SCENERF_D_HIDDEN + slot * 8);
+                    const float4 w1 = *(const float4*)(wl + j * SCENERF_D_HIDDEN + slot * 8 + 4);
+                    o[j] = fmaf(f[0], w0.x, o[j]); o[j] = fmaf(f[1], w0.y, o[j]); o[j] = fmaf(f[2], w0.z, o[j]); o[j] = fmaf(f[3], w0.w, o[j]);
+                    o[j] = fmaf(f[4], w1.x, o[j]); o[j] = fmaf(f[5], w1.y, o[j]); o[j] = fmaf(f[6], w1.z, o[j]); o[j] = fmaf(f[7], w1.w, o[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] += __shfl_xor(o[j], 1);
+            o[j] += __shfl_xor(o[j], 2);
+            o[j] += __shfl_xor(o[j], 4);
+        }
+        if (part == 0 && m0 + row < p.M) {
+            for (int j = 0; j < p.d_out; ++j) p.logits[(size_t)(m0 + row) * p.d_out + j] = o[j] + p.b_out[j];
+        }
+    }
+}
+
+// chunk descriptors for the 32 possible scale masks (forward): like fused.hip's table, every layer padded to a multiple of four chunks
+struct StreamTable {
+    int seg_len[5] = {-1, -1, -1, -1, -1};
+    int* d_desc = nullptr;
+};
+static StreamTable g_stream_table;
+
+static int stream_table_get(const scenerf_cfg* cfg, hipStream_t s, const int** desc) {
+    bool same = g_stream_table.d_desc != nullptr;
+    for (int i = 0; i < 5; ++i) same = same && g_stream_table.seg_len[i] == cfg->map_C[i];
+    if (!same) {
+        std::vector<int> tab((size_t)32 * F_MAXCH, 0);
+        int seg_off[5], off = 0;
+        for (int i = 0; i < 5; ++i) { seg_off[i] = off; off += cfg->map_C[i]; }
+        SRF_CHECK(off == SCENERF_D_LATENT, "stream mlp: map channels do not add up to the latent width");
+        const int layer_k[7] = {3 * SCENERF_D_XENC + SCENERF_D_LATENT, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN + SCENERF_D_LATENT, SCENERF_D_HIDDEN,
+                                SCENERF_D_HIDDEN + SCENERF_D_LATENT, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN};
+        int layer_block0[7], nb = 0;
+        for (int i = 0; i < 7; ++i) { layer_block0[i] = nb; nb += layer_k[i] / F_BK; }
+        for (int mask = 0; mask < 32; ++mask) {
+            int* ch = tab.data() + (size_t)mask * F_MAXCH + 1;
+            int n = 0;
+            bool ok = true;
+            auto seg = [&](int layer, int src, int a0, int w0, int len) {
+                if (len % F_BK || a0 % F_BK) ok = false;
+                for (int k = 0; k + F_BK <= len; k += F_BK) {
+                    if (n >= F_MAXCH - 20) { ok = false; return; }   // (all five scales: 680 chunks with the padding; the window reads 17 entries further)
+                    ch[n] = (layer_block0[layer] + (w0 + k) / F_BK) | (((a0 + k) / F_BK) << 10) | (src << 18) | (layer << 20) | ((n % G_NSTG) << 26);
+                    ++n;
+                }
+            };
+            auto zsegs = [&](int layer, int wbase) {
+                for (int i = 0; i < 5; ++i) {
+                    if ((mask >> i) & 1) seg(layer, 2, seg_off[i], wbase, cfg->map_C[i]);
+                    wbase += cfg->map_C[i];
+                }
+            };
+            auto pad = [&](int layer) {   // no-op chunks up to a multiple of four: resident operand (always finite), block 0, MFMAs skipped
+                while (n % G_D) { ch[n] = (layer << 20) | (1 << 25) | ((n % G_NSTG) << 26); ++n; }
+            };
+            seg(0, 1, 0, 0, 3 * SCENERF_D_XENC);
+            zsegs(0, 3 * SCENERF_D_XENC);
+            pad(0);
+            for (int b = 0; b < 3; ++b) {
+                seg(1 + 2 * b, 0, 0, 0, SCENERF_D_HIDDEN);
+                pad(1 + 2 * b);
+                seg(2 + 2 * b, 0, 0, 0, SCENERF_D_HIDDEN);
+                if (b < 2) zsegs(2 + 2 * b, SCENERF_D_HIDDEN);
+                pad(2 + 2 * b);
+            }
+            SRF_CHECK(ok && n % G_D == 0, "stream mlp: segment lengths must be multiples of 16 and fit the descriptor table");
+            for (int i = 0; i < n; ++i) {
+                if (i + 1 == n || FD_LAYER(ch[i + 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 23;
+                if (i == 0 || FD_LAYER(ch[i - 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 24;
+            }
+            ch[-1] = n;   // entries n .. n + 15 stay zero: prefetches past the end read block 0 and are never used
+        }
+        if (!g_stream_table.d_desc) SRF_HIP(hipMalloc((void**)&g_stream_table.d_desc, tab.size() * sizeof(int)));
+        SRF_HIP(hipStreamSynchronize(s));
+        SRF_HIP(hipMemcpy(g_stream_table.d_desc, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        for (int i = 0; i < 5; ++i) g_stream_table.seg_len[i] = cfg->map_C[i];
+    }
+    *desc = g_stream_table.d_desc;
+    return 0;
+}
+
+int launch_mlp_fwd_stream(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const uint8_t* tile_mask, int M,
+                          const scenerf_mlp_acts* a, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        SRF_HIP(hipFuncSetAttribute((const void*)mlp_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+        attr_done = true;
+    }
+    FusedArgs p = {};
+    const int H = SCENERF_D_HIDDEN;
+    const size_t sign_layer = (size_t)cdiv(M, SCENERF_TILE_ROWS) * SCENERF_TILE_ROWS * 64;
+    auto sign = [&](int l) { return a->sign_bits ? a->sign_bits + l * sign_layer : nullptr; };
+    p.layer[0] = {w->b_h[0], a->H[0], sign(0), 0, H};
+    for (int b = 0; b < 3; ++b) {
+        p.layer[1 + 2 * b] = {w->b_fc0[b], a->Nn[b], sign(1 + 2 * b), 1, H};
+        p.layer[2 + 2 * b] = {w->b_h[b + 1], a->H[b + 1], b < 2 ? sign(2 + 2 * b) : nullptr, 2, H};
+    }
+    p.Wst = w->w_stream;
+    p.X3 = a->h0pre;
+    p.Z = Z;
+    p.tile_mask = tile_mask;
+    if (int e = stream_table_get(cfg, s, &p.desc)) return e;
+    p.M = M;
+    p.w_out = w->w_out;
+    p.b_out = w->b_out;
+    p.logits = a->logits;
+    p.d_out = w->d_out;
+    double flops = 0;   // FLOPs actually issued (profile mode only; synchronises to read the scale-activity mask)
+    if (srf_prof_on()) {
+        const int tiles = cdiv(M, SCENERF_TILE_ROWS);
+        std::vector<uint8_t> hm(tiles, 0x1f);
+        if (hipMemcpyAsync(hm.data(), tile_mask, tiles, hipMemcpyDeviceToHost, s) == hipSuccess) (void)hipStreamSynchronize(s);
+        for (int t = 0; t < tiles; ++t) {
+            const int rows = M - t * SCENERF_TILE_ROWS < SCENERF_TILE_ROWS ? M - t * SCENERF_TILE_ROWS : SCENERF_TILE_ROWS;
+            double kz = 0;
+            for (int i = 0; i < 5; ++i)
+                if ((hm[t] >> i) & 1) kz += cfg->map_C[i];
+            flops += 2.0 * rows * 512.0 * (3.0 * SCENERF_D_XENC + 6.0 * SCENERF_D_HIDDEN + 3.0 * kz);
+        }
+    }
+#ifdef G_DBG
+    static long long* dbg = nullptr;
+    const int nwg = cdiv(M, F_BM);
+    if (!dbg) SRF_HIP(hipMalloc((void**)&dbg, (size_t)4096 * 8 * 2 * 8));
+    p.dH3 = nwg <= 4096 ? dbg : nullptr;
+#endif
+    {
+        SrfLaunchScope ps(s, w->d_out == 2 ? "mlp_fwd_fused/g" : "mlp_fwd_fused", flops, 0);
+        mlp_stream_kernel<<<cdiv(M, F_BM), G_THREADS, G_LDS, s>>>(p);
+        SRF_LAUNCH_CHECK("mlp_stream_kernel");
+    }
+#ifdef G_DBG
+    static int calls = 0;
+    if (++calls == 12 && nwg <= 4096) {
+        std::vector<long long> h((size_t)nwg * 16);
+        SRF_HIP(hipStreamSynchronize(s));
+        SRF_HIP(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double a0 = 0, a1 = 0;
+        for (size_t i = 0; i < h.size(); i += 2) { a0 += (double)h[i]; a1 += (double)h[i + 1]; }
+        a0 /= (double)nwg * 8; a1 /= (double)nwg * 8;
+        fprintf(stderr, "[stream dbg] mean per wave: loop %.0f cycles, of which epilogues %.0f\n", a0, a1);
+    }
+#endif
+    return 0;
+}

@@ -18,7 +18,7 @@ cc = rcfg.to_c()
 state = synth.mlp_state(1, 4)
 params = [torch.as_tensor(state[n]).to(dev) for n in MLP_PARAM_NAMES]
 pk = PackedMLP(params, 4, rcfg)
-run = _MlpRun(M, 4, 1, dev, keep_acts=os.environ.get("PROBE_LEAN") is None)   # PROBE_LEAN=1: inference buffers (no activation / sign-bit writes)
+run = _MlpRun(M, 4, 1, dev, keep_acts=not os.environ.get("PROBE_LEAN"))   # PROBE_LEAN=1: inference buffers (no activation / sign-bit writes)
 run.Z.copy_(torch.randn(run.Z.shape, device=dev) * 0.5)
 run.xenc.copy_(torch.randn(run.xenc.shape, device=dev).clamp(-1, 1))
 run.tile_mask.fill_(maskv)
