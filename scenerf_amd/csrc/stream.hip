@@ -1,42 +1,46 @@
 // Register-streamed fused ResnetFC forward for gfx950 (bf16 operands): the whole 7-GEMM trunk (lin_in + lin_z.0, three residual
 // blocks fc_0 / fc_1 + lin_z.b) and lin_out for a block of 64 rows in ONE kernel.  reference scenerf/models/resnetfc.py:133-164.
 //
-// Same arithmetic, data layouts and HBM traffic as the LDS-ring kernel in fused.hip (which it replaces for the forward pass;
-// results are bit-identical), different plumbing.  What bound that kernel was the weight stream: every 64-row workgroup pulls each
-// layer's weights through L2 -> LDS DMA, only two 18-KiB chunks could be in flight (LDS holds the 64-KiB resident operand too) and
-// all twelve waves met at a barrier per 16-wide K chunk: ~850 cycles per chunk for 256 cycles of MFMA.  Here
-//   * there are 8 waves and NO weight ring in LDS: wave w owns output columns [64 w, 64 w + 64) for all 64 rows (2 x 2 MFMA
-//     32x32x16 tiles) and streams exactly ITS slice of w_stream (2 KiB per chunk: two coalesced 1-KiB global_load_dwordx4)
-//     straight into a 4-deep VGPR ring -- 64 KiB in flight per CU, nothing shared between waves, so the K loop of a hidden layer
-//     runs 32 chunks without a single barrier (tools/ubench/wreg_stream.hip: 390 cycles per chunk at 1.35 PFLOP/s for this shape);
+// Same arithmetic, data layouts and HBM traffic as the LDS-ring kernel in fused.hip (results are bit-identical), different plumbing:
+//   * 8 waves and NO weight ring in LDS: wave w owns output columns [64 w, 64 w + 64) for all 64 rows (2 x 2 MFMA 32x32x16 tiles)
+//     and streams exactly ITS slice of w_stream (two coalesced 1-KiB global_load_dwordx4 per 16-wide K chunk) straight into a VGPR
+//     ring, four steps deep -- nothing is shared between waves, so a hidden layer's K loop runs without a single barrier;
+//   * a step covers a PAIR of chunks (K = 32): what limits a 64-row block is not memory but instruction issue -- a wave issues at
+//     most one instruction per 4 cycles, and a step's bookkeeping (descriptor window, branches, addresses: ~45 instructions)
+//     against 4 MFMAs left the matrix pipe 40 % busy whatever the memory system did; 8 MFMAs per step halve that overhead;
 //   * the loads are plain C++ loads: hipcc counts vmcnt for them by itself once a scheduling barrier per step stops it from
 //     sinking them to their first use.  Therefore NO other load kind may sit in the loop (an LDS-DMA makes hipcc wait vmcnt(0)):
-//     the streamed activation operand of the lin_in / lin_z segments (X3 / Z rows, 2 KiB per chunk, shared by all waves) is
-//     register-staged -- a wave pair loads it six chunks ahead, writes it to one of eight small LDS stages two chunks ahead, and
-//     only those chunks start with a barrier; the activation / sign-bit stores are inline asm (the compiler must not see them:
-//     a pending store would turn every counted wait into vmcnt(0); hidden stores only make a counted wait more conservative);
-//   * layer ends fall on multiples of four chunks (host-padded with no-op chunks) so that the ring slot is static in the 4x
-//     unrolled loop and there is ONE epilogue site; biases of all layers and w_out sit in LDS from the start (104 KiB in all).
+//     the streamed activation operand of the lin_in / lin_z segments (X3 / Z rows, shared by all waves) is register-staged -- in
+//     step 0 of every group of four steps wave pair q writes chunk pair c + 1 + q to one of eight 4-KiB LDS stages and fetches chunk
+//     pair c + 5 + q; only streamed steps start with a barrier; the activation / sign-bit stores are inline asm (the compiler
+//     must not see them: a pending store would turn every counted wait into vmcnt(0); hidden stores only make a counted wait more
+//     conservative);
+//   * layer ends fall on multiples of four steps (host-padded with no-op pairs; odd segments end in a half no-op pair) so that the
+//     ring slot is static in the 4x unrolled loop and the epilogue has ONE site; biases of all layers, w_out and the descriptors sit
+//     in LDS from the start (121 KiB in all).
 #include "fused.h"
 #include <type_traits>
 #include <vector>
-#include <cstdio>
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_f;
 
 #define G_THREADS 512
-#define G_D 4                                  // weight ring depth in chunks = chunks per group of the chunk loop (8: no faster)
-#define G_NW 12                                // descriptor window: chunks c .. c + 11 (staging looks 9 ahead; 12 keeps the groups of
-                                               // four that join it inside one 64-entry block of the table)
-#define G_NSTG 8                               // streamed-operand stages (2 KiB each)
+#define G_D 4                                  // weight ring depth in steps (= steps per group of the unrolled loop)
+#define G_NW 12                                // descriptor window: steps c .. c + 11 (staging looks 8 ahead; 12 keeps the four that
+                                               // join it per group inside one 64-entry block of the table)
+#define G_NSTG 8                               // streamed-operand stages
+#define G_STGB (2 * F_A2STG)                   // 4 KiB: both chunks of a step
 #define G_STG F_ABUF                           // 65536
-#define G_BIAS (G_STG + G_NSTG * F_A2STG)      // 81920: 7 layers x 2 KiB
-#define G_WOUT (G_BIAS + 7 * 2048)             // 96256: w_out, <= 8 KiB
-#define G_TAB (G_WOUT + 8192)                  // 104448: this tile mask's chunk descriptors, <= 704 (+ 64 read slack)
-#define G_LDS (G_TAB + 768 * 4)                // 107520
-// descriptor bits as in fused.h except [25] = no-op chunk (padding: loads happen, MFMAs do not) and [26:28] = stage (chunk mod 8)
-#define GD_SKIP(d) (((d) >> 25) & 1)
+#define G_BIAS (G_STG + G_NSTG * G_STGB)       // 98304: 7 layers x 2 KiB
+#define G_WOUT (G_BIAS + 7 * 2048)             // 112640: w_out, <= 8 KiB
+#define G_TAB (G_WOUT + 8192)                  // 120832: this tile mask's step descriptors (+ read slack)
+#define G_LDS (G_TAB + 768 * 4)                // 123904
+// One descriptor per step = pair of consecutive 16-wide K chunks: fields as in fused.h for the FIRST chunk (w_stream block, A column,
+// src, layer, end) -- the second chunk is block + 1 / column + 16 -- except [25] = the second chunk is a no-op (odd segment: staged as zeros),
+// [26:28] = stage (step mod 8), [29] = the whole step is a no-op (padding; the loads still happen, from valid addresses)
+#define GD_SKIP2(d) (((d) >> 25) & 1)
 #define GD_STAGE(d) (((d) >> 26) & 7)
+#define GD_SKIPALL(d) (((d) >> 29) & 1)
 
 __device__ static inline void g_store16(void* p, uint4 v) {
     const u32x4_f t = {v.x, v.y, v.z, v.w};
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(G_THREADS) void mlp_stream_kernel(FusedArgs p) {
     const int m0 = blockIdx.x * F_BM;
     const unsigned mask = __builtin_amdgcn_readfirstlane((unsigned)p.tile_mask[m0 / SCENERF_TILE_ROWS] & 31u);
     desc_ptr D = (desc_ptr)(uintptr_t)(p.desc + mask * F_MAXCH);
-    const int nch = D[0];   // header: number of chunks (a multiple of 4); the descriptors follow, zero-padded
+    const int nch = D[0];   // header: number of steps (a multiple of 4); the descriptors follow, zero-padded
     ++D;
 
     // ---- one-time LDS contents: the biases of all seven layers, w_out
@@ -78,11 +82,18 @@ __global__ __launch_bounds__(G_THREADS) void mlp_stream_kernel(FusedArgs p) {
     const int pls = ((lane & 1) ^ ((lane >> 4) & 1)) << 4;
     const unsigned ox3 = (unsigned)gm_a * (3 * SCENERF_D_XENC * 2) + pls;   // < 4 GiB: M * 4960 B fits 32 bits up to 865k rows
     const unsigned oz = (unsigned)gm_a * (SCENERF_D_LATENT * 2) + pls;
-    auto s_load = [&](const int d) -> uint4 {   // (wave-uniform d with src != 0)
+    auto s_load = [&](const int d, uint4& v0, uint4& v1) __attribute__((always_inline)) {   // (wave-uniform d, src != 0) both chunks of a step
         const char* base = FD_SRC(d) == 1 ? (const char*)p.X3 : (const char*)p.Z;
-        return *(const uint4*)(base + ((FD_SRC(d) == 1 ? ox3 : oz) + (unsigned)FD_Y(d) * 2));
+        const unsigned o = (FD_SRC(d) == 1 ? ox3 : oz) + (unsigned)FD_Y(d) * 2;
+        v0 = *(const uint4*)(base + o);
+        v1 = *(const uint4*)(base + o + (GD_SKIP2(d) ? 0u : 32u));   // (a no-op second chunk re-reads the first: never past the buffer ...
+        if (GD_SKIP2(d)) v1 = uint4{0, 0, 0, 0};                     //  ... and is staged as zeros: its MFMAs add exactly nothing, no branch)
     };
-    auto s_write = [&](const int d, const uint4 v) { *(uint4*)(lds + G_STG + GD_STAGE(d) * F_A2STG + (wvu & 1) * 1024 + lane * 16) = v; };
+    auto s_write = [&](const int d, const uint4 v0, const uint4 v1) __attribute__((always_inline)) {
+        char* st = lds + G_STG + GD_STAGE(d) * G_STGB + (wvu & 1) * 1024 + lane * 16;
+        *(uint4*)st = v0;
+        *(uint4*)(st + F_A2STG) = v1;
+    };
 
     // ---- fragments.  Transposed accumulator tile (i, j): lane holds activation row m = 32 i + (lane & 31) and outputs
     // n = 64 w + 32 j + 8 q + 4 (lane >> 5) + e in register 4 q + e.  hp: the residual stream as packed bf16 pairs.
@@ -171,23 +182,24 @@ __global__ __launch_bounds__(G_THREADS) void mlp_stream_kernel(FusedArgs p) {
     // (named scalars, not an array: hipcc turns a select chain over array elements into a dynamically indexed load and the array
     //  moves to scratch memory)
     int q0 = D[0], q1 = D[1], q2 = D[2], q3 = D[3], q4 = D[4], q5 = D[5], q6 = D[6], q7 = D[7], q8 = D[8], q9 = D[9], q10 = D[10], q11 = D[11];
-    // staging register of this wave's pair: all pairs stage in step 0 of a group (pair q: chunk c + 2 + q written, chunk c + 6 + q
-    // fetched) -- ONE load site, so hipcc sees eight ring loads between the fetch and the write and waits vmcnt(8), not vmcnt(0)
-    uint4 zr = {0, 0, 0, 0};
-    {   // chunks 0, 1: straight into their stages (pairs 0, 1); chunks 2..5: fetched here, written in step 0
-        const int dnow = pr == 0 ? q0 : q1;
-        if (pr < 2 && FD_SRC(dnow)) s_write(dnow, s_load(dnow));
-        const int dlat = pr == 0 ? q2 : pr == 1 ? q3 : pr == 2 ? q4 : q5;
-        if (FD_SRC(dlat)) zr = s_load(dlat);
+    // staging registers of this wave's pair: all pairs stage in step 0 of a group (wave pair q: step c + 1 + q written, step c + 5 + q
+    // fetched) -- ONE load site, so hipcc sees the ring loads of four steps between the fetch and the write and keeps its wait counted
+    uint4 zr0 = {0, 0, 0, 0}, zr1 = {0, 0, 0, 0};
+    {   // step 0: straight into its stage (wave pair 0); steps 1..4: fetched here, written in step 0
+        if (pr == 0 && FD_SRC(q0)) { uint4 t0, t1; s_load(q0, t0, t1); s_write(q0, t0, t1); }
+        const int dlat = pr == 0 ? q1 : pr == 1 ? q2 : pr == 2 ? q3 : q4;
+        if (FD_SRC(dlat)) s_load(dlat, zr0, zr1);
     }
-    // (the ring loads come AFTER the staging loads: the first staging write then has eight younger loads in front of it on every
-    // path, like in the steady state, and hipcc's counted wait there stays vmcnt(8) instead of draining the ring)
-    uint4 ring[G_D][2];
+    // (the ring loads come AFTER the staging loads: the first staging write then has a full ring of younger loads in front of it on
+    // every path, like in the steady state, and hipcc's counted wait there does not drain the ring)
+    uint4 ring[G_D][2][2];
 #pragma unroll
     for (int s = 0; s < G_D; ++s) {
-        const uint4* b = Wb + (size_t)FD_Z((s == 0 ? q0 : s == 1 ? q1 : s == 2 ? q2 : q3)) * 1024 + woff;
-        ring[s][0] = b[0];
-        ring[s][1] = b[64];
+        const uint4* b = Wb + (size_t)FD_Z(s == 0 ? q0 : s == 1 ? q1 : s == 2 ? q2 : q3) * 1024 + woff;
+        ring[s][0][0] = b[0];
+        ring[s][0][1] = b[64];
+        ring[s][1][0] = b[1024];
+        ring[s][1][1] = b[1024 + 64];
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -201,69 +213,62 @@ __global__ __launch_bounds__(G_THREADS) void mlp_stream_kernel(FusedArgs p) {
     int dv = tab[lane];                   // descriptors 64 k .. 64 k + 63 of the block the window's head (c + G_NW) is in
     __builtin_amdgcn_sched_barrier(0);
 
-#ifdef G_DBG
-    const long long tloop = __builtin_readcyclecounter();
-    long long tepi = 0;
-#endif
     int c = 0;
-    uint4 afr[2][2];
-    bool pre = false;                     // afr[c & 1] already holds chunk c's fragments
-    int dend = 0;                         // descriptor of the last chunk of the group just done
+    int dend = 0;                         // descriptor of the last step of the group just done
     auto step = [&](auto SC) __attribute__((always_inline)) {
         constexpr int S = decltype(SC)::value;
         const int idx = c + G_NW;         // joins the window at the end of the step
         if ((idx & 63) == 0) dv = tab[idx + lane];
         const int dn = __builtin_amdgcn_readlane(dv, idx & 63);
         const int d0 = q0;
-        if (FD_SRC(d0)) {         // streamed chunk: its stage was written two steps ago by another pair
+        if (FD_SRC(d0)) {                 // streamed step: its stage was written at least one step ago by some wave pair
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        // activation fragments, ping-pong over the steps: a resident-operand chunk's fragments are read one step ahead (while the
-        // previous chunk's MFMAs run), so its MFMAs can start at once; a streamed chunk's only after its barrier, a layer's first
-        // only after the epilogue
-        uint4 (&a)[2] = afr[S & 1];
-        if (!pre) {
-            if (FD_SRC(d0) == 0) {
-                const int kslot = (FD_Y(d0) >> 3) + (lane >> 5);
+        uint4 a[2][2];                    // [chunk][row tile]
+        if (FD_SRC(d0) == 0) {
+            const int kslot = (FD_Y(d0) >> 3) + (lane >> 5);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = *(const uint4*)(Abuf + i * 32 * F_AROW + arow + ((kslot ^ axor) << 4));
-            } else {
-                const char* St = lds + G_STG + GD_STAGE(d0) * F_A2STG + offA2;
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = *(const uint4*)(St + i * 1024);
-            }
+                for (int i = 0; i < 2; ++i) a[k][i] = *(const uint4*)(Abuf + i * 32 * F_AROW + arow + (((kslot + 2 * k) ^ axor) << 4));
+        } else {
+            const char* St = lds + G_STG + GD_STAGE(d0) * G_STGB + offA2;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[k][i] = *(const uint4*)(St + k * F_A2STG + i * 1024);
         }
-        pre = FD_SRC(q1) == 0 && !FD_END(d0);
-        if (pre) {
-            const int kslot = (FD_Y(q1) >> 3) + (lane >> 5);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) afr[(S + 1) & 1][i] = *(const uint4*)(Abuf + i * 32 * F_AROW + arow + ((kslot ^ axor) << 4));
-        }
-#ifdef G_DBG_NOMFMA
-        acc[0][0][0] += __builtin_bit_cast(float, ring[S][0].x ^ ring[S][1].y ^ a[0].x ^ a[1].y);
-#else
-        if (!GD_SKIP(d0)) {
+        if (!GD_SKIPALL(d0)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)   // C^T tile: rows = outputs n, cols = activation rows m
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_f, ring[S][j]), __builtin_bit_cast(bf16x8_f, a[i]),
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_f, ring[S][0][j]), __builtin_bit_cast(bf16x8_f, a[0][i]),
                                                                         acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)   // (the second chunk of an odd segment's last pair is staged as zeros)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_f, ring[S][1][j]), __builtin_bit_cast(bf16x8_f, a[1][i]),
+                                                                        acc[i][j], 0, 0, 0);
+            // all four fragment reads first, then the MFMAs back to back (left alone, hipcc reuses one fragment register set and
+            // exposes the LDS latency four times per step)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         }
-#endif
-#ifndef G_DBG_NOLOAD
-        {   // refill this ring slot with chunk c + G_D
+        {   // refill this ring slot with step c + 4 (two consecutive blocks)
             const uint4* b = Wb + (size_t)FD_Z(q4) * 1024 + woff;
-            ring[S][0] = b[0];
-            ring[S][1] = b[64];
+            ring[S][0][0] = b[0];
+            ring[S][0][1] = b[64];
+            ring[S][1][0] = b[1024];
+            ring[S][1][1] = b[1024 + 64];
         }
-#endif
-        if (S == 0) {                     // staging: pair q writes chunk c + 2 + q (used >= 2 steps later), fetches chunk c + 6 + q
-            const int dw = pr == 0 ? q2 : pr == 1 ? q3 : pr == 2 ? q4 : q5;
-            const int dl = pr == 0 ? q6 : pr == 1 ? q7 : pr == 2 ? q8 : q9;
-            if (FD_SRC(dw)) s_write(dw, zr);
-            if (FD_SRC(dl)) zr = s_load(dl);
+        if (S == 0) {                     // staging: wave pair q writes step c + 1 + q (used >= 1 step later), fetches step c + 5 + q
+            const int dw = pr == 0 ? q1 : pr == 1 ? q2 : pr == 2 ? q3 : q4;
+            const int dl = pr == 0 ? q5 : pr == 1 ? q6 : pr == 2 ? q7 : q8;
+            if (FD_SRC(dw)) s_write(dw, zr0, zr1);
+            if (FD_SRC(dl)) s_load(dl, zr0, zr1);
         }
         if (save_i < 8) save_piece();
         if (S == G_D - 1) dend = d0;      // (layer ends only here: the epilogue runs after the group, at its single site)
@@ -277,21 +282,9 @@ __global__ __launch_bounds__(G_THREADS) void mlp_stream_kernel(FusedArgs p) {
         step(std::integral_constant<int, 1>{});
         step(std::integral_constant<int, 2>{});
         step(std::integral_constant<int, 3>{});
-#ifdef G_DBG
-        const long long te0 = __builtin_readcyclecounter();
-#endif
         if (FD_END(dend)) epilogue(FD_LAYER(dend));
-#ifdef G_DBG
-        tepi += __builtin_readcyclecounter() - te0;
-#endif
         __builtin_amdgcn_sched_barrier(0);
     }
-#ifdef G_DBG
-    if (p.dH3 && lane == 0) {
-        long long* o = (long long*)p.dH3 + ((size_t)blockIdx.x * 8 + wvu) * 2;
-        o[0] = __builtin_readcyclecounter() - tloop; o[1] = tepi;
-    }
-#endif
     while (save_i < 8) save_piece();
     if (p.logits) {
         // lin_out on the rectified H3 tile still resident in the A buffer (all waves are past the last epilogue's second barrier);
@@ -349,11 +342,13 @@ static int stream_table_get(const scenerf_cfg* cfg, hipStream_t s, const int** d
             int* ch = tab.data() + (size_t)mask * F_MAXCH + 1;
             int n = 0;
             bool ok = true;
-            auto seg = [&](int layer, int src, int a0, int w0, int len) {
-                if (len % F_BK || a0 % F_BK) ok = false;
-                for (int k = 0; k + F_BK <= len; k += F_BK) {
-                    if (n >= F_MAXCH - 20) { ok = false; return; }   // (all five scales: 680 chunks with the padding; the window reads 17 entries further)
-                    ch[n] = (layer_block0[layer] + (w0 + k) / F_BK) | (((a0 + k) / F_BK) << 10) | (src << 18) | (layer << 20) | ((n % G_NSTG) << 26);
+            auto seg = [&](int layer, int src, int a0, int w0, int len) {   // one descriptor per PAIR of chunks of the segment
+                if (len % F_BK || a0 % F_BK || w0 % F_BK) ok = false;
+                const int nchunk = len / F_BK;
+                for (int k = 0; k < nchunk; k += 2) {
+                    if (n >= F_MAXCH - 20) { ok = false; return; }
+                    ch[n] = (layer_block0[layer] + w0 / F_BK + k) | ((a0 / F_BK + k) << 10) | (src << 18) | (layer << 20) |
+                            (k + 1 >= nchunk ? 1 << 25 : 0) | ((n % G_NSTG) << 26);
                     ++n;
                 }
             };
@@ -363,8 +358,8 @@ static int stream_table_get(const scenerf_cfg* cfg, hipStream_t s, const int** d
                     wbase += cfg->map_C[i];
                 }
             };
-            auto pad = [&](int layer) {   // no-op chunks up to a multiple of four: resident operand (always finite), block 0, MFMAs skipped
-                while (n % G_D) { ch[n] = (layer << 20) | (1 << 25) | ((n % G_NSTG) << 26); ++n; }
+            auto pad = [&](int layer) {   // no-op steps up to a multiple of four: resident operand, blocks 0 / 1, MFMAs skipped
+                while (n % G_D) { ch[n] = (layer << 20) | (1 << 29) | ((n % G_NSTG) << 26); ++n; }
             };
             seg(0, 1, 0, 0, 3 * SCENERF_D_XENC);
             zsegs(0, 3 * SCENERF_D_XENC);
@@ -431,28 +426,8 @@ int launch_mlp_fwd_stream(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, 
             flops += 2.0 * rows * 512.0 * (3.0 * SCENERF_D_XENC + 6.0 * SCENERF_D_HIDDEN + 3.0 * kz);
         }
     }
-#ifdef G_DBG
-    static long long* dbg = nullptr;
-    const int nwg = cdiv(M, F_BM);
-    if (!dbg) SRF_HIP(hipMalloc((void**)&dbg, (size_t)4096 * 8 * 2 * 8));
-    p.dH3 = nwg <= 4096 ? dbg : nullptr;
-#endif
-    {
-        SrfLaunchScope ps(s, w->d_out == 2 ? "mlp_fwd_fused/g" : "mlp_fwd_fused", flops, 0);
-        mlp_stream_kernel<<<cdiv(M, F_BM), G_THREADS, G_LDS, s>>>(p);
-        SRF_LAUNCH_CHECK("mlp_stream_kernel");
-    }
-#ifdef G_DBG
-    static int calls = 0;
-    if (++calls == 12 && nwg <= 4096) {
-        std::vector<long long> h((size_t)nwg * 16);
-        SRF_HIP(hipStreamSynchronize(s));
-        SRF_HIP(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double a0 = 0, a1 = 0;
-        for (size_t i = 0; i < h.size(); i += 2) { a0 += (double)h[i]; a1 += (double)h[i + 1]; }
-        a0 /= (double)nwg * 8; a1 /= (double)nwg * 8;
-        fprintf(stderr, "[stream dbg] mean per wave: loop %.0f cycles, of which epilogues %.0f\n", a0, a1);
-    }
-#endif
+    SrfLaunchScope ps(s, w->d_out == 2 ? "mlp_fwd_fused/g" : "mlp_fwd_fused", flops, 0);
+    mlp_stream_kernel<<<cdiv(M, F_BM), G_THREADS, G_LDS, s>>>(p);
+    SRF_LAUNCH_CHECK("mlp_stream_kernel");
     return 0;
 }
