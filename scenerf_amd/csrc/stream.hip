@@ -69,7 +69,7 @@ __global__ __launch_bounds__(G_THREADS) void mlp_stream_kernel(FusedArgs p) {
         *(float4*)(lds + G_BIAS + i * 16) = *(const float4*)(p.layer[i >> 7].bias + (i & 127) * 4);
     if (p.logits && tid < p.d_out * (SCENERF_D_HIDDEN / 4)) *(float4*)(lds + G_WOUT + tid * 16) = *(const float4*)(p.w_out + tid * 4);
     // the descriptors too: a scalar load per step shares lgkmcnt with the fragment reads and returns out of order, so every step
-    // would start by waiting out its latency (measured: ~2x on the whole kernel); from LDS, 64 at a time into one VGPR + v_readlane
+    // would start by waiting out its latency; from LDS, 64 at a time into one VGPR + v_readlane (no measurable difference in the end)
     int* const tab = (int*)(lds + G_TAB);
     for (int i = tid; i < nch + G_NW + 8; i += G_THREADS) tab[i] = D[i];
 
