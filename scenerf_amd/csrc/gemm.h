@@ -38,6 +38,16 @@ struct GemmNT {
     const int32_t* tap_texel = nullptr;
     const float* tap_weight = nullptr;
     int scatter_scale = -1;
+    // multi-scale scatter (ms_n > 0): ONE launch computes dZ for all scales -- the N axis is the concatenation of the scales' column
+    // tiles (ms_t0[s] = first 128-column tile of scale s), W / gmap / strides / column count are taken per scale, skip_bit and
+    // scatter_scale become the tile's scale.  All column tiles of a row tile run back to back on one XCD, so the K = 1536 operand
+    // rows (dH) are fetched from HBM once instead of once per scale launch.
+    int ms_n = 0;
+    int ms_t0[GEMM_MAX_SEG + 1] = {0, 0, 0, 0, 0, 0};
+    int ms_C[GEMM_MAX_SEG] = {0, 0, 0, 0, 0};
+    const void* ms_W[GEMM_MAX_SEG] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* ms_gmap[GEMM_MAX_SEG] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // NULL: that scale needs no gradient
+    long ms_st[GEMM_MAX_SEG] = {0, 0, 0, 0, 0}, ms_sc[GEMM_MAX_SEG] = {1, 1, 1, 1, 1};
     int force_tile = 0;  // 0 = pick by shape, 1 = 128x128 tile, 2 = 128x512 tile (needs N == 512)
     const char* name = "gemm_nt";
 };

@@ -161,8 +161,11 @@ __device__ __forceinline__ void epi_item(const GemmNT& p, float* v, int m, int n
 }
 
 // ---- epilogue shared by the register-staged and the direct-to-LDS kernels ---------------------------------------
+struct NtScatter {   // where a tile's scatter epilogue goes (the launch's single scale, or the tile's scale of a multi-scale launch)
+    float* gmap; size_t st; long sc; int scale; int N;
+};
 template <typename T, typename CF>
-__device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16_t (&acc)[2][CF::TJ], char* lds, int m0, int n0, int tid) {
+__device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16_t (&acc)[2][CF::TJ], char* lds, int m0, int n0, int tid, const NtScatter sct) {
     constexpr int TJ = CF::TJ, NWN = CF::NWN, BN = CF::BN, NT = CF::NT;
     const int lane = tid & 63, wv = tid >> 6, wm = wv / NWN, wn = wv % NWN;
     // ---- epilogue: stage 128 x 128 fp32 column passes in LDS (reusing the operand buffers), then every thread
@@ -180,7 +183,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16_t (&acc)[2][
     if (p.scatter_scale >= 0) {
         for (int i = tid; i < BM * 4; i += NT) {
             const int m = m0 + (i >> 2);
-            const size_t o = ((size_t)m * 5 + p.scatter_scale) * 4 + (i & 3);
+            const size_t o = ((size_t)m * 5 + sct.scale) * 4 + (i & 3);
             s_tx[i] = m < p.M ? p.tap_texel[o] : -1;
             s_tw[i] = m < p.M ? p.tap_weight[o] : 0.f;
         }
@@ -209,7 +212,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16_t (&acc)[2][
             // serialise in L2 -- so rows of a wave's contiguous block with identical taps are summed first and
             // scattered once.
             constexpr int RPW = BM / (NT / 64);
-            const size_t gst = p.gmap_st ? (size_t)p.gmap_st : (size_t)p.N;
+            const size_t gst = sct.st;
             int r = wv * RPW;
             const int rend = min(r + RPW, p.M - m0);
             while (r < rend) {
@@ -220,13 +223,13 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16_t (&acc)[2][
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int col = h * 64 + lane, n = nb + col;
-                        if (n < p.N) {
+                        if (n < sct.N) {
                             float v = 0.f;
                             for (int q = r; q < e; ++q) v += Cs[q * CLD + col];
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
                                 const int tx = s_tx[r * 4 + t];
-                                if (tx >= 0) unsafeAtomicAdd(p.gmap + (size_t)tx * gst + (size_t)n * p.gmap_sc, v * s_tw[r * 4 + t]);
+                                if (tx >= 0) unsafeAtomicAdd(sct.gmap + (size_t)tx * gst + (size_t)n * sct.sc, v * s_tw[r * 4 + t]);
                             }
                         }
                     }
@@ -262,13 +265,35 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_nt_kernel(GemmNT p) {
     constexpr int BK = (CF::RB - 16) / ES;
     constexpr int TJ = CF::TJ, NWN = CF::NWN, RB = CF::RB, BN = CF::BN, NT = CF::NT;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv / NWN, wn = wv % NWN;
-    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_n = p.ms_n > 0 ? p.ms_t0[GEMM_MAX_SEG] : (p.N + BN - 1) / BN;
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (lin / tiles_n) * BM, n0 = (lin % tiles_n) * BN;
+    const int m0 = (lin / tiles_n) * BM;
+    int n0 = (lin % tiles_n) * BN;
+    // this tile's W rows / column count / scatter target: the launch's, or its scale's (multi-scale scatter, BN == 128)
+    const void* Wl = p.W;
+    int Nl = p.N, skip_bit = p.skip_bit;
+    NtScatter sct = {p.gmap, p.gmap_st ? (size_t)p.gmap_st : (size_t)p.N, p.gmap_sc, p.scatter_scale, p.N};
+    if (p.ms_n > 0) {
+        const int tn = lin % tiles_n;
+        int sc = 0;
+#pragma unroll
+        for (int i = 1; i < GEMM_MAX_SEG; ++i)
+            if (i < p.ms_n && tn >= p.ms_t0[i]) sc = i;
+        n0 = (tn - p.ms_t0[sc]) * BN;
+        Wl = p.ms_W[sc];
+        Nl = p.ms_C[sc];
+        skip_bit = sc;
+        sct.gmap = p.ms_gmap[sc];
+        sct.st = p.ms_st[sc] ? (size_t)p.ms_st[sc] : (size_t)Nl;
+        sct.sc = p.ms_sc[sc];
+        sct.scale = sc;
+        sct.N = Nl;
+        if (!sct.gmap) return;
+    }
 
     unsigned mask = 0xffffffffu;
     if (p.tile_mask) mask = p.tile_mask[m0 / SCENERF_TILE_ROWS];
-    if (p.skip_bit >= 0 && !((mask >> p.skip_bit) & 1u)) return;  // uniform: whole tile contributes exact zeros
+    if (skip_bit >= 0 && !((mask >> skip_bit) & 1u)) return;  // uniform: whole tile contributes exact zeros
 
     if (tid == 0) {
         int n = 0;
@@ -323,8 +348,8 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
         for (int i = 0; i < CF::NPW; ++i) {
             const int q = min(tid + i * NT, (BN << sh) - 1);
-            const int gn = min(n0 + (q >> sh), p.N - 1);
-            rw[i] = *(const uint4*)((const char*)p.W + ((size_t)gn * p.ldw + ch.z) * ES + (q & pm) * 16);
+            const int gn = min(n0 + (q >> sh), Nl - 1);
+            rw[i] = *(const uint4*)((const char*)Wl + ((size_t)gn * p.ldw + ch.z) * ES + (q & pm) * 16);
         }
     };
     auto store_chunk = [&](int c, int buf, const uint4 (&ra)[CF::NPA], const uint4 (&rw)[CF::NPW]) {
@@ -349,7 +374,7 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_nt_kernel(GemmNT p) {
             const int q = tid + i * NT;
             if (q < (BN << sh)) {
                 const int row = q >> sh;
-                *(uint4*)(Ws + row * RB + (q & pm) * 16) = (n0 + row < p.N) ? rw[i] : zero4();
+                *(uint4*)(Ws + row * RB + (q & pm) * 16) = (n0 + row < Nl) ? rw[i] : zero4();
             }
         }
     };
@@ -381,7 +406,7 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_nt_kernel(GemmNT p) {
         }
     }
 
-    nt_epilogue<T, CF>(p, acc, lds, m0, n0, tid);
+    nt_epilogue<T, CF>(p, acc, lds, m0, n0, tid, sct);
 }
 
 // ================================================================================================ NT, direct-to-LDS
@@ -562,7 +587,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_glds_kernel(GemmNT p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (redundant) prefetches must land before LDS is reused
     __syncthreads();
-    nt_epilogue<T, CfgG>(p, acc, lds, m0, n0, tid);
+    nt_epilogue<T, CfgG>(p, acc, lds, m0, n0, tid, NtScatter{p.gmap, p.gmap_st ? (size_t)p.gmap_st : (size_t)p.N, p.gmap_sc, p.scatter_scale, p.N});
 }
 
 // ================================================================================================ TN
@@ -800,9 +825,18 @@ template <typename T, typename CF> static int launch_nt_t(const GemmNT& p, hipSt
         SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
         attr_done = true;
     }
-    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, CF::BN));
+    dim3 grid(cdiv(p.M, BM) * (p.ms_n > 0 ? p.ms_t0[GEMM_MAX_SEG] : cdiv(p.N, CF::BN)));
     double flops = 0;
-    if (srf_prof_on()) flops = nt_issued_flops(p, s);
+    if (srf_prof_on()) {
+        if (p.ms_n > 0) {   // sum over the scales, each with its own activity bit
+            for (int i = 0; i < p.ms_n; ++i) {
+                if (!p.ms_gmap[i]) continue;
+                GemmNT q = p;
+                q.ms_n = 0; q.N = p.ms_C[i]; q.skip_bit = i;
+                flops += nt_issued_flops(q, s);
+            }
+        } else flops = nt_issued_flops(p, s);
+    }
     SrfLaunchScope ps(s, p.name, flops, 0);
     gemm_nt_kernel<T, CF><<<grid, CF::NT, CF::LDS, s>>>(p);
     SRF_LAUNCH_CHECK(p.name);
@@ -825,16 +859,20 @@ static int launch_nt_glds(const GemmNT& p, hipStream_t s) {
 }
 
 int launch_gemm_nt(int precision, const GemmNT& p, hipStream_t s) {
-    SRF_CHECK(p.W && p.M > 0 && p.N > 0, "%s: bad operands", p.name);
+    SRF_CHECK((p.W || p.ms_n > 0) && p.M > 0 && p.N > 0, "%s: bad operands", p.name);
     SRF_CHECK(p.K1 % 16 == 0 && p.N % 8 == 0, "%s: K1=%d must be a multiple of 16, N=%d of 8", p.name, p.K1, p.N);
     SRF_CHECK(p.K1 == 0 || p.A1, "%s: A1 NULL", p.name);
     SRF_CHECK(p.nseg == 0 || p.A2, "%s: A2 NULL", p.name);
     for (int i = 0; i < p.nseg; ++i) SRF_CHECK(p.seg_len[i] % 16 == 0 && p.seg_off[i] % 8 == 0, "%s: segment %d misaligned", p.name, i);
-    SRF_CHECK(p.scatter_scale >= 0 ? (p.gmap && p.tap_texel && p.tap_weight) : (p.out != nullptr), "%s: missing output", p.name);
+    SRF_CHECK(p.scatter_scale >= 0 ? ((p.gmap || p.ms_n > 0) && p.tap_texel && p.tap_weight) : (p.out != nullptr), "%s: missing output", p.name);
     // wide tile when the output is a full 512-column hidden layer and there are enough row tiles to fill the chip
     // hidden layers (N = 512) with enough row tiles to fill the chip: 128 x 256 tiles, two 8-wave workgroups per CU
     // (measured 466 TF/s vs 330 for the 128 x 512 single-workgroup tile and 377 for 128 x 128 at K = 512: with two
     // resident workgroups one's epilogue / LDS refill overlaps the other's MFMAs)
+    if (p.ms_n > 0) {   // multi-scale scatter: 128-column tiles of the register-staged kernel only
+        SRF_CHECK(p.scatter_scale >= 0 && p.ms_n <= GEMM_MAX_SEG && p.ms_t0[GEMM_MAX_SEG] > 0, "%s: bad multi-scale setup", p.name);
+        return precision ? launch_nt_t<bf16_t, CfgS>(p, s) : launch_nt_t<float, CfgS>(p, s);
+    }
     const bool big = (p.N % 256 == 0) && cdiv(p.M, BM) >= 192;
     if (precision && (p.force_tile == 4 || (p.force_tile == 0 && big))) return launch_nt_glds(p, s);
     if (p.force_tile == 3 || p.force_tile == 4 || (p.force_tile == 0 && big)) return precision ? launch_nt_t<bf16_t, CfgM>(p, s) : launch_nt_t<float, CfgM>(p, s);

@@ -221,15 +221,42 @@ static void set_segments(GemmNT& g, const scenerf_cfg* cfg, const void* Z, const
 static int feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const uint8_t* tile_mask, const int32_t* tap_texel,
                          const float* tap_weight, int M, const void* dH, float* const gmaps_hwc[SCENERF_N_SCALES], hipStream_t s) {
     const bool head = w->d_out == 2;
+    static const bool per_scale = getenv("SRF_DFEAT_PER_SCALE") != nullptr;   // one launch per scale (the older form), for A/B runs
+    GemmNT g;
+    g.name = head ? "gemm_dfeat_scatter/g" : "gemm_dfeat_scatter";
+    g.A1 = dH; g.lda1 = 4 * SCENERF_D_HIDDEN; g.K1 = 3 * SCENERF_D_HIDDEN;
+    g.ldw = 3 * SCENERF_D_HIDDEN;
+    g.M = M;
+    g.tile_mask = tile_mask;
+    g.tap_texel = tap_texel; g.tap_weight = tap_weight;
+    if (!per_scale) {
+        // ONE launch for all scales: the row tile's dH (K = 1536: 393 KB per 128 rows) is read from HBM once and feeds the column
+        // tiles of every scale it touches back to back on one XCD (five launches re-read all of dH, 472 MB, each)
+        bool any = false;
+        int t = 0;
+        for (int sc = 0; sc < 5; ++sc) {
+            g.ms_t0[sc] = t;
+            g.ms_C[sc] = cfg->map_C[sc];
+            g.ms_W[sc] = w->w_z_t[sc];
+            g.ms_gmap[sc] = gmaps_hwc[sc];
+            if (cfg->map_chw[sc]) { g.ms_st[sc] = 1; g.ms_sc[sc] = (long)cfg->map_H[sc] * cfg->map_W[sc]; }   // (C,H,W) gradient buffer
+            any = any || gmaps_hwc[sc];
+            t += cdiv(cfg->map_C[sc], 128);
+        }
+        if (!any) return 0;
+        g.ms_t0[5] = t;
+        g.ms_n = 5;
+        g.N = SCENERF_D_LATENT;
+        g.scatter_scale = 0;
+        return launch_gemm_nt(cfg->precision, g, s);
+    }
     for (int sc = 0; sc < 5; ++sc) {
         if (!gmaps_hwc[sc]) continue;
-        GemmNT g;
-        g.name = head ? "gemm_dfeat_scatter/g" : "gemm_dfeat_scatter";
-        g.A1 = dH; g.lda1 = 4 * SCENERF_D_HIDDEN; g.K1 = 3 * SCENERF_D_HIDDEN;
-        g.W = w->w_z_t[sc]; g.ldw = 3 * SCENERF_D_HIDDEN;
-        g.M = M; g.N = cfg->map_C[sc];
-        g.tile_mask = tile_mask; g.skip_bit = sc;
-        g.gmap = gmaps_hwc[sc]; g.tap_texel = tap_texel; g.tap_weight = tap_weight; g.scatter_scale = sc;
+        g.W = w->w_z_t[sc];
+        g.N = cfg->map_C[sc];
+        g.skip_bit = sc;
+        g.gmap = gmaps_hwc[sc]; g.scatter_scale = sc;
+        g.gmap_st = 0; g.gmap_sc = 1;
         if (cfg->map_chw[sc]) { g.gmap_st = 1; g.gmap_sc = (long)cfg->map_H[sc] * cfg->map_W[sc]; }   // (C,H,W) gradient buffer
         if (int e = launch_gemm_nt(cfg->precision, g, s)) return e;
     }
