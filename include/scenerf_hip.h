@@ -246,6 +246,12 @@ int scenerf_hip_test_gemm_nt(int precision, const void* A, const void* W, const 
 int scenerf_hip_test_gemm_tn(int precision, const void* D, const void* A, int M, int N, int K, int relu_a,
                              float* C, float* colsum, scenerf_stream_t stream);
 
+/* Host-only (no GPU needed): the chunk-descriptor tables the fused ResnetFC kernels walk -- kind 0: fused.hip (33 sets: one per
+ * scale mask for the forward, set 32 = backward chain), kind 1: stream.hip (32 sets).  A set is SCENERF_CHUNK_TABLE_STRIDE ints:
+ * entry 0 = number of descriptors, then the descriptors, zero-padded.  Returns the number of ints written (<= cap) or < 0. */
+#define SCENERF_CHUNK_TABLE_STRIDE 704
+int scenerf_hip_test_chunk_table(const scenerf_cfg* cfg, int kind, int32_t* out, int cap);
+
 /* ---- in-library kernel timing (bench.py's roofline leg) ----------------------------------------------------- */
 /* While enabled every kernel launch is bracketed by hipEvents on its own stream. */
 int scenerf_hip_profile_enable(int on);

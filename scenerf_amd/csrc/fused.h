@@ -2,6 +2,7 @@
 // register-streamed forward).
 #pragma once
 #include "gemm.h"
+#include <vector>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_f;
 typedef __attribute__((ext_vector_type(16))) float f32x16_f;
@@ -47,4 +48,8 @@ typedef const __attribute__((address_space(4))) int* desc_ptr;   // constant add
 #define FD_END(d) (((d) >> 23) & 1)
 #define FD_BEGIN(d) (((d) >> 24) & 1)
 #define FD_STAGE(d) (((d) >> 25) & 7)
-#define F_MAXCH 704     // 666 chunks with all five scales + header + zero padding (the pipeline reads a few entries past the end)
+#define F_MAXCH SCENERF_CHUNK_TABLE_STRIDE   // 704:     // 666 chunks with all five scales + header + zero padding (the pipeline reads a few entries past the end)
+
+// host-only builders of the chunk-descriptor tables (also reachable through scenerf_hip_test_chunk_table for the CPU tests)
+int fused_table_build(const scenerf_cfg* cfg, std::vector<int>& tab);    // fused.hip: 33 sets of F_MAXCH ints
+int stream_table_build(const scenerf_cfg* cfg, std::vector<int>& tab);   // stream.hip: 32 sets of F_MAXCH ints

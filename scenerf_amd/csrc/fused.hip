@@ -363,65 +363,72 @@ struct FusedTable {
 };
 static FusedTable g_table;
 
+// host-only: the descriptor sets of the ring kernels (sets 0..31: forward per scale mask ; set 32: backward chain)
+int fused_table_build(const scenerf_cfg* cfg, std::vector<int>& tab) {
+    tab.assign((size_t)33 * F_MAXCH, 0);
+    int seg_off[5], off = 0;
+    for (int i = 0; i < 5; ++i) { seg_off[i] = off; off += cfg->map_C[i]; }
+    SRF_CHECK(off == SCENERF_D_LATENT, "fused mlp: map channels do not add up to the latent width");
+    // first w_stream block of each layer (order: w_h[0], w_fc0[0], w_h[1], w_fc0[1], w_h[2], w_fc0[2], w_h[3])
+    const int layer_k[7] = {3 * SCENERF_D_XENC + SCENERF_D_LATENT, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN + SCENERF_D_LATENT, SCENERF_D_HIDDEN,
+                            SCENERF_D_HIDDEN + SCENERF_D_LATENT, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN};
+    int layer_block0[7], nb = 0;
+    for (int i = 0; i < 7; ++i) { layer_block0[i] = nb; nb += layer_k[i] / F_BK; }
+    SRF_CHECK(nb < 1024, "fused mlp: w_stream block index does not fit the descriptor");
+    for (int mask = 0; mask < 32; ++mask) {
+        int* ch = tab.data() + (size_t)mask * F_MAXCH + 1;   // entry 0 is the header
+        int n = 0;
+        bool ok = true;
+        auto seg = [&](int layer, int src, int a0, int w0, int len) {
+            if (len % F_BK || a0 % F_BK) ok = false;
+            for (int k = 0; k + F_BK <= len; k += F_BK) {
+                if (n >= F_MAXCH - 10) { ok = false; return; }
+                ch[n] = (layer_block0[layer] + (w0 + k) / F_BK) | (((a0 + k) / F_BK) << 10) | (src << 18) | (layer << 20) | ((n % F_NST) << 25);
+                ++n;
+            }
+        };
+        auto zsegs = [&](int layer, int wbase) {
+            for (int i = 0; i < 5; ++i) {
+                if ((mask >> i) & 1) seg(layer, 2, seg_off[i], wbase, cfg->map_C[i]);
+                wbase += cfg->map_C[i];
+            }
+        };
+        // layer 0: [x_hi | x_lo | x_hi | z] ; layers 1,3,5: fc_0 ; layers 2,4: [relu(n) | z] ; layer 6: relu(n)
+        seg(0, 1, 0, 0, 3 * SCENERF_D_XENC);
+        zsegs(0, 3 * SCENERF_D_XENC);
+        for (int b = 0; b < 3; ++b) {
+            seg(1 + 2 * b, 0, 0, 0, SCENERF_D_HIDDEN);
+            seg(2 + 2 * b, 0, 0, 0, SCENERF_D_HIDDEN);
+            if (b < 2) zsegs(2 + 2 * b, SCENERF_D_HIDDEN);
+        }
+        SRF_CHECK(ok, "fused mlp: segment lengths must be multiples of 16 and fit the descriptor table");
+        for (int i = 0; i < n; ++i) {
+            if (i + 1 == n || FD_LAYER(ch[i + 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 23;
+            if (i == 0 || FD_LAYER(ch[i - 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 24;
+        }
+        for (int i = n; i < n + 8; ++i) ch[i] = (i % F_NST) << 25;   // padding: in-bounds no-ops
+        ch[-1] = n;
+    }
+    {   // backward chain: 6 layers of 32 chunks, operand always the resident A buffer, blocks after the forward ones
+        int* ch = tab.data() + (size_t)32 * F_MAXCH + 1;
+        int n = 0;
+        for (int l = 0; l < 6; ++l)
+            for (int i = 0; i < SCENERF_D_HIDDEN / F_BK; ++i, ++n)
+                ch[n] = (nb + l * (SCENERF_D_HIDDEN / F_BK) + i) | (i << 10) | (l << 20) | ((n % F_NST) << 25) |
+                        (i + 1 == SCENERF_D_HIDDEN / F_BK ? 1 << 23 : 0) | (i == 0 ? 1 << 24 : 0);
+        for (int i = n; i < n + 8; ++i) ch[i] = (i % F_NST) << 25;
+        ch[-1] = n;
+        SRF_CHECK(nb + 6 * (SCENERF_D_HIDDEN / F_BK) == SCENERF_W_STREAM_BLOCKS, "fused mlp: w_stream block count");
+    }
+    return 0;
+}
+
 static int fused_table_get(const scenerf_cfg* cfg, hipStream_t s, const int** desc) {
     bool same = g_table.d_desc != nullptr;
     for (int i = 0; i < 5; ++i) same = same && g_table.seg_len[i] == cfg->map_C[i];
     if (!same) {
-        std::vector<int> tab((size_t)33 * F_MAXCH, 0);   // sets 0..31: forward per scale mask ; set 32: backward
-        int seg_off[5], off = 0;
-        for (int i = 0; i < 5; ++i) { seg_off[i] = off; off += cfg->map_C[i]; }
-        SRF_CHECK(off == SCENERF_D_LATENT, "fused mlp: map channels do not add up to the latent width");
-        // first w_stream block of each layer (order: w_h[0], w_fc0[0], w_h[1], w_fc0[1], w_h[2], w_fc0[2], w_h[3])
-        const int layer_k[7] = {3 * SCENERF_D_XENC + SCENERF_D_LATENT, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN + SCENERF_D_LATENT, SCENERF_D_HIDDEN,
-                                SCENERF_D_HIDDEN + SCENERF_D_LATENT, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN};
-        int layer_block0[7], nb = 0;
-        for (int i = 0; i < 7; ++i) { layer_block0[i] = nb; nb += layer_k[i] / F_BK; }
-        SRF_CHECK(nb < 1024, "fused mlp: w_stream block index does not fit the descriptor");
-        for (int mask = 0; mask < 32; ++mask) {
-            int* ch = tab.data() + (size_t)mask * F_MAXCH + 1;   // entry 0 is the header
-            int n = 0;
-            bool ok = true;
-            auto seg = [&](int layer, int src, int a0, int w0, int len) {
-                if (len % F_BK || a0 % F_BK) ok = false;
-                for (int k = 0; k + F_BK <= len; k += F_BK) {
-                    if (n >= F_MAXCH - 10) { ok = false; return; }
-                    ch[n] = (layer_block0[layer] + (w0 + k) / F_BK) | (((a0 + k) / F_BK) << 10) | (src << 18) | (layer << 20) | ((n % F_NST) << 25);
-                    ++n;
-                }
-            };
-            auto zsegs = [&](int layer, int wbase) {
-                for (int i = 0; i < 5; ++i) {
-                    if ((mask >> i) & 1) seg(layer, 2, seg_off[i], wbase, cfg->map_C[i]);
-                    wbase += cfg->map_C[i];
-                }
-            };
-            // layer 0: [x_hi | x_lo | x_hi | z] ; layers 1,3,5: fc_0 ; layers 2,4: [relu(n) | z] ; layer 6: relu(n)
-            seg(0, 1, 0, 0, 3 * SCENERF_D_XENC);
-            zsegs(0, 3 * SCENERF_D_XENC);
-            for (int b = 0; b < 3; ++b) {
-                seg(1 + 2 * b, 0, 0, 0, SCENERF_D_HIDDEN);
-                seg(2 + 2 * b, 0, 0, 0, SCENERF_D_HIDDEN);
-                if (b < 2) zsegs(2 + 2 * b, SCENERF_D_HIDDEN);
-            }
-            SRF_CHECK(ok, "fused mlp: segment lengths must be multiples of 16 and fit the descriptor table");
-            for (int i = 0; i < n; ++i) {
-                if (i + 1 == n || FD_LAYER(ch[i + 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 23;
-                if (i == 0 || FD_LAYER(ch[i - 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 24;
-            }
-            for (int i = n; i < n + 8; ++i) ch[i] = (i % F_NST) << 25;   // padding: in-bounds no-ops
-            ch[-1] = n;
-        }
-        {   // backward chain: 6 layers of 32 chunks, operand always the resident A buffer, blocks after the forward ones
-            int* ch = tab.data() + (size_t)32 * F_MAXCH + 1;
-            int n = 0;
-            for (int l = 0; l < 6; ++l)
-                for (int i = 0; i < SCENERF_D_HIDDEN / F_BK; ++i, ++n)
-                    ch[n] = (nb + l * (SCENERF_D_HIDDEN / F_BK) + i) | (i << 10) | (l << 20) | ((n % F_NST) << 25) |
-                            (i + 1 == SCENERF_D_HIDDEN / F_BK ? 1 << 23 : 0) | (i == 0 ? 1 << 24 : 0);
-            for (int i = n; i < n + 8; ++i) ch[i] = (i % F_NST) << 25;
-            ch[-1] = n;
-            SRF_CHECK(nb + 6 * (SCENERF_D_HIDDEN / F_BK) == SCENERF_W_STREAM_BLOCKS, "fused mlp: w_stream block count");
-        }
+        std::vector<int> tab;
+        if (int e = fused_table_build(cfg, tab)) return e;
         if (!g_table.d_desc) SRF_HIP(hipMalloc((void**)&g_table.d_desc, tab.size() * sizeof(int)));
         SRF_HIP(hipStreamSynchronize(s));
         SRF_HIP(hipMemcpy(g_table.d_desc, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));

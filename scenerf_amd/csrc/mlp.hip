@@ -3,7 +3,7 @@
 // around them: lin_out (512 -> 4|2), bias-gradient column sums and an fp32->bf16 row conversion.
 #include <stdlib.h>
 
-#include "gemm.h"
+#include "fused.h"
 
 
 // ------------------------------------------------------------------------------------------------ lin_out
@@ -513,6 +513,15 @@ int scenerf_hip_test_gemm_nt(int precision, const void* A, const void* W, const 
     g.W = W; g.ldw = K; g.M = M; g.N = N; g.bias = bias;
     g.out = C; g.ldout = N; g.out_f32 = 1;
     return launch_gemm_nt(precision, g, as_stream(stream));
+}
+
+int scenerf_hip_test_chunk_table(const scenerf_cfg* cfg, int kind, int32_t* out, int cap) {
+    if (!(cfg && out && (kind == 0 || kind == 1))) { srf_set_error("test_chunk_table: bad arguments"); return -1; }
+    std::vector<int> tab;
+    if (int e = kind == 0 ? fused_table_build(cfg, tab) : stream_table_build(cfg, tab)) return -e;
+    if ((int)tab.size() > cap) { srf_set_error("test_chunk_table: output buffer too small (%d ints needed)", (int)tab.size()); return -2; }
+    for (size_t i = 0; i < tab.size(); ++i) out[i] = tab[i];
+    return (int)tab.size();
 }
 
 int scenerf_hip_test_gemm_tn(int precision, const void* D, const void* A, int M, int N, int K, int relu_a, float* C,

@@ -326,58 +326,65 @@ struct StreamTable {
 };
 static StreamTable g_stream_table;
 
+// host-only: the 32 descriptor sets of the streamed forward
+int stream_table_build(const scenerf_cfg* cfg, std::vector<int>& tab) {
+    tab.assign((size_t)32 * F_MAXCH, 0);
+    int seg_off[5], off = 0;
+    for (int i = 0; i < 5; ++i) { seg_off[i] = off; off += cfg->map_C[i]; }
+    SRF_CHECK(off == SCENERF_D_LATENT, "stream mlp: map channels do not add up to the latent width");
+    const int layer_k[7] = {3 * SCENERF_D_XENC + SCENERF_D_LATENT, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN + SCENERF_D_LATENT, SCENERF_D_HIDDEN,
+                            SCENERF_D_HIDDEN + SCENERF_D_LATENT, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN};
+    int layer_block0[7], nb = 0;
+    for (int i = 0; i < 7; ++i) { layer_block0[i] = nb; nb += layer_k[i] / F_BK; }
+    for (int mask = 0; mask < 32; ++mask) {
+        int* ch = tab.data() + (size_t)mask * F_MAXCH + 1;
+        int n = 0;
+        bool ok = true;
+        auto seg = [&](int layer, int src, int a0, int w0, int len) {   // one descriptor per PAIR of chunks of the segment
+            if (len % F_BK || a0 % F_BK || w0 % F_BK) ok = false;
+            const int nchunk = len / F_BK;
+            for (int k = 0; k < nchunk; k += 2) {
+                if (n >= F_MAXCH - 20) { ok = false; return; }
+                ch[n] = (layer_block0[layer] + w0 / F_BK + k) | ((a0 / F_BK + k) << 10) | (src << 18) | (layer << 20) |
+                        (k + 1 >= nchunk ? 1 << 25 : 0) | ((n % G_NSTG) << 26);
+                ++n;
+            }
+        };
+        auto zsegs = [&](int layer, int wbase) {
+            for (int i = 0; i < 5; ++i) {
+                if ((mask >> i) & 1) seg(layer, 2, seg_off[i], wbase, cfg->map_C[i]);
+                wbase += cfg->map_C[i];
+            }
+        };
+        auto pad = [&](int layer) {   // no-op steps up to a multiple of four: resident operand, blocks 0 / 1, MFMAs skipped
+            while (n % G_D) { ch[n] = (layer << 20) | (1 << 29) | ((n % G_NSTG) << 26); ++n; }
+        };
+        seg(0, 1, 0, 0, 3 * SCENERF_D_XENC);
+        zsegs(0, 3 * SCENERF_D_XENC);
+        pad(0);
+        for (int b = 0; b < 3; ++b) {
+            seg(1 + 2 * b, 0, 0, 0, SCENERF_D_HIDDEN);
+            pad(1 + 2 * b);
+            seg(2 + 2 * b, 0, 0, 0, SCENERF_D_HIDDEN);
+            if (b < 2) zsegs(2 + 2 * b, SCENERF_D_HIDDEN);
+            pad(2 + 2 * b);
+        }
+        SRF_CHECK(ok && n % G_D == 0, "stream mlp: segment lengths must be multiples of 16 and fit the descriptor table");
+        for (int i = 0; i < n; ++i) {
+            if (i + 1 == n || FD_LAYER(ch[i + 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 23;
+            if (i == 0 || FD_LAYER(ch[i - 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 24;
+        }
+        ch[-1] = n;   // entries n .. n + 15 stay zero: prefetches past the end read block 0 and are never used
+    }
+    return 0;
+}
+
 static int stream_table_get(const scenerf_cfg* cfg, hipStream_t s, const int** desc) {
     bool same = g_stream_table.d_desc != nullptr;
     for (int i = 0; i < 5; ++i) same = same && g_stream_table.seg_len[i] == cfg->map_C[i];
     if (!same) {
-        std::vector<int> tab((size_t)32 * F_MAXCH, 0);
-        int seg_off[5], off = 0;
-        for (int i = 0; i < 5; ++i) { seg_off[i] = off; off += cfg->map_C[i]; }
-        SRF_CHECK(off == SCENERF_D_LATENT, "stream mlp: map channels do not add up to the latent width");
-        const int layer_k[7] = {3 * SCENERF_D_XENC + SCENERF_D_LATENT, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN + SCENERF_D_LATENT, SCENERF_D_HIDDEN,
-                                SCENERF_D_HIDDEN + SCENERF_D_LATENT, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN};
-        int layer_block0[7], nb = 0;
-        for (int i = 0; i < 7; ++i) { layer_block0[i] = nb; nb += layer_k[i] / F_BK; }
-        for (int mask = 0; mask < 32; ++mask) {
-            int* ch = tab.data() + (size_t)mask * F_MAXCH + 1;
-            int n = 0;
-            bool ok = true;
-            auto seg = [&](int layer, int src, int a0, int w0, int len) {   // one descriptor per PAIR of chunks of the segment
-                if (len % F_BK || a0 % F_BK || w0 % F_BK) ok = false;
-                const int nchunk = len / F_BK;
-                for (int k = 0; k < nchunk; k += 2) {
-                    if (n >= F_MAXCH - 20) { ok = false; return; }
-                    ch[n] = (layer_block0[layer] + w0 / F_BK + k) | ((a0 / F_BK + k) << 10) | (src << 18) | (layer << 20) |
-                            (k + 1 >= nchunk ? 1 << 25 : 0) | ((n % G_NSTG) << 26);
-                    ++n;
-                }
-            };
-            auto zsegs = [&](int layer, int wbase) {
-                for (int i = 0; i < 5; ++i) {
-                    if ((mask >> i) & 1) seg(layer, 2, seg_off[i], wbase, cfg->map_C[i]);
-                    wbase += cfg->map_C[i];
-                }
-            };
-            auto pad = [&](int layer) {   // no-op steps up to a multiple of four: resident operand, blocks 0 / 1, MFMAs skipped
-                while (n % G_D) { ch[n] = (layer << 20) | (1 << 29) | ((n % G_NSTG) << 26); ++n; }
-            };
-            seg(0, 1, 0, 0, 3 * SCENERF_D_XENC);
-            zsegs(0, 3 * SCENERF_D_XENC);
-            pad(0);
-            for (int b = 0; b < 3; ++b) {
-                seg(1 + 2 * b, 0, 0, 0, SCENERF_D_HIDDEN);
-                pad(1 + 2 * b);
-                seg(2 + 2 * b, 0, 0, 0, SCENERF_D_HIDDEN);
-                if (b < 2) zsegs(2 + 2 * b, SCENERF_D_HIDDEN);
-                pad(2 + 2 * b);
-            }
-            SRF_CHECK(ok && n % G_D == 0, "stream mlp: segment lengths must be multiples of 16 and fit the descriptor table");
-            for (int i = 0; i < n; ++i) {
-                if (i + 1 == n || FD_LAYER(ch[i + 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 23;
-                if (i == 0 || FD_LAYER(ch[i - 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 24;
-            }
-            ch[-1] = n;   // entries n .. n + 15 stay zero: prefetches past the end read block 0 and are never used
-        }
+        std::vector<int> tab;
+        if (int e = stream_table_build(cfg, tab)) return e;
         if (!g_stream_table.d_desc) SRF_HIP(hipMalloc((void**)&g_stream_table.d_desc, tab.size() * sizeof(int)));
         SRF_HIP(hipStreamSynchronize(s));
         SRF_HIP(hipMemcpy(g_stream_table.d_desc, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));

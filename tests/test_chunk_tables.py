@@ -1,0 +1,115 @@
+"""Host logic of the fused ResnetFC kernels: the chunk-descriptor tables they walk (csrc/fused.hip, csrc/stream.hip), read back
+through the host-only C entry scenerf_hip_test_chunk_table.  No GPU needed.  For every scale mask the descriptors must cover each
+16-wide K chunk of each layer exactly once, in order, with the right operand source / column / weight block, and satisfy the
+structural rules the kernels rely on (layer ends on group boundaries, stages, padding)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from scenerf_amd import _capi
+from scenerf_amd.config import RenderConfig
+
+STRIDE = 704
+D_X3, D_H, D_L = 144, 512, 2480
+
+
+def _tables(kind, variant="kitti"):
+    lib = _capi.load()
+    rcfg = RenderConfig.kitti(precision="bf16") if variant == "kitti" else RenderConfig.bundlefusion(precision="bf16")
+    cc = rcfg.to_c()
+    out = (C.c_int32 * (33 * STRIDE))()
+    n = lib.scenerf_hip_test_chunk_table(C.byref(cc), kind, out, len(out))
+    assert n == (33 if kind == 0 else 32) * STRIDE, _capi.load().scenerf_hip_last_error()
+    return np.frombuffer(out, dtype=np.int32, count=n).reshape(-1, STRIDE).copy(), [c for c, _, _ in rcfg.map_shapes()]
+
+
+def _expected_chunks(mask, chans):
+    """(layer, src, a_col, w_block) of every 16-wide K chunk of the forward trunk, in order.  w_stream block order: the K chunks of
+    w_h[0] (144 + 2480 columns), w_fc0[0], w_h[1] (512 + 2480), w_fc0[1], w_h[2], w_fc0[2], w_h[3] (512)."""
+    layer_k = [D_X3 + D_L, D_H, D_H + D_L, D_H, D_H + D_L, D_H, D_H]
+    block0 = np.concatenate([[0], np.cumsum([k // 16 for k in layer_k])])
+    seg_off = np.concatenate([[0], np.cumsum(chans)])
+    out = []
+
+    def zsegs(layer, wbase):
+        for i, c in enumerate(chans):
+            if (mask >> i) & 1:
+                out.extend((layer, 2, (seg_off[i] + k) // 16, block0[layer] + (wbase + k) // 16) for k in range(0, c, 16))
+            wbase += c
+    out.extend((0, 1, k // 16, block0[0] + k // 16) for k in range(0, D_X3, 16))
+    zsegs(0, D_X3)
+    for b in range(3):
+        out.extend((1 + 2 * b, 0, k // 16, block0[1 + 2 * b] + k // 16) for k in range(0, D_H, 16))
+        out.extend((2 + 2 * b, 0, k // 16, block0[2 + 2 * b] + k // 16) for k in range(0, D_H, 16))
+        if b < 2:
+            zsegs(2 + 2 * b, D_H)
+    return out, int(block0[-1])
+
+
+def _fields(d):
+    return dict(block=d & 1023, acol=(d >> 10) & 255, src=(d >> 18) & 3, layer=(d >> 20) & 7, end=(d >> 23) & 1, begin=(d >> 24) & 1)
+
+
+@pytest.mark.parametrize("variant", ["kitti", "bundlefusion"])
+def test_ring_kernel_tables(variant):
+    tabs, chans = _tables(0, variant)
+    assert sum(chans) == D_L
+    for mask in range(32):
+        n, d = int(tabs[mask, 0]), tabs[mask, 1:]
+        want, nfwd = _expected_chunks(mask, chans)
+        assert n == len(want)
+        for i, (layer, src, acol, block) in enumerate(want):
+            f = _fields(int(d[i]))
+            assert (f["layer"], f["src"], f["acol"], f["block"]) == (layer, src, acol, block), (mask, i)
+            assert (int(d[i]) >> 25) & 7 == i % 5                                  # ring stage
+            assert f["end"] == (i + 1 == n or want[i + 1][0] != layer) and f["begin"] == (i == 0 or want[i - 1][0] != layer)
+        assert np.all((d[n:n + 8] & 0x01FFFFFF) == 0)                              # the pipeline reads a few no-op entries past the end
+    # backward chain: six layers of 32 resident-operand chunks, weight blocks after the forward ones
+    n, d = int(tabs[32, 0]), tabs[32, 1:]
+    assert n == 6 * 32 and nfwd + n == _capi.W_STREAM_BLOCKS
+    for i in range(n):
+        f = _fields(int(d[i]))
+        assert (f["layer"], f["src"], f["acol"], f["block"]) == (i // 32, 0, i % 32, nfwd + i)
+        assert f["end"] == (i % 32 == 31) and f["begin"] == (i % 32 == 0) and (int(d[i]) >> 25) & 7 == i % 5
+
+
+@pytest.mark.parametrize("variant", ["kitti", "bundlefusion"])
+def test_stream_kernel_tables(variant):
+    """stream.hip: one descriptor per PAIR of chunks; layers padded to groups of four steps; odd segments end in a half no-op pair."""
+    tabs, chans = _tables(1, variant)
+    for mask in range(32):
+        n, d = int(tabs[mask, 0]), [int(x) for x in tabs[mask, 1:]]
+        want, _ = _expected_chunks(mask, chans)
+        assert n % 4 == 0 and n + 20 <= STRIDE - 1                                 # the kernel copies n + 20 entries into LDS
+        got = []
+        for i in range(n):
+            f = _fields(d[i])
+            skip2, stage, skipall = (d[i] >> 25) & 1, (d[i] >> 26) & 7, (d[i] >> 29) & 1
+            assert stage == i % 8
+            if skipall:
+                assert f["src"] == 0 and f["block"] == 0                          # harmless loads, MFMAs skipped
+            else:
+                got.append((f["layer"], f["src"], f["acol"], f["block"]))
+                if not skip2:
+                    got.append((f["layer"], f["src"], f["acol"] + 1, f["block"] + 1))
+                else:
+                    assert f["src"] != 0                                           # only streamed (odd) segments end in a half pair:
+                                                                                   # their second half is staged as zeros
+            last_of_layer = i + 1 == n or _fields(d[i + 1])["layer"] != f["layer"]
+            assert f["end"] == last_of_layer
+            if last_of_layer:
+                assert i % 4 == 3                                                  # the epilogue site is the end of a group
+        assert got == [tuple(int(v) for v in w) for w in want], mask               # every chunk exactly once, in order
+        # pairs never straddle two segments: the second chunk continues the first one's column run and weight run
+        assert all(x == 0 for x in d[n:n + 20])
+
+
+def test_chunk_table_argument_checks():
+    lib = _capi.load()
+    cc = RenderConfig.kitti(precision="bf16").to_c()
+    small = (C.c_int32 * 16)()
+    assert lib.scenerf_hip_test_chunk_table(C.byref(cc), 0, small, 16) == -2      # too small
+    assert b"too small" in lib.scenerf_hip_last_error()
+    assert lib.scenerf_hip_test_chunk_table(C.byref(cc), 7, small, 16) == -1      # unknown kind
+    assert lib.scenerf_hip_test_chunk_table(None, 0, small, 16) == -1
