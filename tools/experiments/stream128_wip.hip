@@ -1,10 +1,11 @@
-// EXPERIMENT, NOT BUILT, NOT CORRECT YET -- kept as the starting point for the next round.
+// EXPERIMENT, NOT BUILT, NOT VALIDATED -- kept as the starting point for the next round.
 // 128-row variant of csrc/stream.hip: wave tile 128 x 64 (128 accumulators), residual stream parked in HBM (`hres`).  Measured at
 // M = 153,600, mask 0, inference buffers (in-kernel cycle counters): K loop 835 cycles per 128-row chunk against 620 per 64-row chunk
 // for stream.hip -- 1.5x fewer cycles per row -- but 16,800 cycles per layer epilogue (residual round trip, bias loads, vmcnt(0)
 // before the second barrier) against 4,000, so 0.79 ms overall against 0.73; L2-coherent (sc0 sc1) residual accesses made the
-// epilogue 27,000 cycles.  Its logits do not match the ring kernel yet (bug not found).  Needs: the residual kept on chip or
-// prefetched under the K loop's tail, and the mismatch found.
+// epilogue 27,000 cycles.  Validation state: logits finite but not bit-equal to the ring kernel's -- expected, its lin_out tail
+// sums 4 x 128 columns per row where the ring kernel sums 8 x 64 -- and the test stopped there: the saved activations and sign bits
+// (which must be identical) were never compared.  Needs: the residual kept on chip or prefetched under the K loop's tail.
 // Register-streamed fused ResnetFC forward for gfx950 (bf16 operands), 128-row blocks: the whole 7-GEMM trunk (lin_in + lin_z.0, three
 // residual blocks fc_0 / fc_1 + lin_z.b) and lin_out in ONE kernel.  reference scenerf/models/resnetfc.py:133-164.
 //
