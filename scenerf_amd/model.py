@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from .config import BF_FOV, KITTI_FOV, RenderConfig
 from .renderer import MLP_PARAM_NAMES, OUTPUT_KEYS, RenderSession
-from .training import TrainingMixin
+from .training import BundleFusionTrainingMixin, TrainingMixin
 
 try:  # the reference derives from pl.LightningModule; Lightning is optional here
     import pytorch_lightning as pl
@@ -241,14 +241,11 @@ class SceneRF(TrainingMixin, _Base):
         return [optimizer], [scheduler]
 
 
-class SceneRFBundleFusion(SceneRF):
-    """scenerf/models/scenerf_bf.py: same kernels, indoor constants (FOV, +0.5 floors, loss weights x5 / x0.1).
-
-    ``forward`` follows the KITTI batch layout; the BundleFusion collate format (``cam_K_depth``, ``source_depths``,
-    grid sampling, scenerf_bf.py:134-207) is not mirrored -- use ``render_rays_batch`` from the reference's own loop."""
+class SceneRFBundleFusion(BundleFusionTrainingMixin, SceneRF):
+    """scenerf/models/scenerf_bf.py: same kernels, indoor constants (FOV, +0.5 floors, loss weights x5 / x0.1) and the
+    BundleFusion batch layout in ``forward`` (``cam_K_depth``, ``source_depths``, ``n_rays // sample_grid_size**2`` rays per source:
+    scenerf_amd.training.BundleFusionTrainingMixin)."""
     _VARIANT = "bf"
-    reproj_weight = 5.0          # scenerf_bf.py:215
-    dist2closest_weight = 0.1    # scenerf_bf.py:238
 
     def __init__(self, som_sigma, lr=1e-4, weight_decay=0, img_size=(640, 480), sample_grid_size=2, n_rays=1000,
                  max_sample_depth=12, eval_depth=10, std=0.2, n_gaussians=4, n_pts_uni=32, n_pts_per_gaussian=8,

@@ -25,15 +25,24 @@ def sample_pix_features(pix: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
     return out.reshape(img.shape[0], -1)
 
 
-def depth_errors(gt: torch.Tensor, pred: torch.Tensor, min_depth: float = 1e-3, max_depth: float = 80.0):
-    """loss/depth_metrics.py:3-24 on device: abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3."""
+def depth_errors(gt: torch.Tensor, pred: torch.Tensor, min_depth: float = 1e-3, max_depth: float = 80.0, mask=None):
+    """loss/depth_metrics.py:3-24 on device: abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3.  With ``mask`` the means run over the
+    masked entries only (== the reference's ``gt[mask], pred[mask]``, without the boolean indexing's host sync; all zeros if the
+    mask is empty, where the reference skips the logging)."""
     pred = pred.clamp(min=min_depth, max=max_depth)
+    if mask is None:
+        mean = lambda t: t.float().mean()
+    else:
+        m = mask.to(pred.dtype)
+        gt = torch.where(mask, gt, torch.ones_like(gt))          # keeps log / division finite where masked out
+        den = m.sum().clamp(min=1.0)
+        mean = lambda t: (t.to(pred.dtype) * m).sum() / den
     thresh = torch.maximum(gt / pred, pred / gt)
-    a1, a2, a3 = [(thresh < 1.25 ** k).float().mean() for k in (1, 2, 3)]
-    rmse = torch.sqrt(((gt - pred) ** 2).mean())
-    rmse_log = torch.sqrt(((torch.log(gt) - torch.log(pred)) ** 2).mean())
-    abs_rel = (torch.abs(gt - pred) / gt).mean()
-    sq_rel = (((gt - pred) ** 2) / gt).mean()
+    a1, a2, a3 = [mean(thresh < 1.25 ** k) for k in (1, 2, 3)]
+    rmse = torch.sqrt(mean((gt - pred) ** 2))
+    rmse_log = torch.sqrt(mean((torch.log(gt) - torch.log(pred)) ** 2))
+    abs_rel = mean(torch.abs(gt - pred) / gt)
+    sq_rel = mean(((gt - pred) ** 2) / gt)
     return abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3
 
 
@@ -42,6 +51,9 @@ class TrainingMixin:
 
     reproj_weight = 1.0        # scenerf_bf.py:215 uses 5.0
     dist2closest_weight = 0.01  # scenerf_bf.py:238 uses 0.1
+
+    def _metric_max_depth(self) -> float:
+        return 80.0            # compute_depth_errors' default (scenerf.py:325-328 passes none)
 
     def compute_reprojection_loss(self, pix_source, sampled_color_source, depth_rendered, img_target, inv_K, cam_K,
                                   T_source2target):
@@ -87,12 +99,14 @@ class TrainingMixin:
         loss_color = torch.abs(color - col_src.T)
         loss_rep = self.compute_reprojection_loss(pix_source, col_src, depth, img_target, inv_K, cam_K, T_source2target)
         return dict(loss_kl=out["loss_kl"], loss_dist2closest_gauss=min_diff, loss_reprojection=loss_rep, loss_color=loss_color,
-                    min_som_vars=min_som_vars, min_stds=min_stds)
+                    min_som_vars=min_som_vars, min_stds=min_stds, depth_source_rendered=depth, pix_source=pix_source)
 
-    def evaluate_depth(self, step_type, gt_depth, pred_depth):
-        """scenerf.py:322-346 (metrics computed on device)."""
+    def evaluate_depth(self, step_type, gt_depth, pred_depth, mask=None):
+        """scenerf.py:322-346 (predictions clamped at the metric's default 80 m) / scenerf_bf.py:340-366 (at ``self.eval_depth``);
+        metrics computed on device."""
         names = ["abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3"]
-        vals = depth_errors(gt_depth.reshape(-1).detach().float(), pred_depth.reshape(-1).detach().float())
+        vals = depth_errors(gt_depth.reshape(-1).detach().float(), pred_depth.reshape(-1).detach().float(),
+                            max_depth=self._metric_max_depth(), mask=None if mask is None else mask.reshape(-1))
         for n, v in zip(names, vals):
             self.log(step_type + "depth/" + n, v, on_epoch=True, sync_dist=True)
 
@@ -149,3 +163,58 @@ class TrainingMixin:
 
     def validation_step(self, batch, batch_idx):
         self.step(batch, "val")
+
+
+class BundleFusionTrainingMixin(TrainingMixin):
+    """``forward`` of the indoor model for the BundleFusion collate layout (reference scenerf/models/scenerf_bf.py:124-247): one
+    shared depth-camera intrinsic matrix, ``n_rays // sample_grid_size**2`` rays per source frame, depth metrics against the
+    source frames' sensor depth at the sampled pixels, reprojection x5 and closest-gaussian x0.1 in the total.  Like the KITTI
+    loop above it keeps the arithmetic and drops the host syncs (``if total > 0``, ``mask.sum() > 0``, boolean indexing)."""
+
+    reproj_weight = 5.0          # scenerf_bf.py:215
+    dist2closest_weight = 0.1    # scenerf_bf.py:238
+
+    def _metric_max_depth(self) -> float:
+        return float(self.eval_depth)   # scenerf_bf.py:347
+
+    def forward(self, batch, step_type):
+        if getattr(self, "smooth_loss_weight", 0) > 0:
+            raise NotImplementedError("smooth_loss_weight > 0 calls compute_smooth_depth_loss, which the reference does not define")
+        img_input = batch["img_inputs"]
+        bs = img_input.shape[0]
+        cam_K = batch["cam_K_depth"][0]
+        inv_K = torch.inverse(cam_K)
+        pix, pix_sphere, _ = self.spherical_mapping.from_pixels(inv_K=inv_K)
+        x_rgbs = self.net_rgb(img_input, pix=pix, pix_sphere=pix_sphere)
+        n_grids = self.n_rays // (self.sample_grid_size ** 2)
+        tot = dict(rep=0.0, col=0.0, kl=0.0, somv=0.0, stds=0.0, d2c=0.0)
+        for i in range(bs):
+            x_rgb = {k: x_rgbs[k][i] for k in x_rgbs}
+            for sid in range(len(batch["img_sources"][i])):
+                ret = self.process_single_source(n_grids, x_rgb=x_rgb, cam_K=cam_K, inv_K=inv_K,
+                                                 img_source=batch["img_sources"][i][sid], img_target=batch["img_targets"][i][sid],
+                                                 T_source2target=batch["T_source2targets"][i][sid],
+                                                 T_source2infer=batch["T_source2infers"][i][sid], T_cam2velo=None, step_type=step_type)
+                tot["somv"] = tot["somv"] + ret["min_som_vars"].mean()
+                tot["kl"] = tot["kl"] + ret["loss_kl"].mean()
+                tot["d2c"] = tot["d2c"] + ret["loss_dist2closest_gauss"].mean()
+                tot["stds"] = tot["stds"] + ret["min_stds"].mean()
+                tot["rep"] = tot["rep"] + ret["loss_reprojection"].mean()
+                tot["col"] = tot["col"] + ret["loss_color"].mean()
+                ps = ret["pix_source"].detach().long()
+                depth_gt = torch.as_tensor(batch["source_depths"][i][sid]).to(ps.device)[ps[:, 1], ps[:, 0]]      # scenerf_bf.py:201-205
+                self.evaluate_depth(step_type, depth_gt, ret["depth_source_rendered"], mask=depth_gt > 0)
+        total = 0.0
+        if self.use_reprojection:
+            total = total + tot["rep"] / bs * self.reproj_weight
+            self.log(step_type + "/loss_reprojection", (tot["rep"] / bs).detach(), on_epoch=True, sync_dist=True)
+        if self.use_color:
+            total = total + tot["col"] / bs
+            self.log(step_type + "/loss_color", (tot["col"] / bs).detach(), on_epoch=True, sync_dist=True)
+        total = total + tot["kl"] / bs
+        self.log(step_type + "/loss_som_kl", (tot["kl"] / bs).detach(), on_epoch=True, sync_dist=True)
+        self.log(step_type + "/min_som_vars", (tot["somv"] / bs).detach(), on_epoch=True, sync_dist=True)
+        total = total + tot["d2c"] / bs * self.dist2closest_weight
+        self.log(step_type + "/loss_dist2closest_gauss", (tot["d2c"] / bs).detach(), on_epoch=True, sync_dist=True)
+        self.log(step_type + "/total_loss", total.detach(), on_epoch=True, sync_dist=True)
+        return {"total_loss": total}

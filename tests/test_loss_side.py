@@ -45,3 +45,36 @@ def test_depth_errors_match_reference_metrics():
     gt, pred = torch.from_numpy(G["depth/gt"]), torch.from_numpy(G["depth/pred"])
     got = torch.stack(depth_errors(gt, pred)).double().numpy()
     np.testing.assert_allclose(got, G["depth/metrics"], rtol=1e-6, atol=1e-9)      # loss/depth_metrics.py:3-24
+
+
+def test_bundlefusion_forward_matches_the_reference_loop():
+    """scenerf_bf.py:124-247 (BundleFusion batch layout, n_rays // grid**2 rays per source, x5 / x0.1 weights, depth metrics at the
+    sampled pixels with eval_depth as the clamp): scenerf_amd's sync-free loop against the reference's own forward, both around the
+    same deterministic fake renderer / encoder (tests/golden/bf_fakes.py, make_golden_bf_forward.py)."""
+    from bf_fakes import FakeNetRgb, fake_batch, fake_render
+    from scenerf_amd.model import SceneRFBundleFusion
+    g = np.load(os.path.join(HERE, "golden", "bf_forward.npz"))
+    m = SceneRFBundleFusion(som_sigma=2.0, img_size=(64, 48), n_rays=256, sample_grid_size=2, sphere_H=48, sphere_W=64, eval_depth=10)
+    m.net_rgb = FakeNetRgb()
+    m.render_rays_batch = lambda cam_K, T, x_rgb, ray_batch_size=None, sampled_pixels=None, **k: fake_render(sampled_pixels, T)
+    logs = {}
+    m.log = lambda key, val, **k: logs.setdefault(key, []).append(float(val))
+    orig = torch.randn
+    torch.randn = lambda *a, **k: torch.zeros(*a, **{kk: vv for kk, vv in k.items() if kk in ("device", "dtype")})
+    try:
+        torch.manual_seed(5)
+        out = m.forward(fake_batch(seed=3), "train")
+    finally:
+        torch.randn = orig
+    assert abs(float(out["total_loss"]) - float(g["total_loss"])) < 2e-6
+    keys = [k[4:] for k in g.files if k.startswith("log/")]
+    assert sorted(keys) == sorted(logs), (sorted(set(keys) ^ set(logs)))
+    for k in keys:
+        np.testing.assert_allclose(np.asarray(logs[k]), g["log/" + k], rtol=2e-5, atol=2e-6, err_msg=k)
+    with torch.no_grad():
+        m.smooth_loss_weight = 0.1
+    try:
+        m.forward(fake_batch(seed=3), "train")
+        raise AssertionError("smooth_loss_weight > 0 must fail like the reference (compute_smooth_depth_loss does not exist)")
+    except NotImplementedError:
+        pass
