@@ -37,3 +37,18 @@ def fake_batch(seed, bs=2, n_src=2, H=48, W=64):
                 img_sources=[[img() for _ in range(n_src)] for _ in range(bs)],
                 img_targets=[[img() for _ in range(n_src)] for _ in range(bs)],
                 source_depths=[[depth() for _ in range(n_src)] for _ in range(bs)])
+
+
+def fake_batch_kitti(seed, bs=2, n_src=2, H=48, W=64, n_lidar=40):
+    """The KITTI collate layout (scenerf.py:119-201): per-sample intrinsics, velodyne extrinsics, lidar pixels + depths."""
+    b = fake_batch(seed, bs=bs, n_src=n_src, H=H, W=W)
+    rng = np.random.Generator(np.random.PCG64(seed + 100))
+    b["cam_K"] = b.pop("cam_K_depth")
+    b.pop("source_depths")
+    Tv = torch.eye(4)
+    Tv[:3, 3] = torch.tensor([0.1, -0.2, 0.3])
+    b["T_velo_2_cam"] = [Tv for _ in range(bs)]
+    b["loc2d_with_depths"] = [[torch.from_numpy(np.stack([rng.integers(0, W, n_lidar), rng.integers(0, H, n_lidar)], 1).astype(np.int64))
+                               for _ in range(n_src)] for _ in range(bs)]
+    b["lidar_depths"] = [[torch.from_numpy(rng.uniform(1.0, 9.0, n_lidar).astype(np.float32)) for _ in range(n_src)] for _ in range(bs)]
+    return b

@@ -78,3 +78,29 @@ def test_bundlefusion_forward_matches_the_reference_loop():
         raise AssertionError("smooth_loss_weight > 0 must fail like the reference (compute_smooth_depth_loss does not exist)")
     except NotImplementedError:
         pass
+
+
+def test_kitti_forward_matches_the_reference_loop():
+    """scenerf.py:119-241 (per-sample intrinsics, n_rays rays per source, x1 / x0.01 weights, lidar depth metrics from a second
+    render): scenerf_amd's sync-free loop -- metric render under no_grad -- against the reference's own forward around the same
+    fake renderer / encoder."""
+    from bf_fakes import FakeNetRgb, fake_batch_kitti, fake_render
+    from scenerf_amd.model import SceneRF
+    g = np.load(os.path.join(HERE, "golden", "kitti_forward.npz"))
+    m = SceneRF(som_sigma=2.0, img_size=(64, 48), n_rays=200, sphere_H=48, sphere_W=64)
+    m.net_rgb = FakeNetRgb()
+    m.render_rays_batch = lambda cam_K, T, x_rgb, ray_batch_size=None, sampled_pixels=None, **k: fake_render(sampled_pixels, T)
+    logs = {}
+    m.log = lambda key, val, **k: logs.setdefault(key, []).append(float(val))
+    orig = torch.randn
+    torch.randn = lambda *a, **k: torch.zeros(*a, **{kk: vv for kk, vv in k.items() if kk in ("device", "dtype")})
+    try:
+        torch.manual_seed(6)
+        out = m.forward(fake_batch_kitti(seed=4), "train")
+    finally:
+        torch.randn = orig
+    assert abs(float(out["total_loss"]) - float(g["total_loss"])) < 2e-6
+    keys = [k[4:] for k in g.files if k.startswith("log/")]
+    assert sorted(keys) == sorted(logs), (sorted(set(keys) ^ set(logs)))
+    for k in keys:
+        np.testing.assert_allclose(np.asarray(logs[k]), g["log/" + k], rtol=2e-5, atol=2e-6, err_msg=k)
