@@ -44,7 +44,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_f;
 
 __device__ static inline void g_store16(void* p, uint4 v) {
     const u32x4_f t = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(t) : "memory");
+    // (s_nop: a 16-byte store reads its data registers after issue, and the compiler -- which does not know this statement is a
+    //  store -- may overwrite them with the very next instruction; without the wait states the 128-row experiment stored garbage)
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
 __device__ static inline void g_store1(void* p, uint32_t v) { asm volatile("global_store_byte %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 

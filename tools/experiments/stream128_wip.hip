@@ -1,11 +1,14 @@
-// EXPERIMENT, NOT BUILT, NOT VALIDATED -- kept as the starting point for the next round.
-// 128-row variant of csrc/stream.hip: wave tile 128 x 64 (128 accumulators), residual stream parked in HBM (`hres`).  Measured at
-// M = 153,600, mask 0, inference buffers (in-kernel cycle counters): K loop 835 cycles per 128-row chunk against 620 per 64-row chunk
-// for stream.hip -- 1.5x fewer cycles per row -- but 16,800 cycles per layer epilogue (residual round trip, bias loads, vmcnt(0)
-// before the second barrier) against 4,000, so 0.79 ms overall against 0.73; L2-coherent (sc0 sc1) residual accesses made the
-// epilogue 27,000 cycles.  Validation state: logits finite but not bit-equal to the ring kernel's -- expected, its lin_out tail
-// sums 4 x 128 columns per row where the ring kernel sums 8 x 64 -- and the test stopped there: the saved activations and sign bits
-// (which must be identical) were never compared.  Needs: the residual kept on chip or prefetched under the K loop's tail.
+// EXPERIMENT, NOT BUILT -- kept as the starting point for the next round.
+// 128-row variant of csrc/stream.hip: wave tile 128 x 64 (128 accumulators), residual stream parked in HBM (`hres`, to be added to
+// scenerf_mlp_acts; the experiment used a static scratch buffer in the launcher).  Validated on the GPU against the ring kernel at
+// M = 4,133 with mixed tile masks: all seven saved activations and all sign bits IDENTICAL, logits within 3e-7 (its lin_out tail sums
+// 4 x 128 columns per row where the ring kernel sums 8 x 64).  Measured at M = 153,600, mask 0, inference buffers (in-kernel cycle
+// counters): K loop 835 cycles per 128-row chunk against 620 per 64-row chunk for stream.hip -- 1.5x fewer cycles per row -- but
+// 16,800 cycles per layer epilogue (residual round trip, bias loads from global memory, vmcnt(0) before the second barrier) against
+// 4,000, so 0.79 ms overall against 0.73.  Next: residual prefetch under the tail of the K loop (half of it, the other half inside the
+// epilogue), biases from an LDS table (three stages instead of four make room), no vmcnt(0) before the second barrier.
+// (The first version stored garbage residuals for one row tile in four: its inline-asm stores lacked the wait states a 16-byte store
+// needs before its data registers are overwritten -- fixed below with s_nop, and in csrc/stream.hip.)
 // Register-streamed fused ResnetFC forward for gfx950 (bf16 operands), 128-row blocks: the whole 7-GEMM trunk (lin_in + lin_z.0, three
 // residual blocks fc_0 / fc_1 + lin_z.b) and lin_out in ONE kernel.  reference scenerf/models/resnetfc.py:133-164.
 //
@@ -50,7 +53,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_f;
 
 __device__ static inline void s_store16(void* p, uint4 v) {
     const u32x4_f t = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(t) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
 __device__ static inline void s_store1(void* p, uint32_t v) { asm volatile("global_store_byte %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 
