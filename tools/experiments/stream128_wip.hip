@@ -1,14 +1,17 @@
 // EXPERIMENT, NOT BUILT -- kept as the starting point for the next round.
 // 128-row variant of csrc/stream.hip: wave tile 128 x 64 (128 accumulators), residual stream parked in HBM (`hres`, to be added to
-// scenerf_mlp_acts; the experiment used a static scratch buffer in the launcher).  Validated on the GPU against the ring kernel at
-// M = 4,133 with mixed tile masks: all seven saved activations and all sign bits IDENTICAL, logits within 3e-7 (its lin_out tail sums
+// scenerf_mlp_acts; the experiment used a static scratch buffer in the launcher), biases in an LDS table, three streamed-operand
+// stages, residual fetch split around the first epilogue barrier.  Validated on the GPU against the ring kernel at M = 64, 4,133 and
+// 40,000 with mixed tile masks: all seven saved activations and all sign bits IDENTICAL, logits within 4e-7 (its lin_out tail sums
 // 4 x 128 columns per row where the ring kernel sums 8 x 64).  Measured at M = 153,600, mask 0, inference buffers (in-kernel cycle
-// counters): K loop 835 cycles per 128-row chunk against 620 per 64-row chunk for stream.hip -- 1.5x fewer cycles per row -- but
-// 16,800 cycles per layer epilogue (residual round trip, bias loads from global memory, vmcnt(0) before the second barrier) against
-// 4,000, so 0.79 ms overall against 0.73.  Next: residual prefetch under the tail of the K loop (half of it, the other half inside the
-// epilogue), biases from an LDS table (three stages instead of four make room), no vmcnt(0) before the second barrier.
+// counters, mean per wave): 279k cycles per 128-row workgroup against 2 x 146k for stream.hip's 64-row workgroups -- 0.79 ms against
+// 0.73 ms at 5 instead of 10 rounds of workgroups.  Of the 279k, 170k are spent in the K loop (835 cycles per chunk against 620 per
+// 64-row chunk: 1.5x fewer per row) and 110k between the loop and the end of the layer epilogue -- which is mostly the wait at the
+// epilogue's first barrier for the slowest wave (eight waves run 32+ chunks without synchronisation and drift apart), not epilogue
+// work: moving the residual fetch, the bias loads and the store wait out of the way changed it by 7 %.  So per row it costs what
+// the 64-row kernels cost; the open question is why the slowest wave of a workgroup takes ~1.6x the mean.
 // (The first version stored garbage residuals for one row tile in four: its inline-asm stores lacked the wait states a 16-byte store
-// needs before its data registers are overwritten -- fixed below with s_nop, and in csrc/stream.hip.)
+// needs before its data registers are overwritten -- fixed with s_nop here and in csrc/stream.hip.)
 // Register-streamed fused ResnetFC forward for gfx950 (bf16 operands), 128-row blocks: the whole 7-GEMM trunk (lin_in + lin_z.0, three
 // residual blocks fc_0 / fc_1 + lin_z.b) and lin_out in ONE kernel.  reference scenerf/models/resnetfc.py:133-164.
 //
@@ -42,11 +45,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_f;
 #define S_D 4                                   // weight ring depth in chunks (= chunks per group of the unrolled loop)
 #define S_NW 12                                 // descriptor window: chunks c .. c + 11 (a group of four joins inside one 64-entry block)
 #define S_ABUF (S_BM * F_AROW)                  // 131072
-#define S_NSTG 4                                // streamed-operand stages
+#define S_NSTG 3                                // streamed-operand stages
 #define S_STGB (S_BM * F_BK * 2)                // 4096: 128 rows x 32 B
 #define S_STG S_ABUF
-#define S_TAB (S_STG + S_NSTG * S_STGB)         // 147456: this tile mask's chunk descriptors (+ read slack)
-#define S_LDS (S_TAB + 768 * 4)                 // 150528
+#define S_BIAS (S_STG + S_NSTG * S_STGB)        // 143360: 7 layers x 2 KiB
+#define S_TAB (S_BIAS + 7 * 2048)               // 157696: this tile mask's chunk descriptors (+ read slack)
+#define S_LDS (S_TAB + 768 * 4)                 // 160768 of 163840
 // descriptor bits as in fused.h except [25] = no-op chunk (padding: loads happen, MFMAs do not) and [26:27] = stage (chunk mod 4)
 #define SD_SKIP(d) (((d) >> 25) & 1)
 #define SD_STAGE(d) (((d) >> 26) & 3)
@@ -74,6 +78,8 @@ __global__ __launch_bounds__(S_THREADS) void mlp_stream_kernel(FusedArgs p) {
     ++D;
     int* const tab = (int*)(lds + S_TAB);
     for (int i = tid; i < nch + S_NW + 8; i += S_THREADS) tab[i] = D[i];
+    for (int i = tid; i < 7 * 128; i += S_THREADS)
+        *(float4*)(lds + S_BIAS + i * 16) = *(const float4*)(p.layer[i >> 7].bias + (i & 127) * 4);
 
     // ---- weights: lane's 16 bytes of tile j of a 16-KiB w_stream block ([512 rows n][32 B], halves swapped when (n >> 3) & 1)
     const uint4* const Wb = (const uint4*)p.Wst;
@@ -98,13 +104,13 @@ __global__ __launch_bounds__(S_THREADS) void mlp_stream_kernel(FusedArgs p) {
     const int arow = (lane & 31) * F_AROW;
     const int axor = lane & 15;
     const int offA2 = (lane & 31) * 32 + (((lane >> 5) ^ ((lane >> 3) & 1)) << 4);
-    auto init_acc = [&](const int layer) __attribute__((always_inline)) {   // accumulators start from the layer's bias (L2-resident)
-        const float* bb = p.layer[layer].bias + wvu * 64 + 4 * (lane >> 5);
+    auto init_acc = [&](const int layer) __attribute__((always_inline)) {   // accumulators start from the layer's bias (LDS copy)
+        const char* bb = lds + S_BIAS + layer * 2048 + (wvu * 64 + 4 * (lane >> 5)) * 4;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 b = *(const float4*)(bb + j * 32 + q * 8);
+                const float4 b = *(const float4*)(bb + (j * 32 + q * 8) * 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { acc[i][j][4 * q] = b.x; acc[i][j][4 * q + 1] = b.y; acc[i][j][4 * q + 2] = b.z; acc[i][j][4 * q + 3] = b.w; }
             }
@@ -140,18 +146,22 @@ __global__ __launch_bounds__(S_THREADS) void mlp_stream_kernel(FusedArgs p) {
         while (save_i < 16) save_piece();
         const bool is_res = L.kind != 1;      // residual layers (the first one too: h starts at 0) ; fc_0 layers: out = acc
         const bool has_h = is_res && layer > 0;
+        // residual values of the lane, two row tiles at a time: tiles 0, 1 are fetched before the barrier (their latency hides behind
+        // the wait for the slowest wave), tiles 2, 3 while tile 0 is converted
+        uint4 hall[4][4];
+        auto fetch = [&](const int i) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hall[i][t] = has_h ? *(const uint4*)(hres + i * 64 + t * 16) : uint4{0, 0, 0, 0};
+        };
+        if (has_h) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's own residual stores of two layers ago (long done)
+        fetch(0);
+        fetch(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();         // every wave has finished reading the A buffer for this layer
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            uint4 hv[4];                      // this row tile's 32 residual values per lane: [j][q pair]
-            if (has_h) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) hv[t] = *(const uint4*)(hres + i * 64 + t * 16);
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) hv[t] = uint4{0, 0, 0, 0};
-            }
+            if (i == 1) { fetch(2); fetch(3); }
+            uint4 (&hv)[4] = hall[i];
             int wbase = (32 * i + (lane & 31)) * F_AROW + 8 * (lane >> 5);
             asm volatile("" : "+v"(wbase));
 #pragma unroll
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(S_THREADS) void mlp_stream_kernel(FusedArgs p) {
         }
         asm volatile("" ::: "memory");
         init_acc(layer < 6 ? layer + 1 : 6);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // (the residual stores too: the next reader is this lane)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();         // A buffer complete
         save_ptr = (char*)L.save;
         sign_ptr = L.sign;
@@ -247,6 +257,12 @@ __global__ __launch_bounds__(S_THREADS) void mlp_stream_kernel(FusedArgs p) {
                 for (int j = 0; j < 2; ++j)   // C^T tile: rows = outputs n, cols = activation rows m
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_f, ring[S][j]), __builtin_bit_cast(bf16x8_f, a[i]),
                                                                         acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         {   // refill this ring slot with chunk c + 4
             const uint4* b = Wb + (size_t)FD_Z(q4) * 1024 + woff;
