@@ -215,6 +215,8 @@ class SceneRF(TrainingMixin, _Base):
         """
         if sampled_pixels is None:
             raise ValueError("sampled_pixels is required")
+        if sampled_pixels.shape[0] == 0:
+            raise ValueError("sampled_pixels is empty (the reference fails in torch.cat over zero chunks here, scenerf.py:459-470)")
         self.ray_som  # noqa: B018  (attribute kept for parity with the reference module tree)
         cfg = self.render_cfg
         cfg.som_sigma = float(self.ray_som.som_sigma)

@@ -94,6 +94,11 @@ def test_hot_path_refuses_cpu_tensors():
         m.render_rays_batch(synth.kitti_cam_K(), torch.eye(4), maps, sampled_pixels=torch.zeros(8, 2), ray_batch_size=8)
     with pytest.raises(RuntimeError, match="HIP MLP pass"):
         m.mlp(torch.zeros(1, 2522))
+    # empty / missing ray sets fail up front with a clear message (the reference dies in torch.cat over zero chunks)
+    with pytest.raises(ValueError, match="empty"):
+        m.render_rays_batch(synth.kitti_cam_K(), torch.eye(4), maps, sampled_pixels=torch.zeros(0, 2), ray_batch_size=8)
+    with pytest.raises(ValueError, match="required"):
+        m.render_rays_batch(synth.kitti_cam_K(), torch.eye(4), maps)
 
 
 def test_split_bf16_linin_arithmetic():
