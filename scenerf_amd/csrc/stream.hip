@@ -41,6 +41,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_f;
 #define GD_SKIP2(d) (((d) >> 25) & 1)
 #define GD_STAGE(d) (((d) >> 26) & 7)
 #define GD_SKIPALL(d) (((d) >> 29) & 1)
+#define GD_FAST(d) (((d) >> 30) & 1)           // first step of a layer whose first G_FASTN steps may run as one tight loop (below)
+#define G_FASTN 8                              // steps per fast run (16 chunks)
 
 __device__ static inline void g_store16(void* p, uint4 v) {
     const u32x4_f t = {v.x, v.y, v.z, v.w};
@@ -278,8 +280,58 @@ __global__ __launch_bounds__(G_THREADS) void mlp_stream_kernel(FusedArgs p) {
         ++c;
         __builtin_amdgcn_sched_barrier(0);   // nothing moves across a step: the ring loads stay where they are written
     };
+    // Fast run: the first G_FASTN steps of a layer whose K loop starts with the resident operand (every layer but the first) when no
+    // staging work falls into them (host flag).  Same arithmetic as G_FASTN steps, but with the bookkeeping a step pays per pair
+    // of chunks -- descriptor window, branches, address arithmetic: ~70 instructions per 8 MFMAs, which is what holds the MFMA pipe
+    // at ~40 % (tools/ubench/mfma_overlap) -- reduced to the operands themselves: fragment addresses are eight precomputed
+    // registers + immediate offsets (the XOR swizzle only sees the slot index mod 16), the weight block of step c + 4 comes from
+    // one v_readlane, the first eight steps carry the previous layer's eight save pieces.
+    int aoff[4][2];                       // [step & 3][chunk]: row base + swizzled 16-byte slot of this lane
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) aoff[s4][k] = arow + (((4 * s4 + 2 * k + (lane >> 5)) ^ axor) << 4);
+    auto fast_run = [&]() __attribute__((always_inline)) {
+        const int dvf = tab[c + lane];    // descriptors of steps c .. c + 63 (the run and the steps after it)
+#pragma unroll
+        for (int t = 0; t < G_FASTN; ++t) {
+            uint4 a[2][2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[k][i] = *(const uint4*)(Abuf + i * 32 * F_AROW + (t >> 2) * 256 + aoff[t & 3][k]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_f, ring[t & 3][k][j]), __builtin_bit_cast(bf16x8_f, a[k][i]),
+                                                                            acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            const uint4* b = Wb + (size_t)FD_Z(__builtin_amdgcn_readlane(dvf, t + 4)) * 1024 + woff;
+            ring[t & 3][0][0] = b[0];
+            ring[t & 3][0][1] = b[64];
+            ring[t & 3][1][0] = b[1024];
+            ring[t & 3][1][1] = b[1024 + 64];
+            save_piece();                 // (a fast run starts a layer: pieces 0 .. 7 of the previous layer's output)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        c += G_FASTN;
+        // the window behind the run, and the descriptor block the next step's window head (c + G_NW) lives in
+        q0 = __builtin_amdgcn_readlane(dvf, G_FASTN + 0); q1 = __builtin_amdgcn_readlane(dvf, G_FASTN + 1);
+        q2 = __builtin_amdgcn_readlane(dvf, G_FASTN + 2); q3 = __builtin_amdgcn_readlane(dvf, G_FASTN + 3);
+        q4 = __builtin_amdgcn_readlane(dvf, G_FASTN + 4); q5 = __builtin_amdgcn_readlane(dvf, G_FASTN + 5);
+        q6 = __builtin_amdgcn_readlane(dvf, G_FASTN + 6); q7 = __builtin_amdgcn_readlane(dvf, G_FASTN + 7);
+        q8 = __builtin_amdgcn_readlane(dvf, G_FASTN + 8); q9 = __builtin_amdgcn_readlane(dvf, G_FASTN + 9);
+        q10 = __builtin_amdgcn_readlane(dvf, G_FASTN + 10); q11 = __builtin_amdgcn_readlane(dvf, G_FASTN + 11);
+        dv = tab[((c + G_NW - 1) & ~63) + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    };
 #pragma unroll 1
     while (c < nch) {
+        if (GD_FAST(q0)) fast_run();
         step(std::integral_constant<int, 0>{});
         step(std::integral_constant<int, 1>{});
         step(std::integral_constant<int, 2>{});
@@ -375,6 +427,16 @@ int stream_table_build(const scenerf_cfg* cfg, std::vector<int>& tab) {
         for (int i = 0; i < n; ++i) {
             if (i + 1 == n || FD_LAYER(ch[i + 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 23;
             if (i == 0 || FD_LAYER(ch[i - 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 24;
+        }
+        // fast runs: the first G_FASTN steps of a layer, all from the resident operand and real, the layer longer than the run
+        // (so no layer end inside), and no staging work in the run's groups (the group at step g writes steps g+1 .. g+4 and
+        // fetches steps g+5 .. g+8: steps f+1 .. f+G_FASTN+4 must not be streamed)
+        for (int f = 0; f + G_FASTN < n; f += 4) {
+            if (!FD_BEGIN(ch[f])) continue;
+            bool fast = true;
+            for (int i = 0; i < G_FASTN; ++i) fast = fast && FD_SRC(ch[f + i]) == 0 && !GD_SKIPALL(ch[f + i]) && !FD_END(ch[f + i]);
+            for (int i = 1; i <= G_FASTN + 4; ++i) fast = fast && FD_SRC(ch[f + i]) == 0;
+            if (fast) ch[f] |= 1 << 30;
         }
         ch[-1] = n;   // entries n .. n + 15 stay zero: prefetches past the end read block 0 and are never used
     }
