@@ -15,6 +15,8 @@
 //     pair c + 5 + q; only streamed steps start with a barrier; the activation / sign-bit stores are inline asm (the compiler
 //     must not see them: a pending store would turn every counted wait into vmcnt(0); hidden stores only make a counted wait more
 //     conservative);
+//   * the first eight steps of every layer that starts with the resident operand run as a "fast run": fragment addresses from eight
+//     precomputed registers + immediate offsets, the weight block from one v_readlane -- ~16 non-MFMA instructions per 8 MFMAs;
 //   * layer ends fall on multiples of four steps (host-padded with no-op pairs; odd segments end in a half no-op pair) so that the
 //     ring slot is static in the 4x unrolled loop and the epilogue has ONE site; biases of all layers, w_out and the descriptors sit
 //     in LDS from the start (121 KiB in all).
