@@ -8,8 +8,9 @@
  *
  * Conventions
  *   - all pointers are DEVICE pointers unless the name ends in `_host`; all work is enqueued on `stream`
- *     and returns immediately (no hidden synchronisation, no allocation, no global state => re-entrant,
- *     one process per GPU, hipGraph-capturable);
+ *     and returns immediately (no hidden synchronisation; the only library-owned device state is per-device
+ *     and created once under a lock -- see scenerf_hip_prepare; re-entrant, hipGraph-capturable).  `stream`
+ *     must belong to the calling thread's current device (hipSetDevice), like the buffers;
  *   - return value 0 = ok, otherwise an error code; `scenerf_hip_last_error()` gives the message.  Bad
  *     arguments are reported, never abort();
  *   - "rows" M = rays * points-per-ray.  Activation buffers are row-major [M][ld];
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SCENERF_HIP_ABI_VERSION 3
+#define SCENERF_HIP_ABI_VERSION 4
 #define SCENERF_N_SCALES 5          /* feature maps "1_1","1_2","1_4","1_8","1_16" */
 #define SCENERF_D_LATENT 2480       /* 80+160+320+640+1280 (resnetfc d_latent, scenerf.py:100-114) */
 #define SCENERF_D_HIDDEN 512
@@ -66,7 +67,18 @@ typedef struct scenerf_cfg {
                                           feature gradient is scattered into an fp32 (C,H,W) buffer (slow per access, meant for the coarse
                                           scales that quirk Q1 keeps out of range for all but <= 1/s^2 of the sphere) ; 0: (H,W,C) act copy
                                           and (H,W,C) fp32 gradient accumulator */
+    /* kernel-path selection (explicit state of the call, never ambient: no environment variable changes what a call computes) */
+    int32_t fused_min_rows;         /* bf16: row count M from which the ResnetFC trunk (forward) and the dgrad chain (backward) each run as
+                                       ONE fused kernel; below it the per-layer GEMM path runs.  0 = library default (4096); < 0 = never */
+    int32_t fwd_kernel;             /* fused forward variant: 0 = LDS-ring pipeline (fused.hip), 1 = register-streamed (stream.hip);
+                                       identical results bit for bit */
+    uint32_t flags;                 /* SCENERF_FLAG_* */
 } scenerf_cfg;
+#define SCENERF_FUSED_MIN_ROWS_DEFAULT 4096
+#define SCENERF_FLAG_NO_FUSED_BWD    1u  /* dgrad chain as six per-layer GEMMs even where the fused chain applies */
+#define SCENERF_FLAG_NO_WGRAD_TR     2u  /* weight gradients through gemm_tn only (no transposing-read batched kernel) */
+#define SCENERF_FLAG_DFEAT_PER_SCALE 4u  /* feature-gradient GEMM + scatter as one launch per pyramid level (A/B runs) */
+#define SCENERF_FLAG_WGRAD_OVERLAP   8u  /* per-layer backward: weight-gradient GEMMs on an internal side stream */
 
 /* Packed ResnetFC operands (built by the host from the nn.Linear parameters).
  * T = float (precision 0) or bf16 (precision 1).  reference scenerf/models/resnetfc.py:88-118,133-164 */
@@ -137,6 +149,12 @@ typedef struct scenerf_mlp_acts {
 
 int scenerf_hip_abi_version(void);
 const char* scenerf_hip_last_error(void);
+
+/* One-time setup for the CURRENT device (hipSetDevice) and this configuration: kernel attributes (dynamic LDS sizes), the chunk-descriptor
+ * tables of the fused ResnetFC kernels (uploaded asynchronously on `stream`), the zero page.  Every entry point does this lazily on
+ * first use, per device and thread-safe; call it explicitly before capturing a hipGraph (the first-use allocations are not capturable).
+ * The library keeps no other state: descriptors and attributes are per device ordinal, everything else lives in caller buffers. */
+int scenerf_hip_prepare(const scenerf_cfg* cfg, scenerf_stream_t stream);
 
 /* ---- feature-map layout ------------------------------------------------------------------------------- */
 /* (C,H,W) fp32 encoder output -> (H,W,C) act (bf16 or fp32): one sample's 2x2 gather becomes 4 contiguous

@@ -23,7 +23,7 @@ D_HIDDEN = 512
 D_XENC = 48
 TILE_ROWS = 128
 W_STREAM_BLOCKS = (3 * D_XENC + D_LATENT) // 16 + 2 * ((512 + D_LATENT) // 16) + 10 * (512 // 16)   # scenerf_hip.h
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 vp = C.c_void_p
 
@@ -39,6 +39,7 @@ class Cfg(C.Structure):
         ("div_H", C.c_int32 * N_SCALES), ("div_W", C.c_int32 * N_SCALES),
         ("precision", C.c_int32),
         ("map_chw", C.c_int32 * N_SCALES),
+        ("fused_min_rows", C.c_int32), ("fwd_kernel", C.c_int32), ("flags", C.c_uint32),
     ]
 
 
@@ -84,6 +85,7 @@ i32 = C.c_int
 _PROTOS = {
     "scenerf_hip_abi_version": (C.c_int, []),
     "scenerf_hip_last_error": (C.c_char_p, []),
+    "scenerf_hip_prepare": (C.c_int, [C.POINTER(Cfg), vp]),
     "scenerf_hip_maps_chw_to_hwc": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "scenerf_hip_grads_hwc_to_chw": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "scenerf_hip_ray_setup": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
@@ -138,9 +140,8 @@ def load() -> C.CDLL:
     return lib
 
 
-def fused_min_rows() -> int:
-    """Row count from which libscenerf_hip.so runs the ResnetFC trunk as one fused kernel (bf16; mlp.hip reads the same variable)."""
-    return int(os.environ.get("SRF_FUSED_MIN_M", "4096"))
+FUSED_MIN_ROWS_DEFAULT = 4096    # SCENERF_FUSED_MIN_ROWS_DEFAULT
+FLAG_NO_FUSED_BWD, FLAG_NO_WGRAD_TR, FLAG_DFEAT_PER_SCALE, FLAG_WGRAD_OVERLAP = 1, 2, 4, 8   # SCENERF_FLAG_*
 
 
 def check(code: int, what: str) -> None:

@@ -47,6 +47,13 @@ class RenderConfig:
     # adding level 2 saves 80 us more in conversions but its 0.14 % of samples cluster in a few row tiles whose 1280 strided
     # cache-line reads per sample stretch the gather by 100 us.
     direct_scales: Tuple[int, ...] = (3, 4)
+    # kernel-path selection (scenerf_cfg.fused_min_rows / fwd_kernel / flags): explicit per-call state, no environment variables
+    fused_min_rows: int = _capi.FUSED_MIN_ROWS_DEFAULT   # bf16: rows from which the ResnetFC trunk / dgrad chain run as one fused kernel; < 0 never
+    fwd_kernel: str = "ring"          # fused forward variant: "ring" (fused.hip) or "stream" (stream.hip); identical results
+    fused_backward: bool = True       # False: the dgrad chain as six per-layer GEMMs even where the fused chain applies
+    wgrad_tr: bool = True             # False: weight gradients through gemm_tn only
+    dfeat_per_scale: bool = False     # True: feature-gradient GEMM + scatter as one launch per pyramid level
+    wgrad_overlap: bool = False       # True: per-layer backward runs the weight-gradient GEMMs on an internal side stream
 
     # ---- derived -----------------------------------------------------------------------------------------
     @property
@@ -80,6 +87,13 @@ class RenderConfig:
         if self.n_samples > 512:
             raise ValueError("n_samples = %d exceeds the 512-sample limit of the wave-per-ray kernels" % self.n_samples)
         _ = self.precision_code
+        if self.fwd_kernel not in ("ring", "stream"):
+            raise ValueError("fwd_kernel must be 'ring' or 'stream', got %r" % (self.fwd_kernel,))
+
+    def uses_fused(self, rows: int) -> bool:
+        """Whether an MLP pass over ``rows`` rows runs on the fused kernels (mirrors srf_use_fused in csrc/common.h)."""
+        th = _capi.FUSED_MIN_ROWS_DEFAULT if self.fused_min_rows == 0 else self.fused_min_rows
+        return self.precision_code == 1 and th > 0 and rows >= th
 
     def to_c(self) -> "_capi.Cfg":
         self.validate()
@@ -102,6 +116,10 @@ class RenderConfig:
         c.precision = self.precision_code
         for i in range(5):
             c.map_chw[i] = 1 if i in self.direct_scales else 0
+        c.fused_min_rows = int(self.fused_min_rows)
+        c.fwd_kernel = 1 if self.fwd_kernel == "stream" else 0
+        c.flags = ((0 if self.fused_backward else _capi.FLAG_NO_FUSED_BWD) | (0 if self.wgrad_tr else _capi.FLAG_NO_WGRAD_TR)
+                   | (_capi.FLAG_DFEAT_PER_SCALE if self.dfeat_per_scale else 0) | (_capi.FLAG_WGRAD_OVERLAP if self.wgrad_overlap else 0))
         return c
 
     @staticmethod

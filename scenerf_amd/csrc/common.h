@@ -45,6 +45,35 @@ struct SrfLaunchScope {
         if (e_ != hipSuccess) { srf_set_error("launch %s: %s", name, hipGetErrorString(e_)); return 3; } \
     } while (0)
 
+// ---- per-device one-time state ------------------------------------------------------------------------------
+// A process may drive several GPUs (and several host threads): hipFuncSetAttribute is a per-device attribute and device
+// allocations belong to the device that was current when they were made, so "once" means once per device ordinal, under a lock.
+#include <mutex>
+#define SRF_MAX_DEVICES 64
+int srf_device();                 // ordinal of the calling thread's current device (hipGetDevice), -1 on error
+const char* srf_zero_page();      // 4 KiB of device zeros on the current device (allocated on first use), nullptr on error
+struct SrfPerDeviceOnce {
+    std::mutex mu;
+    bool done[SRF_MAX_DEVICES] = {};
+};
+#define SRF_ONCE_PER_DEVICE(...)                                                          \
+    do {                                                                                  \
+        static SrfPerDeviceOnce once_;                                                    \
+        const int dev_ = srf_device();                                                    \
+        SRF_CHECK(dev_ >= 0 && dev_ < SRF_MAX_DEVICES, "no current HIP device");         \
+        std::lock_guard<std::mutex> lk_(once_.mu);                                        \
+        if (!once_.done[dev_]) {                                                          \
+            __VA_ARGS__;                                                                  \
+            once_.done[dev_] = true;                                                      \
+        }                                                                                 \
+    } while (0)
+
+// rows from which the fused ResnetFC kernels run (scenerf_cfg.fused_min_rows: 0 = default, < 0 = never)
+static inline bool srf_use_fused(const scenerf_cfg* cfg, int M) {
+    const int th = cfg->fused_min_rows == 0 ? SCENERF_FUSED_MIN_ROWS_DEFAULT : cfg->fused_min_rows;
+    return th > 0 && M >= th;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline hipStream_t as_stream(scenerf_stream_t s) { return (hipStream_t)s; }
 

@@ -50,6 +50,24 @@ typedef const __attribute__((address_space(4))) int* desc_ptr;   // constant add
 #define FD_STAGE(d) (((d) >> 25) & 7)
 #define F_MAXCH SCENERF_CHUNK_TABLE_STRIDE   // 704:     // 666 chunks with all five scales + header + zero padding (the pipeline reads a few entries past the end)
 
+// Per-device cache of a host-built descriptor table (one per kernel family): built once per (device, segment layout), uploaded with an
+// asynchronous copy on the caller's stream from a host image that stays alive (no stream synchronisation, no blocking copy).  A first
+// use inside a hipGraph capture is not capturable -- call scenerf_hip_prepare before capturing.
+struct SrfDescCache {
+    std::mutex mu;
+    struct Slot {
+        int seg_len[5] = {-1, -1, -1, -1, -1};
+        int* d_desc = nullptr;
+    } slot[SRF_MAX_DEVICES];
+};
+int srf_desc_cache_get(SrfDescCache& C, const scenerf_cfg* cfg, hipStream_t s, int (*build)(const scenerf_cfg*, std::vector<int>&),
+                       const int** desc);
+// one-time per-device setup of each kernel family (kernel attributes, descriptor tables, the zero page)
+int fused_prepare(const scenerf_cfg* cfg, hipStream_t s);
+int stream_prepare(const scenerf_cfg* cfg, hipStream_t s);
+int wgrad_prepare();
+int gemm_prepare();
+
 // host-only builders of the chunk-descriptor tables (also reachable through scenerf_hip_test_chunk_table for the CPU tests)
 int fused_table_build(const scenerf_cfg* cfg, std::vector<int>& tab);    // fused.hip: 33 sets of F_MAXCH ints
 int stream_table_build(const scenerf_cfg* cfg, std::vector<int>& tab);   // stream.hip: 32 sets of F_MAXCH ints

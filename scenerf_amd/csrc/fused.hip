@@ -356,12 +356,31 @@ __global__ __launch_bounds__(F_THREADS) void mlp_fused_kernel(FusedArgs p) {
     }
 }
 
-// chunk descriptors for the 32 possible scale masks, built once per segment layout and kept on the device
-struct FusedTable {
-    int seg_len[5] = {-1, -1, -1, -1, -1};
-    int* d_desc = nullptr;
-};
-static FusedTable g_table;
+// chunk descriptors for the 32 possible scale masks, built once per (device, segment layout) and kept on that device
+static SrfDescCache g_table;
+
+int srf_desc_cache_get(SrfDescCache& C, const scenerf_cfg* cfg, hipStream_t s, int (*build)(const scenerf_cfg*, std::vector<int>&),
+                       const int** desc) {
+    const int dev = srf_device();
+    SRF_CHECK(dev >= 0 && dev < SRF_MAX_DEVICES, "no current HIP device");
+    std::lock_guard<std::mutex> lk(C.mu);
+    SrfDescCache::Slot& S = C.slot[dev];
+    bool same = S.d_desc != nullptr;
+    for (int i = 0; i < 5; ++i) same = same && S.seg_len[i] == cfg->map_C[i];
+    if (!same) {
+        // a new layout gets a NEW device buffer and a NEW host image (both live for the rest of the process: ~90 KB per layout):
+        // launches still in flight on other streams keep reading the old table, and the asynchronous upload never reads freed memory
+        std::vector<int>* tab = new std::vector<int>();
+        if (int e = build(cfg, *tab)) { delete tab; return e; }
+        int* d = nullptr;
+        SRF_HIP(hipMalloc((void**)&d, tab->size() * sizeof(int)));
+        SRF_HIP(hipMemcpyAsync(d, tab->data(), tab->size() * sizeof(int), hipMemcpyHostToDevice, s));
+        S.d_desc = d;
+        for (int i = 0; i < 5; ++i) S.seg_len[i] = cfg->map_C[i];
+    }
+    *desc = S.d_desc;
+    return 0;
+}
 
 // host-only: the descriptor sets of the ring kernels (sets 0..31: forward per scale mask ; set 32: backward chain)
 int fused_table_build(const scenerf_cfg* cfg, std::vector<int>& tab) {
@@ -424,27 +443,25 @@ int fused_table_build(const scenerf_cfg* cfg, std::vector<int>& tab) {
 }
 
 static int fused_table_get(const scenerf_cfg* cfg, hipStream_t s, const int** desc) {
-    bool same = g_table.d_desc != nullptr;
-    for (int i = 0; i < 5; ++i) same = same && g_table.seg_len[i] == cfg->map_C[i];
-    if (!same) {
-        std::vector<int> tab;
-        if (int e = fused_table_build(cfg, tab)) return e;
-        if (!g_table.d_desc) SRF_HIP(hipMalloc((void**)&g_table.d_desc, tab.size() * sizeof(int)));
-        SRF_HIP(hipStreamSynchronize(s));
-        SRF_HIP(hipMemcpy(g_table.d_desc, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
-        for (int i = 0; i < 5; ++i) g_table.seg_len[i] = cfg->map_C[i];
-    }
-    *desc = g_table.d_desc;
+    return srf_desc_cache_get(g_table, cfg, s, fused_table_build, desc);
+}
+
+static int fused_attrs() {
+    SRF_ONCE_PER_DEVICE(
+        SRF_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+        SRF_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BWD)));
     return 0;
+}
+
+int fused_prepare(const scenerf_cfg* cfg, hipStream_t s) {
+    if (int e = fused_attrs()) return e;
+    const int* d = nullptr;
+    return fused_table_get(cfg, s, &d);
 }
 
 int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const uint8_t* tile_mask, int M,
                          const scenerf_mlp_acts* a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        SRF_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
-        attr_done = true;
-    }
+    if (int e = fused_attrs()) return e;
     FusedArgs p = {};
     const int H = SCENERF_D_HIDDEN;
     const size_t sign_layer = (size_t)cdiv(M, SCENERF_TILE_ROWS) * SCENERF_TILE_ROWS * 64;   // bytes per layer of a->sign_bits
@@ -490,11 +507,7 @@ int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
 // blocks after the forward operands.  Descriptor table: entry set 32 of the device table.
 int launch_mlp_bwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, int M, const scenerf_mlp_acts* a, void* dH, void* dN,
                          hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        SRF_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BWD));
-        attr_done = true;
-    }
+    if (int e = fused_attrs()) return e;
     FusedArgs p = {};
     const int H = SCENERF_D_HIDDEN;
     const size_t sign_layer = (size_t)cdiv(M, SCENERF_TILE_ROWS) * SCENERF_TILE_ROWS * 64;

@@ -64,6 +64,7 @@ struct GemmTN {
     float* out = nullptr;
     int ldo = 0;
     float* colsum = nullptr;  // optional [N]: += sum_m D[m][n]  (bias gradient, folded into the k-tile-0 workgroups)
+    int allow_tr = 1;         // 0: never the transposing-read kernel (scenerf_cfg.flags & SCENERF_FLAG_NO_WGRAD_TR)
     const char* name = "gemm_tn";
 };
 

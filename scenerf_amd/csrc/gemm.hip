@@ -820,11 +820,7 @@ static double tn_issued_flops(const GemmTN& p, hipStream_t s) {
 }
 
 template <typename T, typename CF> static int launch_nt_t(const GemmNT& p, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
-        attr_done = true;
-    }
+    SRF_ONCE_PER_DEVICE(SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS)));
     dim3 grid(cdiv(p.M, BM) * (p.ms_n > 0 ? p.ms_t0[GEMM_MAX_SEG] : cdiv(p.N, CF::BN)));
     double flops = 0;
     if (srf_prof_on()) {
@@ -844,17 +840,28 @@ template <typename T, typename CF> static int launch_nt_t(const GemmNT& p, hipSt
 }
 
 static int launch_nt_glds(const GemmNT& p, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CfgG::LDS));
-        attr_done = true;
-    }
+    SRF_ONCE_PER_DEVICE(SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CfgG::LDS)));
     dim3 grid(cdiv(p.M, BM) * cdiv(p.N, CfgG::BN));
     double flops = 0;
     if (srf_prof_on()) flops = nt_issued_flops(p, s);
     SrfLaunchScope ps(s, p.name, flops, 0);
     gemm_nt_glds_kernel<<<grid, CfgG::NT, CfgG::LDS, s>>>(p);
     SRF_LAUNCH_CHECK(p.name);
+    return 0;
+}
+
+// every dynamic-LDS attribute of this file, for the current device (scenerf_hip_prepare: before a hipGraph capture)
+int gemm_prepare() {
+    SRF_ONCE_PER_DEVICE(
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16_t, CfgS>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgS::LDS));
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<float, CfgS>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgS::LDS));
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16_t, CfgM>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgM::LDS));
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<float, CfgM>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgM::LDS));
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16_t, CfgW>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgW::LDS));
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<float, CfgW>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgW::LDS));
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CfgG::LDS));
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE));
+        SRF_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE)));
     return 0;
 }
 
@@ -881,20 +888,11 @@ int launch_gemm_nt(int precision, const GemmNT& p, hipStream_t s) {
 }
 
 template <typename T> static int launch_tn_t(const GemmTN& p, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        SRF_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE));
-        attr_done = true;
-    }
+    SRF_ONCE_PER_DEVICE(SRF_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE)));
     constexpr int MC = TnStage<T>::MC;
     int tiles = cdiv(p.N, 128) * cdiv(p.K, 128);
     int chunks = cdiv(p.M, MC);
-    static int target = 0;
-    if (!target) {
-        const char* e = getenv("SRF_TN_WG_TARGET");   // tuning knob: workgroups per launch the M-split aims for
-        target = e ? atoi(e) : 512;   // 256 CUs x 2 resident workgroups: one full wave of workgroups, no tail (measured best)
-        if (target < 1) target = 512;
-    }
+    const int target = 512;   // workgroups the M-split aims for: 256 CUs x 2 resident workgroups = one full wave, no tail (measured best)
     int slices = target / tiles;
     if (slices < 1) slices = 1;
     if (slices > chunks) slices = chunks;

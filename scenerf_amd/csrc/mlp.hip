@@ -184,7 +184,9 @@ struct SideCtx {
     int next = 0;
 };
 static SideCtx* side_ctx(hipStream_t main) {
-    static std::map<hipStream_t, SideCtx*> g_map;
+    static std::map<hipStream_t, SideCtx*> g_map;   // keyed by the caller's stream (a stream belongs to one device)
+    static std::mutex g_mu;
+    std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_map.find(main);
     if (it != g_map.end()) return it->second;
     SideCtx* c = new SideCtx();
@@ -221,7 +223,7 @@ static void set_segments(GemmNT& g, const scenerf_cfg* cfg, const void* Z, const
 static int feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const uint8_t* tile_mask, const int32_t* tap_texel,
                          const float* tap_weight, int M, const void* dH, float* const gmaps_hwc[SCENERF_N_SCALES], hipStream_t s) {
     const bool head = w->d_out == 2;
-    static const bool per_scale = getenv("SRF_DFEAT_PER_SCALE") != nullptr;   // one launch per scale (the older form), for A/B runs
+    const bool per_scale = (cfg->flags & SCENERF_FLAG_DFEAT_PER_SCALE) != 0;   // one launch per scale (the older form), for A/B runs
     GemmNT g;
     g.name = head ? "gemm_dfeat_scatter/g" : "gemm_dfeat_scatter";
     g.A1 = dH; g.lda1 = 4 * SCENERF_D_HIDDEN; g.K1 = 3 * SCENERF_D_HIDDEN;
@@ -264,6 +266,18 @@ static int feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
 }
 
 extern "C" {
+
+int scenerf_hip_prepare(const scenerf_cfg* cfg, scenerf_stream_t stream) {
+    SRF_CHECK(cfg, "prepare: cfg is NULL");
+    hipStream_t s = as_stream(stream);
+    if (int e = gemm_prepare()) return e;
+    if (int e = wgrad_prepare()) return e;
+    if (cfg->precision) {
+        if (int e = fused_prepare(cfg, s)) return e;
+        if (int e = stream_prepare(cfg, s)) return e;
+    }
+    return 0;
+}
 
 int scenerf_hip_mlp_feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const uint8_t* tile_mask,
                                   const int32_t* tap_texel, const float* tap_weight, int M, const void* dH,
@@ -308,14 +322,11 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
             split_xenc_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(xenc, x3, M);
             SRF_LAUNCH_CHECK("split_xenc_kernel");
         }
-        // rows from which the whole trunk runs as ONE fused kernel (fused.hip); read per call so a test can compare paths
-        const char* fenv = getenv("SRF_FUSED_MIN_M");
-        const int fused_min_m = fenv ? atoi(fenv) : 4096;
-        if (M >= fused_min_m && w->w_stream) {   // lin_out included
-            // two kernels with identical results: fused.hip's LDS-ring pipeline (default) and stream.hip's register-streamed one
-            const char* kv = getenv("SRF_FWD_KERNEL");
-            const bool stream = kv && kv[0] == 's';
-            return stream ? launch_mlp_fwd_stream(cfg, w, Z, tile_mask, M, a, s) : launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s);
+        // rows from which the whole trunk runs as ONE fused kernel (scenerf_cfg.fused_min_rows), lin_out included
+        if (srf_use_fused(cfg, M) && w->w_stream) {
+            // two kernels with identical results: fused.hip's LDS-ring pipeline and stream.hip's register-streamed one (scenerf_cfg.fwd_kernel)
+            SRF_CHECK(cfg->fwd_kernel == 0 || cfg->fwd_kernel == 1, "mlp_forward: unknown fwd_kernel %d", cfg->fwd_kernel);
+            return cfg->fwd_kernel == 1 ? launch_mlp_fwd_stream(cfg, w, Z, tile_mask, M, a, s) : launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s);
         }
         SRF_CHECK(a->H[3], "mlp_forward: acts->H[3] is NULL");
         SRF_CHECK(a->H[0] && a->H[1] && a->H[2] && a->Nn[0] && a->Nn[1] && a->Nn[2],
@@ -381,7 +392,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     auto dHcol = [&](int b) { return (void*)((char*)dH + (size_t)b * SCENERF_D_HIDDEN * es); };
 
     // measured neutral on MI355X at R=1200 (6.89 vs 6.86 ms/step: both kernels are bandwidth-limited), so opt-in
-    static const bool overlap = getenv("SRF_WGRAD_OVERLAP") != nullptr;
+    const bool overlap = (cfg->flags & SCENERF_FLAG_WGRAD_OVERLAP) != 0;
     SideCtx* sc_ = overlap ? side_ctx(s) : nullptr;
     hipStream_t s2 = sc_ ? sc_->side : s;   // weight-gradient stream (== s when overlap is off)
     auto fork = [&]() -> int { return sc_ ? order_after(sc_, s, s2) : 0; };
@@ -396,8 +407,8 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     if (int e = fork()) return e;
     // bf16, enough rows: the whole dgrad chain (6 GEMMs) runs as ONE kernel (fused.hip); the weight-gradient GEMMs below then
     // only consume dH / dN
-    const char* fenv = getenv("SRF_FUSED_MIN_M");
-    const bool fused_chain = prec && w->w_stream && a->sign_bits && M >= (fenv ? atoi(fenv) : 4096) && !getenv("SRF_NO_FUSED_BWD");
+    const bool fused_chain = prec && w->w_stream && a->sign_bits && srf_use_fused(cfg, M) && !(cfg->flags & SCENERF_FLAG_NO_FUSED_BWD);
+    const int allow_tr = (cfg->flags & SCENERF_FLAG_NO_WGRAD_TR) ? 0 : 1;
     if (fused_chain) {
         if (int e = launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
         if (int e = fork()) return e;
@@ -411,6 +422,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             t.D = dHcol(b + 1); t.ldd = LDH; t.A = a->Nn[b]; t.lda = SCENERF_D_HIDDEN; t.relu_a = 1;
             t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc1[b]; t.ldo = SCENERF_D_HIDDEN;
             t.colsum = g_->b_fc1[b];  // fc_1.b.bias gradient = column sums of dH_{b+1}
+            t.allow_tr = allow_tr;
             if (fused_chain && wgrad_tr_applicable(t)) { t.name = "gemm_wgrad_fc"; wg[nwg++] = t; }
             else if (int e = launch_gemm_tn(prec, t, s2)) return e;
         }
@@ -431,6 +443,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             t.D = dNb(b); t.ldd = SCENERF_D_HIDDEN; t.A = a->H[b]; t.lda = SCENERF_D_HIDDEN; t.relu_a = 1;
             t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc0[b]; t.ldo = SCENERF_D_HIDDEN;
             t.colsum = g_->b_fc0[b];
+            t.allow_tr = allow_tr;
             if (fused_chain && wgrad_tr_applicable(t)) { t.name = "gemm_wgrad_fc"; wg[nwg++] = t; }
             else if (int e = launch_gemm_tn(prec, t, s2)) return e;
         }
@@ -459,6 +472,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         t.A = Z; t.lda = SCENERF_D_LATENT;
         t.M = M; t.N = 3 * SCENERF_D_HIDDEN; t.K = SCENERF_Z_DENSE_COLS;
         t.out = g_->w_z; t.ldo = SCENERF_D_LATENT;
+        t.allow_tr = allow_tr;
         if (wgrad_tr_applicable(t)) { wg[nwg++] = t; linz_done = SCENERF_Z_DENSE_COLS; }
     }
     if (nwg) {
@@ -475,6 +489,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         t.M = M; t.N = 3 * SCENERF_D_HIDDEN; t.K = c1 - c0;
         t.tile_mask = tile_mask; t.skip_bit = sc;
         t.out = g_->w_z + c0; t.ldo = SCENERF_D_LATENT;
+        t.allow_tr = allow_tr;
         if (int e = launch_gemm_tn(prec, t, s2)) return e;
     }
     // [side] dWin += dH0^T xenc   (bf16 mode: the hi part of the split encoding kept in h0pre is bf16(xenc))
@@ -489,6 +504,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         }
         t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_XENC; t.out = g_->w_in; t.ldo = SCENERF_D_XENC;
         t.colsum = g_->b_in;  // lin_in.bias gradient = column sums of dH_0
+        t.allow_tr = allow_tr;
         if (int e = launch_gemm_tn(prec, t, s2)) return e;
     }
     // lin_z.b.bias is added at the same place as lin_in.bias (b=0) / fc_1.(b-1).bias: same column sums of dH_b

@@ -16,6 +16,27 @@ void srf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int srf_device() {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) return -1;
+    return d;
+}
+
+const char* srf_zero_page() {
+    static std::mutex mu;
+    static char* page[SRF_MAX_DEVICES] = {};
+    const int d = srf_device();
+    if (d < 0 || d >= SRF_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!page[d]) {
+        char* p = nullptr;
+        if (hipMalloc((void**)&p, 4096) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 4096) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        page[d] = p;
+    }
+    return page[d];
+}
+
 struct ProfEntry {
     std::string name;
     hipEvent_t a, b;

@@ -376,11 +376,7 @@ __global__ __launch_bounds__(G_THREADS) void mlp_stream_kernel(FusedArgs p) {
 }
 
 // chunk descriptors for the 32 possible scale masks (forward): like fused.hip's table, every layer padded to a multiple of four chunks
-struct StreamTable {
-    int seg_len[5] = {-1, -1, -1, -1, -1};
-    int* d_desc = nullptr;
-};
-static StreamTable g_stream_table;
+static SrfDescCache g_stream_table;
 
 // host-only: the 32 descriptor sets of the streamed forward
 int stream_table_build(const scenerf_cfg* cfg, std::vector<int>& tab) {
@@ -446,27 +442,23 @@ int stream_table_build(const scenerf_cfg* cfg, std::vector<int>& tab) {
 }
 
 static int stream_table_get(const scenerf_cfg* cfg, hipStream_t s, const int** desc) {
-    bool same = g_stream_table.d_desc != nullptr;
-    for (int i = 0; i < 5; ++i) same = same && g_stream_table.seg_len[i] == cfg->map_C[i];
-    if (!same) {
-        std::vector<int> tab;
-        if (int e = stream_table_build(cfg, tab)) return e;
-        if (!g_stream_table.d_desc) SRF_HIP(hipMalloc((void**)&g_stream_table.d_desc, tab.size() * sizeof(int)));
-        SRF_HIP(hipStreamSynchronize(s));
-        SRF_HIP(hipMemcpy(g_stream_table.d_desc, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
-        for (int i = 0; i < 5; ++i) g_stream_table.seg_len[i] = cfg->map_C[i];
-    }
-    *desc = g_stream_table.d_desc;
+    return srf_desc_cache_get(g_stream_table, cfg, s, stream_table_build, desc);
+}
+
+static int stream_attrs() {
+    SRF_ONCE_PER_DEVICE(SRF_HIP(hipFuncSetAttribute((const void*)mlp_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS)));
     return 0;
+}
+
+int stream_prepare(const scenerf_cfg* cfg, hipStream_t s) {
+    if (int e = stream_attrs()) return e;
+    const int* d = nullptr;
+    return stream_table_get(cfg, s, &d);
 }
 
 int launch_mlp_fwd_stream(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const uint8_t* tile_mask, int M,
                           const scenerf_mlp_acts* a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        SRF_HIP(hipFuncSetAttribute((const void*)mlp_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
-        attr_done = true;
-    }
+    if (int e = stream_attrs()) return e;
     FusedArgs p = {};
     const int H = SCENERF_D_HIDDEN;
     const size_t sign_layer = (size_t)cdiv(M, SCENERF_TILE_ROWS) * SCENERF_TILE_ROWS * 64;

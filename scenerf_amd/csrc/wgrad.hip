@@ -239,20 +239,20 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
 
 // Used by launch_gemm_tn for the shapes it fits (bf16, N and K multiples of 256, no tile skipping, enough rows).
 bool wgrad_tr_applicable(const GemmTN& p) {
-    static const bool off = getenv("SRF_NO_WGRAD_TR") != nullptr;
-    return !off && p.N % W_TILE == 0 && p.K % W_TILE == 0 && !p.tile_mask && p.M >= 32768 && p.ldd % 8 == 0 && p.lda % 8 == 0;
+    return p.allow_tr && p.N % W_TILE == 0 && p.K % W_TILE == 0 && !p.tile_mask && p.M >= 32768 && p.ldd % 8 == 0 && p.lda % 8 == 0;
+}
+
+int wgrad_prepare() {
+    SRF_ONCE_PER_DEVICE(SRF_HIP(hipFuncSetAttribute((const void*)wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS)));
+    SRF_CHECK(srf_zero_page(), "wgrad: cannot allocate the zero page");
+    return 0;
 }
 
 // `count` problems over the same M rows (N, K multiples of 256, possibly different) in one launch
 int launch_wgrad_tr_batch(const GemmTN* probs, int count, hipStream_t s) {
-    static bool attr_done = false;
-    static char* zero = nullptr;
-    if (!attr_done) {
-        SRF_HIP(hipFuncSetAttribute((const void*)wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
-        SRF_HIP(hipMalloc((void**)&zero, 1024));
-        SRF_HIP(hipMemset(zero, 0, 1024));
-        attr_done = true;
-    }
+    if (int e = wgrad_prepare()) return e;
+    const char* zero = srf_zero_page();
+    SRF_CHECK(zero, "wgrad batch: no zero page on this device");
     SRF_CHECK(count >= 1 && count <= W_MAXPROB, "wgrad batch: 1..%d problems", W_MAXPROB);
     const GemmTN& p0 = probs[0];
     WgradArgs a;
@@ -269,7 +269,7 @@ int launch_wgrad_tr_batch(const GemmTN* probs, int count, hipStream_t s) {
     }
     a.M = p0.M;
     a.zero = zero;
-    static const int wg_target = getenv("SRF_WGRAD_TR_WGS") ? atoi(getenv("SRF_WGRAD_TR_WGS")) : 256;   // one workgroup per CU (128 KiB of LDS)
+    const int wg_target = 256;   // one workgroup per CU (128 KiB of LDS)
     int splits = wg_target / tile_units > 1 ? wg_target / tile_units : 1;
     if (splits > 64) splits = 64;
     int rows = cdiv(cdiv(p0.M, splits), W_BM) * W_BM;   // (a multiple of the step)

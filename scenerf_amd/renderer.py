@@ -36,8 +36,17 @@ OUTPUT_KEYS = ["depth", "color", "gaussian_means", "gaussian_stds", "weights_at_
                "loss_kl", "alphas", "som_vars", "densities", "weights", "depth_volumes"]
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(dev=None) -> int:
+    """hipStream_t of torch's current stream ON ``dev`` (the device of the tensors handed to the C ABI, not whatever device
+    happens to be current)."""
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _on(dev):
+    """Context: make ``dev`` the calling thread's current device for the duration of a group of C-ABI calls.  The library keys its
+    per-device state (kernel attributes, descriptor tables) on the current device and launches on the stream it is given, so both
+    must be the device the buffers live on -- also when the model sits on a non-current GPU or a process drives several."""
+    return torch.cuda.device(dev)
 
 
 _SIDE = {}
@@ -72,6 +81,7 @@ class MapHolder:
         self.hwc: List[torch.Tensor] = []
         self.shapes = []
         self.gmaps: Optional[List[torch.Tensor]] = None
+        self.debug_aux: Optional[Dict[str, torch.Tensor]] = None   # dict when the session was opened with debug_aux=True
 
     def convert(self, chw: Sequence[torch.Tensor]) -> None:
         lib = _capi.load()
@@ -89,7 +99,7 @@ class MapHolder:
                 dst = src   # read in place, (C,H,W) fp32 (RenderConfig.direct_scales)
             else:
                 dst = torch.empty((h, w, c), dtype=_act_dtype(prec), device=src.device)
-                _capi.check(lib.scenerf_hip_maps_chw_to_hwc(src.data_ptr(), dst.data_ptr(), c, h, w, prec, _stream()),
+                _capi.check(lib.scenerf_hip_maps_chw_to_hwc(src.data_ptr(), dst.data_ptr(), c, h, w, prec, _stream(src.device)),
                             "maps_chw_to_hwc")
             self.hwc.append(dst)
             self.shapes.append((c, h, w))
@@ -123,6 +133,14 @@ class PrepareMaps(torch.autograd.Function):
             return (None,) + tuple(None for _ in holder.shapes)
         lib = _capi.load()
         outs = []
+        with _on(holder.gmaps[0].device):
+            outs = PrepareMaps._transpose_back(ctx, holder, lib)
+        holder.gmaps = None
+        return (None,) + tuple(outs)
+
+    @staticmethod
+    def _transpose_back(ctx, holder, lib):
+        outs = []
         for i, (c, h, w) in enumerate(holder.shapes):
             if not ctx.needs_input_grad[1 + i]:
                 outs.append(None)
@@ -131,11 +149,10 @@ class PrepareMaps(torch.autograd.Function):
                 outs.append(holder.gmaps[i])
                 continue
             g = torch.empty((c, h, w), dtype=torch.float32, device=holder.gmaps[i].device)
-            _capi.check(lib.scenerf_hip_grads_hwc_to_chw(holder.gmaps[i].data_ptr(), g.data_ptr(), c, h, w, _stream()),
+            _capi.check(lib.scenerf_hip_grads_hwc_to_chw(holder.gmaps[i].data_ptr(), g.data_ptr(), c, h, w, _stream(g.device)),
                         "grads_hwc_to_chw")
             outs.append(g)
-        holder.gmaps = None
-        return (None,) + tuple(outs)
+        return outs
 
 
 # ------------------------------------------------------------------------------------------------ MLP operands
@@ -195,7 +212,7 @@ class PackedMLP:
             raw.fc1_w[i], raw.fc1_b[i] = p["blocks.%d.fc_1.weight" % i].data_ptr(), p["blocks.%d.fc_1.bias" % i].data_ptr()
             raw.linz_w[i], raw.linz_b[i] = p["lin_z.%d.weight" % i].data_ptr(), p["lin_z.%d.bias" % i].data_ptr()
         ccfg = cfg.to_c()
-        _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(raw), C.byref(s), _stream()), "mlp_pack")
+        _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(raw), C.byref(s), _stream(dev)), "mlp_pack")
         # gradient sink (flat fp32 buffer carved into the scenerf_mlp_grads fields), allocated on first backward
         self.gflat: Optional[torch.Tensor] = None
         self.gviews: Dict[str, torch.Tensor] = {}
@@ -268,6 +285,15 @@ class PackMLP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _g):
         pk: PackedMLP = ctx.holder.packed
+        if getattr(ctx, "done", False):
+            raise RuntimeError("scenerf_amd: the MLP gradients of this render_rays_batch session were already handed to autograd "
+                               "(a second backward over the same graph is not supported; call render_rays_batch again)")
+        ctx.done = True
+        with _on(pk.device):
+            return PackMLP._backward(ctx, pk)
+
+    @staticmethod
+    def _backward(ctx, pk):
         # data-parallel hook: reduce the packed fp32 gradient sink in ONE collective (21.7 MB per MLP) before it is
         # carved into per-parameter views -- no flatten/unflatten copies, one large message per MLP over xGMI
         if ctx.holder.pending is not None:      # started in RenderChunk.backward, overlapped with the feature-gradient scatter
@@ -286,11 +312,12 @@ class PackMLP(torch.autograd.Function):
 class _MlpRun:
     """Buffers of one ResnetFC evaluation over M rows (kept for backward when grad is enabled)."""
 
-    def __init__(self, M: int, d_out: int, prec: int, dev, keep_acts: bool = True):
+    def __init__(self, M: int, d_out: int, prec: int, dev, lean: bool = False):
         act = _act_dtype(prec)
-        # inference (no_grad) on the fused bf16 path: lin_out runs inside the kernel, so no activation is ever read again: neither
-        # they nor the sign bits are allocated or written (NULL in scenerf_mlp_acts)
-        lean = (not keep_acts) and prec == 1 and M >= _capi.fused_min_rows()
+        # lean = inference (no_grad) on the fused bf16 path (RenderConfig.uses_fused): lin_out runs inside the kernel, so no activation
+        # is ever read again: neither they nor the sign bits are allocated or written (NULL in scenerf_mlp_acts)
+        if lean and prec != 1:
+            raise ValueError("lean activation buffers exist only on the fused bf16 path")
         self.M = M
         self.Mpad = (M + _capi.TILE_ROWS - 1) // _capi.TILE_ROWS * _capi.TILE_ROWS
         self.sphere_idx = torch.empty((M, 2), dtype=torch.int32, device=dev)
@@ -320,8 +347,8 @@ class _MlpRun:
 def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dist_ray_stride, ppr, unit_dir, viewdir,
               K, inv_K, T, M, keep_acts: bool = True) -> _MlpRun:
     lib = _capi.load()
-    st = _stream()
-    run = _MlpRun(M, pk.d_out, cfg.precision_code, dist.device, keep_acts=keep_acts)
+    st = _stream(dist.device)
+    run = _MlpRun(M, pk.d_out, cfg.precision_code, dist.device, lean=(not keep_acts) and cfg.uses_fused(M))
     _capi.check(lib.scenerf_hip_encode_points(C.byref(ccfg), dist.data_ptr(), dist_ray_stride, ppr, unit_dir.data_ptr(),
                                               viewdir.data_ptr(), K.data_ptr(), inv_K.data_ptr(), T.data_ptr(), M, None,
                                               run.sphere_idx.data_ptr(), run.xenc.data_ptr(), st), "encode_points")
@@ -349,11 +376,11 @@ def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: 
     _capi.check(lib.scenerf_hip_mlp_backward(C.byref(ccfg), C.byref(pk.c), C.byref(g), run.Z.data_ptr(), run.xenc.data_ptr(),
                                              run.tile_mask.data_ptr(), run.tap_texel.data_ptr(), run.tap_weight.data_ptr(),
                                              run.M, C.byref(run.c), d_logits.data_ptr(), dH.data_ptr(), dN.data_ptr(),
-                                             None if split else gm, _stream()), "mlp_backward")
+                                             None if split else gm, _stream(dev)), "mlp_backward")
     finish = sync_async(pk.gflat) if sync_async is not None else None
     if split:
         _capi.check(lib.scenerf_hip_mlp_feature_grads(C.byref(ccfg), C.byref(pk.c), run.tile_mask.data_ptr(), run.tap_texel.data_ptr(),
-                                                      run.tap_weight.data_ptr(), run.M, dH.data_ptr(), gm, _stream()),
+                                                      run.tap_weight.data_ptr(), run.M, dH.data_ptr(), gm, _stream(dev)),
                     "mlp_feature_grads")
     return finish
 
@@ -365,11 +392,16 @@ class RenderChunk(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg: RenderConfig, maps: MapHolder, mlp: MlpHolder, mlpg: MlpHolder, pixels, cam_K, inv_K, T_s2i,
                 noise_u, noise_g, tok_maps, tok_mlp, tok_mlpg):
+        with _on(pixels.device):
+            return RenderChunk._forward(ctx, cfg, maps, mlp, mlpg, pixels, cam_K, inv_K, T_s2i, noise_u, noise_g)
+
+    @staticmethod
+    def _forward(ctx, cfg, maps, mlp, mlpg, pixels, cam_K, inv_K, T_s2i, noise_u, noise_g):
         ctx.set_materialize_grads(False)   # outputs nobody differentiates arrive as None, not as freshly filled zero tensors
         lib = _capi.load()
-        st = _stream()
-        ccfg = cfg.to_c()
         dev = pixels.device
+        st = _stream(dev)
+        ccfg = cfg.to_c()
         R = pixels.shape[0]
         U, G, P, N = cfg.n_pts_uni, cfg.n_gaussians, cfg.n_pts_per_gaussian, cfg.n_samples
         f32 = dict(dtype=torch.float32, device=dev)
@@ -426,22 +458,35 @@ class RenderChunk(torch.autograd.Function):
         ctx.keep = dict(R=R, anchors=anchors, noise_g=noise_g, unit_dir=unit_dir, gmeans=gmeans, gstds=gstds, perm=perm,
                         dist_s=dist_s, z_s=z_s, kl_saved=kl_saved, run_g=run_g, run_m=run_m)
         ctx.mark_non_differentiable(w_at, closest, som_vars, som_means)
-        ctx.aux = dict(perm=perm, sphere_idx=run_m.sphere_idx, closest_idx=closest_idx, tile_mask=run_m.tile_mask,
-                       offsets=run_g.logits, logits=run_m.logits, dist_sorted=dist_s, xenc=run_m.xenc,
-                       sphere_idx_g=run_g.sphere_idx, unit_dir=unit_dir, viewdir=viewdir, dist_u=dist_u,
-                       tile_mask_g=run_g.tile_mask)
-        RenderChunk.last_aux = ctx.aux
+        if maps.debug_aux is not None:
+            # opt-in debug hook (RenderSession(debug_aux=True)): stage intermediates of the LAST chunk of this session, for the
+            # per-stage parity tests.  Off by default: it would pin logits / xenc / indices of a chunk (GBs at N = 512) for as long
+            # as the session lives, and a process-wide slot would be shared between models and threads.
+            maps.debug_aux.clear()
+            maps.debug_aux.update(perm=perm, sphere_idx=run_m.sphere_idx, closest_idx=closest_idx, tile_mask=run_m.tile_mask,
+                                  offsets=run_g.logits, logits=run_m.logits, dist_sorted=dist_s, xenc=run_m.xenc,
+                                  sphere_idx_g=run_g.sphere_idx, unit_dir=unit_dir, viewdir=viewdir, dist_u=dist_u,
+                                  tile_mask_g=run_g.tile_mask)
         # order = OUTPUT_KEYS + som_means
         return depth, color, gmeans, gstds, w_at, closest, loss_kl, alphas, som_vars, dens, weights, z_s, som_means
 
-    last_aux: Dict[str, torch.Tensor] = {}
+    @staticmethod
+    def backward(ctx, *grads):
+        if ctx.keep is None:
+            # the saved activations (GBs per chunk) are released by the first backward and the gradient sinks are handed to autograd
+            # once per session: a second pass over the same graph cannot be served
+            raise RuntimeError("scenerf_amd: this render_rays_batch graph was already back-propagated (retain_graph=True / a second "
+                               "backward or autograd.grad over the same outputs is not supported: the saved activations are freed "
+                               "by the first pass).  Call render_rays_batch again for another backward.")
+        with _on(ctx.keep["dist_s"].device):
+            return RenderChunk._backward(ctx, *grads)
 
     @staticmethod
-    def backward(ctx, g_depth, g_color, g_gmeans, g_gstds, _g_wat, _g_closest, g_kl, g_alphas, _g_somv, g_dens, g_weights,
-                 g_zvol, _g_somm):
+    def _backward(ctx, g_depth, g_color, g_gmeans, g_gstds, _g_wat, _g_closest, g_kl, g_alphas, _g_somv, g_dens, g_weights,
+                  g_zvol, _g_somm):
         lib = _capi.load()
-        st = _stream()
         k = ctx.keep
+        st = _stream(k["dist_s"].device)
         cfg, ccfg = ctx.cfg, ctx.ccfg
         R, N, G = k["R"], cfg.n_samples, cfg.n_gaussians
         dev = k["dist_s"].device
@@ -474,7 +519,7 @@ class RenderChunk(torch.autograd.Function):
         # The gaussian head's backward (R*G rows: small grids) is independent of the radiance MLP's backward: run it
         # on a side stream so its workgroups fill the gaps of the big GEMMs.  Both scatter into the same map-gradient
         # accumulators with atomics; the main stream waits for the side stream before anything reads them.
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
         do_head = bool(ctx.needs_input_grad[12] or want_maps)
         if do_head:
@@ -509,18 +554,36 @@ class RenderSession:
     """Per-call state of ``render_rays_batch``: converted maps + packed MLPs, shared by all chunks."""
 
     def __init__(self, cfg: RenderConfig, x_rgb: Dict[str, torch.Tensor], mlp_params: Sequence[torch.Tensor],
-                 mlpg_params: Sequence[torch.Tensor], grad_sync=None, grad_sync_async=None):
-        _capi.load()
+                 mlpg_params: Sequence[torch.Tensor], grad_sync=None, grad_sync_async=None, debug_aux: bool = False):
+        chw = [x_rgb["1_%d" % s] for s in (1, 2, 4, 8, 16)]
+        _require_cuda(chw[0], "x_rgb map 0")
+        self.device = chw[0].device
+        with _on(self.device):
+            self._open(cfg, chw, mlp_params, mlpg_params, grad_sync, grad_sync_async, debug_aux)
+
+    def _open(self, cfg, chw, mlp_params, mlpg_params, grad_sync, grad_sync_async, debug_aux):
+        lib = _capi.load()
         cfg.validate()
         self.cfg = cfg
-        chw = [x_rgb["1_%d" % s] for s in (1, 2, 4, 8, 16)]
+        # per-device one-time setup (kernel attributes, descriptor tables): explicit, so that a later hipGraph capture of a chunk
+        # never meets a first-use allocation
+        _capi.check(lib.scenerf_hip_prepare(C.byref(cfg.to_c()), _stream(self.device)), "prepare")
         # autograd runs ready nodes newest-first: the MLP tokens are created BEFORE the map token so that in backward the map
         # transposes (PrepareMaps.backward) are queued before PackMLP.backward waits for a gradient all-reduce in flight
         self.mlp, self.mlpg = MlpHolder(grad_sync, grad_sync_async), MlpHolder(grad_sync)
         self.tok_mlp = PackMLP.apply(self.mlp, 4, cfg, *mlp_params)
         self.tok_mlpg = PackMLP.apply(self.mlpg, 2, cfg, *mlpg_params)
         self.maps = MapHolder(cfg)
+        if debug_aux:
+            self.maps.debug_aux = {}
         self.tok_maps = PrepareMaps.apply(self.maps, *chw)
+
+    @property
+    def last_aux(self) -> Dict[str, torch.Tensor]:
+        """Stage intermediates of the last rendered chunk (only with ``debug_aux=True``)."""
+        if self.maps.debug_aux is None:
+            raise RuntimeError("open the RenderSession with debug_aux=True to keep stage intermediates")
+        return self.maps.debug_aux
 
     def draw_noise(self, R: int, device):
         """The reference's in-path RNG calls, same generators and order (SURVEY §5 RNG row)."""

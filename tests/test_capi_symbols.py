@@ -49,10 +49,37 @@ def test_struct_layouts_match_header_constants():
     assert consts["SCENERF_D_HIDDEN"] == _capi.D_HIDDEN
     assert consts["SCENERF_D_XENC"] == _capi.D_XENC
     assert consts["SCENERF_TILE_ROWS"] == _capi.TILE_ROWS
-    # scenerf_cfg: 6 int32 + 10 float + 5*5 int32 + 1 int32
-    assert ctypes.sizeof(_capi.Cfg) == 4 * (6 + 10 + 25 + 1 + 5)
+    # scenerf_cfg: 6 int32 + 10 float + 5*5 int32 + precision + map_chw[5] + fused_min_rows + fwd_kernel + flags
+    assert ctypes.sizeof(_capi.Cfg) == 4 * (6 + 10 + 25 + 1 + 5 + 3)
     assert ctypes.sizeof(_capi.MlpActs) == 8 * 10   # H[4], Nn[3], h0pre, logits, sign_bits
     assert ctypes.sizeof(_capi.ProfRec) == 48 + 4 + 4 + 8 + 8
+
+
+def test_struct_layouts_match_the_c_compiler(tmp_path):
+    """sizeof / offsetof of every ABI struct as gcc lays them out from include/scenerf_hip.h == the ctypes mirror."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    structs = {"scenerf_cfg": _capi.Cfg, "scenerf_mlp_weights": _capi.MlpWeights, "scenerf_mlp_params": _capi.MlpParams,
+               "scenerf_mlp_grads": _capi.MlpGrads, "scenerf_mlp_acts": _capi.MlpActs, "scenerf_prof_rec": _capi.ProfRec}
+    lines = []
+    for cname, cls in structs.items():
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, f[0], cname, f[0]))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void) {\n%s\nreturn 0; }\n' % (HEADER, "\n".join(lines)))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-o", str(exe), str(src)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        c, f, v = ln.split()
+        got[(c, f)] = int(v)
+    for cname, cls in structs.items():
+        assert got[(cname, "sizeof")] == ctypes.sizeof(cls), cname
+        for f in cls._fields_:
+            assert got[(cname, f[0])] == getattr(cls, f[0]).offset, "%s.%s" % (cname, f[0])
 
 
 def test_bad_arguments_are_reported_not_fatal():

@@ -365,10 +365,9 @@ def test_inference_chunk_replays_as_a_graph():
 def test_full_size_config3_bundlefusion_fused_vs_layers_and_subset_parity():
     """BASELINE.json configs[3] at full size (BundleFusion 640x480, sphere 960x720 from the CLI, R=1080, N=96, D=12, std 0.1,
     floors +0.5), a different scale-activity pattern and K-segment mix than KITTI for the fused kernels.  (1) fp32 forward: the first 24 rays equal the CPU oracle run on just those rays (rays are independent).
-    (2) bf16 training step on the fused kernels vs the same step on the per-layer kernels (SRF_FUSED_MIN_M): outputs within bf16
+    (2) bf16 training step on the fused kernels vs the same step on the per-layer kernels (render_cfg.fused_min_rows = -1): outputs within bf16
     rounding, every parameter / feature-map gradient within 2e-2 relative L2 (the dgrad chain itself is bit-identical; the
     forward's residual stream is rounded at the same places but accumulated in a different order)."""
-    import os
     from scenerf_amd import synth
     R, U, P = 1080, 64, 8
     kw = dict(som_sigma=0.02, std=0.1, add_fov_hor=14, add_fov_ver=11, sphere_W=960, sphere_H=720, n_pts_uni=U, n_pts_per_gaussian=P,
@@ -379,8 +378,10 @@ def test_full_size_config3_bundlefusion_fused_vs_layers_and_subset_parity():
     nu, ng = synth.sampling_noise(R, U, 4 * P, 65)
     K, T = synth.bundlefusion_cam_K(), synth.rel_pose(0.3, 8.0)
 
-    def run(precision, grad):
+    def run(precision, grad, fused=True):
         m = SceneRFBundleFusion(precision=precision, **kw).to(DEV)
+        if not fused:
+            m.render_cfg.fused_min_rows = -1   # per-layer GEMM path (explicit call state: scenerf_cfg.fused_min_rows)
         m.mlp.load_state_dict(mlp)
         m.mlp_gaussian.load_state_dict(mlpg)
         x = {k: v.to(DEV).requires_grad_(grad) for k, v in maps.items()}
@@ -404,11 +405,7 @@ def test_full_size_config3_bundlefusion_fused_vs_layers_and_subset_parity():
         assert fr >= 0.9, "%s: %.3f of the subset rays within tolerance" % (k, fr)
     assert bool((o32["gaussian_means"] >= 0.5).all()) and bool((o32["gaussian_stds"] >= 0.5).all())   # scenerf_bf.py:606-608
     # (2) fused vs per-layer kernels, bf16, forward + backward
-    os.environ["SRF_FUSED_MIN_M"] = str(1 << 30)
-    try:
-        ol, gl = run("bf16", True)
-    finally:
-        os.environ.pop("SRF_FUSED_MIN_M")
+    ol, gl = run("bf16", True, fused=False)
     of, gf = run("bf16", True)
     rel = (of["depth"] - ol["depth"]).abs() / ol["depth"].abs().clamp(min=1e-3)
     assert float(rel.median()) < 2e-3 and float(rel.quantile(0.99)) < 3e-2, (float(rel.median()), float(rel.max()))

@@ -471,11 +471,10 @@ def test_mlp_forward_fused_matches_layer_path(case, M):
     same packed weights: saved activations are relu(H_b) / relu(N_b) -- what the backward pass consumes -- and must agree
     with the layer path's within bf16 rounding of the residual stream; logits against the fp32 oracle must be at least
     as close as the layer path's.  Tiles use different scale masks (skipped K segments)."""
-    import os
+    import dataclasses
     from scenerf_amd.renderer import _MlpRun
     lib = _capi.load()
     rcfg, xin0, state, d_out, pk = _mlp_case(case, "bf16", "mlp")
-    cc = rcfg.to_c()
     gen = torch.Generator().manual_seed(M)
     z = torch.randn(M, 2480, generator=gen) * 0.5
     xe = torch.zeros((M, 48))
@@ -490,8 +489,8 @@ def test_mlp_forward_fused_matches_layer_path(case, M):
             if not (int(masks[t]) >> s_) & 1:
                 z[t * 128:(t + 1) * 128, seg[s_]:seg[s_ + 1]] = 0
     runs = {}
-    for name, env in (("layers", str(1 << 30)), ("fused", "0")):
-        os.environ["SRF_FUSED_MIN_M"] = env
+    for name, min_rows in (("layers", -1), ("fused", 1)):
+        cc = dataclasses.replace(rcfg, fused_min_rows=min_rows).to_c()   # kernel path = explicit call state (scenerf_cfg.fused_min_rows)
         run = _MlpRun(M, d_out, 1, torch.device(DEV))
         run.Z.zero_()
         run.Z[:M] = dv(z, torch.bfloat16)
@@ -502,7 +501,6 @@ def test_mlp_forward_fused_matches_layer_path(case, M):
                                                 M, C.byref(run.c), _st()), "mlp_forward")
         torch.cuda.synchronize()
         runs[name] = run
-    os.environ.pop("SRF_FUSED_MIN_M")
     a, b = runs["layers"], runs["fused"]
     xin = torch.cat([run.Z[:M].float().cpu(), xe[:, :42]], dim=1)
     keep = {}
@@ -534,11 +532,10 @@ def test_mlp_forward_stream_equals_ring_kernel(case, M, lean):
     """stream.hip (weights streamed into a register ring, no per-chunk barrier) against fused.hip's LDS-ring kernel: the same chunk
     order and arithmetic, so every saved activation, sign bit and logit must be IDENTICAL -- mixed tile masks, a ragged tail, the
     lean inference buffers (nothing but the logits kept) and the full bench row count."""
-    import os
+    import dataclasses
     from scenerf_amd.renderer import _MlpRun
     lib = _capi.load()
     rcfg, xin0, state, d_out, pk = _mlp_case(case, "bf16", "mlp")
-    cc = rcfg.to_c()
     gen = torch.Generator().manual_seed(M + 1)
     ntile = (M + 127) // 128
     masks = torch.tensor([7, 31, 1, 5, 0, 24, 3, 16], dtype=torch.uint8)[torch.arange(ntile) % 8]
@@ -552,9 +549,8 @@ def test_mlp_forward_stream_equals_ring_kernel(case, M, lean):
     reps = (M + nz - 1) // nz
     runs = {}
     for name in ("ring", "stream"):
-        os.environ["SRF_FUSED_MIN_M"] = "0"
-        os.environ["SRF_FWD_KERNEL"] = name
-        run = _MlpRun(M, d_out, 1, torch.device(DEV), keep_acts=not lean)
+        cc = dataclasses.replace(rcfg, fused_min_rows=1, fwd_kernel=name).to_c()
+        run = _MlpRun(M, d_out, 1, torch.device(DEV), lean=lean)
         run.Z.fill_(float("nan"))      # columns of scales a tile does not touch must never be read (beyond the dense first 256)
         run.Z[:, :256] = 0
         zz = dv(z).repeat(reps, 1)[:M]
@@ -569,8 +565,6 @@ def test_mlp_forward_stream_equals_ring_kernel(case, M, lean):
                                                 M, C.byref(run.c), _st()), "mlp_forward")
         torch.cuda.synchronize()
         runs[name] = run
-    os.environ.pop("SRF_FUSED_MIN_M")
-    os.environ.pop("SRF_FWD_KERNEL", None)
     a, b = runs["ring"], runs["stream"]
     assert torch.isfinite(b.logits).all()
     assert torch.equal(a.logits, b.logits)
@@ -588,7 +582,7 @@ def test_mlp_backward_fused_matches_layer_path(case, M):
     """fused.hip MODE 1 (the six dgrad GEMMs of the residual blocks in one kernel, sign gates rebuilt from the saved activations by
     the producer waves) against the per-layer dgrad GEMMs on the same forward state: dH column blocks 0..2, dN and every parameter
     gradient.  Both paths round dH / dN to bf16 at the same places; only the accumulation order inside a K = 512 product differs."""
-    import os
+    import dataclasses
     from scenerf_amd.renderer import MLP_PARAM_NAMES, _MlpRun
     lib = _capi.load()
     rcfg, xin0, state, d_out, pk = _mlp_case(case, "bf16", "mlp")
@@ -607,10 +601,7 @@ def test_mlp_backward_fused_matches_layer_path(case, M):
     tw = torch.zeros((M, 5, 4), device=DEV)
     res = {}
     for name in ("layers", "fused"):
-        if name == "layers":
-            os.environ["SRF_NO_FUSED_BWD"] = "1"
-        else:
-            os.environ.pop("SRF_NO_FUSED_BWD", None)
+        cc = dataclasses.replace(rcfg, fused_backward=(name == "fused")).to_c()   # scenerf_cfg.flags & SCENERF_FLAG_NO_FUSED_BWD
         gs = pk.grad_sink()
         pk.gflat.zero_()
         dH = torch.zeros((M, 2048), dtype=torch.bfloat16, device=DEV)
@@ -620,7 +611,6 @@ def test_mlp_backward_fused_matches_layer_path(case, M):
                                                  dl.data_ptr(), dH.data_ptr(), dN.data_ptr(), None, _st()), "mlp_backward")
         torch.cuda.synchronize()
         res[name] = (dH.float().cpu(), dN.float().cpu(), [g.clone().cpu() for g in pk.unpack_grads()])
-    os.environ.pop("SRF_NO_FUSED_BWD", None)
     (dHa, dNa, ga), (dHb, dNb, gb) = res["layers"], res["fused"]
     assert torch.equal(dHa[:, 1536:], dHb[:, 1536:])          # lin_out's backward is shared
     bad = []
