@@ -261,11 +261,17 @@ def ray_som_kl(means, stds, dist, alphas, som_sigma: float, kl_std_floor: float 
 def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: Dict[str, torch.Tensor],
                  cam_K: torch.Tensor, T_source2infer: torch.Tensor, x_rgb: Dict[str, torch.Tensor],
                  pixels: torch.Tensor, noise_u: torch.Tensor, noise_g: torch.Tensor,
-                 keep_intermediates: bool = False) -> Dict[str, torch.Tensor]:
+                 keep_intermediates: bool = False, head_offsets: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """scenerf.py:598-700 (batchify_depth_and_color) for one chunk of R rays.
 
     Returns the 12 tensors of ``render_rays_batch`` (scenerf.py:456-469) under the same keys,
     plus ``som_means`` and, if asked, stage intermediates used by the per-kernel parity tests.
+
+    ``head_offsets`` (R, G, 2), parity tests only: the VALUE of the gaussian head's output is replaced by this tensor while its
+    gradient still flows through the head computed here (straight-through).  With the offsets a reduced-precision
+    implementation produced, everything downstream -- sample positions, sort order, sphere indices -- is evaluated at that
+    implementation's sample positions, so the two can be compared sample by sample instead of through the chaos of samples
+    that cross a texel boundary.  None (the default) is the reference's arithmetic, unchanged.
     """
     inv_K = torch.inverse(cam_K)
     R = pixels.shape[0]
@@ -290,6 +296,8 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
     xin_g, idx_g = point_inputs(apts, vd_g, x_rgb, cam_K, cfg)
     keep_g = {} if keep_intermediates else None
     off = resnetfc_forward(mlp_gaussian, xin_g, keep=keep_g).reshape(R, G, 2)
+    if head_offsets is not None:
+        off = off + (head_offsets.reshape(R, G, 2).to(off.dtype) - off).detach()
     g_means = torch.relu(anchors.squeeze(-1) + off[:, :, 0]) + cfg.gauss_floor
     g_stds = torch.relu(off[:, :, 1] + cfg.std) + cfg.gauss_floor
 

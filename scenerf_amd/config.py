@@ -84,6 +84,14 @@ class RenderConfig:
             raise ValueError("n_gaussians must be in [1, 8]")
         if self.n_pts_per_gaussian < 1 or self.n_pts_uni < 0:
             raise ValueError("bad sample counts")
+        if self.n_pts_uni == 0 and self.n_pts_per_gaussian == 1:
+            # scenerf.py:647-650 / scenerf_bf.py:662-665: with n_pts_uni == 0 and n_pts_per_gaussian == 1 the reference renders the
+            # *uniform* sample set instead of the gaussian one.  In the KITTI model that set is empty and the call dies earlier with
+            # ZeroDivisionError (utils.py:77, step = (d_max - d_min) / 0 -- for ANY n_pts_per_gaussian); the BundleFusion model
+            # substitutes 2 uniform samples (scenerf_bf.py:623-626) and composites those two.  Neither is a configuration the
+            # renderer kernels implement (they merge uniform + gaussian samples); refuse it instead of computing something else.
+            raise NotImplementedError("n_pts_uni == 0 with n_pts_per_gaussian == 1 selects the reference's uniform-only branch "
+                                      "(scenerf.py:647-650), which this renderer does not implement")
         if self.n_samples > 512:
             raise ValueError("n_samples = %d exceeds the 512-sample limit of the wave-per-ray kernels" % self.n_samples)
         _ = self.precision_code

@@ -194,6 +194,10 @@ class SceneRF(TrainingMixin, _Base):
         # optional early form of the same hook (scenerf_amd.dist.allreduce_mean_async): the radiance MLP's collective then starts
         # before the feature-gradient scatter of a single-chunk (training) step instead of after it
         self.grad_sync_async = None
+        # debugging / parity tests: keep the stage intermediates of the last rendered chunk in ``self.last_aux`` (off by default: it
+        # pins a chunk's logits / encodings / indices for as long as the model lives)
+        self.debug_aux = False
+        self.last_aux = None
 
     # ---- the hot path ---------------------------------------------------------------------------------------
     def _inv_K(self, cam_K: torch.Tensor) -> torch.Tensor:
@@ -222,7 +226,7 @@ class SceneRF(TrainingMixin, _Base):
         cfg.som_sigma = float(self.ray_som.som_sigma)
         inv_K = self._inv_K(cam_K)
         sess = RenderSession(cfg, x_rgb, self.mlp.ordered_params(), self.mlp_gaussian.ordered_params(),
-                             grad_sync=self.grad_sync, grad_sync_async=self.grad_sync_async)
+                             grad_sync=self.grad_sync, grad_sync_async=self.grad_sync_async, debug_aux=self.debug_aux)
         outs = []
         n = sampled_pixels.shape[0]
         sess.mlpg.single_chunk = n <= ray_batch_size   # training (scenerf.py:262-275): lets the head's gradient all-reduce start early
@@ -231,6 +235,8 @@ class SceneRF(TrainingMixin, _Base):
             nu = noise[0][s:e] if noise is not None else None
             ng = noise[1][s:e] if noise is not None else None
             outs.append(sess.render_chunk(sampled_pixels[s:e], cam_K, inv_K, T_source2infer, nu, ng))
+        if self.debug_aux:
+            object.__setattr__(self, "last_aux", dict(sess.last_aux))
         if len(outs) == 1:
             ret = outs[0]
         else:

@@ -93,6 +93,13 @@ CASES = {
     "bf_small_n96": dict(variant="bf", ctor=dict(som_sigma=0.02, std=0.1, add_fov_hor=14, add_fov_ver=11,
                          sphere_W=240, sphere_H=180, n_pts_uni=64, n_pts_per_gaussian=8, max_sample_depth=12),
                          R=16, chunk=16, pose=(0.4, 10.0), seed=404, smooth=True),
+    # above the fused-kernel threshold (>= 4096 rows per chunk): the bf16 path under test is the one bench.py times (fused forward,
+    # fused dgrad chain), white-noise maps (a +-1 sphere index picks an unrelated texel: nothing hides index errors)
+    "kitti_full_n128_r64": dict(variant="kitti", ctor=dict(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, n_pts_uni=64,
+                                n_pts_per_gaussian=16), R=64, chunk=64, pose=(1.0, 0.0), seed=606, smooth=False),
+    "bf_full_n96_r48": dict(variant="bf", ctor=dict(som_sigma=0.02, std=0.1, add_fov_hor=14, add_fov_ver=11, sphere_W=960,
+                            sphere_H=720, n_pts_uni=64, n_pts_per_gaussian=8, max_sample_depth=12), R=48, chunk=48,
+                            pose=(0.3, 8.0), seed=707, smooth=False),
     # BASELINE.json configs[0] ("4k rays x 64 samples, 4-layer 128-wide MLP, CPU forward only"): both MLPs replaced by
     # ResnetFC(d_in=42, n_blocks=1, d_hidden=128) = lin_in + (lin_z.0, fc_0, fc_1) + lin_out.  Forward only; the (R, N)
     # outputs are stored as digests to keep the fixture small.

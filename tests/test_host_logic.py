@@ -155,3 +155,13 @@ def test_spherical_mapping_from_pixels_matches_reference_formula_and_caches_the_
     sm = m.spherical_mapping
     py = torch.round((v - sm.v_angle_min) / sm.v_fov * (sm.out_img_H - 1)).long()
     assert torch.equal(sph[:, 1], py)
+
+
+def test_uniform_only_branch_is_refused_explicitly():
+    """scenerf.py:647-650: n_pts_uni == 0 and n_pts_per_gaussian == 1 would render the (empty / 2-point) uniform set; the
+    renderer refuses that configuration by name instead of silently rendering the gaussian samples."""
+    import pytest
+    from scenerf_amd.config import RenderConfig
+    with pytest.raises(NotImplementedError, match="uniform-only branch"):
+        RenderConfig.kitti(n_pts_uni=0, n_pts_per_gaussian=1).validate()
+    RenderConfig.kitti(n_pts_uni=0, n_pts_per_gaussian=2).validate()      # gaussians only: the `else` branch (scenerf.py:651-654)
