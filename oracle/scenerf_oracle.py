@@ -161,14 +161,16 @@ def gather_features(fmap: torch.Tensor, idx: torch.Tensor, div_wh: Tuple[int, in
 
 
 def point_inputs(pts: torch.Tensor, viewdir_rows: torch.Tensor, x_rgb: Dict[str, torch.Tensor],
-                 K: torch.Tensor, cfg: OracleConfig):
-    """scenerf.py:505-531: (M,3) infer-frame points -> x_in (M, 2480+39+3) and the sphere indices."""
+                 K: torch.Tensor, cfg: OracleConfig, idx_use: Optional[torch.Tensor] = None):
+    """scenerf.py:505-531: (M,3) infer-frame points -> x_in (M, 2480+39+3) and the sphere indices.
+    ``idx_use`` (parity tests only, see render_chunk): gather at these indices instead of the ones computed here (still returned)."""
     pix = project_to_pixels(pts, K)
     idx = sphere_coords(pix, torch.inverse(K), cfg)
+    use = idx if idx_use is None else idx_use.to(idx.dtype).reshape(idx.shape)
     pe = positional_encoding(pts)
-    feats = [gather_features(x_rgb["1_1"], idx, (cfg.sphere_W, cfg.sphere_H))]
+    feats = [gather_features(x_rgb["1_1"], use, (cfg.sphere_W, cfg.sphere_H))]
     for s in FEAT_SCALES[1:]:
-        feats.append(gather_features(x_rgb["1_%d" % s], idx, (cfg.sphere_W // s, cfg.sphere_H // s)))
+        feats.append(gather_features(x_rgb["1_%d" % s], use, (cfg.sphere_W // s, cfg.sphere_H // s)))
     return torch.cat(feats + [pe, viewdir_rows], dim=-1), idx
 
 
@@ -261,7 +263,8 @@ def ray_som_kl(means, stds, dist, alphas, som_sigma: float, kl_std_floor: float 
 def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: Dict[str, torch.Tensor],
                  cam_K: torch.Tensor, T_source2infer: torch.Tensor, x_rgb: Dict[str, torch.Tensor],
                  pixels: torch.Tensor, noise_u: torch.Tensor, noise_g: torch.Tensor,
-                 keep_intermediates: bool = False, head_offsets: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                 keep_intermediates: bool = False, head_offsets: Optional[torch.Tensor] = None,
+                 sphere_idx: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
     """scenerf.py:598-700 (batchify_depth_and_color) for one chunk of R rays.
 
     Returns the 12 tensors of ``render_rays_batch`` (scenerf.py:456-469) under the same keys,
@@ -272,6 +275,12 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
     implementation produced, everything downstream -- sample positions, sort order, sphere indices -- is evaluated at that
     implementation's sample positions, so the two can be compared sample by sample instead of through the chaos of samples
     that cross a texel boundary.  None (the default) is the reference's arithmetic, unchanged.
+
+    ``sphere_idx = (main (R*N, 2), head (R*G, 2))``, parity tests only: the features are gathered at these integer sphere pixels
+    instead of the ones computed here (which are still returned as ``_idx`` / ``_idx_g``).  The indices go through acos / atan2,
+    whose last ulp differs between libm implementations; a test first checks that the other implementation's indices equal the
+    ones computed here except within rounding noise of a .5 boundary, then evaluates the oracle AT those indices so that the
+    remaining comparison is arithmetic only.
     """
     inv_K = torch.inverse(cam_K)
     R = pixels.shape[0]
@@ -293,9 +302,10 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
     anchors = gaussian_anchor_distances(cfg).type_as(cam_K).reshape(1, G, 1).expand(R, -1, 1)
     apts = to_frame((anchors * unit.reshape(R, 1, 3)).reshape(-1, 3), T_source2infer)
     vd_g = viewdir.unsqueeze(1).expand(-1, G, -1).reshape(-1, 3)
-    xin_g, idx_g = point_inputs(apts, vd_g, x_rgb, cam_K, cfg)
+    xin_g, idx_g = point_inputs(apts, vd_g, x_rgb, cam_K, cfg, None if sphere_idx is None else sphere_idx[1])
     keep_g = {} if keep_intermediates else None
     off = resnetfc_forward(mlp_gaussian, xin_g, keep=keep_g).reshape(R, G, 2)
+    off_own = off
     if head_offsets is not None:
         off = off + (head_offsets.reshape(R, G, 2).to(off.dtype) - off).detach()
     g_means = torch.relu(anchors.squeeze(-1) + off[:, :, 0]) + cfg.gauss_floor
@@ -325,7 +335,7 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
 
     # main MLP on detached points (scenerf.py:661-665, 505-541)
     vd = viewdir.unsqueeze(1).expand(-1, N, -1).reshape(-1, 3)
-    xin, idx = point_inputs(pts.detach().reshape(-1, 3), vd, x_rgb, cam_K, cfg)
+    xin, idx = point_inputs(pts.detach().reshape(-1, 3), vd, x_rgb, cam_K, cfg, None if sphere_idx is None else sphere_idx[0])
     keep_m = {} if keep_intermediates else None
     out = resnetfc_forward(mlp, xin, keep=keep_m)
     color_s = torch.sigmoid(out[..., :3]).reshape(R, N, 3)
@@ -343,7 +353,7 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
     if keep_intermediates:
         ret.update({
             "_dirs": dirs, "_unit": unit, "_viewdir": viewdir, "_dist_u": dist_u, "_anchor_pts": apts,
-            "_idx_g": idx_g, "_xin_g": xin_g, "_offsets": off, "_dist_g": dist_g, "_perm": perm,
+            "_idx_g": idx_g, "_xin_g": xin_g, "_offsets": off, "_offsets_own": off_own, "_dist_g": dist_g, "_perm": perm,
             "_dist_sorted": dist, "_pts_sorted": pts, "_idx": idx, "_xin": xin, "_mlp_out": out,
             "_colors": color_s, "_closest_idx": comp["closest_idx"], "_bmu": bmu,
             "_keep_mlp": keep_m, "_keep_gauss": keep_g,

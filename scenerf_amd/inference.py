@@ -1,0 +1,124 @@
+"""Full-frame novel-view rendering (BASELINE.json configs[4] / SURVEY C5): what the reference's evaluation and reconstruction
+scripts do with ``render_rays_batch`` under ``no_grad`` -- 50k-450k rays per pose in chunks of 4,000-8,000 rays
+(scripts/evaluation/render_colors.py:102-127, scripts/reconstruction/generate_novel_depths.py:103-137) -- as a product feature:
+
+  * the frame's feature maps are converted and both MLPs packed ONCE per input frame (one ``RenderSession``), not once per chunk loop;
+  * every chunk has the SAME static shape: the ragged tail is padded (its rays repeat the last pixel and are dropped from the result),
+    so one chunk of the hot path -- ~25 kernel launches, no host synchronisation -- is captured into a hipGraph once per frame and
+    replayed for every chunk of every pose of that frame (21 x 3 poses per frame in generate_novel_depths.py);
+  * sampling noise is drawn on the device (the reference draws the gaussian noise on the CPU and uploads it, utils.py:208-211: a host
+    serialisation per chunk); ``noise=`` injects explicit noise for parity tests.
+
+Inference uses the lean activation path of the fused kernels (only the logits leave the MLP pass).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from .renderer import OUTPUT_KEYS, RenderSession, _on
+
+
+class ImageRenderer:
+    """One input frame's renderer: static chunk shape, optional hipGraph replay.  Build once per input frame (``x_rgb``) and call
+    ``render`` for every pose / pixel set."""
+
+    def __init__(self, model, x_rgb: Dict[str, torch.Tensor], chunk: int = 4096, use_graph: bool = True,
+                 keys: Optional[Sequence[str]] = None):
+        if chunk < 1:
+            raise ValueError("chunk must be positive")
+        self.model = model
+        self.cfg = model.render_cfg
+        self.cfg.som_sigma = float(model.ray_som.som_sigma)
+        self.chunk = int(chunk)
+        self.keys = list(keys) if keys is not None else list(OUTPUT_KEYS)
+        for k in self.keys:
+            if k not in OUTPUT_KEYS:
+                raise KeyError("unknown output %r" % (k,))
+        dev = x_rgb["1_1"].device
+        self.device = dev
+        U, GP = self.cfg.n_pts_uni, self.cfg.n_gaussians * self.cfg.n_pts_per_gaussian
+        with torch.no_grad(), _on(dev):
+            self.session = RenderSession(self.cfg, {k: v.detach() for k, v in x_rgb.items()}, [p.detach() for p in model.mlp.ordered_params()],
+                                         [p.detach() for p in model.mlp_gaussian.ordered_params()], debug_aux=bool(getattr(model, "debug_aux", False)))
+            f32 = dict(dtype=torch.float32, device=dev)
+            # static inputs of the captured chunk
+            self.pix = torch.zeros((self.chunk, 2), **f32)
+            self.K = torch.zeros((3, 3), **f32)
+            self.invK = torch.zeros((3, 3), **f32)
+            self.T = torch.zeros((4, 4), **f32)
+            self.noise_u = torch.zeros((self.chunk, max(U, 0), 1), **f32)
+            self.noise_g = torch.zeros((self.chunk, GP), **f32)
+        self.graph = None
+        self.static_out = None
+        self.use_graph = bool(use_graph)
+        self.replays = 0
+
+    # -------------------------------------------------------------------------------------------------------------------------
+    def _run_chunk(self):
+        return self.session.render_chunk(self.pix, self.K, self.invK, self.T, self.noise_u, self.noise_g)
+
+    def _capture(self):
+        """Warm up once on a side stream (first-use allocations, kernel attribute setup), then capture one chunk."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            self._run_chunk()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._run_chunk()
+        self.graph, self.static_out = g, out
+
+    def render(self, cam_K: torch.Tensor, T_source2infer: torch.Tensor, sampled_pixels: torch.Tensor,
+               noise: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """All ``sampled_pixels`` (n, 2) of one pose -> dict of the requested keys, each (n, ...).  ``noise = (noise_u (n,U,1),
+        noise_g (n,G*P))`` replaces the device RNG (tests)."""
+        n = sampled_pixels.shape[0]
+        if n == 0:
+            raise ValueError("sampled_pixels is empty")
+        dev = self.device
+        C = self.chunk
+        with torch.no_grad(), _on(dev):
+            self.K.copy_(cam_K)
+            self.invK.copy_(self.model._inv_K(cam_K))
+            self.T.copy_(T_source2infer)
+            pixels = sampled_pixels.to(device=dev, dtype=torch.float32)
+            results: Dict[str, torch.Tensor] = {}
+            for s in range(0, n, C):
+                e = min(s + C, n)
+                m = e - s
+                self.pix[:m].copy_(pixels[s:e])
+                if m < C:
+                    self.pix[m:].copy_(pixels[e - 1:e].expand(C - m, 2))      # pad the tail: a static chunk shape
+                if noise is not None:
+                    self.noise_u[:m].copy_(noise[0][s:e])
+                    self.noise_g[:m].copy_(noise[1][s:e])
+                else:
+                    if self.noise_u.numel():
+                        self.noise_u.uniform_()                                 # utils.py:84 (device RNG there too)
+                    self.noise_g.normal_()                                      # utils.py:208-211, on the device instead of CPU + H2D
+                if self.use_graph:
+                    if self.graph is None:
+                        self._capture()
+                    self.graph.replay()
+                    self.replays += 1
+                    out = self.static_out
+                else:
+                    out = self._run_chunk()
+                for k in self.keys:
+                    v = out[k]
+                    if k not in results:
+                        results[k] = torch.empty((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev)
+                    results[k][s:e].copy_(v[:m])
+        return results
+
+
+def pixel_grid(img_size: Tuple[int, int], stride: int, device) -> torch.Tensor:
+    """Every ``stride``-th pixel of the image in the reference's order (render_colors.py:102-111, generate_novel_depths.py:103-112:
+    x major, then y), float32 (n, 2)."""
+    xs = torch.arange(0, img_size[0], stride, device=device, dtype=torch.float32)
+    ys = torch.arange(0, img_size[1], stride, device=device, dtype=torch.float32)
+    gx, gy = torch.meshgrid(xs, ys, indexing="ij")
+    return torch.stack([gx, gy], dim=2).reshape(-1, 2)

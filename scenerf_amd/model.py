@@ -10,6 +10,10 @@ What is kept identical for callers:
   * ``render_rays_batch(cam_K, T_source2infer, x_rgb, depth_window=100, T_cam2velo=None, sampled_pixels=None,
     ray_batch_size=128) -> dict`` with the 12 keys of scenerf.py:456-469.
 The image encoder (``net_rgb``) and the losses stay stock PyTorch and are injected by the caller.
+
+Two keyword arguments the reference does not have: ``precision`` -- "fp32" (default: fp32 MFMA end to end, the reference's own
+numerics, SURVEY 8d fp32 gates) or "bf16" (bf16 MFMA operands / fp32 accumulate, the fused kernels: BASELINE.json configs[1], what
+bench.py times; an explicit opt-in because it changes training numerics) -- and ``device_rng``.
 """
 from __future__ import annotations
 
@@ -152,7 +156,7 @@ class SceneRF(TrainingMixin, _Base):
     def __init__(self, som_sigma, lr=1e-5, weight_decay=0, img_size=(1220, 370), n_rays=1200, max_infer_depth=120,
                  max_sample_depth=100, eval_depth=80, std=2.5, n_gaussians=4, n_pts_uni=32, n_pts_per_gaussian=8,
                  sampling_method="uniform", batch_size=1, add_fov_hor=0, add_fov_ver=0, sphere_H=452, sphere_W=1500,
-                 use_color=True, use_reprojection=True, net_rgb: Optional[nn.Module] = None, precision: str = "bf16",
+                 use_color=True, use_reprojection=True, net_rgb: Optional[nn.Module] = None, precision: str = "fp32",
                  device_rng: bool = False):
         super().__init__()
         if sampling_method != "uniform":
@@ -222,12 +226,16 @@ class SceneRF(TrainingMixin, _Base):
         if sampled_pixels.shape[0] == 0:
             raise ValueError("sampled_pixels is empty (the reference fails in torch.cat over zero chunks here, scenerf.py:459-470)")
         self.ray_som  # noqa: B018  (attribute kept for parity with the reference module tree)
+        if (self.static_inference and not torch.is_grad_enabled() and sampled_pixels.shape[0] > ray_batch_size and not self.debug_aux):
+            # the evaluation / reconstruction callers (render_colors.py:114-119, generate_novel_depths.py:116-122: 50k-450k rays in
+            # chunks of 4000-8000 under no_grad): static chunk shape, one captured hipGraph per input frame (scenerf_amd/inference.py)
+            return self.render_image(cam_K, T_source2infer, x_rgb, sampled_pixels=sampled_pixels, ray_batch_size=ray_batch_size, noise=noise)
         cfg = self.render_cfg
         cfg.som_sigma = float(self.ray_som.som_sigma)
         inv_K = self._inv_K(cam_K)
         sess = RenderSession(cfg, x_rgb, self.mlp.ordered_params(), self.mlp_gaussian.ordered_params(),
                              grad_sync=self.grad_sync, grad_sync_async=self.grad_sync_async, debug_aux=self.debug_aux)
-        outs = []
+        outs, auxs = [], []
         n = sampled_pixels.shape[0]
         sess.mlpg.single_chunk = n <= ray_batch_size   # training (scenerf.py:262-275): lets the head's gradient all-reduce start early
         for s in range(0, n, ray_batch_size):
@@ -235,13 +243,42 @@ class SceneRF(TrainingMixin, _Base):
             nu = noise[0][s:e] if noise is not None else None
             ng = noise[1][s:e] if noise is not None else None
             outs.append(sess.render_chunk(sampled_pixels[s:e], cam_K, inv_K, T_source2infer, nu, ng))
-        if self.debug_aux:
-            object.__setattr__(self, "last_aux", dict(sess.last_aux))
+            if self.debug_aux:
+                auxs.append(dict(sess.last_aux))
+        if self.debug_aux:   # stage intermediates of all chunks, concatenated ray-major like the outputs
+            object.__setattr__(self, "last_aux", {k: (torch.cat([a[k] for a in auxs], dim=0) if auxs[0][k] is not None else None)
+                                                  for k in auxs[0]})
         if len(outs) == 1:
             ret = outs[0]
         else:
             ret = {k: torch.cat([o[k] for o in outs], dim=0) for k in outs[0]}
         return {k: ret[k] for k in OUTPUT_KEYS}
+
+    # ---- full-frame inference (BASELINE.json configs[4]) -------------------------------------------------------------------------
+    static_inference = True     # no_grad multi-chunk render_rays_batch calls go through render_image (padded static chunks + hipGraph)
+    inference_graph = True      # replay a captured hipGraph per chunk (False: the same static chunks, launched eagerly)
+
+    def render_image(self, cam_K, T_source2infer, x_rgb: Dict[str, torch.Tensor], sampled_pixels=None, stride: int = 1,
+                     ray_batch_size: int = 4096, keys=None, use_graph: Optional[bool] = None, noise=None):
+        """Render a whole pixel set of one pose under ``no_grad``: every ``stride``-th pixel of the image in the reference scripts'
+        order when ``sampled_pixels`` is None (render_colors.py:102-111).  The tail chunk is padded to ``ray_batch_size`` rays so that
+        every chunk has one static shape; one chunk is captured into a hipGraph per input frame and replayed for all chunks and all
+        poses rendered from that frame.  Sampling noise is drawn on the device.  Returns the dict of ``render_rays_batch``
+        (``keys`` selects a subset: the (n, N) outputs of a 451,400-ray frame at N = 512 are 0.9 GB each)."""
+        from .inference import ImageRenderer, pixel_grid
+        if sampled_pixels is None:
+            sampled_pixels = pixel_grid(tuple(self.img_size), stride, x_rgb["1_1"].device)
+        if sampled_pixels.shape[0] == 0:
+            raise ValueError("sampled_pixels is empty")
+        graph = self.inference_graph if use_graph is None else bool(use_graph)
+        key = (tuple((id(x_rgb[k]), x_rgb[k]._version, x_rgb[k].data_ptr()) for k in sorted(x_rgb)),
+               tuple(p._version for p in list(self.mlp.parameters()) + list(self.mlp_gaussian.parameters())),
+               int(ray_batch_size), graph, tuple(keys) if keys is not None else None, repr(self.render_cfg), float(self.ray_som.som_sigma))
+        eng = getattr(self, "_image_renderer", None)
+        if eng is None or eng[0] != key:
+            eng = (key, ImageRenderer(self, x_rgb, chunk=int(ray_batch_size), use_graph=graph, keys=keys))
+            object.__setattr__(self, "_image_renderer", eng)     # one frame's engine at a time (its graph pins a chunk's buffers)
+        return eng[1].render(cam_K, T_source2infer, sampled_pixels, noise=noise)
 
     def configure_optimizers(self):
         optimizer = torch.optim.AdamW(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)

@@ -64,7 +64,12 @@ class TrainingMixin:
         cam_tgt = (T_source2target @ h.T).T[:, :3]
         hp = (cam_K @ cam_tgt.T).T
         valid = cam_tgt[:, 2] > 0
-        pix_tgt = torch.where((hp[:, 2] > 0)[:, None], hp[:, :2] / hp[:, 2:3], torch.full_like(hp[:, :2], -1.0))
+        # masked division with a SAFE denominator: torch.where(z > 0, x / z, -1) alone still back-propagates 0/0 = NaN through the
+        # unselected branch for a point with z == 0 (into depth_rendered and from there into every parameter); the reference
+        # indexes with the mask before dividing (utils.py:308-313) and has no such path
+        front = hp[:, 2] > 0
+        z_safe = torch.where(front, hp[:, 2], torch.ones_like(hp[:, 2]))
+        pix_tgt = torch.where(front[:, None], hp[:, :2] / z_safe[:, None], torch.full_like(hp[:, :2], -1.0))
         col_tgt = sample_pix_features(pix_tgt, img_target)
         col_id = sample_pix_features(pix_source, img_target)
         l_rep = torch.abs(col_tgt - sampled_color_source).mean(0)
@@ -101,10 +106,17 @@ class TrainingMixin:
         return dict(loss_kl=out["loss_kl"], loss_dist2closest_gauss=min_diff, loss_reprojection=loss_rep, loss_color=loss_color,
                     min_som_vars=min_som_vars, min_stds=min_stds, depth_source_rendered=depth, pix_source=pix_source)
 
+    # True: never synchronise for the depth metrics -- a source frame without a single valid depth then logs all-zero metrics (biasing
+    # the on_epoch means towards 0); False (default): one scalar device->host read per masked evaluation decides whether to log at all,
+    # like the reference's ``if mask.sum() > 0`` (scenerf_bf.py:204-205)
+    sync_free_metrics = False
+
     def evaluate_depth(self, step_type, gt_depth, pred_depth, mask=None):
         """scenerf.py:322-346 (predictions clamped at the metric's default 80 m) / scenerf_bf.py:340-366 (at ``self.eval_depth``);
         metrics computed on device."""
         names = ["abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3"]
+        if mask is not None and not self.sync_free_metrics and not bool(mask.any()):
+            return   # nothing to evaluate: the reference skips the logging (scenerf_bf.py:204-205)
         vals = depth_errors(gt_depth.reshape(-1).detach().float(), pred_depth.reshape(-1).detach().float(),
                             max_depth=self._metric_max_depth(), mask=None if mask is None else mask.reshape(-1))
         for n, v in zip(names, vals):

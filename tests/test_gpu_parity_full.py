@@ -8,21 +8,27 @@ configs[4]-sized chunk (N = 512, 16,384 rows) are rendered + back-propagated on 
 gradient by gradient (both MLPs' 20 tensors each, the 5 feature maps), with `oracle.render_chunk` + torch autograd on the same
 pixels, noise, weights and WHITE-NOISE maps (a +-1 sphere index picks an unrelated texel: nothing hides an index error).
 
-Two comparisons:
-  free     the oracle as the reference computes it.  fp32 mode: sample positions agree to ~1e-6, so every index is identical
-           except where acos/atan2's last ulp (torch-CPU SLEEF vs ROCm ocml) decides a rounding: those
-           samples are identified EXACTLY (the GPU's own indices against the oracle's), each must sit within 2e-3 px of a
-           rounding boundary, their rays must be few, and EVERY other ray has to meet the per-ray gate (required fraction 1.0).
-           bf16 mode: the gaussian head's bf16 offsets move the 4*P gaussian samples of a ray by ~1e-2 m; on white-noise maps a
-           sample that crosses a texel boundary reads unrelated features, so this comparison measures that chaos, not the
-           kernels -- it is reported and gated at what it measures.
-  matched  bf16 only: the oracle re-run with the gaussian head's VALUE replaced by the GPU's offsets (gradient still through the
-           oracle's head: `render_chunk(head_offsets=...)`).  Sample positions, sort order and indices are then identical
-           (same boundary-ambiguity rule as fp32), and outputs + every gradient are compared at bf16 arithmetic level: this is
-           the direct check of the fused forward, the fused dgrad chain, the batched weight gradients and the feature scatter.
+Two things on this path are discontinuous, so a plain output comparison would measure chaos instead of arithmetic:
+  * spherical indices go through acos / atan2, whose last ulp differs between libms (torch-CPU SLEEF vs ROCm ocml; the reference on
+    CUDA vs CPU differs the same way): ~1e-4 of the samples round to the neighbouring texel.  Step 1 compares the GPU's own indices
+    with the oracle's, sample by sample: they must be EQUAL except where the oracle's pre-rounding coordinate lies within 2e-3 px
+    of a .5 boundary (there +-1), and such samples must be rarer than 5e-4.
+  * in bf16 mode the gaussian head's offsets carry bf16 rounding (~1e-2 m), which moves the 4*P gaussian samples of every ray; on
+    white-noise maps a sample that crosses a texel boundary reads unrelated features.
+Step 2 therefore evaluates the oracle AT the GPU's indices and head offsets (`render_chunk(head_offsets=, sphere_idx=)`: values
+substituted, gradients still through the oracle's own head) and requires EVERY ray -- fraction 1.0, no exemptions -- to meet the
+per-ray gates and every gradient tensor its relative-L2 gate: that comparison is arithmetic only (fp32: MFMA accumulation order;
+bf16: the fused forward, the fused dgrad chain, the batched weight gradients, the feature scatter).  The head itself is compared
+directly (GPU offsets vs the offsets the oracle's head computes from the same indices).  Step 3 (bf16) reports the free-running
+comparison against the unmodified oracle, texel-crossing chaos included, and gates its summary statistics.
 
-Gates are the values measured on MI355X (printed by this test, stored in gpurun_out/parity_full_*.json when that directory
-exists) times two; the fp32 gates of SURVEY section 8d (depth rel 1e-4, colour abs 1e-5, grads rel 1e-3) are used as they are."""
+loss_kl / som_vars: RaySOM's BMU is an argmax over values that tie at the additive floors (1e-5, 1e-8) for samples far from every
+gaussian (ray_som_kl.py:46-52; in the KITTI golden every ray has samples with a relative margin < 1e-5 and those samples carry
+O(1) weight), so individual rays flip under ANY rounding difference: gated by the error of the mean (what the loss uses) and by
+the fraction of rays within tolerance, at what was measured.
+
+Gates: fp32 = SURVEY section 8d (depth rel 1e-4, colour abs 1e-5, grads rel 1e-3); the rest = values measured on MI355X (printed
+by this test and stored in gpurun_out/parity_full_*.json when that directory exists) times two."""
 import json
 import os
 
@@ -48,18 +54,20 @@ CASES = {
 }
 
 # ---- gates -------------------------------------------------------------------------------------------------------------------
-# per-ray: |got - ref| <= tol * (1 + |ref|) ("rel" keys) or <= tol (ABS_KEYS), required of EVERY ray whose sample indices equal
-# the oracle's.  fp32 = SURVEY 8d.  "matched" (bf16 arithmetic at identical sample positions) and "free" (bf16, own positions)
-# = 2 x measured on MI355X, round 2.
+# per-ray: |got - ref| <= tol * (1 + |ref|) ("rel" keys) or <= tol (ABS_KEYS), required of EVERY ray in the matched comparison.
 ABS_KEYS = ("color", "alphas", "weights")
 OUT_GATE = {
-    "fp32": dict(depth=1e-4, color=1e-5, gaussian_means=1e-4, gaussian_stds=1e-4, depth_volumes=1e-5, alphas=2e-5, weights=2e-5, densities=1e-4),
-    "matched": dict(depth=3e-2, color=3e-2, gaussian_means=1e-6, gaussian_stds=1e-6, depth_volumes=1e-6, alphas=6e-2, weights=6e-2, densities=1e-1),
+    # depth rel 1e-4, colour abs 1e-5; the (R, N) outputs at 2 x measured (alphas 3.4e-5, weights 2.9e-6 rel, densities 2.3e-5)
+    "fp32": dict(depth=1e-4, color=1e-5, gaussian_means=1e-6, gaussian_stds=1e-6, depth_volumes=1e-6, alphas=1e-4, weights=2e-5, densities=1e-4),
+    # measured at identical sample positions (KITTI R=1200 worst case): depth 3.9e-4, colour 1.5e-4, alphas 1.6e-3, weights 1.1e-4, densities 8e-4
+    "bf16": dict(depth=1e-3, color=3e-4, gaussian_means=1e-6, gaussian_stds=1e-6, depth_volumes=1e-6, alphas=3e-3, weights=2.5e-4, densities=2e-3),
 }
-GRAD_GATE = {"fp32": 1e-3, "matched": 1e-1, "free": 3e-1}      # relative L2 of a whole gradient tensor (fp32: SURVEY 8d)
-LOSS_GATE = {"fp32": 2e-5, "matched": 5e-3, "free": 2e-2}      # relative error of the training proxy loss
-FREE_BF16_GATE = dict(depth_rel_median=1e-2, depth_rel_p99=1e-1, color_abs_p99=1e-1, gaussian_means_rel_max=3e-2)
-MAX_FLIPPED_RAY_FRACTION = 0.03                                # rays containing a sample whose index differs (boundary ambiguity)
+GRAD_GATE = {"fp32": 1e-3, "bf16": 1e-1, "free": 4e-1}         # relative L2 of a whole gradient tensor (fp32: SURVEY 8d)
+LOSS_GATE = {"fp32": 2e-5, "bf16": 5e-4, "free": 1e-3}         # relative error of the training proxy loss
+HEAD_GATE = {"fp32": 2e-5, "bf16": 1.5e-2}                     # relative L2 of the gaussian head's offsets (measured 6.4e-3 in bf16)
+KL_GATE = {"fp32": dict(mean_rel=2e-3, frac=0.9), "bf16": dict(mean_rel=2e-2, frac=0.85)}   # see the docstring: BMU ties
+FREE_BF16_GATE = dict(depth_rel_median=1e-3, depth_rel_p99=5e-3, color_abs_p99=2e-3, gaussian_means_rel_max=3e-3)   # measured 3.0e-4 / 2.3e-3 / 6.6e-4 / 1.5e-3
+MAX_FLIPPED_SAMPLE_FRACTION = 5e-4                             # samples whose sphere index differs from the oracle's (measured 1.2e-4)
 
 
 def _inputs(spec):
@@ -81,7 +89,7 @@ def _ctor(spec):
                                      sphere_H=spec["sphere"][1], n_pts_uni=spec["U"], n_pts_per_gaussian=spec["P"], max_sample_depth=12)
 
 
-def _oracle_run(name, head_offsets=None):
+def _oracle_run(name, head_offsets=None, sphere_idx=None):
     """oracle.render_chunk + autograd of the proxy loss -> outputs, gradients, indices, boundary-ambiguity flags."""
     spec = CASES[name]
     mlp, mlpg, maps, pix, nu, ng, K, T = _inputs(spec)
@@ -91,7 +99,7 @@ def _oracle_run(name, head_offsets=None):
     po = {k: v.clone().requires_grad_(True) for k, v in mlp.items()}
     pg = {k: v.clone().requires_grad_(True) for k, v in mlpg.items()}
     xm = {k: v.clone().requires_grad_(True) for k, v in maps.items()}
-    ref = orc.render_chunk(ocfg, po, pg, K, T, xm, pix, nu, ng, keep_intermediates=True, head_offsets=head_offsets)
+    ref = orc.render_chunk(ocfg, po, pg, K, T, xm, pix, nu, ng, keep_intermediates=True, head_offsets=head_offsets, sphere_idx=sphere_idx)
     loss = orc.training_proxy_loss(ref)
     loss.backward()
     grads = {"mlp." + n: po[n].grad for n in MLP_PARAM_NAMES}
@@ -103,7 +111,8 @@ def _oracle_run(name, head_offsets=None):
         amb[key] = ((fl - torch.floor(fl) - 0.5).abs() < 2e-3).any(dim=1)
     res = dict(out={k: ref[k].detach().clone() for k in OUT_KEYS}, loss=float(loss.item()), grads=grads, amb=amb,
                idx=dict(main=ref["_idx"].clone(), head=ref["_idx_g"].clone(), perm=ref["_perm"].clone(), closest=ref["_closest_idx"].clone()),
-               dist_sorted=ref["_dist_sorted"].detach().clone(), offsets=ref["_offsets"].detach().clone())
+               dist_sorted=ref["_dist_sorted"].detach().clone(), offsets=ref["_offsets"].detach().clone(),
+               offsets_own=ref["_offsets_own"].detach().clone())
     del ref
     return res
 
@@ -123,56 +132,25 @@ def _within(got, ref, tol, absolute):
     return ((got - ref).abs() <= lim).all(dim=1)
 
 
-def _compare(tag, o, out, grads, aux, loss, R, N, rep, out_gate, grad_gate, loss_gate, exact_positions):
-    """Fill rep[tag] with measured errors; return the list of gate violations."""
-    r = rep[tag] = {}
+def _compare(tag, o, out, grads, loss, R, rep, out_gate, grad_gate, loss_gate):
+    """Fill rep[tag] with measured errors of the 12 outputs, the proxy loss and every gradient; return the gate violations."""
+    r = rep[tag] = {"out": {}, "grad": {}}
     fails = []
-    # ---- indices -----------------------------------------------------------------------------------------------------------------
-    clean = torch.ones(R, dtype=torch.bool)
-    if exact_positions:
-        idx_main, idx_head = aux["sphere_idx"].cpu().long(), aux["sphere_idx_g"].cpu().long()
-        d_main, d_head = (idx_main != o["idx"]["main"]).any(dim=1), (idx_head != o["idx"]["head"]).any(dim=1)
-        if not (bool(((idx_main - o["idx"]["main"]).abs() <= 1).all()) and bool(((idx_head - o["idx"]["head"]).abs() <= 1).all())):
-            fails.append("a sphere index is off by more than one")
-        if bool((d_main & ~o["amb"]["main"]).any()) or bool((d_head & ~o["amb"]["head"]).any()):
-            fails.append("sphere indices differ away from rounding boundaries: %d main, %d anchors" % (
-                int((d_main & ~o["amb"]["main"]).sum()), int((d_head & ~o["amb"]["head"]).sum())))
-        flipped = d_main.reshape(R, N).any(dim=1) | d_head.reshape(R, -1).any(dim=1)
-        r["samples_with_flipped_index"] = int(d_main.sum()) + int(d_head.sum())
-        r["rays_with_flipped_index"] = int(flipped.sum())
-        if float(flipped.float().mean()) > MAX_FLIPPED_RAY_FRACTION:
-            fails.append("%d of %d rays contain a flipped index" % (int(flipped.sum()), R))
-        clean = ~flipped
-        # sorted sample distances and the sort permutation (where keys are unique) are bit-exact
-        ds = o["dist_sorted"]
-        r["dist_sorted_equal"] = bool(torch.equal(aux["dist_sorted"].cpu(), ds))
-        uniq = torch.ones_like(ds, dtype=torch.bool)
-        uniq[:, 1:] &= ds[:, 1:] != ds[:, :-1]
-        uniq[:, :-1] &= ds[:, 1:] != ds[:, :-1]
-        r["perm_equal"] = bool(torch.equal(aux["perm"].cpu().long()[uniq], o["idx"]["perm"][uniq]))
-        if tag != "free_fp32" and not (r["dist_sorted_equal"] and r["perm_equal"]):
-            fails.append("sorted distances / permutation not bit-exact at identical head offsets")
-        r["closest_idx_equal_frac_clean"] = float((aux["closest_idx"].cpu().long() == o["idx"]["closest"])[clean].float().mean())
-    # ---- the 12 outputs ----------------------------------------------------------------------------------------------------------
-    r["out"] = {}
     for k in OUT_KEYS:
         got, ref = out[k].detach().float().cpu(), o["out"][k]
         assert got.shape == ref.shape and bool(torch.isfinite(got).all()), k
         e, rr = (got - ref).reshape(R, -1), ref.reshape(R, -1)
         m = dict(rel_l2=float(e.double().norm() / max(float(rr.double().norm()), 1e-30)),
-                 max_rel_clean=float((e[clean].abs() / (1.0 + rr[clean].abs())).max()), max_abs_clean=float(e[clean].abs().max()))
+                 max_rel=float((e.abs() / (1.0 + rr.abs())).max()), max_abs=float(e.abs().max()))
         if out_gate is not None and k in out_gate:
-            ok = _within(got, ref, out_gate[k], k in ABS_KEYS)
-            m["frac_clean_rays_within_gate"] = float(ok[clean].float().mean())
-            if m["frac_clean_rays_within_gate"] < 1.0:
-                fails.append("%s: %.4f of the index-identical rays within %.1e (max rel %.2e, max abs %.2e)" % (
-                    k, m["frac_clean_rays_within_gate"], out_gate[k], m["max_rel_clean"], m["max_abs_clean"]))
+            m["frac_rays_within_gate"] = float(_within(got, ref, out_gate[k], k in ABS_KEYS).float().mean())
+            if m["frac_rays_within_gate"] < 1.0:
+                fails.append("[%s] %s: %.4f of the rays within %.1e (max rel %.2e, max abs %.2e)" % (
+                    tag, k, m["frac_rays_within_gate"], out_gate[k], m["max_rel"], m["max_abs"]))
         r["out"][k] = m
     r["loss"] = dict(got=float(loss), ref=o["loss"], rel=abs(float(loss) - o["loss"]) / abs(o["loss"]))
     if r["loss"]["rel"] > loss_gate:
-        fails.append("proxy loss rel %.2e > %.1e" % (r["loss"]["rel"], loss_gate))
-    # ---- every gradient ------------------------------------------------------------------------------------------------------------
-    r["grad"] = {}
+        fails.append("[%s] proxy loss rel %.2e > %.1e" % (tag, r["loss"]["rel"], loss_gate))
     for nm, ref in o["grads"].items():
         g = grads[nm]
         rn = float(ref.double().norm())
@@ -180,17 +158,17 @@ def _compare(tag, o, out, grads, aux, loss, R, N, rep, out_gate, grad_gate, loss
             gz = 0.0 if g is None else float(g.abs().max())
             r["grad"][nm] = dict(ref_norm=0.0, got_max=gz)
             if gz != 0.0:
-                fails.append("%s: non-zero (%.2e) where the oracle's gradient is exactly zero" % (nm, gz))
+                fails.append("[%s] %s: non-zero (%.2e) where the oracle's gradient is exactly zero" % (tag, nm, gz))
             continue
         assert g is not None, nm
         gc = g.detach().double().cpu()
         rel = float((gc - ref.double()).norm() / rn)
         r["grad"][nm] = dict(rel_l2=rel, cosine=float((gc * ref.double()).sum() / (gc.norm() * rn)), ref_norm=rn)
         if rel > grad_gate:
-            fails.append("%s: gradient rel L2 %.2e > %.1e" % (nm, rel, grad_gate))
+            fails.append("[%s] %s: gradient rel L2 %.2e > %.1e" % (tag, nm, rel, grad_gate))
     worst = sorted(((v["rel_l2"], k) for k, v in r["grad"].items() if "rel_l2" in v), reverse=True)[:4]
-    print("\n[%s] flipped rays %s, loss rel %.2e" % (tag, r.get("rays_with_flipped_index", "-"), r["loss"]["rel"]))
-    print("   outputs (max rel on clean rays / rel L2):", {k: "%.1e/%.1e" % (v["max_rel_clean"], v["rel_l2"]) for k, v in r["out"].items()})
+    print("\n[%s] loss rel %.2e" % (tag, r["loss"]["rel"]))
+    print("   outputs (max rel / max abs):", {k: "%.1e/%.1e" % (v["max_rel"], v["max_abs"]) for k, v in r["out"].items()})
     print("   worst gradients (rel L2):", ["%s %.2e" % (k, v) for v, k in worst])
     return fails
 
@@ -219,36 +197,66 @@ def test_timed_path_matches_oracle_outputs_and_every_gradient(name, precision):
     grads.update({"x_rgb." + k: v.grad for k, v in x.items()})
     rep = {"case": name, "precision": precision, "rows": R * N}
     fails = []
-    free = _oracle_free(name)
-    if precision == "fp32":
-        fails += _compare("free_fp32", free, out, grads, aux, loss.item(), R, N, rep, OUT_GATE["fp32"], GRAD_GATE["fp32"], LOSS_GATE["fp32"], True)
-        kl_ok = _within(out["loss_kl"].detach().cpu(), free["out"]["loss_kl"], 2e-4, False)
-        rep["loss_kl_frac_within"] = float(kl_ok.float().mean())
-        if rep["loss_kl_frac_within"] < 0.995:
-            fails.append("loss_kl: %.4f of the rays within 2e-4" % rep["loss_kl_frac_within"])
-    else:
-        # (1) the gaussian head on its own: bf16 offsets against the oracle's (same inputs: the anchors do not depend on anything bf16)
-        off_gpu = aux["offsets"].detach().float().cpu().reshape(R, -1, 2)
-        rep["head_offsets"] = dict(max_abs=float((off_gpu - free["offsets"]).abs().max()), scale=float(free["offsets"].abs().max()),
-                                   rel_l2=float((off_gpu - free["offsets"]).norm() / free["offsets"].norm()))
-        if rep["head_offsets"]["rel_l2"] > 2e-2:
-            fails.append("gaussian head offsets rel L2 %.2e" % rep["head_offsets"]["rel_l2"])
-        # (2) bf16 arithmetic at identical sample positions
-        matched = _oracle_run(name, head_offsets=off_gpu)
-        fails += _compare("matched_bf16", matched, out, grads, aux, loss.item(), R, N, rep, OUT_GATE["matched"], GRAD_GATE["matched"],
-                          LOSS_GATE["matched"], True)
-        kl_ok = _within(out["loss_kl"].detach().cpu(), matched["out"]["loss_kl"], 5e-2, False)
-        rep["loss_kl_frac_within"] = float(kl_ok.float().mean())
-        del matched
-        # (3) free-running: the reference's own positions (index chaos of moved gaussian samples on white-noise maps included)
-        fails += _compare("free_bf16", free, out, grads, aux, loss.item(), R, N, rep, None, GRAD_GATE["free"], LOSS_GATE["free"], False)
+
+    # ---- the oracle at the GPU's head offsets and sphere indices -------------------------------------------------------------------
+    off_gpu = aux["offsets"].detach().float().cpu().reshape(R, -1, 2)
+    idx_main, idx_head = aux["sphere_idx"].cpu().long(), aux["sphere_idx_g"].cpu().long()
+    o = _oracle_run(name, head_offsets=off_gpu, sphere_idx=(idx_main, idx_head))
+
+    # step 1: indices -- equal to the oracle's own except at rounding boundaries; sorted distances / permutation bit-exact
+    d_main, d_head = (idx_main != o["idx"]["main"]).any(dim=1), (idx_head != o["idx"]["head"]).any(dim=1)
+    if not (bool(((idx_main - o["idx"]["main"]).abs() <= 1).all()) and bool(((idx_head - o["idx"]["head"]).abs() <= 1).all())):
+        fails.append("a sphere index is off by more than one")
+    stray = int((d_main & ~o["amb"]["main"]).sum()) + int((d_head & ~o["amb"]["head"]).sum())
+    if stray:
+        fails.append("%d sphere indices differ away from rounding boundaries" % stray)
+    nflip, ntot = int(d_main.sum()) + int(d_head.sum()), d_main.numel() + d_head.numel()
+    rep["index"] = dict(flipped_samples=nflip, samples=ntot, rays_touched=int((d_main.reshape(R, N).any(1) | d_head.reshape(R, -1).any(1)).sum()),
+                        ambiguous_samples=int(o["amb"]["main"].sum()) + int(o["amb"]["head"].sum()))
+    if nflip > MAX_FLIPPED_SAMPLE_FRACTION * ntot:
+        fails.append("%d of %d samples have a flipped sphere index" % (nflip, ntot))
+    ds = o["dist_sorted"]
+    uniq = torch.ones_like(ds, dtype=torch.bool)
+    uniq[:, 1:] &= ds[:, 1:] != ds[:, :-1]
+    uniq[:, :-1] &= ds[:, 1:] != ds[:, :-1]
+    rep["index"]["dist_sorted_equal"] = bool(torch.equal(aux["dist_sorted"].cpu(), ds))
+    rep["index"]["perm_equal"] = bool(torch.equal(aux["perm"].cpu().long()[uniq], o["idx"]["perm"][uniq]))
+    rep["index"]["closest_idx_equal_frac"] = float((aux["closest_idx"].cpu().long() == o["idx"]["closest"]).float().mean())
+    if not (rep["index"]["dist_sorted_equal"] and rep["index"]["perm_equal"]):
+        fails.append("sorted sample distances / sort permutation are not bit-exact at identical head offsets")
+    if rep["index"]["closest_idx_equal_frac"] < (0.999 if precision == "fp32" else 0.98):
+        fails.append("closest-sample index equal on %.4f of the rays" % rep["index"]["closest_idx_equal_frac"])
+    print("\n%s %s: %d of %d samples with a flipped index (%d rays), %d ambiguous" % (
+        name, precision, nflip, ntot, rep["index"]["rays_touched"], rep["index"]["ambiguous_samples"]))
+
+    # the gaussian head on its own (same indices, the oracle's own head arithmetic)
+    e = off_gpu - o["offsets_own"]
+    rep["head_offsets"] = dict(max_abs=float(e.abs().max()), scale=float(o["offsets_own"].abs().max()), rel_l2=float(e.norm() / o["offsets_own"].norm()))
+    if rep["head_offsets"]["rel_l2"] > HEAD_GATE[precision]:
+        fails.append("gaussian head offsets rel L2 %.2e > %.1e" % (rep["head_offsets"]["rel_l2"], HEAD_GATE[precision]))
+
+    # step 2: every ray, every gradient, arithmetic only
+    fails += _compare("matched", o, out, grads, loss.item(), R, rep, OUT_GATE[precision], GRAD_GATE[precision], LOSS_GATE[precision])
+    kl_got, kl_ref = out["loss_kl"].detach().cpu(), o["out"]["loss_kl"]
+    rep["loss_kl"] = dict(mean_rel=abs(float(kl_got.mean()) - float(kl_ref.mean())) / abs(float(kl_ref.mean())),
+                          frac_within=float(_within(kl_got, kl_ref, 2e-4 if precision == "fp32" else 2e-2, False).float().mean()))
+    print("   head offsets rel L2 %.2e; loss_kl mean rel %.2e, frac within %.4f; closest idx equal %.4f" % (
+        rep["head_offsets"]["rel_l2"], rep["loss_kl"]["mean_rel"], rep["loss_kl"]["frac_within"], rep["index"]["closest_idx_equal_frac"]))
+    if rep["loss_kl"]["mean_rel"] > KL_GATE[precision]["mean_rel"] or rep["loss_kl"]["frac_within"] < KL_GATE[precision]["frac"]:
+        fails.append("loss_kl: mean rel %.2e, %.4f of the rays within tolerance" % (rep["loss_kl"]["mean_rel"], rep["loss_kl"]["frac_within"]))
+    del o
+
+    # step 3 (bf16): free-running against the unmodified oracle
+    if precision == "bf16":
+        free = _oracle_free(name)
+        fails += _compare("free", free, out, grads, loss.item(), R, rep, None, GRAD_GATE["free"], LOSS_GATE["free"])
         dref, dgot = free["out"]["depth"], out["depth"].detach().cpu()
         rel = (dgot - dref).abs() / dref.abs().clamp(min=1e-3)
         cerr = (out["color"].detach().cpu() - free["out"]["color"]).abs().reshape(-1)
         gm = (out["gaussian_means"].detach().cpu() - free["out"]["gaussian_means"]).abs() / free["out"]["gaussian_means"].abs()
         fb = dict(depth_rel_median=float(rel.median()), depth_rel_p99=float(rel.quantile(0.99)), color_abs_p99=float(cerr.quantile(0.99)),
                   gaussian_means_rel_max=float(gm.max()))
-        rep["free_bf16"]["summary"] = fb
+        rep["free"]["summary"] = fb
         print("   free-running bf16:", {k: "%.2e" % v for k, v in fb.items()})
         for k, v in fb.items():
             if v > FREE_BF16_GATE[k]:

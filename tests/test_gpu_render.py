@@ -11,10 +11,14 @@ from scenerf_amd.renderer import MLP_PARAM_NAMES
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-# per-ray tolerances (SURVEY §8d parity gates).  fp32 mode: depth rel 1e-4 / colour abs 1e-5 class; bf16 mode:
-# 2e-2 class.  A ray may additionally be an "index outlier": one of its samples sits within rounding noise of a
-# spherical-pixel boundary (acos/atan2 differ in the last ulp between libms) and picks the neighbouring texel.
-TOL = {"fp32": dict(depth=2e-4, color=2e-4, other=5e-4), "bf16": dict(depth=3e-2, color=3e-2, other=6e-2)}
+# per-ray gates: |got - ref| <= tol * (1 + |ref|), colour / alphas / weights absolute.  fp32 = SURVEY 8d (depth rel 1e-4, colour abs
+# 1e-5; measured max 2.7e-6 / 6e-7 at R = 1200).  bf16 = SURVEY 8d (depth rel 2e-2, colour abs 2e-2): against a golden vector the bf16
+# run is free-running -- its gaussian samples sit ~1e-2 m off the reference's and some cross a texel boundary (measured max
+# 8e-3 / 1.6e-3 at R = 1200 on white-noise maps, tests/test_gpu_parity_full.py); the arithmetic-only bf16 gates live in that file.
+TOL = {"fp32": dict(depth=1e-4, color=1e-5, other=1e-4), "bf16": dict(depth=2e-2, color=2e-2, other=6e-2)}
+ABS_KEYS = ("color", "alphas", "weights")
+# gradient digests (norm, the reference's top-256 entries): relative.  bf16 and small R: a texel-crossing sample is 1 of ~1000
+GRAD_TOL = {"fp32": dict(norm=1e-2, topk=1e-2), "bf16": dict(norm=1.5e-1, topk=2e-1)}
 
 
 def build_model(g: Golden, precision: str):
@@ -34,10 +38,38 @@ def run_model(m, g: Golden, maps, grad=True):
     return out, x
 
 
-def frac_within(a, b, rtol, atol):
+def frac_within(a, b, tol, absolute=False):
     a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
-    ok = ((a - b).abs() <= atol + rtol * b.abs()).all(dim=1)
+    lim = tol if absolute else tol * (1.0 + b.abs())
+    ok = ((a - b).abs() <= lim).all(dim=1)
     return float(ok.float().mean()), ok
+
+
+def clean_mask(aux, o, ocfg, K, n_rays):
+    """Rays (the first ``n_rays`` of the render) whose every sample and anchor got the sphere index the oracle computes: the GPU's own
+    indices (model.debug_aux) against the oracle's intermediates.  A differing index must be a +-1 at a rounding boundary (acos /
+    atan2 last-ulp differences between libms: torch-CPU SLEEF vs ROCm ocml)."""
+    n_main, n_head = o["_idx"].shape[0], o["_idx_g"].shape[0]
+    dm = (aux["sphere_idx"].cpu().long()[:n_main] - o["_idx"]).abs()
+    dh = (aux["sphere_idx_g"].cpu().long()[:n_head] - o["_idx_g"]).abs()
+    assert int(dm.max()) <= 1 and int(dh.max()) <= 1
+    for pts, d in ((o["_pts_sorted"].detach().reshape(-1, 3), dm), (o["_anchor_pts"].detach(), dh)):
+        _, fl = orc.sphere_coords(orc.project_to_pixels(pts, K), torch.inverse(K), ocfg, return_float=True)
+        amb = ((fl - torch.floor(fl) - 0.5).abs() < 2e-3).any(dim=1)
+        assert not bool(((d != 0).any(dim=1) & ~amb).any()), "sphere index differs away from a rounding boundary"
+    flipped = (dm != 0).any(dim=1).reshape(n_rays, -1).any(dim=1) | (dh != 0).any(dim=1).reshape(n_rays, -1).any(dim=1)
+    assert int(flipped.sum()) <= max(1, n_rays // 16), "too many rays with a flipped sphere index: %d of %d" % (int(flipped.sum()), n_rays)
+    return ~flipped
+
+
+def _clean_rays(m, g: Golden, R):
+    """clean_mask for a golden case (single chunk): the oracle is pinned on the reference (test_oracle_golden.py)."""
+    ocfg = (orc.OracleConfig.kitti if g.variant == "kitti" else orc.OracleConfig.bundlefusion)(**g.cfg_kwargs())
+    mlp, mlpg = g.mlp_states()
+    outs = [orc.render_chunk(ocfg, mlp, mlpg, g.cam_K, g.T, g.feature_maps(), g.pixels[s:s + g.chunk], g.noise_u[s:s + g.chunk],
+                             g.noise_g[s:s + g.chunk], keep_intermediates=True) for s in range(0, R, g.chunk)]
+    o = {k: torch.cat([c[k] for c in outs], dim=0) for k in ("_idx", "_idx_g", "_pts_sorted", "_anchor_pts")}
+    return clean_mask(m.last_aux, o, ocfg, g.cam_K, R)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -45,34 +77,38 @@ def frac_within(a, b, rtol, atol):
 def test_render_matches_reference_golden(name, precision):
     g = Golden(name)
     m = build_model(g, precision)
+    R = g.pixels.shape[0]
+    m.debug_aux = precision == "fp32"   # (bf16: free-running, the gaussian samples sit elsewhere anyway)
     out, x = run_model(m, g, g.feature_maps())
     assert set(out) == set(OUT_KEYS)
+    clean = _clean_rays(m, g, R) if m.debug_aux else torch.ones(R, dtype=torch.bool)
     tol = TOL[precision]
-    report = {}
+    report, worst = {}, {}
     for k in OUT_KEYS:
         ref = g.out(k)
         got = out[k].detach().float().cpu()
         assert got.shape == ref.shape, k
         t = tol["depth"] if k in ("depth", "depth_volumes", "gaussian_means", "gaussian_stds") else tol["color"] if k == "color" else tol["other"]
-        fr, _ = frac_within(got, ref, t, t)
-        report[k] = fr
-    print(name, precision, {k: round(v, 3) for k, v in report.items()})
-    # every ray must match on the quantities upstream of the feature gather
-    assert report["depth_volumes"] == 1.0 or precision == "bf16"
-    smooth = g.meta["smooth"]
-    need = 0.98 if smooth else 0.85
-    for k in ("depth", "color", "weights", "alphas", "densities", "gaussian_means", "gaussian_stds"):
-        assert report[k] >= need, "%s: only %.3f of the rays within tolerance" % (k, report[k])
-    # loss_kl contains hard thresholds (|mean diff| > 0.1, |std diff| > 0.1, ray_som_kl.py:66-70): a ray whose SOM
-    # statistics sit at a threshold flips a mask term under bf16-level perturbations of the gaussian head
-    assert report["loss_kl"] >= (0.98 if precision == "fp32" else 0.85), report["loss_kl"]
-    # aggregate (the training loss proxy) must agree closely: outliers are few and small
+        _, ok = frac_within(got, ref, t, k in ABS_KEYS)
+        report[k] = float(ok[clean].float().mean())
+        e = (got - ref).reshape(R, -1)[clean]
+        worst[k] = float((e.abs() / (1.0 if k in ABS_KEYS else 1.0 + ref.reshape(R, -1)[clean].abs())).max())
+    print("\n%s %s: %d/%d rays with oracle-identical indices; max errors %s" % (
+        name, precision, int(clean.sum()), R, {k: "%.1e" % v for k, v in worst.items()}))
+    # every ray (with reference-identical sample indices) within the gate -- fraction 1.0
+    for k in ("depth", "color", "weights", "alphas", "densities", "gaussian_means", "gaussian_stds", "depth_volumes"):
+        assert report[k] == 1.0, "%s: only %.3f of the rays within tolerance (max error %.2e)" % (k, report[k], worst[k])
+    # loss_kl: RaySOM's BMU is an argmax over values that tie at the additive floors for samples far from every gaussian
+    # (ray_som_kl.py:46-52), so single rays flip under any rounding difference (tests/test_gpu_parity_full.py docstring)
+    assert report["loss_kl"] >= 0.85, report["loss_kl"]
+    # aggregate (the training loss proxy) must agree closely
     loss = out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
     ref_loss = float(g.z["loss"])
-    assert abs(loss.item() - ref_loss) <= (2e-3 if precision == "fp32" else 2e-2) * abs(ref_loss)
+    lrel = abs(loss.item() - ref_loss) / abs(ref_loss)
+    assert lrel <= (5e-4 if precision == "fp32" else 5e-3), lrel
     # gradients: norm + the reference's top-|g| entries
     loss.backward()
-    gt = 5e-3 if precision == "fp32" else 8e-2
+    gt = GRAD_TOL[precision]
     tensors = {}
     for pn, p in zip(MLP_PARAM_NAMES, m.mlp.ordered_params()):
         tensors["mlp." + pn] = p.grad
@@ -80,18 +116,19 @@ def test_render_matches_reference_golden(name, precision):
         tensors["mlp_gaussian." + pn] = p.grad
     for key, v in x.items():
         tensors["x_rgb." + key] = v.grad if v.grad is not None else torch.zeros_like(v)
-    bad = []
+    bad, wn, wt = [], 0.0, 0.0
     for nm, grad in tensors.items():
         assert grad is not None, nm
         d = g.grad_digest(nm)
         flat = grad.detach().float().cpu().reshape(-1)
         nrm = float(flat.double().norm())
-        if abs(nrm - d["norm"]) > gt * 4 * d["norm"] + 1e-7:
-            bad.append((nm, "norm", nrm, d["norm"]))
-        e = float((flat[d["idx"]] - d["val"]).abs().max())
+        en = abs(nrm - d["norm"]) / max(d["norm"], 1e-30) if d["norm"] > 0 else nrm
         s = float(d["val"].abs().max())
-        if e > gt * 4 * max(s, 1e-9):
-            bad.append((nm, "topk", e, s))
+        et = float((flat[d["idx"]] - d["val"]).abs().max()) / max(s, 1e-30) if s > 0 else float(flat[d["idx"]].abs().max())
+        wn, wt = max(wn, en), max(wt, et)
+        if en > gt["norm"] or et > gt["topk"]:
+            bad.append((nm, "norm %.2e topk %.2e" % (en, et)))
+    print("   loss rel %.2e, loss_kl frac %.3f, worst gradient norm error %.2e, worst top-k error %.2e" % (lrel, report["loss_kl"], wn, wt))
     assert not bad, bad
 
 
@@ -127,20 +164,24 @@ def test_larger_chunk_against_oracle_bf16_and_fp32():
     pix = synth.stride2_pixels((1220, 370), R, 14)
     nu, ng = synth.sampling_noise(R, 64, 64, 15)
     K, T = synth.kitti_cam_K(), synth.rel_pose(2.0, 10.0)
-    ref = orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix, nu, ng)
+    ref = orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix, nu, ng, keep_intermediates=True)
     for precision in ("fp32", "bf16"):
         m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision=precision, **kw).to(DEV)
         m.mlp.load_state_dict(mlp)
         m.mlp_gaussian.load_state_dict(mlpg)
+        m.debug_aux = precision == "fp32"
         with torch.no_grad():
             out = m.render_rays_batch(K.to(DEV), T.to(DEV), {k: v.to(DEV) for k, v in maps.items()}, sampled_pixels=pix.to(DEV),
                                       ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
         t = TOL[precision]
-        fd, _ = frac_within(out["depth"].cpu(), ref["depth"].detach(), t["depth"], t["depth"])
-        fc, _ = frac_within(out["color"].cpu(), ref["color"].detach(), t["color"], t["color"])
-        print(precision, "depth frac", fd, "color frac", fc,
-              "max rel depth err", float(((out["depth"].cpu() - ref["depth"].detach()).abs() / ref["depth"].detach().abs()).max()))
-        assert fd >= 0.97 and fc >= 0.97
+        clean = clean_mask(m.last_aux, ref, ocfg, K, R) if m.debug_aux else torch.ones(R, dtype=torch.bool)
+        _, okd = frac_within(out["depth"].cpu(), ref["depth"].detach(), t["depth"])
+        _, okc = frac_within(out["color"].cpu(), ref["color"].detach(), t["color"], True)
+        fd, fc = float(okd[clean].float().mean()), float(okc[clean].float().mean())
+        print(precision, "rays with oracle-identical indices", int(clean.sum()), "depth frac", fd, "color frac", fc,
+              "max rel depth err", float(((out["depth"].cpu() - ref["depth"].detach()).abs() / ref["depth"].detach().abs())[clean].max()),
+              "max abs colour err", float((out["color"].cpu() - ref["color"].detach()).abs()[clean].max()))
+        assert fd == 1.0 and fc == 1.0
 
 
 # ------------------------------------------------------------------------------------------------ edge cases
@@ -168,23 +209,28 @@ def test_edge_cases_against_oracle_fp32(name, over, R, chunk, pose):
     U, GP = ocfg.n_pts_uni, ocfg.n_gaussians * ocfg.n_pts_per_gaussian
     nu, ng = synth.sampling_noise(R, U, GP, 25)
     K, T = synth.kitti_cam_K(), synth.rel_pose(*pose)
-    ref = orc.render_rays_batch(ocfg, mlp, mlpg, K, T, maps, pix, nu, ng, ray_batch_size=chunk) if U > 0 else None
-    if U == 0:   # the oracle's uniform branch needs U > 0 tensors: run it chunk by chunk with empty uniform noise
-        ref = orc.render_rays_batch(ocfg, mlp, mlpg, K, T, maps, pix, torch.zeros(R, 0, 1), ng, ray_batch_size=chunk)
+    if U == 0:   # gaussian samples only: the oracle takes empty uniform noise
+        nu = torch.zeros(R, 0, 1)
+    chunks = [orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix[s:s + chunk], nu[s:s + chunk], ng[s:s + chunk], keep_intermediates=True)
+              for s in range(0, R, chunk)]
+    ref = {k: torch.cat([c[k] for c in chunks], dim=0) for k in OUT_KEYS + ["_idx", "_idx_g", "_pts_sorted", "_anchor_pts"]}
     m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="fp32", **kw).to(DEV)
     m.mlp.load_state_dict(mlp)
     m.mlp_gaussian.load_state_dict(mlpg)
+    m.debug_aux = True
     x = {k: v.to(DEV).requires_grad_(True) for k, v in maps.items()}
     out = m.render_rays_batch(K.to(DEV), T.to(DEV), x, sampled_pixels=pix.to(DEV), ray_batch_size=chunk,
                               noise=(nu.to(DEV), ng.to(DEV)))
+    clean = clean_mask(m.last_aux, ref, ocfg, K, R)   # every ray except those with a +-1 sphere index at a rounding boundary
     for k in OUT_KEYS:
         got, want = out[k].detach().cpu(), ref[k].detach()
         assert got.shape == want.shape, (k, got.shape, want.shape)
         assert torch.isfinite(got).all(), k
         if k in ("loss_kl", "som_vars", "closest_pts_to_depths", "weights_at_depth"):
             continue   # threshold / argmin outputs: covered by the stage tests with identical inputs
-        fr, _ = frac_within(got, want, 5e-4, 5e-4)
-        assert fr >= (0.9 if R >= 10 else 0.6), "%s: %.2f of rays within tolerance" % (k, fr)
+        _, ok = frac_within(got, want, TOL["fp32"]["color"] if k == "color" else 1e-4, k in ABS_KEYS)
+        assert bool(ok[clean].all()), "%s: %.3f of the rays within tolerance, max rel error %.2e" % (
+            k, float(ok[clean].float().mean()), float(((got - want).abs() / (1 + want.abs())).reshape(R, -1)[clean].max()))
     (out["depth"].sum() + out["color"].sum() + out["loss_kl"].sum()).backward()
     assert all(torch.isfinite(p.grad).all() for p in m.mlp.parameters())
     assert all(torch.isfinite(v.grad).all() for v in x.values())
@@ -292,10 +338,13 @@ def test_full_size_config2_properties_and_subset_parity():
         m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision=precision, **kw).to(DEV)
         m.mlp.load_state_dict(mlp)
         m.mlp_gaussian.load_state_dict(mlpg)
+        m.debug_aux = precision == "fp32"
         with torch.no_grad():
             o = m.render_rays_batch(K.to(DEV), T.to(DEV), {k: v.to(DEV) for k, v in maps.items()}, sampled_pixels=pix.to(DEV),
                                     ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
         outs[precision] = {k: v.cpu() for k, v in o.items()}
+        if precision == "fp32":
+            aux32 = {k: m.last_aux[k].cpu() for k in ("sphere_idx", "sphere_idx_g")}
     o = outs["fp32"]
     w, a, z, dep = o["weights"], o["alphas"], o["depth_volumes"], o["depth"]
     assert w.shape == (R, N)
@@ -315,10 +364,11 @@ def test_full_size_config2_properties_and_subset_parity():
     # subset parity against the oracle (CPU) on identical inputs
     S = 40
     ocfg = orc.OracleConfig.kitti(**kw)
-    ref = orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix[:S], nu[:S], ng[:S])
+    ref = orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix[:S], nu[:S], ng[:S], keep_intermediates=True)
+    clean = clean_mask(aux32, ref, ocfg, K, S)
     for k in ("depth", "color", "weights", "alphas", "densities", "gaussian_means", "gaussian_stds", "depth_volumes"):
-        fr, _ = frac_within(o[k][:S], ref[k].detach(), 5e-4, 5e-4)
-        assert fr >= 0.95, "%s: %.3f of the subset rays within tolerance" % (k, fr)
+        _, ok = frac_within(o[k][:S], ref[k].detach(), TOL["fp32"]["color"] if k == "color" else 1e-4, k in ABS_KEYS)
+        assert bool(ok[clean].all()), "%s: %.3f of the subset rays within tolerance" % (k, float(ok[clean].float().mean()))
 
 
 @pytest.mark.gpu
@@ -378,8 +428,11 @@ def test_full_size_config3_bundlefusion_fused_vs_layers_and_subset_parity():
     nu, ng = synth.sampling_noise(R, U, 4 * P, 65)
     K, T = synth.bundlefusion_cam_K(), synth.rel_pose(0.3, 8.0)
 
+    auxs = {}
+
     def run(precision, grad, fused=True):
         m = SceneRFBundleFusion(precision=precision, **kw).to(DEV)
+        m.debug_aux = precision == "fp32"
         if not fused:
             m.render_cfg.fused_min_rows = -1   # per-layer GEMM path (explicit call state: scenerf_cfg.fused_min_rows)
         m.mlp.load_state_dict(mlp)
@@ -388,6 +441,8 @@ def test_full_size_config3_bundlefusion_fused_vs_layers_and_subset_parity():
         with torch.set_grad_enabled(grad):
             o = m.render_rays_batch(K.to(DEV), T.to(DEV), x, sampled_pixels=pix.to(DEV), ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
         grads = None
+        if m.debug_aux:
+            auxs[precision] = {k: m.last_aux[k].cpu() for k in ("sphere_idx", "sphere_idx_g")}
         if grad:
             (o["depth"].mean() + o["color"].mean() + o["loss_kl"].mean() + o["gaussian_means"].mean()).backward()
             grads = {"mlp." + n: p.grad.cpu() for n, p in m.mlp.named_parameters()}
@@ -399,10 +454,11 @@ def test_full_size_config3_bundlefusion_fused_vs_layers_and_subset_parity():
     o32, _ = run("fp32", False)
     S = 24
     ocfg = orc.OracleConfig.bundlefusion(**{k: v for k, v in kw.items()})
-    ref = orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix[:S], nu[:S], ng[:S])
+    ref = orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix[:S], nu[:S], ng[:S], keep_intermediates=True)
+    clean = clean_mask(auxs["fp32"], ref, ocfg, K, S)
     for k in ("depth", "color", "weights", "alphas", "gaussian_means", "gaussian_stds", "depth_volumes"):
-        fr, _ = frac_within(o32[k][:S], ref[k].detach(), 5e-4, 5e-4)
-        assert fr >= 0.9, "%s: %.3f of the subset rays within tolerance" % (k, fr)
+        _, ok = frac_within(o32[k][:S], ref[k].detach(), TOL["fp32"]["color"] if k == "color" else 1e-4, k in ABS_KEYS)
+        assert bool(ok[clean].all()), "%s: %.3f of the subset rays within tolerance" % (k, float(ok[clean].float().mean()))
     assert bool((o32["gaussian_means"] >= 0.5).all()) and bool((o32["gaussian_stds"] >= 0.5).all())   # scenerf_bf.py:606-608
     # (2) fused vs per-layer kernels, bf16, forward + backward
     ol, gl = run("bf16", True, fused=False)
@@ -458,3 +514,80 @@ def test_chunked_call_equals_single_chunk_on_the_fused_path():
             continue
         r = float((a - b).norm() / a.norm())
         assert r <= 2e-3, "%s: chunked vs single relative L2 %.3e" % (n, r)
+
+
+# ------------------------------------------------------------------------------------------------ full-frame inference (C5)
+@pytest.mark.gpu
+def test_render_image_static_chunks_and_graph_replay():
+    """SceneRF.render_image (scenerf_amd/inference.py): the tail chunk is padded to the static chunk size and one captured hipGraph
+    is replayed per chunk.  (1) graph replay == the same static chunks launched eagerly, bit for bit; (2) a no_grad multi-chunk
+    render_rays_batch call (what render_colors.py / generate_novel_depths.py issue) takes that route by itself; (3) against the
+    reference-style ragged chunk loop: identical for the full chunks, within bf16 rounding for the rays of the tail chunk (padded
+    to 8,192 rows it runs on the fused kernels, ragged at 2,816 rows on the per-layer ones)."""
+    from scenerf_amd import synth
+    kw = dict(sphere_W=376, sphere_H=114, n_pts_uni=32, n_pts_per_gaussian=8)
+    R, CH = 300, 128
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="bf16", **kw).to(DEV).eval()
+    m.mlp.load_state_dict(synth.mlp_state(91, 4))
+    m.mlp_gaussian.load_state_dict(synth.mlp_state(92, 2, out_scale=4.0))
+    maps = {k: v.to(DEV) for k, v in synth.feature_maps(376, 114, 93, smooth=True).items()}
+    K, T = synth.kitti_cam_K().to(DEV), synth.rel_pose(2.0, 10.0).to(DEV)
+    pix = synth.stride2_pixels((1220, 370), R, 94).to(DEV)
+    nu, ng = synth.sampling_noise(R, 32, 32, 95)
+    noise = (nu.to(DEV), ng.to(DEV))
+    with torch.no_grad():
+        a = m.render_image(K, T, maps, sampled_pixels=pix, ray_batch_size=CH, noise=noise, use_graph=True)
+        eng = m._image_renderer[1]
+        assert eng.graph is not None and eng.replays == 3
+        a2 = m.render_image(K, T, maps, sampled_pixels=pix, ray_batch_size=CH, noise=noise, use_graph=True)   # same frame: same engine, same graph
+        assert m._image_renderer[1] is eng and eng.replays == 6
+        b = m.render_image(K, T, maps, sampled_pixels=pix, ray_batch_size=CH, noise=noise, use_graph=False)
+        c = m.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=CH, noise=noise)                # routed through render_image
+        m.static_inference = False
+        d = m.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=CH, noise=noise)                # the reference's ragged loop
+    assert set(a) == set(OUT_KEYS)
+    for k in OUT_KEYS:
+        assert a[k].shape[0] == R
+        assert torch.equal(a[k], a2[k]) and torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+        assert torch.equal(a[k][:2 * CH], d[k][:2 * CH]), k
+    rel = (a["depth"][2 * CH:] - d["depth"][2 * CH:]).abs() / d["depth"][2 * CH:].abs()
+    assert float(rel.max()) < 3e-2, float(rel.max())
+    # device RNG (no noise given): runs, finite, and differs from call to call (inference is stochastic in the reference too)
+    with torch.no_grad():
+        m.static_inference = True
+        e1 = m.render_image(K, T, maps, sampled_pixels=pix, ray_batch_size=CH, keys=("depth", "color"))
+        e2 = m.render_image(K, T, maps, sampled_pixels=pix, ray_batch_size=CH, keys=("depth", "color"))
+    assert set(e1) == {"depth", "color"} and bool(torch.isfinite(e1["depth"]).all()) and not torch.equal(e1["depth"], e2["depth"])
+
+
+@pytest.mark.gpu
+def test_render_image_n512_bf16_against_position_matched_oracle():
+    """BASELINE.json configs[4] sampling (N = 512: U=256, G=4, P=64), bf16, one padded chunk of 32 rays = 16,384 rows on the fused
+    lean-inference path, replayed from the captured graph, white-noise maps at the full KITTI sphere: depth and colour of every ray
+    against the CPU oracle evaluated at the GPU's own gaussian-head offsets (render_chunk(head_offsets=...): identical sample
+    positions, so the comparison is bf16 arithmetic, not samples crossing texel boundaries)."""
+    from scenerf_amd import synth
+    U, P, R = 256, 64, 20
+    kw = dict(n_pts_uni=U, n_pts_per_gaussian=P)
+    mlp, mlpg = synth.mlp_state(101, 4), synth.mlp_state(102, 2, out_scale=4.0)
+    maps = synth.feature_maps(1500, 452, 103, smooth=False)
+    pix = synth.stride2_pixels((1220, 370), R, 104)
+    nu, ng = synth.sampling_noise(R, U, 4 * P, 105)
+    K, T = synth.kitti_cam_K(), synth.rel_pose(2.0, 5.0)
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="bf16", **kw).to(DEV).eval()
+    m.mlp.load_state_dict(mlp)
+    m.mlp_gaussian.load_state_dict(mlpg)
+    m.debug_aux = True
+    with torch.no_grad():
+        out = m.render_image(K.to(DEV), T.to(DEV), {k: v.to(DEV) for k, v in maps.items()}, sampled_pixels=pix.to(DEV), ray_batch_size=32,
+                             noise=(nu.to(DEV), ng.to(DEV)))
+    eng = m._image_renderer[1]
+    assert eng.graph is not None and m.render_cfg.uses_fused(32 * 512)
+    off = eng.session.last_aux["offsets"].float().cpu().reshape(32, 4, 2)[:R]
+    ref = orc.render_chunk(orc.OracleConfig.kitti(**kw), mlp, mlpg, K, T, maps, pix, nu, ng, head_offsets=off)
+    rel = (out["depth"].cpu() - ref["depth"].detach()).abs() / ref["depth"].detach().abs()
+    cerr = (out["color"].cpu() - ref["color"].detach()).abs()
+    print("N=512 bf16 render_image vs matched oracle: depth rel max %.2e median %.2e, colour abs max %.2e" % (
+        float(rel.max()), float(rel.median()), float(cerr.max())))
+    assert torch.equal(out["gaussian_means"].cpu(), ref["gaussian_means"].detach())
+    assert float(rel.max()) < 3e-2 and float(cerr.max()) < 3e-2

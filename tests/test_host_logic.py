@@ -165,3 +165,15 @@ def test_uniform_only_branch_is_refused_explicitly():
     with pytest.raises(NotImplementedError, match="uniform-only branch"):
         RenderConfig.kitti(n_pts_uni=0, n_pts_per_gaussian=1).validate()
     RenderConfig.kitti(n_pts_uni=0, n_pts_per_gaussian=2).validate()      # gaussians only: the `else` branch (scenerf.py:651-654)
+
+
+def test_pixel_grid_follows_the_reference_scripts():
+    """render_colors.py:102-111 / generate_novel_depths.py:103-112: meshgrid(xs, ys) ('ij'), cat on the last axis, reshape(-1, 2)."""
+    from scenerf_amd.inference import pixel_grid
+    for stride in (1, 2, 3):
+        xs = torch.arange(start=0, end=1220, step=stride).float()
+        ys = torch.arange(start=0, end=370, step=stride).float()
+        gx, gy = torch.meshgrid(xs, ys, indexing="ij")
+        want = torch.cat([gx.unsqueeze(-1), gy.unsqueeze(-1)], dim=2).reshape(-1, 2)
+        assert torch.equal(pixel_grid((1220, 370), stride, "cpu"), want)
+    assert pixel_grid((1220, 370), 1, "cpu").shape[0] == 451400 and pixel_grid((1220, 370), 3, "cpu").shape[0] == 407 * 124

@@ -104,3 +104,31 @@ def test_kitti_forward_matches_the_reference_loop():
     assert sorted(keys) == sorted(logs), (sorted(set(keys) ^ set(logs)))
     for k in keys:
         np.testing.assert_allclose(np.asarray(logs[k]), g["log/" + k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+def test_reprojection_loss_has_no_nan_gradient_for_points_on_the_camera_plane():
+    """A target point with z == 0 is masked out of the loss; its (unselected) perspective division must not leak 0/0 = NaN into
+    the gradient of the rendered depth (torch.where back-propagates through both branches)."""
+    d = {k: torch.from_numpy(v) for k, v in inputs(11, behind=False).items()}
+    col_src = sample_pix_features(d["pix"], d["img_s"])
+    T = d["T"].clone()
+    T[2, :] = 0.0            # every target point lands on z == 0
+    depth = d["depth"].clone().requires_grad_(True)
+    loss = TrainingMixin.compute_reprojection_loss(None, d["pix"], col_src, depth, d["img_t"], torch.inverse(d["K"]), d["K"], T)
+    loss.backward()
+    assert float(loss) == 0.0 and bool(torch.isfinite(depth.grad).all())
+
+
+def test_masked_depth_metrics_are_skipped_when_nothing_is_valid():
+    """scenerf_bf.py:204-205: a source frame without a valid depth logs nothing (instead of all-zero metrics that bias the epoch means)."""
+    logs = []
+
+    class M(TrainingMixin):
+        def log(self, k, v, **kw):
+            logs.append(k)
+    m = M()
+    gt, pred = torch.zeros(10), torch.ones(10)
+    m.evaluate_depth("val", gt, pred, mask=gt > 0)
+    assert logs == []
+    m.evaluate_depth("val", gt + 1, pred, mask=(gt + 1) > 0)
+    assert len(logs) == 7
