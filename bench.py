@@ -14,7 +14,12 @@ Workload = BASELINE.json configs[1]: KITTI 370x1220, sphere 1500x452, 128 sample
 rays per GPU per step, bf16 GEMM operands / fp32 accumulate.  Weak scaling: every rank renders its own R rays.
 Prints ONE JSON line (rank 0).  Extra objects: ``roofline`` (dominant MFMA kernel, HIP-event timed inside the
 library on its launch stream), ``roofline_composite`` (HBM-bound compositing pass), ``cpu_baseline`` (the CPU
-oracle = a port of the reference, timed on this box's host cores on a bounded sample).
+oracle = a port of the reference, timed on this box's host cores: best of 3 at the bench's own R), ``fp32_mode`` (the same
+step with fp32 MFMA end to end) next to ``eager_gpu_baseline`` (the eager fp32 port on this GPU: matched precision),
+``allreduce`` (N > 1: per-rank time of the gradient collectives and how much of it the backward waited for).
+
+    python bench.py --mode infer            # BASELINE.json configs[4]: full-frame novel-view render, N = 512, static chunks + hipGraph
+    python bench.py --dry-run ...           # CPU / gloo run of the control flow only (tests/test_dist_gloo.py)
 """
 import argparse
 import json
@@ -74,17 +79,30 @@ def pmc_traffic(logical_name):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; infer: 5 frames)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 5; infer: 1 frame)")
     ap.add_argument("--rays", type=int, default=1200, help="rays per GPU per step (reference n_rays)")
-    ap.add_argument("--samples", type=int, default=128, choices=[64, 96, 128, 256, 512])
+    ap.add_argument("--samples", type=int, default=None, choices=[64, 96, 128, 256, 512], help="default 128 (train) / 512 (infer)")
+    ap.add_argument("--chunk", type=int, default=4096, help="infer: rays per static chunk")
+    ap.add_argument("--stride", type=int, default=1, help="infer: pixel stride of the rendered frame (1 = all 451,400 px)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: run the control flow (collectives, timing, JSON) around a stub step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=1024, help="rays of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-rays", type=int, default=0, help="rays of the CPU-baseline sample (0 = the bench's own --rays)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="CPU-baseline repetitions (best is reported)")
+    ap.add_argument("--no-fp32-mode", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true")
     ap.add_argument("--kernels-json", default="", help="write the per-kernel table here")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 5 if a.mode == "infer" else 20
+    if a.warmup is None:
+        a.warmup = 1 if a.mode == "infer" else 5
+    if a.samples is None:
+        a.samples = 512 if a.mode == "infer" else 128
+    return a
 
 
 def sample_split(n):
@@ -94,10 +112,10 @@ def sample_split(n):
     return n // 2, n // 8
 
 
-def make_model(args, dev):
+def make_model(args, dev, precision=None):
     U, P = sample_split(args.samples)
     m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, n_pts_uni=U, n_pts_per_gaussian=P,
-                precision=args.precision, device_rng=False).to(dev)
+                precision=precision or args.precision, device_rng=False).to(dev)
     m.mlp.load_state_dict(synth.mlp_state(1, 4))
     m.mlp_gaussian.load_state_dict(synth.mlp_state(2, 2, out_scale=4.0))
     return m
@@ -126,19 +144,23 @@ def _oracle_setup(args, dev):
 
 
 def cpu_baseline(args):
-    """The oracle (port of the reference's eager path) on the host cores, bounded sample, fwd+bwd."""
+    """The oracle (port of the reference's eager path) on the host cores, fwd+bwd at the bench's own ray count, best of --cpu-reps
+    (BASELINE.md section 3)."""
     cores = os.cpu_count() or 1
     threads = min(cores, 32)   # torch's CPU kernels stop scaling (and regress) beyond a few dozen threads
     torch.set_num_threads(threads)
     run = _oracle_setup(args, "cpu")
     run(8, 50)  # warm-up (allocators, thread pool)
-    R = args.cpu_rays
-    t0 = time.perf_counter()
-    run(R, 60)
-    best = time.perf_counter() - t0
+    R = args.cpu_rays or args.rays
+    times = []
+    for i in range(max(1, args.cpu_reps)):
+        t0 = time.perf_counter()
+        run(R, 60 + i)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
     return {"value": round(R / best, 2), "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": "%d rays x %d samples fwd+bwd on %d of %d host threads, full KITTI maps (%.1f s)" % (
-                R, args.samples, threads, cores, best)}
+            "sample": "%d rays x %d samples fwd+bwd on %d of %d host threads, full KITTI maps, best of %d (%s s)" % (
+                R, args.samples, threads, cores, len(times), ", ".join("%.1f" % t for t in times))}
 
 
 def eager_gpu_baseline(args, dev):
@@ -159,45 +181,16 @@ def eager_gpu_baseline(args, dev):
             "ms_per_step": round(dt * 1e3, 2), "sample": "%d rays x %d samples fwd+bwd, 3 steps" % (R, args.samples)}
 
 
-def main():
-    args = parse()
-    rank, world, local = sdist.init_from_env()
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
-    dev = torch.device("cuda", local % torch.cuda.device_count())   # (modulo only matters for the 1-GPU gloo self-test)
-    torch.cuda.set_device(dev)
-    _capi.load()
-    torch.manual_seed(42 + rank)  # train_kitti.py:11 seed_everything(42), decorrelated per rank
-
-    R = args.rays
-    model = make_model(args, dev)
-    params = list(model.mlp.parameters()) + list(model.mlp_gaussian.parameters())
-    opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, fused=True)
-    # N > 1: each MLP's packed gradient sink is all-reduced (RCCL) right before it is handed to autograd: 2 x 21.7 MB
-    model.grad_sync = sdist.allreduce_mean_ if world > 1 else None
-    model.grad_sync_async = sdist.allreduce_mean_async if world > 1 else None   # radiance MLP: started before the feature scatter
-    maps = {k: v.to(dev).requires_grad_(True) for k, v in synth.feature_maps(1500, 452, 3 + rank).items()}
-    K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
-    pix = synth.stride2_pixels((1220, 370), R, 100 + rank).to(dev)
-
-    def step():
-        for v in maps.values():
-            v.grad = None
-        out = model.render_rays_batch(K, T, maps, T_cam2velo=None, sampled_pixels=pix, ray_batch_size=R)
-        loss = out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
-        loss.backward()
-        opt.step()
-        opt.zero_grad(set_to_none=True)
-        return loss
-
+def _timed(step, args, world, dev, sync):
+    """W untimed + exactly K timed steps between barrier + synchronize; MAX over ranks.  Returns (seconds, last step result)."""
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        sync()
 
+    last = None
     for _ in range(args.warmup):
-        step()
+        last = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -208,64 +201,265 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    return dt, last
+
+
+def _allreduce_report(world, steps_recorded):
+    """Per-rank collective timing of the LAST recorded steps (sdist.TIMING), gathered on every rank (a collective: all ranks call it)."""
+    rec = sdist.TIMING or []
+    if rec:
+        torch.cuda.synchronize()
+    mine = {"wait": 0.0, "sync": 0.0}
+    for kind, e0, e1 in rec:
+        mine[kind] += e0.elapsed_time(e1)
+    mine = {k: v / max(steps_recorded, 1) for k, v in mine.items()}
+    allr = [None] * world
+    torch.distributed.all_gather_object(allr, mine)
+    return {"per_rank_ms_per_step": [{"radiance_mlp_exposed_wait": round(r["wait"], 4), "gaussian_head_on_side_stream": round(r["sync"], 4)}
+                                     for r in allr],
+            "max_exposed_wait_ms_per_step": round(max(r["wait"] for r in allr), 4),
+            "note": "exposed wait = time the backward stream blocks on the radiance MLP's asynchronous all-reduce (21.7 MB, started "
+                    "before the feature-gradient scatter); the head's all-reduce (21.7 MB) runs in stream order on the backward's side stream"}
+
+
+class _StubModel:
+    """--dry-run: stands in for SceneRF on a CPU/gloo process group: its step issues the renderer's collectives in the renderer's order
+    through the same two hooks (grad_sync in stream order for the gaussian head, grad_sync_async started early / finished late for the
+    radiance MLP), so the bench's own control flow -- which ranks call what, when the hooks are removed, what runs on rank 0 only --
+    is exercised without a GPU (tests/test_dist_gloo.py)."""
+
+    def __init__(self, rank):
+        self.rank = rank
+        self.grad_sync = self.grad_sync_async = None
+        self.head, self.main = torch.zeros(1024), torch.zeros(1024)
+
+    def step(self):
+        self.head.fill_(self.rank + 1.0)
+        self.main.fill_(2.0 * (self.rank + 1))
+        if self.grad_sync is not None:
+            self.grad_sync(self.head)
+        fin = self.grad_sync_async(self.main) if self.grad_sync_async is not None else None
+        if fin is not None:
+            fin()
+        return self.head[0] + self.main[0]
+
+
+def infer_main(args, rank, world, dev):
+    """BASELINE.json configs[4]: novel-view inference, full frame, 512 samples/ray (U=256, G=4, P=64), no_grad, static chunks of
+    --chunk rays with the tail padded, one captured hipGraph per frame replayed per chunk, device RNG (scenerf_amd/inference.py).
+    A step = one full frame of one pose.  N > 1 = N independent replicas (inference does not shard)."""
+    from scenerf_amd.inference import pixel_grid
+    model = make_model(args, dev).eval()
+    maps = {k: v.to(dev) for k, v in synth.feature_maps(1500, 452, 3 + rank).items()}
+    K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
+    grid = pixel_grid((1220, 370), args.stride, dev)
+    n = grid.shape[0]
+
+    def frame(graph=True):
+        with torch.no_grad():
+            return model.render_image(K, T, maps, sampled_pixels=grid, ray_batch_size=args.chunk, keys=("depth", "color"), use_graph=graph)
+
+    dt, last = _timed(frame, args, world, dev, torch.cuda.synchronize)
+    assert bool(torch.isfinite(last["depth"]).all()), "depth is not finite"
+    value = world * n * args.steps / dt
+    roof = roof_c = eager = None
+    if rank == 0:
+        # the same frame with every chunk launched eagerly (no graph): what the graph buys
+        frame(False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frame(False)
+        torch.cuda.synchronize()
+        eager = {"value": round(n / (time.perf_counter() - t0), 1), "unit": "rays/s", "kind": "same static chunks, launched eagerly (1 frame)"}
+    if rank == 0 and not args.no_roofline:
+        lib = _capi.load()
+        lib.scenerf_hip_profile_enable(1)
+        frame(False)
+        torch.cuda.synchronize()
+        kernels = _capi.profile_collect()
+        lib.scenerf_hip_profile_enable(0)
+        roof, roof_c = _rooflines(kernels, args, 1, None, None)
+        if args.kernels_json:
+            json.dump(kernels, open(args.kernels_json, "w"), indent=1)
+    if rank == 0:
+        U, P = sample_split(args.samples)
+        print(json.dumps({
+            "metric": "rays/sec (novel-view inference, full-frame render, %d samples/ray, hipGraph-replayed static chunks)" % args.samples,
+            "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "KITTI 370x1220 novel-view render, sphere 1500x452, %d px per frame (stride %d), %d samples/ray (U=%d,G=4,P=%d), "
+                                   "chunks of %d rays (tail padded), no_grad, one hipGraph per frame replayed per chunk, device RNG; "
+                                   "N>1 = independent replicas" % (n, args.stride, args.samples, U, P, args.chunk),
+                       "rays_per_frame": n, "samples_per_ray": args.samples, "chunk": args.chunk, "parallelism": "replicas%d" % world,
+                       "precision": args.precision, "mode": "infer"},
+            "roofline": roof, "roofline_composite": roof_c, "eager_launch": eager}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def _rooflines(kernels, args, nprof, value_per_gpu, world):
+    """(roofline of the dominant MFMA kernel, roofline of the compositing pass) from the in-library HIP-event table."""
+    roof = roof_c = None
+    for k in kernels:
+        k["avg_us"] = k["total_ms"] * 1e3 / max(k["launches"], 1)
+        k["launches_per_step"] = k["launches"] / nprof
+        k["ms_per_step"] = k["total_ms"] / nprof
+    mfma = [k for k in kernels if k["flops"] > 0 and k["total_ms"] > 0]
+    if mfma:
+        dom = max(mfma, key=lambda k: k["total_ms"])
+        ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
+        tot_f = sum(k["flops"] for k in mfma)
+        tot_t = sum(k["total_ms"] for k in mfma)
+        roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom["name"]),
+                "avg_launch_us": round(dom["avg_us"], 2), "flops_per_launch": dom["flops"] / dom["launches"],
+                "all_mfma_kernels_achieved": round(tot_f / (tot_t * 1e-3) / 1e12, 2),
+                "all_mfma_kernels_frac": round(tot_f / (tot_t * 1e-3) / 1e12 / peak, 4),
+                "mfma_ms_per_step": round(tot_t / nprof, 3),
+                "per_kernel": {k["name"]: {"achieved": round(k["flops"] / (k["total_ms"] * 1e-3) / 1e12, 1),
+                                           "frac": round(k["flops"] / (k["total_ms"] * 1e-3) / 1e12 / peak, 4), "avg_launch_us": round(k["avg_us"], 1)}
+                               for k in sorted(mfma, key=lambda k: -k["total_ms"])[:6]}}
+        if value_per_gpu is not None:
+            # SURVEY §8d: with zero-K-block skipping, utilisation is reported on the FLOPs issued (above) and the rays/s are
+            # quoted separately against the dense algorithmic count of the reference: fwd 2(N*5,405,696 + G*5,404,672), x3 fwd+bwd
+            dense = 3.0 * 2.0 * (args.samples * 5405696 + 4 * 5404672)
+            roof["dense_equivalent"] = {"flops_per_ray_fwd_bwd": dense, "achieved": round(value_per_gpu * dense / 1e12, 1),
+                                        "unit": "TFLOP/s", "frac_of_peak": round(value_per_gpu * dense / 1e12 / peak, 4),
+                                        "note": "rays/s x the reference's dense FLOPs per ray (it multiplies the out-of-range "
+                                                "scales' zeros); not a utilisation: the kernels skip those K blocks"}
+    comp = [k for k in kernels if k["name"] in ("composite_fwd", "composite_bwd")]
+    if comp:
+        b = sum(k["bytes"] for k in comp)
+        t = sum(k["total_ms"] for k in comp)
+        ach = b / (t * 1e-3) / 1e9
+        roof_c = {"bound": "hbm", "kernel": "+".join(k["name"] for k in comp), "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
+                  "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                  "avg_launch_us": round(sum(k["total_ms"] for k in comp) * 1e3 / sum(k["launches"] for k in comp), 2),
+                  "bytes_per_ray": (80 * args.samples + 64) if len(comp) == 2 else (32 * args.samples + 24)}
+    return roof, roof_c
+
+
+def main():
+    args = parse()
+    if args.dry_run:
+        os.environ.setdefault("SRF_DIST_BACKEND", "gloo")
+    rank, world, local = sdist.init_from_env()
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    dry = args.dry_run
+    if not dry:
+        assert torch.cuda.is_available(), "bench.py needs a GPU"
+        dev = torch.device("cuda", local % torch.cuda.device_count())   # (modulo only matters for the 1-GPU gloo self-test)
+        torch.cuda.set_device(dev)
+        _capi.load()
+        sync = torch.cuda.synchronize
+    else:
+        dev, sync = torch.device("cpu"), (lambda: None)
+    torch.manual_seed(42 + rank)  # train_kitti.py:11 seed_everything(42), decorrelated per rank
+    if args.mode == "infer" and not dry:
+        return infer_main(args, rank, world, dev)
+
+    R = args.rays
+    if dry:
+        model, maps, K, T, pix, opt = _StubModel(rank), {}, None, None, None, None
+    else:
+        model = make_model(args, dev)
+        params = list(model.mlp.parameters()) + list(model.mlp_gaussian.parameters())
+        opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, fused=True)
+        maps = {k: v.to(dev).requires_grad_(True) for k, v in synth.feature_maps(1500, 452, 3 + rank).items()}
+        K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
+        pix = synth.stride2_pixels((1220, 370), R, 100 + rank).to(dev)
+    # N > 1: each MLP's packed gradient sink is all-reduced (RCCL) right before it is handed to autograd: 2 x 21.7 MB
+    model.grad_sync = sdist.allreduce_mean_ if world > 1 else None
+    model.grad_sync_async = sdist.allreduce_mean_async if world > 1 else None   # radiance MLP: started before the feature scatter
+
+    def make_step(model, opt):
+        if dry:
+            return model.step
+        def step():
+            for v in maps.values():
+                v.grad = None
+            out = model.render_rays_batch(K, T, maps, T_cam2velo=None, sampled_pixels=pix, ray_batch_size=R)
+            loss = out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            return loss
+        return step
+
+    step = make_step(model, opt)
+    dt, last = _timed(step, args, world, dev, sync)
     ms = dt / args.steps * 1e3
     value = world * R * args.steps / dt
     assert torch.isfinite(last).item(), "loss is not finite"
+    if dry:   # every rank holds the mean over ranks of both buffers
+        want = 3.0 * sum(r + 1.0 for r in range(world)) / world
+        assert abs(float(last) - want) < 1e-6, (float(last), want)
+
+    allreduce = None
+    if world > 1:   # three more steps with the collectives bracketed by events; every rank takes part, then the group is done
+        sdist.TIMING = []
+        for _ in range(3):
+            step()
+        allreduce = _allreduce_report(world, 3)
+        sdist.TIMING = None
 
     roof = roof_c = None
     kernels = []
     # everything below is rank-0-only side measurement: no collective may be issued from here on (the other ranks are done)
     model.grad_sync = model.grad_sync_async = None
     if rank == 0 and not args.no_roofline:
-        lib = _capi.load()
-        torch.cuda.synchronize()
-        lib.scenerf_hip_profile_enable(1)
         nprof = 3
-        for _ in range(nprof):
-            step()
-        torch.cuda.synchronize()
-        kernels = _capi.profile_collect()
-        lib.scenerf_hip_profile_enable(0)
-        for k in kernels:
-            k["avg_us"] = k["total_ms"] * 1e3 / max(k["launches"], 1)
-            k["launches_per_step"] = k["launches"] / nprof
-            k["ms_per_step"] = k["total_ms"] / nprof
-        mfma = [k for k in kernels if k["flops"] > 0 and k["total_ms"] > 0]
-        if mfma:
-            dom = max(mfma, key=lambda k: k["total_ms"])
-            ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-            peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
-            tot_f = sum(k["flops"] for k in mfma)
-            tot_t = sum(k["total_ms"] for k in mfma)
-            roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom["name"]),
-                    "avg_launch_us": round(dom["avg_us"], 2), "flops_per_launch": dom["flops"] / dom["launches"],
-                    "all_mfma_kernels_achieved": round(tot_f / (tot_t * 1e-3) / 1e12, 2),
-                    "all_mfma_kernels_frac": round(tot_f / (tot_t * 1e-3) / 1e12 / peak, 4),
-                    "mfma_ms_per_step": round(tot_t / nprof, 3)}
-            # with zero-K-block skipping, utilisation is reported on the FLOPs issued (above) and the rays/s are
-            # quoted separately against the dense algorithmic count of the reference: fwd 2(N*5,405,696 + G*5,404,672), x3 fwd+bwd
-            dense = 3.0 * 2.0 * (args.samples * 5405696 + 4 * 5404672)
-            roof["dense_equivalent"] = {"flops_per_ray_fwd_bwd": dense, "achieved": round(value / world * dense / 1e12, 1),
-                                        "unit": "TFLOP/s", "frac_of_peak": round(value / world * dense / 1e12 / peak, 4),
-                                        "note": "rays/s x the reference's dense FLOPs per ray (it multiplies the out-of-range "
-                                                "scales' zeros); not a utilisation: the kernels skip those K blocks"}
-        comp = [k for k in kernels if k["name"] in ("composite_fwd", "composite_bwd")]
-        if comp:
-            b = sum(k["bytes"] for k in comp)
-            t = sum(k["total_ms"] for k in comp)
-            ach = b / (t * 1e-3) / 1e9
-            roof_c = {"bound": "hbm", "kernel": "composite_fwd+composite_bwd", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
-                      "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
-                      "bytes_per_ray_fwd_bwd": 80 * args.samples + 64}
+        if dry:
+            for _ in range(nprof):
+                step()     # (the other ranks are gone: a collective here would hang -- the regression this mode exists for)
+        else:
+            lib = _capi.load()
+            torch.cuda.synchronize()
+            lib.scenerf_hip_profile_enable(1)
+            for _ in range(nprof):
+                step()
+            torch.cuda.synchronize()
+            kernels = _capi.profile_collect()
+            lib.scenerf_hip_profile_enable(0)
+            roof, roof_c = _rooflines(kernels, args, nprof, value / world, world)
         if args.kernels_json:
             with open(args.kernels_json, "w") as f:
                 json.dump(kernels, f, indent=1)
 
-    cpu = eager = None
+    cpu = eager = fp32 = None
+    if dry:
+        args.no_fp32_mode = args.no_eager_baseline = args.no_cpu_baseline = True
+    if rank == 0 and world == 1 and args.precision == "bf16" and not args.no_fp32_mode:
+        # the same step with fp32 MFMA end to end (RenderConfig.precision = "fp32": the per-layer GEMM path), so that the eager fp32
+        # baseline below has a matched-precision partner
+        try:
+            m32 = make_model(args, dev, precision="fp32")
+            o32 = torch.optim.AdamW(list(m32.mlp.parameters()) + list(m32.mlp_gaussian.parameters()), lr=1e-5, weight_decay=0.0, fused=True)
+            s32 = make_step(m32, o32)
+            for _ in range(2):
+                s32()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n32 = 5
+            for _ in range(n32):
+                s32()
+            torch.cuda.synchronize()
+            d32 = (time.perf_counter() - t0) / n32
+            fp32 = {"value": round(R / d32, 1), "unit": "rays/s", "ms_per_step": round(d32 * 1e3, 3),
+                    "kind": "this renderer with precision='fp32' (fp32 MFMA, per-layer GEMMs), same step, %d steps" % n32}
+            del m32, o32, s32
+        except Exception as e:  # never let the side measurement break the bench line
+            fp32 = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_eager_baseline:
         try:
             eager = eager_gpu_baseline(args, dev)
+            if fp32 and "value" in fp32:
+                eager["speedup_at_matched_precision_fp32"] = round(fp32["value"] / eager["value"], 2)
+            eager["speedup_bf16_vs_eager_fp32"] = round(value / eager["value"], 2)
         except Exception as e:  # never let the side measurement break the bench line
             eager = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
@@ -284,8 +478,11 @@ def main():
                                    "gradients, grad all-reduce (N>1), fused AdamW on both MLPs" % (args.samples, U, P, R),
                        "rays_per_gpu": R, "samples_per_ray": args.samples, "parallelism": "dp%d" % world,
                        "precision": args.precision},
-            "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager,
+            "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager, "fp32_mode": fp32,
+            "allreduce": allreduce,
         }
+        if dry:
+            line.update(metric="dry-run (control flow only, stub step over gloo)", dtype="none", data="none")
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

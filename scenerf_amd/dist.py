@@ -43,12 +43,28 @@ def shard_rays(n_rays_total: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+# Optional timing of the collectives (bench.py --gpus N): when a list is installed here, every reduction appends
+# (kind, start_event, end_event); kind "wait" brackets the point where the consuming stream blocks on an asynchronous reduction (the
+# EXPOSED part of that all-reduce), kind "sync" brackets a reduction issued in stream order (its whole duration, on whatever stream
+# it was issued on -- the gaussian head's runs on the backward's side stream, under the radiance MLP's kernels).
+TIMING = None
+
+
+def _mark():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
 def allreduce_mean_(flat: torch.Tensor) -> None:
     """In-place mean over ranks of a flat gradient buffer (no-op for a single process).  Installed as
     ``model.grad_sync``: the renderer calls it once per MLP on the packed fp32 gradient sink (21.7 MB)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
+        t0 = _mark() if (TIMING is not None and flat.is_cuda) else None
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(dist.get_world_size())
+        if t0 is not None:
+            TIMING.append(("sync", t0, _mark()))
 
 
 def allreduce_mean_async(flat: torch.Tensor):
@@ -60,7 +76,10 @@ def allreduce_mean_async(flat: torch.Tensor):
     world = dist.get_world_size()
 
     def finish():
+        t0 = _mark() if (TIMING is not None and flat.is_cuda) else None
         work.wait()          # the current stream waits for the collective
+        if t0 is not None:
+            TIMING.append(("wait", t0, _mark()))
         flat.div_(world)
     return finish
 

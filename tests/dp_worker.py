@@ -47,8 +47,33 @@ def main():
     # atomics make the local gradients reproducible only to rounding, so compare in relative L2
     rel = float((g_sync - mean).norm() / mean.norm())
     differs = float((g_local - mean).norm() / mean.norm())   # sanity: the shards really have different gradients
+
+    # stock DistributedDataParallel around the same step (what Lightning's 'ddp' accelerator does with the reference,
+    # scripts/train_kitti.py:127-156; PL 1.4's plugin passes find_unused_parameters=True): the renderer's custom autograd Functions
+    # (PackMLP / PrepareMaps tokens -> RenderChunk) must be traversable by the reducer and deliver each parameter's gradient once
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    class Step(torch.nn.Module):
+        def __init__(self, model):
+            super().__init__()
+            self.model = model
+
+        def forward(self):
+            out = self.model.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=pix.shape[0], noise=(nu, ng))
+            return out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
+
+    m.grad_sync = m.grad_sync_async = None
+    ddp = DDP(Step(m), device_ids=[0], find_unused_parameters=True)
+    g_ddp = None
+    for _ in range(2):      # twice: the reducer must be re-armed correctly for the next iteration
+        for p in list(m.parameters()) + list(maps.values()):
+            p.grad = None
+        ddp().backward()
+        torch.cuda.synchronize()
+        g_ddp = torch.cat([p.grad.reshape(-1) for p in list(m.mlp.parameters()) + list(m.mlp_gaussian.parameters())]).cpu()
+    rel_ddp = float((g_ddp - mean).norm() / mean.norm())
     if rank == 0:
-        print("DP_RESULT same=%s rel=%.3e local_vs_mean=%.3e" % (same_on_all_ranks, rel, differs))
+        print("DP_RESULT same=%s rel=%.3e local_vs_mean=%.3e ddp=%.3e" % (same_on_all_ranks, rel, differs, rel_ddp))
     dist.destroy_process_group()
 
 

@@ -70,3 +70,20 @@ def test_shard_rays_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+
+
+def test_bench_control_flow_over_gloo():
+    """bench.py --dry-run under torch.distributed.run with two gloo ranks: the bench's own control flow (which rank issues which
+    collective when, the hooks removed before the rank-0-only legs, the per-rank all-reduce report, one JSON line, clean exit) around
+    a stub step.  A rank-0-only leg that issued a collective -- the bug fixed in round 1 -- hangs here and fails by timeout."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert len(d["allreduce"]["per_rank_ms_per_step"]) == 2

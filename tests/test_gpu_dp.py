@@ -17,8 +17,9 @@ def test_two_ranks_average_their_gradients():
            "--master-port", "29533", os.path.join(HERE, "dp_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    m = re.search(r"DP_RESULT same=(\w+) rel=([\d.e+-]+) local_vs_mean=([\d.e+-]+)", r.stdout)
-    assert m, r.stdout[-2000:]
+    m = re.search(r"DP_RESULT same=(\w+) rel=([\d.e+-]+) local_vs_mean=([\d.e+-]+) ddp=([\d.e+-]+)", r.stdout)
+    assert m, r.stdout[-2000:] + r.stderr[-2000:]
     assert m.group(1) == "True"                 # every rank ends up with the same gradient
     assert float(m.group(2)) < 1e-3             # ... which is the mean of the per-rank gradients
     assert float(m.group(3)) > 1e-2             # (and the shards' own gradients do differ)
+    assert float(m.group(4)) < 1e-3             # stock DistributedDataParallel around the same step gives the same mean
