@@ -78,4 +78,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception:
+        import traceback
+        print("DP_ERROR rank %s\n%s" % (os.environ.get("RANK"), traceback.format_exc()), flush=True)
+        raise

@@ -16,7 +16,8 @@ def test_two_ranks_average_their_gradients():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(HERE, "dp_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    err = re.search(r"DP_ERROR.*?(?=DP_ERROR|\Z)", r.stdout, re.S)
+    assert r.returncode == 0, (err.group(0)[-3000:] if err else r.stdout[-1500:] + r.stderr[-1500:])
     m = re.search(r"DP_RESULT same=(\w+) rel=([\d.e+-]+) local_vs_mean=([\d.e+-]+) ddp=([\d.e+-]+)", r.stdout)
     assert m, r.stdout[-2000:] + r.stderr[-2000:]
     assert m.group(1) == "True"                 # every rank ends up with the same gradient
