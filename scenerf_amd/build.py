@@ -15,7 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 # development knobs (kernel experiments, tools/variants.sh): extra -D flags build a separately named library next to the default one
 _TAG = os.environ.get("SRF_LIB_TAG", "")
 LIB = os.path.join(CSRC, "libscenerf_hip%s.so" % ("_" + _TAG if _TAG else ""))
-SOURCES = ["runtime.hip", "rays.hip", "gemm.hip", "wgrad.hip", "fused.hip", "stream.hip", "mlp.hip", "tsdf.hip", "sphere.hip"]
+SOURCES = ["runtime.hip", "rays.hip", "gemm.hip", "wgrad.hip", "fused.hip", "stream.hip", "fwd128.hip", "mlp.hip", "tsdf.hip", "sphere.hip"]
+# fwd128.hip owns the whole accumulator file (a[0:255] by name in inline-asm MFMAs): the compiler must not park spilled VGPRs there
+# (a spill then shows up as scratch usage, which tools/asmcheck.sh and the build's resource check refuse)
+EXTRA = {"fwd128.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
 HEADERS = ["common.h", "gemm.h", "fused.h", os.path.join("..", "..", "include", "scenerf_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"] + os.environ.get("SRF_EXTRA_FLAGS", "").split()
@@ -34,7 +37,7 @@ STAMP = LIB + ".stamp"
 def _digest() -> str:
     """Content hash of sources + flags (mtimes are meaningless after the tree is copied to the GPU box)."""
     import hashlib
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(EXTRA.items()))).encode())
     for f in SOURCES + HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
@@ -56,7 +59,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", (("_" + _TAG) if _TAG else "") + ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

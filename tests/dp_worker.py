@@ -58,7 +58,7 @@ def main():
             super().__init__()
             self.model = model
 
-        def forward(self):
+        def forward(self, _step):   # (DDP's forward wants at least one positional input)
             out = self.model.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=pix.shape[0], noise=(nu, ng))
             return out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
 
@@ -68,7 +68,7 @@ def main():
     for _ in range(2):      # twice: the reducer must be re-armed correctly for the next iteration
         for p in list(m.parameters()) + list(maps.values()):
             p.grad = None
-        ddp().backward()
+        ddp(torch.zeros(1, device=dev)).backward()
         torch.cuda.synchronize()
         g_ddp = torch.cat([p.grad.reshape(-1) for p in list(m.mlp.parameters()) + list(m.mlp_gaussian.parameters())]).cpu()
     rel_ddp = float((g_ddp - mean).norm() / mean.norm())

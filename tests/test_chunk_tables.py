@@ -105,6 +105,34 @@ def test_stream_kernel_tables(variant):
         assert all(x == 0 for x in d[n:n + 20])
 
 
+@pytest.mark.parametrize("variant", ["kitti", "bundlefusion"])
+def test_wide_kernel_tables(variant):
+    """fwd128.hip: one descriptor per chunk; every layer padded with no-op chunks (bit 25: loads happen, MFMAs do not) to a multiple of
+    four so that a layer begins in ring slot 0 and ends in slot 3 of the 4x unrolled loop; the table is zero beyond the end (the
+    weight prefetch runs four chunks ahead, the kernel copies n + 16 entries into LDS)."""
+    tabs, chans = _tables(2, variant)
+    for mask in range(32):
+        n, d = int(tabs[mask, 0]), [int(x) for x in tabs[mask, 1:]]
+        want, _ = _expected_chunks(mask, chans)
+        assert n % 4 == 0 and n + 16 <= STRIDE - 1
+        got = []
+        for i in range(n):
+            f = _fields(d[i])
+            if (d[i] >> 25) & 1:
+                assert f["src"] == 0 and f["block"] == 0 and f["acol"] == 0 and not f["begin"]      # padding: harmless loads
+            else:
+                got.append((f["layer"], f["src"], f["acol"], f["block"]))
+            first = i == 0 or _fields(d[i - 1])["layer"] != f["layer"]
+            last = i + 1 == n or _fields(d[i + 1])["layer"] != f["layer"]
+            assert f["begin"] == first and f["end"] == last
+            if first:
+                assert i % 4 == 0 and not (d[i] >> 25) & 1        # the zero-accumulator MFMA form sits in slot 0 and is a real chunk
+            if last:
+                assert i % 4 == 3
+        assert got == [tuple(int(v) for v in w) for w in want], mask               # every chunk exactly once, in order
+        assert all(x == 0 for x in d[n:n + 16])
+
+
 def test_chunk_table_argument_checks():
     lib = _capi.load()
     cc = RenderConfig.kitti(precision="bf16").to_c()

@@ -1,6 +1,7 @@
-"""Time the ResnetFC forward (layer path vs fused kernel) on random inputs at the bench row count.
-usage: fused_probe.py [M] [reps] [mode: both|fused|layers]"""
-import ctypes as C, os, sys, time
+"""Time the ResnetFC forward (per-layer path and the fused kernels: ring / stream / wide) on random inputs at the bench row count, and
+compare the fused variants' outputs.   usage: fused_probe.py [M] [reps] [kernels: layers,ring,stream,wide]
+env: PROBE_MASK (scale mask of every tile, default 1 = KITTI's common case), PROBE_LEAN=1 (inference buffers)"""
+import ctypes as C, dataclasses, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scenerf_amd import _capi, synth
@@ -9,36 +10,55 @@ from scenerf_amd.renderer import MLP_PARAM_NAMES, PackedMLP, _MlpRun
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 153600
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-mode = sys.argv[3] if len(sys.argv) > 3 else "both"
-maskv = int(os.environ.get("PROBE_MASK", "7"))
+kernels = (sys.argv[3] if len(sys.argv) > 3 else "ring,stream,wide").split(",")
+maskv = int(os.environ.get("PROBE_MASK", "1"))
+lean = bool(os.environ.get("PROBE_LEAN"))
 dev = torch.device("cuda:0")
 lib = _capi.load()
 rcfg = RenderConfig.kitti(precision="bf16")
-cc = rcfg.to_c()
 state = synth.mlp_state(1, 4)
 params = [torch.as_tensor(state[n]).to(dev) for n in MLP_PARAM_NAMES]
 pk = PackedMLP(params, 4, rcfg)
-run = _MlpRun(M, 4, 1, dev, keep_acts=not os.environ.get("PROBE_LEAN"))   # PROBE_LEAN=1: inference buffers (no activation / sign-bit writes)
-run.Z.copy_(torch.randn(run.Z.shape, device=dev) * 0.5)
-run.xenc.copy_(torch.randn(run.xenc.shape, device=dev).clamp(-1, 1))
-run.tile_mask.fill_(maskv)
+gen = torch.Generator().manual_seed(1)
+Z = (torch.randn((M + 127) // 128 * 128, 2480, generator=gen) * 0.5).to(torch.bfloat16).to(dev)
+X = torch.randn(M, 48, generator=gen).clamp(-1, 1).to(dev)
+X[:, 42:] = 0
 st = torch.cuda.current_stream().cuda_stream
-for name, env in (("layers", str(1 << 30)), ("fused", "0")):
-    if mode not in ("both", name):
-        continue
-    os.environ["SRF_FUSED_MIN_M"] = env
+res = {}
+for name in kernels:
+    cfg = dataclasses.replace(rcfg, fused_min_rows=-1) if name == "layers" else dataclasses.replace(rcfg, fused_min_rows=1, fwd_kernel=name)
+    cc = cfg.to_c()
+    run = _MlpRun(M, 4, 1, dev, lean=lean and name != "layers")
+    run.Z.copy_(Z); run.xenc.copy_(X); run.tile_mask.fill_(maskv)
+    call = lambda: _capi.check(lib.scenerf_hip_mlp_forward(C.byref(cc), C.byref(pk.c), run.Z.data_ptr(), run.xenc.data_ptr(), run.tile_mask.data_ptr(), M,
+                                                           C.byref(run.c), st), "fwd")
     for _ in range(3):
-        _capi.check(lib.scenerf_hip_mlp_forward(C.byref(cc), C.byref(pk.c), run.Z.data_ptr(), run.xenc.data_ptr(), run.tile_mask.data_ptr(), M,
-                                                C.byref(run.c), st), "fwd")
+        call()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        _capi.check(lib.scenerf_hip_mlp_forward(C.byref(cc), C.byref(pk.c), run.Z.data_ptr(), run.xenc.data_ptr(), run.tile_mask.data_ptr(), M,
-                                                C.byref(run.c), st), "fwd")
+        call()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     nz = sum(c for i, (c, _, _) in enumerate(rcfg.map_shapes()) if (maskv >> i) & 1)
     fl = 2.0 * M * 512 * (144 + 6 * 512 + 3 * nz)
-    print("%-7s M=%d mask=%d: %.3f ms per forward  (%.0f TFLOP/s useful)" % (name, M, maskv, ms, fl / ms / 1e9))
+    print("%-7s M=%d mask=%d%s: %.3f ms per forward  %.0f TFLOP/s issued = %.1f %% of 2.5 PF" % (
+        name, M, maskv, " lean" if lean else "", ms, fl / ms / 1e9, fl / ms / 1e9 / 25), flush=True)
+    res[name] = run
+ref = res.get("ring") or res.get("stream")
+for name, run in res.items():
+    if run is ref or ref is None or name == "layers":
+        continue
+    lg = (run.logits - ref.logits).abs().max().item(), ref.logits.abs().max().item()
+    msg = ["logits max diff %.2e (scale %.2f)" % lg]
+    if not lean:
+        for i in range(4):
+            a, b = ref.H[i].float(), run.H[i].float()
+            msg.append("H%d: %.5f equal, max |diff| / max|x| %.1e" % (i, (a == b).float().mean().item(), ((a - b).abs().max() / a.abs().max()).item()))
+        for i in range(3):
+            a, b = ref.Nn[i].float(), run.Nn[i].float()
+            msg.append("N%d: %.5f equal" % (i, (a == b).float().mean().item()))
+        msg.append("sign bits equal %.6f" % (ref.sign_bits[:6, :M] == run.sign_bits[:6, :M]).float().mean().item())
+    print("%s vs %s: %s" % (name, "ring" if "ring" in res else "stream", "; ".join(msg)))
