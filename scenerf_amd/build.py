@@ -15,10 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 # development knobs (kernel experiments, tools/variants.sh): extra -D flags build a separately named library next to the default one
 _TAG = os.environ.get("SRF_LIB_TAG", "")
 LIB = os.path.join(CSRC, "libscenerf_hip%s.so" % ("_" + _TAG if _TAG else ""))
-SOURCES = ["runtime.hip", "rays.hip", "gemm.hip", "wgrad.hip", "fused.hip", "stream.hip", "fwd128.hip", "mlp.hip", "tsdf.hip", "sphere.hip"]
-# fwd128.hip owns the whole accumulator file (a[0:255] by name in inline-asm MFMAs): the compiler must not park spilled VGPRs there
+SOURCES = ["runtime.hip", "rays.hip", "gemm.hip", "wgrad.hip", "fused.hip", "stream.hip", "wide.hip", "mlp.hip", "tsdf.hip", "sphere.hip"]
+# wide.hip owns the whole accumulator file (a[0:255] by name in inline-asm MFMAs): the compiler must not park spilled VGPRs there
 # (a spill then shows up as scratch usage, which tools/asmcheck.sh and the build's resource check refuse)
-EXTRA = {"fwd128.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
+EXTRA = {"wide.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
 HEADERS = ["common.h", "gemm.h", "fused.h", os.path.join("..", "..", "include", "scenerf_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"] + os.environ.get("SRF_EXTRA_FLAGS", "").split()

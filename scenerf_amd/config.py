@@ -49,11 +49,12 @@ class RenderConfig:
     direct_scales: Tuple[int, ...] = (3, 4)
     # kernel-path selection (scenerf_cfg.fused_min_rows / fwd_kernel / flags): explicit per-call state, no environment variables
     fused_min_rows: int = _capi.FUSED_MIN_ROWS_DEFAULT   # bf16: rows from which the ResnetFC trunk / dgrad chain run as one fused kernel; < 0 never
-    fwd_kernel: str = "ring"          # fused forward variant: "ring" (fused.hip), "stream" (stream.hip; bit-identical), "wide" (fwd128.hip: 128-row blocks)
+    fwd_kernel: str = "ring"          # fused forward variant: "ring" (fused.hip), "stream" (stream.hip; bit-identical), "wide" (wide.hip: 128-row blocks)
     fused_backward: bool = True       # False: the dgrad chain as six per-layer GEMMs even where the fused chain applies
     wgrad_tr: bool = True             # False: weight gradients through gemm_tn only
     dfeat_per_scale: bool = False     # True: feature-gradient GEMM + scatter as one launch per pyramid level
     wgrad_overlap: bool = False       # True: per-layer backward runs the weight-gradient GEMMs on an internal side stream
+    bwd_kernel: str = "ring"          # fused dgrad chain: "ring" (fused.hip, 64-row blocks) or "wide" (wide.hip, 128-row blocks); bit-identical
 
     # ---- derived -----------------------------------------------------------------------------------------
     @property
@@ -97,6 +98,8 @@ class RenderConfig:
         _ = self.precision_code
         if self.fwd_kernel not in ("ring", "stream", "wide"):
             raise ValueError("fwd_kernel must be 'ring', 'stream' or 'wide', got %r" % (self.fwd_kernel,))
+        if self.bwd_kernel not in ("ring", "wide"):
+            raise ValueError("bwd_kernel must be 'ring' or 'wide', got %r" % (self.bwd_kernel,))
 
     def uses_fused(self, rows: int) -> bool:
         """Whether an MLP pass over ``rows`` rows runs on the fused kernels (mirrors srf_use_fused in csrc/common.h)."""
@@ -127,7 +130,8 @@ class RenderConfig:
         c.fused_min_rows = int(self.fused_min_rows)
         c.fwd_kernel = {"ring": 0, "stream": 1, "wide": 2}[self.fwd_kernel]
         c.flags = ((0 if self.fused_backward else _capi.FLAG_NO_FUSED_BWD) | (0 if self.wgrad_tr else _capi.FLAG_NO_WGRAD_TR)
-                   | (_capi.FLAG_DFEAT_PER_SCALE if self.dfeat_per_scale else 0) | (_capi.FLAG_WGRAD_OVERLAP if self.wgrad_overlap else 0))
+                   | (_capi.FLAG_DFEAT_PER_SCALE if self.dfeat_per_scale else 0) | (_capi.FLAG_WGRAD_OVERLAP if self.wgrad_overlap else 0)
+                   | (_capi.FLAG_WIDE_BWD if self.bwd_kernel == "wide" else 0))
         return c
 
     @staticmethod

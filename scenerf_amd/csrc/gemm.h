@@ -80,10 +80,12 @@ int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
 // stream.hip: the register-streamed forward (same arguments and results as launch_mlp_fwd_fused, which it replaces by default)
 int launch_mlp_fwd_stream(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const uint8_t* tile_mask, int M,
                           const scenerf_mlp_acts* a, hipStream_t s);
-// fwd128.hip: the same forward on 128-row blocks, one wave per SIMD (activations agree to the last bf16 ulp, not bit for bit: the bias is
-// added after the K sum)
-int launch_mlp_fwd_128(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const uint8_t* tile_mask, int M,
-                       const scenerf_mlp_acts* a, hipStream_t s);
+// wide.hip: the same forward on 128-row blocks, one wave per SIMD (activations agree to the last bf16 ulp, not bit for bit: the bias is
+// added after the K sum), and the dgrad chain on the same kernel shape (bit-identical to launch_mlp_bwd_fused)
+int launch_mlp_fwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const uint8_t* tile_mask, int M,
+                        const scenerf_mlp_acts* a, hipStream_t s);
+int launch_mlp_bwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, int M, const scenerf_mlp_acts* a, void* dH, void* dN,
+                        hipStream_t s);
 int launch_mlp_bwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, int M, const scenerf_mlp_acts* a, void* dH, void* dN,
                          hipStream_t s);
 // wgrad.hip: bf16 weight-gradient GEMM on transposing LDS reads (256 x 256 output tiles, wave-specialised); launch_gemm_tn uses it

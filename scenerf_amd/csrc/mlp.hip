@@ -275,7 +275,7 @@ int scenerf_hip_prepare(const scenerf_cfg* cfg, scenerf_stream_t stream) {
     if (cfg->precision) {
         if (int e = fused_prepare(cfg, s)) return e;
         if (int e = stream_prepare(cfg, s)) return e;
-        if (int e = fwd128_prepare(cfg, s)) return e;
+        if (int e = wide_prepare(cfg, s)) return e;
     }
     return 0;
 }
@@ -327,7 +327,7 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
         if (srf_use_fused(cfg, M) && w->w_stream) {
             // two kernels with identical results: fused.hip's LDS-ring pipeline and stream.hip's register-streamed one (scenerf_cfg.fwd_kernel)
             SRF_CHECK(cfg->fwd_kernel >= 0 && cfg->fwd_kernel <= 2, "mlp_forward: unknown fwd_kernel %d", cfg->fwd_kernel);
-            if (cfg->fwd_kernel == 2) return launch_mlp_fwd_128(cfg, w, Z, tile_mask, M, a, s);
+            if (cfg->fwd_kernel == 2) return launch_mlp_fwd_wide(cfg, w, Z, tile_mask, M, a, s);
             return cfg->fwd_kernel == 1 ? launch_mlp_fwd_stream(cfg, w, Z, tile_mask, M, a, s) : launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s);
         }
         SRF_CHECK(a->H[3], "mlp_forward: acts->H[3] is NULL");
@@ -412,7 +412,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     const bool fused_chain = prec && w->w_stream && a->sign_bits && srf_use_fused(cfg, M) && !(cfg->flags & SCENERF_FLAG_NO_FUSED_BWD);
     const int allow_tr = (cfg->flags & SCENERF_FLAG_NO_WGRAD_TR) ? 0 : 1;
     if (fused_chain) {
-        if (int e = launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
+        if (int e = (cfg->flags & SCENERF_FLAG_WIDE_BWD) ? launch_mlp_bwd_wide(cfg, w, M, a, dH, dN, s) : launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
         if (int e = fork()) return e;
     }
     GemmTN wg[8];   // the six fc weight gradients (+ lin_z, below): batched into one launch when the chain kernel already produced every dH / dN
@@ -536,7 +536,7 @@ int scenerf_hip_test_gemm_nt(int precision, const void* A, const void* W, const 
 int scenerf_hip_test_chunk_table(const scenerf_cfg* cfg, int kind, int32_t* out, int cap) {
     if (!(cfg && out && kind >= 0 && kind <= 2)) { srf_set_error("test_chunk_table: bad arguments"); return -1; }
     std::vector<int> tab;
-    if (int e = kind == 0 ? fused_table_build(cfg, tab) : kind == 1 ? stream_table_build(cfg, tab) : fwd128_table_build(cfg, tab)) return -e;
+    if (int e = kind == 0 ? fused_table_build(cfg, tab) : kind == 1 ? stream_table_build(cfg, tab) : wide_table_build(cfg, tab)) return -e;
     if ((int)tab.size() > cap) { srf_set_error("test_chunk_table: output buffer too small (%d ints needed)", (int)tab.size()); return -2; }
     for (size_t i = 0; i < tab.size(); ++i) out[i] = tab[i];
     return (int)tab.size();

@@ -1,0 +1,676 @@
+// Fused ResnetFC kernels for gfx950 on 128-row blocks, ONE wave per SIMD (bf16 operands).  MODE 0: the whole 7-GEMM forward trunk
+// (lin_in + lin_z.0, three residual blocks fc_0 / fc_1 + lin_z.b) and lin_out; MODE 1: the 6-GEMM dgrad chain of the blocks in the
+// backward pass (for b = 2, 1, 0: dN_b = (dH_{b+1} W1_b) * [N_b > 0], dH_b = dH_{b+1} + (dN_b W0_b) * [H_b > 0]).
+// reference scenerf/models/resnetfc.py:41-57,133-164.
+//
+// Why this shape (measured history: DESIGN.md section 5).  A 64-row block needs all 16 KiB of a K chunk's weights per 256 MFMA cycles:
+// 64 B/clk/CU, twice what a CU pulls from L2, so every 64-row design (fused.hip, stream.hip) saturates near 45 % MFMA.  A 128-row
+// block halves the weight bytes per FLOP; its 128 x 512 fp32 accumulators are 256 KiB -- HALF of the CU's register file:
+//   * 4 waves, one per SIMD, each with the whole 512-register budget: wave w owns output columns [128 w, 128 w + 128) for all 128 rows
+//     = 4 x 4 MFMA 32x32x16 tiles = 256 accumulators held in a[0:255] (the accumulator file) by inline-asm MFMAs on literal registers;
+//     the 256 architectural VGPRs hold the residual stream of the wave's tile (packed bf16, 128 registers: rounded exactly where the
+//     other kernels round H_b), a 4-deep weight ring (64) and one set of activation fragments (16), re-loaded row tile by row tile;
+//   * the hot loop -- the 32 chunks of a hidden layer, resident operand -- is branch-free: per chunk 16 MFMAs (512 cycles) against
+//     4 LDS fragment reads, 4 weight loads (SGPR base + immediate offsets), 2 address instructions, one counted s_waitcnt; the
+//     fragment address of chunk k is base ^ ((k & 7) << 5) + (k >> 3) * 256 (the A buffer's XOR swizzle only involves k mod 8);
+//   * weights: the wave streams exactly ITS 4 KiB of a w_stream block (four coalesced 1-KiB global_load_dwordx4, already in fragment
+//     layout) four chunks ahead -- every weight byte enters the CU once per 128 rows; nothing is shared between waves in a K loop:
+//     no barrier in it.  The loads are plain loads (the compiler counts vmcnt: at the top of a chunk the 12 youngest -- three chunks --
+//     may be outstanding); the activation stores and the DMA are inline asm and only make that wait conservative (loads return in
+//     order: a count <= 12 still implies the chunk's own four loads have landed);
+//   * the resident A operand (relu of the previous layer / the running gradient, 128 rows x 1 KiB, XOR-swizzled 16-byte slots) fills
+//     128 KiB of LDS; the streamed operand of the lin_in / lin_z segments (X3 / Z columns, 4 KiB per chunk) goes global -> LDS by DMA
+//     (global_load_lds) in ROUNDS: all of layer 0's chunks at once into the (still unused) A buffer + a 24-KiB stage, the lin_z tails of
+//     layers 2 and 4 through the stage -- which at the common scale mask (finest level only: 5 chunks) still holds them from layer 0,
+//     so those layers issue no DMA at all; other masks re-fetch per round of 6 chunks, the first round issued at the layer's start;
+//   * layer epilogue: accumulators + bias (+ residual) -> bf16 -> relu -> A buffer, between two barriers (backward: gate by the
+//     forward's sign bits instead of bias / relu); the finished layer is streamed out of the A buffer (coalesced 16-byte pieces +
+//     sign bits, as in fused.hip) one piece per chunk of the next layer.
+// Results: same rounding points as fused.hip / stream.hip; the forward adds the bias after the K sum instead of before it and sums
+// layer 0's K segments in a different order, so activations agree with those kernels to the last bf16 ulp, not bit for bit; the
+// backward chain has no bias and the same K order: bit-identical to fused.hip's and to the per-layer dgrad GEMMs (tests/test_gpu_stages.py).
+#include "fused.h"
+#include <type_traits>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_h;
+
+#define H_BM 128
+#define H_THREADS 256
+#define H_D 4                                   // weight ring depth in chunks (= chunks per group of the unrolled loop)
+#define H_ABUF (H_BM * F_AROW)                  // 131072
+#define H_ZCAP 6                                // streamed-operand stage: chunks of 128 rows x 32 B
+#define H_ZS H_ABUF
+#define H_LDS (H_ZS + H_ZCAP * 4096)            // 155648 of 163840
+#define H_CAP0 (H_ZCAP + 32)                    // layer 0: stage + the A buffer (nothing resident yet)
+// table set (F_MAXCH ints per tile mask): [0] chunks in total, [1] chunks of layer 0, [2] chunks of a lin_z tail (both incl. padding,
+// multiples of H_D), [3] REAL chunks of a lin_z tail, [4 + c] descriptor of chunk c in execution order.  Descriptor bits as in fused.h,
+// [25] = padding chunk (weights are loaded, MFMAs skipped).  Staged chunks (src != 0) appear in the order they are staged: list
+// position = stage slot (mod the round capacity); layer 0 stages its Z chunks first so that they stay in the stage for layers 2 and 4.
+#define HD_SKIP(d) (((d) >> 25) & 1)
+#define H_HDR 4
+
+// 16 bytes per lane, global -> LDS, no VGPR round trip: source = uniform base (SGPR pair) + 32-bit per-lane offset, destination = M0
+// (wave-uniform LDS address) + 16 * lane.  Inline asm: invisible to the compiler's wait counting (every consumer waits by hand).
+__device__ static inline void h_glds16(const void* sbase, unsigned voff, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_wave_base)
+                 : "memory");
+}
+
+// ---- accumulators: a[0:255], tile (i, j) at a[16 (4 i + j) : +15]; MFMA = C^T tile (rows = outputs n, columns = activation rows m).
+// Written and read BY NAME in inline asm: the kernel declares the whole accumulator file clobbered once, and must keep its own
+// architectural-register pressure below 256 -- on gfx950 the register allocator otherwise moves live ranges into accumulator
+// registers it believes free (tools/asmcheck.sh counts compiler-made v_accvgpr_* / scratch: both must be 0).  Handing the tiles to
+// the compiler as "a"-constrained values instead was tried: it spills and copies them (and the in-flight weight ring) at loop joins.
+typedef u32x4_h hfrag;   // one MFMA operand fragment: 8 bf16 = 4 registers
+template <int B> __device__ __forceinline__ void h_mfma(const hfrag w, const hfrag a) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(a), "i"(B), "i"(B + 15));
+}
+template <int B> __device__ __forceinline__ void h_mfma0(const hfrag w, const hfrag a) {   // first chunk of a layer: C = 0
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(w), "v"(a), "i"(B), "i"(B + 15));
+}
+template <int R> __device__ __forceinline__ float h_acc() {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(R));
+    return v;
+}
+// the four MFMAs of row tile I of a chunk: w[j] = weight fragments of the wave's four 32-column tiles, a = the row tile's activations
+template <bool ZERO, int I> __device__ __forceinline__ void h_row(const hfrag (&w)[4], const hfrag a) {
+    if (ZERO) { h_mfma0<16 * (4 * I)>(w[0], a); h_mfma0<16 * (4 * I + 1)>(w[1], a); h_mfma0<16 * (4 * I + 2)>(w[2], a); h_mfma0<16 * (4 * I + 3)>(w[3], a); }
+    else { h_mfma<16 * (4 * I)>(w[0], a); h_mfma<16 * (4 * I + 1)>(w[1], a); h_mfma<16 * (4 * I + 2)>(w[2], a); h_mfma<16 * (4 * I + 3)>(w[3], a); }
+}
+
+// the wave's 4 KiB of a 16-KiB w_stream block: four 1-KiB loads, uniform base + per-lane offset + immediate.  Plain loads on purpose:
+// the compiler counts vmcnt for them (the inline-asm stores / DMA in between only make its waits conservative -- loads return in
+// order, so "at most N outstanding" still covers the load it waits for), and a register copy it may insert at a control-flow join
+// waits for the data instead of copying a register whose load is still in flight.
+typedef const __attribute__((address_space(1))) hfrag* glb_frag_p;
+__device__ __forceinline__ void h_load_w(hfrag (&w)[4], const char* sbase, const unsigned voff) {
+    const char* b = sbase + voff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = *(glb_frag_p)(uintptr_t)(b + 1024 * j);
+}
+
+__device__ static inline void h_store16(void* p, uint4 v) {
+    const u32x4_h t = {v.x, v.y, v.z, v.w};
+    // (s_nop: a 16-byte store reads its data registers after issue; the compiler does not know this statement is a store)
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+__device__ static inline void h_store1(void* p, uint32_t v) { asm volatile("global_store_byte %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+typedef unsigned short h_ushort2 __attribute__((ext_vector_type(2)));
+__device__ static inline uint32_t h_pk_min_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(h_ushort2, a), __builtin_bit_cast(h_ushort2, b)));
+}
+
+// one quad (four consecutive outputs of one activation row) of the layer epilogue.
+//   forward : v = acc + bias ; residual layers: h = bf16(h + v), out = relu(h) ; fc_0 layers: out = relu(bf16(v))
+//   backward: v = gate ? acc : 0 ; dH layers: h = bf16(h + v), out = h ; dN layers: out = bf16(v)      (gate = 4 sign bits of the quad)
+template <int MODE, bool is_res, int I, int J, int Q>
+__device__ __forceinline__ void h_epi_quad(const float4 bias, const uint32_t gate, uint32_t (&hp)[8], char* wrow,
+                                           const int slot0, const int axor) {
+    // (the accumulator reads are volatile statements: program order = liveness, so a quad needs ~10 temporaries)
+    constexpr int B = 16 * (4 * I + J) + 4 * Q;
+    float v0 = h_acc<B>(), v1 = h_acc<B + 1>(), v2 = h_acc<B + 2>(), v3 = h_acc<B + 3>();
+    if (MODE == 0) {
+        v0 += bias.x; v1 += bias.y; v2 += bias.z; v3 += bias.w;
+    } else {
+        v0 = (gate >> (8 * Q)) & 1u ? v0 : 0.f; v1 = (gate >> (8 * Q + 1)) & 1u ? v1 : 0.f;
+        v2 = (gate >> (8 * Q + 2)) & 1u ? v2 : 0.f; v3 = (gate >> (8 * Q + 3)) & 1u ? v3 : 0.f;
+    }
+    uint32_t p0, p1;
+    if (is_res) {
+        p0 = pack_bf16x2(v0 + bf16lo(hp[2 * Q]), v1 + bf16hi(hp[2 * Q]));
+        p1 = pack_bf16x2(v2 + bf16lo(hp[2 * Q + 1]), v3 + bf16hi(hp[2 * Q + 1]));
+        hp[2 * Q] = p0;
+        hp[2 * Q + 1] = p1;
+    } else {
+        p0 = pack_bf16x2(v0, v1);
+        p1 = pack_bf16x2(v2, v3);
+    }
+    uint2 o;   // outputs 32 j + 8 q + 4 hi + {0..3}: one 8-byte LDS write
+    o.x = MODE == 0 ? relu_bf16x2(p0) : p0;
+    o.y = MODE == 0 ? relu_bf16x2(p1) : p1;
+    *(uint2*)(wrow + (((slot0 + Q) ^ axor) << 4)) = o;
+    // (one huge basic block otherwise: the scheduler hoists every quad's residual unpacking to the top -- 256 more live registers)
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    // the accumulator file is this kernel's: a[0:255] are written by name in the MFMA statements
+    asm volatile("" ::: "a0", "a15", "a16", "a31", "a32", "a63", "a64", "a95", "a96", "a127", "a128", "a159", "a160", "a191", "a192", "a223",
+                 "a224", "a255");
+    char* const Abuf = lds;
+    if ((unsigned)(uintptr_t)lds & 255u) __builtin_trap();   // the fragment addresses XOR bits 5..7 of the absolute LDS address
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * H_BM;
+    const unsigned mask = MODE == 0 ? __builtin_amdgcn_readfirstlane((unsigned)p.tile_mask[m0 / SCENERF_TILE_ROWS] & 31u) : 0u;
+    // this tile mask's table, read with scalar loads (constant address space) a group of four chunks at a time, two groups ahead
+    const desc_ptr tab = (desc_ptr)(uintptr_t)(p.desc + mask * F_MAXCH);
+    typedef int h_int4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) h_int4* desc4_ptr;
+    const int n0 = tab[1];     // layer 0's staged chunks (forward), incl. padding
+    const int nz = tab[2];     // a lin_z tail's staged chunks, incl. padding
+    const int nzr = tab[3];    // ... real ones
+    const bool zres = nzr <= H_ZCAP;                           // the stage keeps layer 0's Z chunks for layers 2 and 4
+
+    // ---- per-lane values.  Everything derived from the lane index is RE-derived from an opaque copy where it is needed: the 256
+    // architectural registers are spoken for (residual stream 128, weight ring 64, fragments 16), and a compiler that hoists a few
+    // dozen loop-invariant addresses has nowhere to put them (a[0:255] hold the accumulators; tools/asmcheck.sh refuses a build with
+    // a compiler-made v_accvgpr_* or scratch).
+    const char* const Wb = (const char*)p.Wst;
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;
+    int ln = lane;   // the opaque copy (refreshed by H_LANE)
+#define H_LANE() asm volatile("" : "+v"(ln))
+    typedef const __attribute__((address_space(3))) hfrag* lds_frag_p;
+    // byte offset of this lane's 16 bytes inside a w_stream block ([512 rows n][32 B], halves swapped when (n >> 3) & 1; tile j: + 1 KiB)
+    auto w_lane = [&]() __attribute__((always_inline)) { return (unsigned)(((wvu * 128 + (ln & 31)) * 2 + ((ln >> 5) ^ ((ln >> 3) & 1))) * 16); };
+    // resident operand, k-half of this lane at column chunk 0: row (ln & 31) of row tile 0, slot hi ^ (row & 15)
+    auto a_lane = [&]() __attribute__((always_inline)) { return lds0 + (unsigned)((ln & 31) * F_AROW + (((ln >> 5) ^ (ln & 15)) << 4)); };
+    // staged chunk (128 rows x 32 B, halves swapped when (row >> 3) & 1): this lane's 16 bytes of row tile 0
+    auto s_lane = [&]() __attribute__((always_inline)) { return (unsigned)((ln & 31) * 32 + (((ln >> 5) ^ ((ln >> 3) & 1)) << 4)); };
+    // stage slot s of a round -> LDS offset: the 24-KiB stage first, then (layer 0 only) the A buffer
+    auto slot_off = [&](const int s) __attribute__((always_inline)) { return s < H_ZCAP ? (unsigned)(H_ZS + s * 4096) : (unsigned)((s - H_ZCAP) * 4096); };
+
+    // ---- layer output -> HBM: the A buffer of the finished layer is streamed out one 16-byte piece per thread per chunk of the NEXT
+    // layer (32 pieces: rows 4 s .. 4 s + 3, one full row per wave), forward: rectified values + sign bits (fused.hip)
+    // (wave-uniform state stays scalar: where the layer being streamed out goes -- fetched from the kernel arguments once per layer,
+    // not per piece -- and the next piece).  A piece is read from LDS at the top of a chunk and stored behind the chunk's first four
+    // MFMAs, so neither the LDS latency nor a scalar load sits in front of an MFMA.
+    char* sv_base = nullptr;
+    uint8_t* sg_base = nullptr;
+    int sv_ld2 = 0;
+    int save_i = 32;
+    auto save_read = [&]() __attribute__((always_inline)) {
+        H_LANE();   // (address arithmetic recomputed per piece, under the MFMAs, instead of being hoisted into live registers)
+        const int row = (4 * save_i + wvu) & (H_BM - 1);
+        return *(const uint4*)(Abuf + row * F_AROW + ((ln ^ (row & 15)) << 4));
+    };
+    auto save_write = [&](const uint4 v) __attribute__((always_inline)) {
+        if (save_i < 32) {
+            const int row = 4 * save_i + wvu, slot = ln;
+            if (sv_base && m0 + row < p.M) {
+                h_store16(sv_base + (size_t)(m0 + row) * sv_ld2 + slot * 16, v);
+                if (MODE == 0 && sg_base) {
+                    uint32_t u = h_pk_min_u16(v.x, 0x00010001u);
+                    u |= h_pk_min_u16(v.y, 0x00010001u) << 2;
+                    u |= h_pk_min_u16(v.z, 0x00010001u) << 4;
+                    u |= h_pk_min_u16(v.w, 0x00010001u) << 6;
+                    h_store1(sg_base + (size_t)(m0 + row) * 64 + slot, (u | (u >> 15)) & 0xffu);
+                }
+            }
+            ++save_i;
+        }
+    };
+    auto save_piece = [&]() __attribute__((always_inline)) { save_write(save_read()); };
+
+    // ---- the residual stream (forward) / running gradient (backward) of the wave's 128 x 128 tile: packed bf16,
+    // hp[i][j][k] = elements 2k, 2k+1 of tile (i, j)
+    uint32_t hp[4][4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) hp[i][j][k] = 0u;
+
+    // (RES: compile-time copy of the layer's kind -- residual layers h += ..., fc_0 / dN layers out = ... -- no branch per quad)
+    auto epilogue = [&](auto RES, const int layer) __attribute__((always_inline)) {
+        constexpr bool is_res = decltype(RES)::value;
+        const FusedLayer& L = p.layer[layer];
+        while (save_i < 32) save_piece();
+        H_LANE();
+        const int hi = ln >> 5, axor = ln & 15;
+        // forward: bias of the wave's tile j, outputs 8 q + 4 hi + {0..3}; backward: the 128 gate bits of row (32 i + lane & 31)
+        const float* const bb = MODE == 0 ? L.bias + wvu * 128 + 4 * hi : nullptr;
+        // (quads in (j, q, i) order: the four row tiles of a (j, q) share one float4 of bias -- one in use, the next one on its way)
+        float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint4 gt[4];
+        if (MODE == 0) {
+            bn = *(const float4*)bb;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gt[i] = *(const uint4*)(L.sign + (size_t)(m0 + 32 * i + (ln & 31)) * 64 + wvu * 16);
+        }
+        // (MFMA results are visible to v_accvgpr_read only after the pipeline has drained: 16 passes)
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // every wave has finished reading the A buffer for this layer
+        char* const wr0 = Abuf + (ln & 31) * F_AROW + 8 * hi;
+#define H_GATE(I, J) (MODE == 1 ? ((J) == 0 ? gt[I].x : (J) == 1 ? gt[I].y : (J) == 2 ? gt[I].z : gt[I].w) >> (4 * hi) : 0u)
+#define H_EPI_JQ(J, Q)                                                                                          \
+    {                                                                                                           \
+        const float4 bq = bn;                                                                                   \
+        if (MODE == 0 && (J) * 4 + (Q) < 15) bn = *(const float4*)(bb + (((J) * 4 + (Q) + 1) >> 2) * 32 + (((Q) + 1) & 3) * 8); \
+        h_epi_quad<MODE, is_res, 0, J, Q>(bq, H_GATE(0, J), hp[0][J], wr0, wvu * 16 + (J) * 4, axor);           \
+        h_epi_quad<MODE, is_res, 1, J, Q>(bq, H_GATE(1, J), hp[1][J], wr0 + 32 * F_AROW, wvu * 16 + (J) * 4, axor); \
+        h_epi_quad<MODE, is_res, 2, J, Q>(bq, H_GATE(2, J), hp[2][J], wr0 + 64 * F_AROW, wvu * 16 + (J) * 4, axor); \
+        h_epi_quad<MODE, is_res, 3, J, Q>(bq, H_GATE(3, J), hp[3][J], wr0 + 96 * F_AROW, wvu * 16 + (J) * 4, axor); \
+    }
+#define H_EPI_J(J) H_EPI_JQ(J, 0) H_EPI_JQ(J, 1) H_EPI_JQ(J, 2) H_EPI_JQ(J, 3)
+        H_EPI_J(0) H_EPI_J(1) H_EPI_J(2) H_EPI_J(3)
+#undef H_EPI_J
+#undef H_EPI_JQ
+#undef H_GATE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // A buffer complete
+        sv_base = (char*)L.save;
+        sv_ld2 = L.save_ld * 2;
+        sg_base = MODE == 0 ? L.sign : nullptr;
+        save_i = 0;
+    };
+
+    // ---- staged chunks: DMA of chunk descriptor d (X3 / Z columns FD_Y .. +15 of the block's 128 rows) into LDS offset `off`: this
+    // wave's 32 rows = one 1-KiB piece; lane -> row lane / 2, physical 16-byte slot lane & 1, fetching the logical slot
+    // physical ^ ((row >> 3) & 1) (swizzle on the source)
+    const char* const gX3 = (const char*)p.X3;
+    const char* const gZ = (const char*)p.Z;
+    auto dma = [&](const int d, const unsigned off) __attribute__((always_inline)) {
+        const int gm = min(m0 + 32 * wvu + (ln >> 1), p.M - 1);                // (rows past M: clamped, computed, dropped)
+        const unsigned pls = (unsigned)(((ln & 1) ^ ((ln >> 4) & 1)) << 4);
+        const bool x3 = FD_SRC(d) == 1;
+        const unsigned voff = (unsigned)gm * (x3 ? 3u * SCENERF_D_XENC * 2u : SCENERF_D_LATENT * 2u) + pls;   // < 4 GiB up to 865k rows
+        const char* sb = (x3 ? gX3 : gZ) + FD_Y(d) * 2;
+        h_glds16(sb, voff, __builtin_amdgcn_readfirstlane(lds0 + off + wvu * 1024));
+    };
+    // DMA of the real chunks [k0, k1) of a staged list starting at table entry c0 (list position = slot)
+    auto dma_round = [&](const int c0, const int k0, const int k1) __attribute__((always_inline)) {
+        for (int k = k0; k < k1; ++k) {
+            const int d = tab[H_HDR + c0 + k];
+            if (!HD_SKIP(d)) dma(d, slot_off(k - k0));
+        }
+    };
+
+    // ---- the weight stream: chunk c's block four chunks ahead of its MFMAs.  d0..d3 = descriptors of the current group of H_D chunks
+    // (ring slots 0..3), e0..e3 = of the next group; `dnv` = the group after that, on its way from the LDS table.
+    hfrag wr[H_D][4], af[4];
+    int c = 0;   // chunks issued so far (table position of the current group)
+    int d0, d1, d2, d3, e0, e1, e2, e3;
+    h_int4 dnv;   // (scalar registers)
+    {
+        const h_int4 a = *(desc4_ptr)(tab + H_HDR), b = *(desc4_ptr)(tab + H_HDR + 4);
+        d0 = a.x; d1 = a.y; d2 = a.z; d3 = a.w;
+        e0 = b.x; e1 = b.y; e2 = b.z; e3 = b.w;
+        dnv = *(desc4_ptr)(tab + H_HDR + 8);
+    }
+#define H_WPTR(d) (Wb + (size_t)FD_Z(d) * 16384)
+    // top of a group: its descriptors become current, the next group's come out of `dnv`, the one after is requested
+#define H_GROUP_TOP()                                                                                 \
+    {                                                                                                 \
+        d0 = e0; d1 = e1; d2 = e2; d3 = e3;                                                           \
+        e0 = dnv.x; e1 = dnv.y; e2 = dnv.z; e3 = dnv.w;                                               \
+        c += H_D;                                                                                     \
+        dnv = *(desc4_ptr)(tab + H_HDR + c + 2 * H_D);                                                \
+    }
+
+    // ---- one RESIDENT chunk: ring slot S, chunk KK (0..7) of a group of eight whose fragment base is `ag` (= lane base + 256 per
+    // eight chunks).  Row tile i's four MFMAs, then -- its fragment register being free once they are issued -- the same row tile's
+    // fragment of the NEXT chunk (a single fragment set, each piece re-loaded 12 MFMAs = 384 cycles before its next use; at a
+    // layer's last chunk that prefetch reads past the row, harmlessly), then the ring slot's next weights and one piece of the
+    // previous layer's output on its way to HBM.
+#define H_RES_ROW(I, S, ZERO, X)                                                    \
+    if (ZERO) h_row<true, I>(wr[S], af[I]);                                         \
+    else h_row<false, I>(wr[S], af[I]);                                             \
+    af[I] = *(lds_frag_p)(uintptr_t)(X);                                            \
+    __builtin_amdgcn_sched_barrier(0);
+#define H_RES_CHUNK(S, KK, ZERO, DW)                                                \
+    {                                                                               \
+        const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5); \
+        const unsigned x1_ = x0_ + 65536u;                                          \
+        const uint4 sv_ = save_read();                                              \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+        H_RES_ROW(0, S, ZERO, x0_)                                                  \
+        save_write(sv_);                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+        H_RES_ROW(1, S, ZERO, x0_ + 32768u) H_RES_ROW(2, S, ZERO, x1_) H_RES_ROW(3, S, ZERO, x1_ + 32768u) \
+        h_load_w(wr[S], H_WPTR(DW), wl);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+    }
+    // 32 resident chunks (a K = 512 operand in the A buffer): four groups of eight; the very first chunk starts the accumulators at 0
+    auto resident_run = [&]() __attribute__((always_inline)) {
+        H_LANE();
+        const unsigned wl = w_lane();
+        unsigned ag = a_lane();
+        // fragments of chunk 0 (the A buffer was completed behind the epilogue's second barrier)
+        af[0] = *(lds_frag_p)(uintptr_t)(ag);
+        af[1] = *(lds_frag_p)(uintptr_t)(ag + 32768u);
+        af[2] = *(lds_frag_p)(uintptr_t)(ag + 65536u);
+        af[3] = *(lds_frag_p)(uintptr_t)(ag + 98304u);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int g = 0; g < 4; ++g) {
+            if (g == 0) {
+                H_RES_CHUNK(0, 0, true, e0)
+            } else {
+                H_RES_CHUNK(0, 0, false, e0)
+            }
+            H_RES_CHUNK(1, 1, false, e1)
+            H_RES_CHUNK(2, 2, false, e2)
+            H_RES_CHUNK(3, 3, false, e3)
+            H_GROUP_TOP()
+            H_RES_CHUNK(0, 4, false, e0)
+            H_RES_CHUNK(1, 5, false, e1)
+            H_RES_CHUNK(2, 6, false, e2)
+            H_RES_CHUNK(3, 7, false, e3)
+            H_GROUP_TOP()
+            ag += 256u;
+        }
+    };
+
+    // ---- STAGED chunks (forward only): `ns` list entries (multiple of H_D, padding at the end), `nreal` of them real, staged in rounds
+    // of `cap` slots.  `pre` = round 0 is already on its way (issued at the layer's start) or resident (cap slots hold it since layer 0:
+    // pre = 2: no wait needed either).  Each chunk: fragments of the NEXT list position are prefetched from its slot (clamped to
+    // the round); a round switch reloads them.
+#define H_STG_ROW(I, S, ZERO, SKIP, X)                                              \
+    if (!(SKIP)) {                                                                  \
+        if (ZERO) h_row<true, I>(wr[S], af[I]);                                     \
+        else h_row<false, I>(wr[S], af[I]);                                         \
+    }                                                                               \
+    af[I] = *(lds_frag_p)(uintptr_t)((X) + (I) * 1024u);                            \
+    __builtin_amdgcn_sched_barrier(0);
+#define H_STG_CHUNK(S, DC, DW, ZERO)                                                \
+    {                                                                               \
+        if (k == rend && k < nreal) {                                               \
+            /* round switch: everyone is done with the previous round's slots; stage the next ones; wait; publish */ \
+            if (k > 0) {                                                            \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  \
+                __builtin_amdgcn_s_barrier();                                       \
+            }                                                                       \
+            if (k > 0 || pre == 0) dma_round(c0, k, min(k + cap, nreal));           \
+            if (k > 0 || pre != 2) {                                                \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    \
+                __builtin_amdgcn_s_barrier();                                       \
+            }                                                                       \
+            rbeg = k; rend = k + cap;                                               \
+            const unsigned x_ = lds0 + slot_off(0) + sl;                            \
+            af[0] = *(lds_frag_p)(uintptr_t)(x_); af[1] = *(lds_frag_p)(uintptr_t)(x_ + 1024u);   \
+            af[2] = *(lds_frag_p)(uintptr_t)(x_ + 2048u); af[3] = *(lds_frag_p)(uintptr_t)(x_ + 3072u); \
+            __builtin_amdgcn_sched_barrier(0);                                      \
+        }                                                                           \
+        const bool skip_ = HD_SKIP(DC) != 0;                                        \
+        const unsigned xn_ = lds0 + slot_off(min(k + 1 - rbeg, cap - 1)) + sl;      \
+        H_STG_ROW(0, S, ZERO, skip_, xn_) H_STG_ROW(1, S, ZERO, skip_, xn_) H_STG_ROW(2, S, ZERO, skip_, xn_) H_STG_ROW(3, S, ZERO, skip_, xn_) \
+        h_load_w(wr[S], H_WPTR(DW), wl);                                            \
+        if (save_i < 32) save_piece();                                              \
+        ++k;                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+    }
+    auto staged_run = [&](const int ns, const int nreal, const int cap, const int pre, const bool first) __attribute__((always_inline)) {
+        H_LANE();
+        const unsigned wl = w_lane();
+        const unsigned sl = s_lane();
+        const int c0 = c;
+        int k = 0, rbeg = 0, rend = 0;
+#pragma unroll 1
+        for (int g = 0; g < ns; g += H_D) {
+            if (g == 0 && first) {
+                H_STG_CHUNK(0, d0, e0, true)
+            } else {
+                H_STG_CHUNK(0, d0, e0, false)
+            }
+            H_STG_CHUNK(1, d1, e1, false)
+            H_STG_CHUNK(2, d2, e2, false)
+            H_STG_CHUNK(3, d3, e3, false)
+            H_GROUP_TOP()
+        }
+    };
+
+    // ---- prologue: the weight ring (chunks 0 .. 3)
+    {
+        H_LANE();
+        const unsigned wl = w_lane();
+        h_load_w(wr[0], H_WPTR(d0), wl); h_load_w(wr[1], H_WPTR(d1), wl); h_load_w(wr[2], H_WPTR(d2), wl); h_load_w(wr[3], H_WPTR(d3), wl);
+    }
+    if (MODE == 0) {
+        // (the two epilogue variants never meet at a join: the residual stream's 128 registers are rewritten in one of them only, and
+        // the register allocator does not coalesce such a join -- it parks the overflow in accumulator registers)
+        staged_run(n0, n0, H_CAP0, 0, true);
+        epilogue(std::true_type(), 0);
+#pragma unroll 1
+        for (int b = 0; b < 3; ++b) {
+            const bool tail = b < 2 && nz > 0;
+            resident_run();
+            epilogue(std::false_type(), 1 + 2 * b);
+            if (tail && !zres) dma_round(c + 32, 0, min(H_ZCAP, nzr));   // round 0 of this layer's lin_z tail: the stage is idle until then
+            resident_run();
+            if (tail) staged_run(nz, nzr, H_ZCAP, zres ? 2 : 1, false);
+            epilogue(std::true_type(), 2 + 2 * b);
+        }
+    } else {
+        // the incoming gradient tile dH3 -> resident A buffer: one row (1 KiB) per piece, 32 rows per wave; lane = physical slot,
+        // fetching the logical slot physical ^ (row & 15)
+        H_LANE();
+        for (int r = 0; r < 32; ++r) {
+            const int row = 32 * wvu + r;
+            const int gm = min(m0 + row, p.M - 1);
+            h_glds16((const char*)p.dH3 + (size_t)gm * (p.dH_ld * 2), (unsigned)((ln ^ (row & 15)) << 4),
+                     __builtin_amdgcn_readfirstlane(lds0 + row * F_AROW));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {   // the running gradient of the wave's tile, in the epilogue's layout
+            const int hi = ln >> 5, axor = ln & 15;
+            const char* const rd0 = Abuf + (ln & 31) * F_AROW + 8 * hi;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint2 v = *(const uint2*)(rd0 + i * 32 * F_AROW + (((wvu * 16 + j * 4 + q) ^ axor) << 4));
+                        hp[i][j][2 * q] = v.x;
+                        hp[i][j][2 * q + 1] = v.y;
+                    }
+        }
+#pragma unroll 1
+        for (int l = 0; l < 6; l += 2) {
+            resident_run();
+            epilogue(std::false_type(), l);       // dN_b = ...
+            resident_run();
+            epilogue(std::true_type(), l + 1);    // dH_b = dH_{b+1} + ...
+        }
+    }
+#undef H_STG_CHUNK
+#undef H_STG_ROW
+#undef H_RES_CHUNK
+#undef H_RES_ROW
+#undef H_GROUP_TOP
+#undef H_WPTR
+    H_LANE();
+    while (save_i < 32) save_piece();
+    if (MODE == 0 && p.logits) {
+        // lin_out on the rectified H3 tile still resident in the A buffer (all waves are past the last epilogue's second barrier):
+        // w_out (fp32, <= 8 KiB) is copied into the now idle stage, then 8 threads per row take 64 columns each, a butterfly adds the
+        // partials; 32 rows per pass (same summation order as fused.hip)
+        float* wl = (float*)(lds + H_ZS);
+        for (int i = wvu * 64 + ln; i < p.d_out * (SCENERF_D_HIDDEN / 4); i += H_THREADS) *(float4*)(wl + i * 4) = *(const float4*)(p.w_out + i * 4);
+        __syncthreads();
+#pragma unroll 1
+        for (int rb = 0; rb < 4; ++rb) {
+            const int t = wvu * 64 + ln;
+            const int row = rb * 32 + (t >> 3), part = t & 7;
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const int slot = part * 8 + s8;
+                const uint4 v = *(const uint4*)(Abuf + row * F_AROW + ((slot ^ (row & 15)) << 4));
+                const float f[8] = {bf16lo(v.x), bf16hi(v.x), bf16lo(v.y), bf16hi(v.y), bf16lo(v.z), bf16hi(v.z), bf16lo(v.w), bf16hi(v.w)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < p.d_out) {
+                        const float4 w0 = *(const float4*)(wl + j * SCENERF_D_HIDDEN + slot * 8);
+                        const float4 w1 = *(const float4*)(wl + j * SCENERF_D_HIDDEN + slot * 8 + 4);
+                        o[j] = fmaf(f[0], w0.x, o[j]); o[j] = fmaf(f[1], w0.y, o[j]); o[j] = fmaf(f[2], w0.z, o[j]); o[j] = fmaf(f[3], w0.w, o[j]);
+                        o[j] = fmaf(f[4], w1.x, o[j]); o[j] = fmaf(f[5], w1.y, o[j]); o[j] = fmaf(f[6], w1.z, o[j]); o[j] = fmaf(f[7], w1.w, o[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] += __shfl_xor(o[j], 1);
+                o[j] += __shfl_xor(o[j], 2);
+                o[j] += __shfl_xor(o[j], 4);
+            }
+            if (part == 0 && m0 + row < p.M) {
+                for (int j = 0; j < p.d_out; ++j) p.logits[(size_t)(m0 + row) * p.d_out + j] = o[j] + p.b_out[j];
+            }
+        }
+    }
+}
+
+// ---- host: tables for the 32 scale masks of the forward (sets 0..31) and the backward chain (set 32)
+int wide_table_build(const scenerf_cfg* cfg, std::vector<int>& tab) {
+    tab.assign((size_t)33 * F_MAXCH, 0);
+    int seg_off[5], off = 0;
+    for (int i = 0; i < 5; ++i) { seg_off[i] = off; off += cfg->map_C[i]; }
+    SRF_CHECK(off == SCENERF_D_LATENT, "wide mlp: map channels do not add up to the latent width");
+    const int layer_k[7] = {3 * SCENERF_D_XENC + SCENERF_D_LATENT, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN + SCENERF_D_LATENT, SCENERF_D_HIDDEN,
+                            SCENERF_D_HIDDEN + SCENERF_D_LATENT, SCENERF_D_HIDDEN, SCENERF_D_HIDDEN};
+    int layer_block0[7], nb = 0;
+    for (int i = 0; i < 7; ++i) { layer_block0[i] = nb; nb += layer_k[i] / F_BK; }
+    SRF_CHECK(nb < 1024, "wide mlp: w_stream block index does not fit the descriptor");
+    for (int mask = 0; mask < 32; ++mask) {
+        int* const hdr = tab.data() + (size_t)mask * F_MAXCH;
+        int* ch = hdr + H_HDR;
+        int n = 0;
+        bool ok = true;
+        auto seg = [&](int layer, int src, int a0, int w0, int len) {
+            if (len % F_BK || a0 % F_BK || w0 % F_BK) ok = false;
+            for (int k = 0; k + F_BK <= len; k += F_BK) {
+                if (n >= F_MAXCH - H_HDR - 16) { ok = false; return; }
+                ch[n++] = (layer_block0[layer] + (w0 + k) / F_BK) | (((a0 + k) / F_BK) << 10) | (src << 18) | (layer << 20);
+            }
+        };
+        auto zsegs = [&](int layer, int wbase) {
+            for (int i = 0; i < 5; ++i) {
+                if ((mask >> i) & 1) seg(layer, 2, seg_off[i], wbase, cfg->map_C[i]);
+                wbase += cfg->map_C[i];
+            }
+        };
+        auto pad = [&](int layer) {   // padding chunks up to a multiple of H_D: resident source, block 0, MFMAs skipped
+            while (n % H_D) ch[n++] = (layer << 20) | (1 << 25);
+        };
+        // layer 0: the Z chunks first (stage slots 0.., where layers 2 and 4 find them again), then [x_hi | x_lo | x_hi]
+        zsegs(0, 3 * SCENERF_D_XENC);
+        const int nzr = n;
+        seg(0, 1, 0, 0, 3 * SCENERF_D_XENC);
+        pad(0);
+        hdr[1] = n;
+        for (int b = 0; b < 3; ++b) {
+            seg(1 + 2 * b, 0, 0, 0, SCENERF_D_HIDDEN);
+            seg(2 + 2 * b, 0, 0, 0, SCENERF_D_HIDDEN);
+            if (b < 2) {
+                const int t0 = n;
+                zsegs(2 + 2 * b, SCENERF_D_HIDDEN);
+                pad(2 + 2 * b);
+                hdr[2] = n - t0;
+            }
+        }
+        SRF_CHECK(ok && n % H_D == 0, "wide mlp: segment lengths must be multiples of 16 and fit the descriptor table");
+        for (int i = 0; i < n; ++i) {
+            if (i + 1 == n || FD_LAYER(ch[i + 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 23;
+            if (i == 0 || FD_LAYER(ch[i - 1]) != FD_LAYER(ch[i])) ch[i] |= 1 << 24;
+        }
+        hdr[0] = n;   // entries past n stay zero: prefetches past the end read block 0 and are never used
+        hdr[3] = nzr;
+    }
+    {   // backward chain: six layers of 32 resident chunks, weight blocks after the forward ones
+        int* const hdr = tab.data() + (size_t)32 * F_MAXCH;
+        int* ch = hdr + H_HDR;
+        int n = 0;
+        for (int l = 0; l < 6; ++l)
+            for (int i = 0; i < SCENERF_D_HIDDEN / F_BK; ++i, ++n)
+                ch[n] = (nb + l * (SCENERF_D_HIDDEN / F_BK) + i) | (i << 10) | (l << 20) | (i + 1 == SCENERF_D_HIDDEN / F_BK ? 1 << 23 : 0) |
+                        (i == 0 ? 1 << 24 : 0);
+        hdr[0] = n;
+        SRF_CHECK(nb + 6 * (SCENERF_D_HIDDEN / F_BK) == SCENERF_W_STREAM_BLOCKS, "wide mlp: w_stream block count");
+    }
+    return 0;
+}
+
+static SrfDescCache g_wide_table;
+
+static int wide_attrs() {
+    SRF_ONCE_PER_DEVICE(
+        SRF_HIP(hipFuncSetAttribute((const void*)mlp_wide_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS));
+        SRF_HIP(hipFuncSetAttribute((const void*)mlp_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS)));
+    return 0;
+}
+
+int wide_prepare(const scenerf_cfg* cfg, hipStream_t s) {
+    if (int e = wide_attrs()) return e;
+    const int* d = nullptr;
+    return srf_desc_cache_get(g_wide_table, cfg, s, wide_table_build, &d);
+}
+
+int launch_mlp_fwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const uint8_t* tile_mask, int M,
+                        const scenerf_mlp_acts* a, hipStream_t s) {
+    if (int e = wide_attrs()) return e;
+    FusedArgs p = {};
+    const int H = SCENERF_D_HIDDEN;
+    const size_t sign_layer = (size_t)cdiv(M, SCENERF_TILE_ROWS) * SCENERF_TILE_ROWS * 64;
+    auto sign = [&](int l) { return a->sign_bits ? a->sign_bits + l * sign_layer : nullptr; };
+    p.layer[0] = {w->b_h[0], a->H[0], sign(0), 0, H};
+    for (int b = 0; b < 3; ++b) {
+        p.layer[1 + 2 * b] = {w->b_fc0[b], a->Nn[b], sign(1 + 2 * b), 1, H};
+        p.layer[2 + 2 * b] = {w->b_h[b + 1], a->H[b + 1], b < 2 ? sign(2 + 2 * b) : nullptr, 2, H};
+    }
+    p.Wst = w->w_stream;
+    p.X3 = a->h0pre;
+    p.Z = Z;
+    p.tile_mask = tile_mask;
+    if (int e = srf_desc_cache_get(g_wide_table, cfg, s, wide_table_build, &p.desc)) return e;
+    p.M = M;
+    p.w_out = w->w_out;
+    p.b_out = w->b_out;
+    p.logits = a->logits;
+    p.d_out = w->d_out;
+    double flops = 0;   // FLOPs actually issued (profile mode only; synchronises to read the scale-activity mask)
+    if (srf_prof_on()) {
+        const int tiles = cdiv(M, SCENERF_TILE_ROWS);
+        std::vector<uint8_t> hm(tiles, 0x1f);
+        if (hipMemcpyAsync(hm.data(), tile_mask, tiles, hipMemcpyDeviceToHost, s) == hipSuccess) (void)hipStreamSynchronize(s);
+        for (int t = 0; t < tiles; ++t) {
+            const int rows = M - t * SCENERF_TILE_ROWS < SCENERF_TILE_ROWS ? M - t * SCENERF_TILE_ROWS : SCENERF_TILE_ROWS;
+            double kz = 0;
+            for (int i = 0; i < 5; ++i)
+                if ((hm[t] >> i) & 1) kz += cfg->map_C[i];
+            flops += 2.0 * rows * 512.0 * (3.0 * SCENERF_D_XENC + 6.0 * SCENERF_D_HIDDEN + 3.0 * kz);
+        }
+    }
+    SrfLaunchScope ps(s, w->d_out == 2 ? "mlp_fwd_fused/g" : "mlp_fwd_fused", flops, 0);
+    mlp_wide_kernel<0><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);
+    SRF_LAUNCH_CHECK("mlp_wide_kernel<0>");
+    return 0;
+}
+
+// Backward dgrad chain on the same kernel shape (arguments and results as launch_mlp_bwd_fused, fused.hip)
+int launch_mlp_bwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, int M, const scenerf_mlp_acts* a, void* dH, void* dN,
+                        hipStream_t s) {
+    if (int e = wide_attrs()) return e;
+    FusedArgs p = {};
+    const int H = SCENERF_D_HIDDEN;
+    const size_t sign_layer = (size_t)cdiv(M, SCENERF_TILE_ROWS) * SCENERF_TILE_ROWS * 64;
+    SRF_CHECK(a->sign_bits, "wide backward: the sign bits of the fused forward are missing");
+    for (int b = 2; b >= 0; --b) {
+        const int l = 2 * (2 - b);
+        // forward layer order of the sign bits: H0, N0, H1, N1, H2, N2, H3
+        p.layer[l] = {nullptr, (char*)dN + (size_t)b * M * H * 2, a->sign_bits + (size_t)(2 * b + 1) * sign_layer, 1, H};   // dN_b = (dH_{b+1} W1_b) * [N_b > 0]
+        p.layer[l + 1] = {nullptr, (char*)dH + (size_t)b * H * 2, a->sign_bits + (size_t)(2 * b) * sign_layer, 2, 4 * H};   // dH_b = dH_{b+1} + (dN_b W0_b) * [H_b > 0]
+    }
+    p.Wst = w->w_stream;
+    p.dH3 = (const char*)dH + (size_t)3 * H * 2;
+    p.dH_ld = 4 * H;
+    const int* desc = nullptr;
+    if (int e = srf_desc_cache_get(g_wide_table, cfg, s, wide_table_build, &desc)) return e;
+    p.desc = desc + 32 * F_MAXCH;
+    p.M = M;
+    SrfLaunchScope ps(s, w->d_out == 2 ? "mlp_bwd_fused/g" : "mlp_bwd_fused", 2.0 * M * 512.0 * 6.0 * 512.0, 0);
+    mlp_wide_kernel<1><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);
+    SRF_LAUNCH_CHECK("mlp_wide_kernel<1>");
+    return 0;
+}

@@ -20,7 +20,7 @@ def _tables(kind, variant="kitti"):
     cc = rcfg.to_c()
     out = (C.c_int32 * (33 * STRIDE))()
     n = lib.scenerf_hip_test_chunk_table(C.byref(cc), kind, out, len(out))
-    assert n == (33 if kind == 0 else 32) * STRIDE, _capi.load().scenerf_hip_last_error()
+    assert n == (32 if kind == 1 else 33) * STRIDE, _capi.load().scenerf_hip_last_error()
     return np.frombuffer(out, dtype=np.int32, count=n).reshape(-1, STRIDE).copy(), [c for c, _, _ in rcfg.map_shapes()]
 
 
@@ -107,14 +107,20 @@ def test_stream_kernel_tables(variant):
 
 @pytest.mark.parametrize("variant", ["kitti", "bundlefusion"])
 def test_wide_kernel_tables(variant):
-    """fwd128.hip: one descriptor per chunk; every layer padded with no-op chunks (bit 25: loads happen, MFMAs do not) to a multiple of
-    four so that a layer begins in ring slot 0 and ends in slot 3 of the 4x unrolled loop; the table is zero beyond the end (the
-    weight prefetch runs four chunks ahead, the kernel copies n + 16 entries into LDS)."""
+    """wide.hip: header {chunks in total, chunks of layer 0, chunks of a lin_z tail (both padded to multiples of four), real chunks of a
+    lin_z tail}, then one descriptor per chunk in execution order.  Layer 0 stages its Z chunks first (stage slot = list position, so
+    layers 2 and 4 find them again), then the split encoding; every layer is padded with no-op chunks (bit 25: weights are loaded, MFMAs
+    skipped) to a multiple of four so that a layer begins in ring slot 0; the table is zero beyond the end (the weight prefetch
+    runs up to three groups ahead).  Set 32 = the backward chain: six layers of 32 resident chunks behind the forward blocks."""
     tabs, chans = _tables(2, variant)
+    assert tabs.shape[0] == 33
     for mask in range(32):
-        n, d = int(tabs[mask, 0]), [int(x) for x in tabs[mask, 1:]]
+        n, n0, nz, nzr = (int(x) for x in tabs[mask, :4])
+        d = [int(x) for x in tabs[mask, 4:]]
         want, _ = _expected_chunks(mask, chans)
-        assert n % 4 == 0 and n + 16 <= STRIDE - 1
+        assert n % 4 == 0 and n0 % 4 == 0 and nz % 4 == 0 and 4 + n + 12 <= STRIDE
+        real_z = sum(c // 16 for i, c in enumerate(chans) if (mask >> i) & 1)
+        assert nzr == real_z and nz == (real_z + 3) // 4 * 4 and n0 == (real_z + 9 + 3) // 4 * 4
         got = []
         for i in range(n):
             f = _fields(d[i])
@@ -129,8 +135,25 @@ def test_wide_kernel_tables(variant):
                 assert i % 4 == 0 and not (d[i] >> 25) & 1        # the zero-accumulator MFMA form sits in slot 0 and is a real chunk
             if last:
                 assert i % 4 == 3
-        assert got == [tuple(int(v) for v in w) for w in want], mask               # every chunk exactly once, in order
-        assert all(x == 0 for x in d[n:n + 16])
+        # layer 0: Z chunks first, then the encoding; every other layer in the reference order
+        l0 = [w for w in want if w[0] == 0]
+        l0 = [w for w in l0 if w[1] == 2] + [w for w in l0 if w[1] == 1]
+        exp = l0 + [w for w in want if w[0] != 0]
+        assert got == [tuple(int(v) for v in w) for w in exp], mask                # every chunk exactly once
+        # the lin_z tails of layers 2 and 4 are the last nz entries of their layers
+        for layer in (2, 4):
+            idx = [i for i in range(n) if _fields(d[i])["layer"] == layer]
+            assert len(idx) == 32 + nz
+            assert all(_fields(d[i])["src"] == 0 and not (d[i] >> 25) & 1 for i in idx[:32])
+            assert all(_fields(d[i])["src"] == 2 for i in idx[32:32 + nzr]) and all((d[i] >> 25) & 1 for i in idx[32 + nzr:])
+        assert all(x == 0 for x in d[n:n + 12])
+    n, d = int(tabs[32, 0]), tabs[32, 4:]
+    _, nfwd = _expected_chunks(0, chans)
+    assert n == 6 * 32 and nfwd + n == _capi.W_STREAM_BLOCKS
+    for i in range(n):
+        f = _fields(int(d[i]))
+        assert (f["layer"], f["src"], f["acol"], f["block"]) == (i // 32, 0, i % 32, nfwd + i)
+        assert f["end"] == (i % 32 == 31) and f["begin"] == (i % 32 == 0)
 
 
 def test_chunk_table_argument_checks():

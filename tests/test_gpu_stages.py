@@ -579,9 +579,9 @@ def test_mlp_forward_stream_equals_ring_kernel(case, M, lean):
 
 @pytest.mark.parametrize("M,lean", [(64, False), (4133, False), (40000, False), (40000, True)])
 def test_mlp_forward_wide_kernel_matches_ring_kernel(case, M, lean):
-    """fwd128.hip (128-row blocks, one wave per SIMD, accumulators in the accumulator file) against fused.hip's ring kernel: the same
-    chunk order and the same rounding points (H_b rounded to bf16 once per block), but the bias is added after the K sum instead of
-    before it, so a saved activation may differ in its last bf16 bit -- and such a difference propagates through the following layers
+    """wide.hip (128-row blocks, one wave per SIMD, accumulators in the accumulator file) against fused.hip's ring kernel: the same
+    rounding points (H_b rounded to bf16 once per block), but the bias is added after the K sum instead of before it (and layer 0
+    sums its K segments in a different order), so a saved activation may differ in its last bf16 bit -- and such a difference propagates through the following layers
     like any bf16 rounding: >= 99 % of the elements bit-identical, every element within 2 % of the tensor's scale (the fused-vs-layers
     test allows 3 %), sign bits >= 99.9 % identical, logits within 1 % of their scale, and against the fp32 oracle the kernel is as
     close as the ring kernel (within 25 %).  Mixed tile masks, a ragged tail, the lean inference buffers."""
@@ -664,8 +664,9 @@ def test_mlp_backward_fused_matches_layer_path(case, M):
     tex = torch.full((M, 5, 4), -1, dtype=torch.int32, device=DEV)
     tw = torch.zeros((M, 5, 4), device=DEV)
     res = {}
-    for name in ("layers", "fused"):
-        cc = dataclasses.replace(rcfg, fused_backward=(name == "fused")).to_c()   # scenerf_cfg.flags & SCENERF_FLAG_NO_FUSED_BWD
+    for name in ("layers", "fused", "wide"):
+        # scenerf_cfg.flags: SCENERF_FLAG_NO_FUSED_BWD (per-layer dgrad GEMMs) / SCENERF_FLAG_WIDE_BWD (wide.hip's 128-row chain)
+        cc = dataclasses.replace(rcfg, fused_backward=(name != "layers"), bwd_kernel="wide" if name == "wide" else "ring").to_c()
         gs = pk.grad_sink()
         pk.gflat.zero_()
         dH = torch.zeros((M, 2048), dtype=torch.bfloat16, device=DEV)
@@ -675,21 +676,23 @@ def test_mlp_backward_fused_matches_layer_path(case, M):
                                                  dl.data_ptr(), dH.data_ptr(), dN.data_ptr(), None, _st()), "mlp_backward")
         torch.cuda.synchronize()
         res[name] = (dH.float().cpu(), dN.float().cpu(), [g.clone().cpu() for g in pk.unpack_grads()])
-    (dHa, dNa, ga), (dHb, dNb, gb) = res["layers"], res["fused"]
-    assert torch.equal(dHa[:, 1536:], dHb[:, 1536:])          # lin_out's backward is shared
-    bad = []
-    for b in (2, 1, 0):   # chain order
-        for nm, x, y in (("dN%d" % b, dNa[b], dNb[b]), ("dH%d" % b, dHa[:, 512 * b:512 * (b + 1)], dHb[:, 512 * b:512 * (b + 1)])):
-            # same K order, same rounding points (dH / dN to bf16 per block), same sign gates: the chain is BIT-IDENTICAL to the six
-            # per-layer dgrad GEMMs
-            if not torch.equal(x, y):
-                bad.append("%s: rel L2 %.3e" % (nm, float((x - y).norm() / max(float(x.norm()), 1e-20))))
-    assert not bad, bad
-    # the weight gradients are summed with fp32 atomics over M splits in both paths: equal up to summation order
-    rels = {n: float((x - y).norm() / max(float(x.norm()), 1e-20)) for n, x, y in zip(MLP_PARAM_NAMES, ga, gb)}
-    print("fused vs layers parameter gradients, rel L2:", {k: "%.1e" % v for k, v in rels.items()})
-    for n, rel in rels.items():
-        assert rel <= 1e-4, "%s: relative L2 difference %.3e" % (n, rel)
+    dHa, dNa, ga = res["layers"]
+    for other in ("fused", "wide"):
+        dHb, dNb, gb = res[other]
+        assert torch.equal(dHa[:, 1536:], dHb[:, 1536:])          # lin_out's backward is shared
+        bad = []
+        for b in (2, 1, 0):   # chain order
+            for nm, x, y in (("dN%d" % b, dNa[b], dNb[b]), ("dH%d" % b, dHa[:, 512 * b:512 * (b + 1)], dHb[:, 512 * b:512 * (b + 1)])):
+                # same K order, same rounding points (dH / dN to bf16 per block), same sign gates: both chains are BIT-IDENTICAL to the six
+                # per-layer dgrad GEMMs
+                if not torch.equal(x, y):
+                    bad.append("%s %s: rel L2 %.3e" % (other, nm, float((x - y).norm() / max(float(x.norm()), 1e-20))))
+        assert not bad, bad
+        # the weight gradients are summed with fp32 atomics over M splits in both paths: equal up to summation order
+        rels = {n: float((x - y).norm() / max(float(x.norm()), 1e-20)) for n, x, y in zip(MLP_PARAM_NAMES, ga, gb)}
+        print("%s vs layers parameter gradients, rel L2:" % other, {k: "%.1e" % v for k, v in rels.items()})
+        for n, rel in rels.items():
+            assert rel <= 1e-4, "%s %s: relative L2 difference %.3e" % (other, n, rel)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
