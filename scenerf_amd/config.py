@@ -49,12 +49,12 @@ class RenderConfig:
     direct_scales: Tuple[int, ...] = (3, 4)
     # kernel-path selection (scenerf_cfg.fused_min_rows / fwd_kernel / flags): explicit per-call state, no environment variables
     fused_min_rows: int = _capi.FUSED_MIN_ROWS_DEFAULT   # bf16: rows from which the ResnetFC trunk / dgrad chain run as one fused kernel; < 0 never
-    fwd_kernel: str = "ring"          # fused forward variant: "ring" (fused.hip), "stream" (stream.hip; bit-identical), "wide" (wide.hip: 128-row blocks)
+    fwd_kernel: str = "wide"          # fused forward variant: "ring" (fused.hip), "stream" (stream.hip; bit-identical), "wide" (wide.hip: 128-row blocks)
     fused_backward: bool = True       # False: the dgrad chain as six per-layer GEMMs even where the fused chain applies
     wgrad_tr: bool = True             # False: weight gradients through gemm_tn only
     dfeat_per_scale: bool = False     # True: feature-gradient GEMM + scatter as one launch per pyramid level
     wgrad_overlap: bool = False       # True: per-layer backward runs the weight-gradient GEMMs on an internal side stream
-    bwd_kernel: str = "ring"          # fused dgrad chain: "ring" (fused.hip, 64-row blocks) or "wide" (wide.hip, 128-row blocks); bit-identical
+    bwd_kernel: str = "wide"          # fused dgrad chain: "ring" (fused.hip, 64-row blocks) or "wide" (wide.hip, 128-row blocks); bit-identical
 
     # ---- derived -----------------------------------------------------------------------------------------
     @property

@@ -605,6 +605,13 @@ template <> struct TnStage<bf16_t> {
     const char* src;
     size_t ld;
     int mrow;   // first row of the block inside a chunk
+    // bias gradient (GemmTN::colsum): sums of this thread's 8 columns of D over the rows it has staged, taken from the REGISTERS on
+    // their way into LDS (zero-filled rows included as zeros) and reduced over the 8 threads of a column block at the end.  An earlier
+    // version re-read the staged tile from LDS under a partial exec mask; at M = 40,000 (six chunks per slice) one block in a few
+    // hundred came back with a wrong sum for 16 columns (lanes 48..63 of wave 0) while the MFMAs fed from the same tile were right
+    // -- not understood; the registers are what the MFMAs' operand is made of, and this form costs fewer instructions.
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool docs = false;
     __device__ inline void init(const GemmTN& p, int tid, int n0, int k0) {
         const int op = tid >> 7, b = tid & 127, mb = b & 7, nb = b >> 3;
         const char* base = (const char*)(op == 0 ? p.D : p.A);
@@ -640,23 +647,31 @@ template <> struct TnStage<bf16_t> {
                 const uint32_t a = w[(2 * q) * 4 + (c >> 1)], bb = w[(2 * q + 1) * 4 + (c >> 1)];
                 o[q] = __builtin_amdgcn_perm(bb, a, (c & 1) ? 0x07060302u : 0x05040100u);
             }
+            if (docs) {   // wave-uniform.  o[q] = rows 2q, 2q+1 of column c: cs[c] += lo * 1 + hi * 1 (fp32 accumulate)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[c]) : "v"(o[q]), "v"(0x3f803f80u));
+            }
             *(uint4*)(tile + (nb * 8 + c) * TN_RB + mb * 16) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
-    // sum of the MC staged values of D-tile row `row` (one output column n)
-    __device__ static inline float rowsum(const char* Dt, int row) {
-        float s = 0.f;
+    // column sums -> colsum[n0 + nb * 8 + c]: butterfly over the 8 threads (mb = lane & 7) of a column block, one atomic per column
+    __device__ inline void flush_colsum(const GemmTN& p, int tid, int n0) {
+        const int b = tid & 127, mb = b & 7, nb = b >> 3;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            uint4 t = *(const uint4*)(Dt + row * TN_RB + q * 16);
-            s += (bf16lo(t.x) + bf16hi(t.x)) + (bf16lo(t.y) + bf16hi(t.y)) + (bf16lo(t.z) + bf16hi(t.z)) + (bf16lo(t.w) + bf16hi(t.w));
+        for (int c = 0; c < 8; ++c) {
+            float v = cs[c];
+            v += __shfl_xor(v, 1, WAVE);
+            v += __shfl_xor(v, 2, WAVE);
+            v += __shfl_xor(v, 4, WAVE);
+            if (mb == 0 && n0 + nb * 8 + c < p.N) unsafeAtomicAdd(p.colsum + n0 + nb * 8 + c, v);
         }
-        return s;
     }
 };
 template <> struct TnStage<float> {
     static constexpr int MC = 32;
     float4 r[2][4];
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of this thread's 4 columns of D (see TnStage<bf16_t>)
+    bool docs = false;
     __device__ inline void init(const GemmTN&, int, int, int) {}
     __device__ inline void load(const GemmTN& p, int tid, int mc, int n0, int k0) {
         const int mb = tid & 7, nb = tid >> 3;
@@ -685,6 +700,7 @@ template <> struct TnStage<float> {
                 float4 v = (cok && mc + mb * 4 + j < p.M) ? r[op][j] : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                 r[op][j] = v;
+                if (op == 0 && docs) { cs[0] += v.x; cs[1] += v.y; cs[2] += v.z; cs[3] += v.w; }
             }
             *(float4*)(tile + (nb * 4 + 0) * TN_RB + mb * 16) = make_float4(r[op][0].x, r[op][1].x, r[op][2].x, r[op][3].x);
             *(float4*)(tile + (nb * 4 + 1) * TN_RB + mb * 16) = make_float4(r[op][0].y, r[op][1].y, r[op][2].y, r[op][3].y);
@@ -692,14 +708,16 @@ template <> struct TnStage<float> {
             *(float4*)(tile + (nb * 4 + 3) * TN_RB + mb * 16) = make_float4(r[op][0].w, r[op][1].w, r[op][2].w, r[op][3].w);
         }
     }
-    __device__ static inline float rowsum(const char* Dt, int row) {
-        float s = 0.f;
+    __device__ inline void flush_colsum(const GemmTN& p, int tid, int n0) {
+        const int mb = tid & 7, nb = tid >> 3;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float4 t = *(const float4*)(Dt + row * TN_RB + q * 16);
-            s += (t.x + t.y) + (t.z + t.w);
+        for (int c = 0; c < 4; ++c) {
+            float v = cs[c];
+            v += __shfl_xor(v, 1, WAVE);
+            v += __shfl_xor(v, 2, WAVE);
+            v += __shfl_xor(v, 4, WAVE);
+            if (mb == 0 && n0 + nb * 4 + c < p.N) unsafeAtomicAdd(p.colsum + n0 + nb * 4 + c, v);
         }
-        return s;
     }
 };
 
@@ -715,7 +733,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
     const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BN;
     const int mbeg = (lin / (tiles_n * tiles_k)) * rows_per_slice;
     const int mend = (mbeg + rows_per_slice < p.M) ? mbeg + rows_per_slice : p.M;
-    const bool do_colsum = p.colsum != nullptr && k0 == 0 && tid < 128;
     const bool relu_b = sizeof(T) == 2 && p.relu_a;   // bf16: ReLU of the activation operand on its fragments
 
     // next row block of a tile that touches the scale: whole inactive tiles are skipped at once, eight at a time where the range
@@ -743,10 +760,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float csum = 0.f;
-
     TnStage<T> st;
     st.init(p, tid, n0, k0);
+    // bias gradient: the k-tile-0 workgroups also sum the columns of D (bf16: the 128 threads that stage D; fp32: every thread stages both)
+    st.docs = p.colsum != nullptr && k0 == 0 && (sizeof(T) == 4 || tid < 128);
     int c = next_valid(mbeg);
     if (c >= mend) return;  // uniform
     st.load(p, tid, c, n0, k0);
@@ -760,7 +777,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
         const char* At = Dt + TN_TILE;
 #pragma unroll
         for (int kk = 0; kk < MC / 16; ++kk) WaveMma<T, 2, TN_RB>::step(acc, Dt, At, kk, lane, wm, wn, relu_b);
-        if (do_colsum) csum += TnStage<T>::rowsum(Dt, tid);  // bias gradient: column sums of D (staged rows are zero-padded)
         if (nx < mend) st.store(p, lds + (buf ^ 1) * TN_STAGE, tid, nx, n0, k0);
         __syncthreads();
         buf ^= 1;
@@ -777,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int rows_per_
                 if (n < p.N && k < p.K) unsafeAtomicAdd(p.out + (size_t)n * p.ldo + k, acc[i][j][r]);
             }
         }
-    if (do_colsum && n0 + tid < p.N) unsafeAtomicAdd(p.colsum + n0 + tid, csum);
+    if (st.docs) st.flush_colsum(p, tid, n0);
 }
 
 // ================================================================================================ launchers

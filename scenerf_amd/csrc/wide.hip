@@ -89,17 +89,50 @@ template <bool ZERO, int I> __device__ __forceinline__ void h_row(const hfrag (&
 // waits for the data instead of copying a register whose load is still in flight.
 typedef const __attribute__((address_space(1))) hfrag* glb_frag_p;
 __device__ __forceinline__ void h_load_w(hfrag (&w)[4], const char* sbase, const unsigned voff) {
+#ifdef H_VAR_NOW   // (development variants, tools/wide_cycles.py: where do the K loop's cycles go)
+    return;
+#endif
     const char* b = sbase + voff;
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = *(glb_frag_p)(uintptr_t)(b + 1024 * j);
 }
 
 __device__ static inline void h_store16(void* p, uint4 v) {
+#ifndef H_VAR_ASMST
+    // plain stores: the compiler counts them in vmcnt together with the weight loads (stores retire in issue order with the loads on
+    // gfx9-class counters), so "wait for this chunk's weights" is exactly "all but the N youngest operations" -- with inline-asm stores
+    // its N ignored up to eight younger stores and the wait reached into the next chunks' loads
+#ifndef H_VAR_PLAINST
+    // non-temporal: each activation is written once and read again only by a later kernel (measured: the kernels 3 % faster -- the next
+    // block's staging reads no longer queue behind these lines -- at an unchanged step time)
+    __builtin_nontemporal_store(v.x, (uint32_t*)p); __builtin_nontemporal_store(v.y, (uint32_t*)p + 1);
+    __builtin_nontemporal_store(v.z, (uint32_t*)p + 2); __builtin_nontemporal_store(v.w, (uint32_t*)p + 3);
+#else
+    *(uint4*)p = v;
+#endif
+    return;
+#endif
     const u32x4_h t = {v.x, v.y, v.z, v.w};
     // (s_nop: a 16-byte store reads its data registers after issue; the compiler does not know this statement is a store)
+#ifdef H_VAR_SC1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#elif defined(H_VAR_NT)
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#elif defined(H_VAR_SC01)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#elif defined(H_VAR_SC1NT)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#else
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#endif
 }
-__device__ static inline void h_store1(void* p, uint32_t v) { asm volatile("global_store_byte %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ static inline void h_store1(void* p, uint32_t v) {
+#ifndef H_VAR_ASMST
+    *(uint8_t*)p = (uint8_t)v;
+    return;
+#endif
+    asm volatile("global_store_byte %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
 typedef unsigned short h_ushort2 __attribute__((ext_vector_type(2)));
 __device__ static inline uint32_t h_pk_min_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(h_ushort2, a), __builtin_bit_cast(h_ushort2, b)));
@@ -134,9 +167,19 @@ __device__ __forceinline__ void h_epi_quad(const float4 bias, const uint32_t gat
     o.x = MODE == 0 ? relu_bf16x2(p0) : p0;
     o.y = MODE == 0 ? relu_bf16x2(p1) : p1;
     *(uint2*)(wrow + (((slot0 + Q) ^ axor) << 4)) = o;
-    // (one huge basic block otherwise: the scheduler hoists every quad's residual unpacking to the top -- 256 more live registers)
-    __builtin_amdgcn_sched_barrier(0);
 }
+
+#ifdef H_CYC   // development build (SRF_EXTRA_FLAGS=-DH_CYC): per-block time stamps of wave 0 (tools/wide_cycles.py)
+__device__ unsigned long long* g_wide_cyc = nullptr;
+extern "C" int scenerf_hip_test_wide_cyc(unsigned long long* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wide_cyc), &ptr, sizeof(ptr)); }
+#define H_STAMP()                                                                                   \
+    if (wvu == 0 && g_wide_cyc && ci < 64) {                                                        \
+        if (lane == 0) g_wide_cyc[(size_t)blockIdx.x * 64 + ci] = __builtin_amdgcn_s_memtime();     \
+        ++ci;                                                                                       \
+    }
+#else
+#define H_STAMP()
+#endif
 
 template <int MODE>
 __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
@@ -148,6 +191,10 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     if ((unsigned)(uintptr_t)lds & 255u) __builtin_trap();   // the fragment addresses XOR bits 5..7 of the absolute LDS address
     const int tid = threadIdx.x, lane = tid & 63;
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef H_CYC
+    int ci = 0;
+#endif
+    H_STAMP()
     const int m0 = blockIdx.x * H_BM;
     const unsigned mask = MODE == 0 ? __builtin_amdgcn_readfirstlane((unsigned)p.tile_mask[m0 / SCENERF_TILE_ROWS] & 31u) : 0u;
     // this tile mask's table, read with scalar loads (constant address space) a group of four chunks at a time, two groups ahead
@@ -158,6 +205,13 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     const int nz = tab[2];     // a lin_z tail's staged chunks, incl. padding
     const int nzr = tab[3];    // ... real ones
     const bool zres = nzr <= H_ZCAP;                           // the stage keeps layer 0's Z chunks for layers 2 and 4
+    // lin_out's bias, fetched now (scalar registers): a load at the tail would sit behind 128 KiB of stores in the in-order vmcnt queue
+    float bo[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0 && p.logits) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < p.d_out) bo[j] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.b_out[j])));
+    }
 
     // ---- per-lane values.  Everything derived from the lane index is RE-derived from an opaque copy where it is needed: the 256
     // architectural registers are spoken for (residual stream 128, weight ring 64, fragments 16), and a compiler that hoists a few
@@ -194,7 +248,11 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     auto save_write = [&](const uint4 v) __attribute__((always_inline)) {
         if (save_i < 32) {
             const int row = 4 * save_i + wvu, slot = ln;
+#ifdef H_VAR_NOSAVE
+            if (false) {
+#else
             if (sv_base && m0 + row < p.M) {
+#endif
                 h_store16(sv_base + (size_t)(m0 + row) * sv_ld2 + slot * 16, v);
                 if (MODE == 0 && sg_base) {
                     uint32_t u = h_pk_min_u16(v.x, 0x00010001u);
@@ -223,6 +281,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     auto epilogue = [&](auto RES, const int layer) __attribute__((always_inline)) {
         constexpr bool is_res = decltype(RES)::value;
         const FusedLayer& L = p.layer[layer];
+        H_STAMP()   // K loop done
         while (save_i < 32) save_piece();
         H_LANE();
         const int hi = ln >> 5, axor = ln & 15;
@@ -240,16 +299,22 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         // (MFMA results are visible to v_accvgpr_read only after the pipeline has drained: 16 passes)
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();     // every wave has finished reading the A buffer for this layer
+        H_STAMP()   // everyone arrived
         char* const wr0 = Abuf + (ln & 31) * F_AROW + 8 * hi;
 #define H_GATE(I, J) (MODE == 1 ? ((J) == 0 ? gt[I].x : (J) == 1 ? gt[I].y : (J) == 2 ? gt[I].z : gt[I].w) >> (4 * hi) : 0u)
 #define H_EPI_JQ(J, Q)                                                                                          \
     {                                                                                                           \
         const float4 bq = bn;                                                                                   \
         if (MODE == 0 && (J) * 4 + (Q) < 15) bn = *(const float4*)(bb + (((J) * 4 + (Q) + 1) >> 2) * 32 + (((Q) + 1) & 3) * 8); \
+        /* quads in pairs between scheduling barriers: two independent dependency chains to interleave (a quad alone is one serial   \
+           chain of ~18 instructions with hazard nops); no barrier at all = one huge basic block whose scheduler hoists every quad's     \
+           residual unpacking to the top -- 256 more live registers */                                             \
         h_epi_quad<MODE, is_res, 0, J, Q>(bq, H_GATE(0, J), hp[0][J], wr0, wvu * 16 + (J) * 4, axor);           \
         h_epi_quad<MODE, is_res, 1, J, Q>(bq, H_GATE(1, J), hp[1][J], wr0 + 32 * F_AROW, wvu * 16 + (J) * 4, axor); \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
         h_epi_quad<MODE, is_res, 2, J, Q>(bq, H_GATE(2, J), hp[2][J], wr0 + 64 * F_AROW, wvu * 16 + (J) * 4, axor); \
         h_epi_quad<MODE, is_res, 3, J, Q>(bq, H_GATE(3, J), hp[3][J], wr0 + 96 * F_AROW, wvu * 16 + (J) * 4, axor); \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
     }
 #define H_EPI_J(J) H_EPI_JQ(J, 0) H_EPI_JQ(J, 1) H_EPI_JQ(J, 2) H_EPI_JQ(J, 3)
         H_EPI_J(0) H_EPI_J(1) H_EPI_J(2) H_EPI_J(3)
@@ -258,6 +323,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
 #undef H_GATE
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();     // A buffer complete
+        H_STAMP()   // epilogue done
         sv_base = (char*)L.save;
         sv_ld2 = L.save_ld * 2;
         sg_base = MODE == 0 ? L.sign : nullptr;
@@ -297,7 +363,11 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         e0 = b.x; e1 = b.y; e2 = b.z; e3 = b.w;
         dnv = *(desc4_ptr)(tab + H_HDR + 8);
     }
+#ifdef H_VAR_W0      // (development: weights from a window of H_VAR_W0 blocks only: 2 = L1-resident, 16 = L2-resident)
+#define H_WPTR(d) (Wb + (size_t)(FD_Z(d) & (H_VAR_W0 - 1)) * 16384)
+#else
 #define H_WPTR(d) (Wb + (size_t)FD_Z(d) * 16384)
+#endif
     // top of a group: its descriptors become current, the next group's come out of `dnv`, the one after is requested
 #define H_GROUP_TOP()                                                                                 \
     {                                                                                                 \
@@ -312,29 +382,210 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     // fragment of the NEXT chunk (a single fragment set, each piece re-loaded 12 MFMAs = 384 cycles before its next use; at a
     // layer's last chunk that prefetch reads past the row, harmlessly), then the ring slot's next weights and one piece of the
     // previous layer's output on its way to HBM.
-#define H_RES_ROW(I, S, ZERO, X)                                                    \
-    if (ZERO) h_row<true, I>(wr[S], af[I]);                                         \
-    else h_row<false, I>(wr[S], af[I]);                                             \
-    af[I] = *(lds_frag_p)(uintptr_t)(X);                                            \
-    __builtin_amdgcn_sched_barrier(0);
-#define H_RES_CHUNK(S, KK, ZERO, DW)                                                \
-    {                                                                               \
-        const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5); \
-        const unsigned x1_ = x0_ + 65536u;                                          \
-        const uint4 sv_ = save_read();                                              \
-        __builtin_amdgcn_sched_barrier(0);                                          \
-        H_RES_ROW(0, S, ZERO, x0_)                                                  \
-        save_write(sv_);                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                          \
-        H_RES_ROW(1, S, ZERO, x0_ + 32768u) H_RES_ROW(2, S, ZERO, x1_) H_RES_ROW(3, S, ZERO, x1_ + 32768u) \
-        h_load_w(wr[S], H_WPTR(DW), wl);                                            \
-        __builtin_amdgcn_sched_barrier(0);                                          \
+    // Everything that is not an MFMA is PINNED between two particular MFMAs (a scheduling barrier after every MFMA + filler group): one
+    // wave per SIMD hides about five single-issue instructions behind a 32-cycle MFMA and none beyond that, so ~50 fillers per chunk
+    // have to be spread over the 16 gaps, not bunched behind every fourth MFMA (measured: 680 -> cycles per chunk without loads).
+    // The stream-out piece of chunk k of a resident run is piece k (a run has exactly 32 chunks and a layer 32 pieces); its stores sit
+    // behind ONE not-taken scalar branch (EXEC-masking them instead was measured: every write to EXEC drains the MFMA pipe, +400 cycles
+    // per chunk).
+#define H_M(I, J, S, ZERO)                                                          \
+    if (ZERO) h_mfma0<16 * (4 * (I) + (J))>(wr[S][J], af[I]);                       \
+    else h_mfma<16 * (4 * (I) + (J))>(wr[S][J], af[I]);
+#define H_SB() __builtin_amdgcn_sched_barrier(0);
+// H_PLACE = MFMAs issued back to back before the fillers that become legal behind them (development knob; measured with
+// tools/wide_cycles.py: see the kernel header)
+#ifndef H_PLACE
+#define H_PLACE 1
+#endif
+#ifdef H_VAR_NOW
+#define H_LW(S, J, OFF)
+#elif defined(H_VAR_HALF)     // (development: half the weight loads)
+#define H_LW(S, J, OFF) if ((J) < 2) wr[S][J] = *(glb_frag_p)(uintptr_t)(wp_ + OFF);
+#else
+#define H_LW(S, J, OFF) wr[S][J] = *(glb_frag_p)(uintptr_t)(wp_ + OFF);
+#endif
+#define H_TOUCH(DP)
+#if H_PLACE == 1
+#define H_RES_CHUNK(S, KK, ZERO, DW, DP) \
+    { \
+        const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
+        const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
+        const bool sok_ = sv_run && (m0 + srow_ < p.M);                                                                                                \
+        H_M(0, 0, S, ZERO)                                                                                                                             \
+        const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
+        H_SB()                                                                                                                                         \
+        H_M(0, 1, S, ZERO)                                                                                                                             \
+        H_SB()                                                                                                                                         \
+        H_M(0, 2, S, ZERO)                                                                                                                             \
+        H_SB()                                                                                                                                         \
+        H_M(0, 3, S, ZERO)                                                                                                                             \
+        af[0] = *(lds_frag_p)(uintptr_t)(x0_);                                                                                                         \
+        H_SB()                                                                                                                                         \
+        H_M(1, 0, S, ZERO)                                                                                                                             \
+        if (sok_) h_store16(sv_base + (size_t)(m0 + srow_) * sv_ld2 + ln * 16, sv_);                                                                   \
+        H_SB()                                                                                                                                         \
+        H_M(1, 1, S, ZERO)                                                                                                                             \
+        uint32_t su_ = 0; if (MODE == 0) { su_ = h_pk_min_u16(sv_.x, 0x00010001u); su_ |= h_pk_min_u16(sv_.y, 0x00010001u) << 2; }                     \
+        H_SB()                                                                                                                                         \
+        H_M(1, 2, S, ZERO)                                                                                                                             \
+        if (MODE == 0) { su_ |= h_pk_min_u16(sv_.z, 0x00010001u) << 4; su_ |= h_pk_min_u16(sv_.w, 0x00010001u) << 6; }                                 \
+        H_SB()                                                                                                                                         \
+        H_M(1, 3, S, ZERO)                                                                                                                             \
+        af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
+        H_SB()                                                                                                                                         \
+        H_M(2, 0, S, ZERO)                                                                                                                             \
+        if (MODE == 0 && sok_ && sg_base) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
+        H_SB()                                                                                                                                         \
+        H_M(2, 1, S, ZERO)                                                                                                                             \
+        const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
+        H_SB()                                                                                                                                         \
+        H_M(2, 2, S, ZERO)                                                                                                                             \
+        H_TOUCH(DP)                                                                                                                                    \
+        H_SB()                                                                                                                                         \
+        H_M(2, 3, S, ZERO)                                                                                                                             \
+        const unsigned x1_ = x0_ + 65536u; af[2] = *(lds_frag_p)(uintptr_t)(x1_);                                                                      \
+        H_SB()                                                                                                                                         \
+        H_M(3, 0, S, ZERO)                                                                                                                             \
+        H_LW(S, 0, 0)                                                                                                                                  \
+        H_SB()                                                                                                                                         \
+        H_M(3, 1, S, ZERO)                                                                                                                             \
+        H_LW(S, 1, 1024)                                                                                                                               \
+        H_SB()                                                                                                                                         \
+        H_M(3, 2, S, ZERO)                                                                                                                             \
+        H_LW(S, 2, 2048)                                                                                                                               \
+        H_SB()                                                                                                                                         \
+        H_M(3, 3, S, ZERO)                                                                                                                             \
+        H_LW(S, 3, 3072)                                                                                                                               \
+        af[3] = *(lds_frag_p)(uintptr_t)(x1_ + 32768u);                                                                                                \
+        H_SB()                                                                                                                                         \
     }
+#elif H_PLACE == 2
+#define H_RES_CHUNK(S, KK, ZERO, DW, DP) \
+    { \
+        const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
+        const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
+        const bool sok_ = sv_run && (m0 + srow_ < p.M);                                                                                                \
+        H_M(0, 0, S, ZERO) H_M(0, 1, S, ZERO)                                                                                                          \
+        const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
+        H_SB()                                                                                                                                         \
+        H_M(0, 2, S, ZERO) H_M(0, 3, S, ZERO)                                                                                                          \
+        af[0] = *(lds_frag_p)(uintptr_t)(x0_);                                                                                                         \
+        H_SB()                                                                                                                                         \
+        H_M(1, 0, S, ZERO) H_M(1, 1, S, ZERO)                                                                                                          \
+        if (sok_) h_store16(sv_base + (size_t)(m0 + srow_) * sv_ld2 + ln * 16, sv_);                                                                   \
+        uint32_t su_ = 0; if (MODE == 0) { su_ = h_pk_min_u16(sv_.x, 0x00010001u); su_ |= h_pk_min_u16(sv_.y, 0x00010001u) << 2; }                     \
+        H_SB()                                                                                                                                         \
+        H_M(1, 2, S, ZERO) H_M(1, 3, S, ZERO)                                                                                                          \
+        if (MODE == 0) { su_ |= h_pk_min_u16(sv_.z, 0x00010001u) << 4; su_ |= h_pk_min_u16(sv_.w, 0x00010001u) << 6; }                                 \
+        af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
+        H_SB()                                                                                                                                         \
+        H_M(2, 0, S, ZERO) H_M(2, 1, S, ZERO)                                                                                                          \
+        if (MODE == 0 && sok_ && sg_base) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
+        const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
+        H_SB()                                                                                                                                         \
+        H_M(2, 2, S, ZERO) H_M(2, 3, S, ZERO)                                                                                                          \
+        H_TOUCH(DP)                                                                                                                                    \
+        const unsigned x1_ = x0_ + 65536u; af[2] = *(lds_frag_p)(uintptr_t)(x1_);                                                                      \
+        H_SB()                                                                                                                                         \
+        H_M(3, 0, S, ZERO) H_M(3, 1, S, ZERO)                                                                                                          \
+        H_LW(S, 0, 0)                                                                                                                                  \
+        H_LW(S, 1, 1024)                                                                                                                               \
+        H_SB()                                                                                                                                         \
+        H_M(3, 2, S, ZERO) H_M(3, 3, S, ZERO)                                                                                                          \
+        H_LW(S, 2, 2048)                                                                                                                               \
+        H_LW(S, 3, 3072)                                                                                                                               \
+        af[3] = *(lds_frag_p)(uintptr_t)(x1_ + 32768u);                                                                                                \
+        H_SB()                                                                                                                                         \
+    }
+#elif H_PLACE == 4
+#define H_RES_CHUNK(S, KK, ZERO, DW, DP) \
+    { \
+        const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
+        const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
+        const bool sok_ = sv_run && (m0 + srow_ < p.M);                                                                                                \
+        H_M(0, 0, S, ZERO) H_M(0, 1, S, ZERO) H_M(0, 2, S, ZERO) H_M(0, 3, S, ZERO)                                                                    \
+        const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
+        af[0] = *(lds_frag_p)(uintptr_t)(x0_);                                                                                                         \
+        H_SB()                                                                                                                                         \
+        H_M(1, 0, S, ZERO) H_M(1, 1, S, ZERO) H_M(1, 2, S, ZERO) H_M(1, 3, S, ZERO)                                                                    \
+        if (sok_) h_store16(sv_base + (size_t)(m0 + srow_) * sv_ld2 + ln * 16, sv_);                                                                   \
+        uint32_t su_ = 0; if (MODE == 0) { su_ = h_pk_min_u16(sv_.x, 0x00010001u); su_ |= h_pk_min_u16(sv_.y, 0x00010001u) << 2; }                     \
+        if (MODE == 0) { su_ |= h_pk_min_u16(sv_.z, 0x00010001u) << 4; su_ |= h_pk_min_u16(sv_.w, 0x00010001u) << 6; }                                 \
+        af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
+        H_SB()                                                                                                                                         \
+        H_M(2, 0, S, ZERO) H_M(2, 1, S, ZERO) H_M(2, 2, S, ZERO) H_M(2, 3, S, ZERO)                                                                    \
+        if (MODE == 0 && sok_ && sg_base) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
+        const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
+        H_TOUCH(DP)                                                                                                                                    \
+        const unsigned x1_ = x0_ + 65536u; af[2] = *(lds_frag_p)(uintptr_t)(x1_);                                                                      \
+        H_SB()                                                                                                                                         \
+        H_M(3, 0, S, ZERO) H_M(3, 1, S, ZERO) H_M(3, 2, S, ZERO) H_M(3, 3, S, ZERO)                                                                    \
+        H_LW(S, 0, 0)                                                                                                                                  \
+        H_LW(S, 1, 1024)                                                                                                                               \
+        H_LW(S, 2, 2048)                                                                                                                               \
+        H_LW(S, 3, 3072)                                                                                                                               \
+        af[3] = *(lds_frag_p)(uintptr_t)(x1_ + 32768u);                                                                                                \
+        H_SB()                                                                                                                                         \
+    }
+#elif H_PLACE == 8
+#define H_RES_CHUNK(S, KK, ZERO, DW, DP) \
+    { \
+        const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
+        const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
+        const bool sok_ = sv_run && (m0 + srow_ < p.M);                                                                                                \
+        H_M(0, 0, S, ZERO) H_M(0, 1, S, ZERO) H_M(0, 2, S, ZERO) H_M(0, 3, S, ZERO) H_M(1, 0, S, ZERO) H_M(1, 1, S, ZERO) H_M(1, 2, S, ZERO) H_M(1, 3, S, ZERO) \
+        const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
+        af[0] = *(lds_frag_p)(uintptr_t)(x0_);                                                                                                         \
+        if (sok_) h_store16(sv_base + (size_t)(m0 + srow_) * sv_ld2 + ln * 16, sv_);                                                                   \
+        uint32_t su_ = 0; if (MODE == 0) { su_ = h_pk_min_u16(sv_.x, 0x00010001u); su_ |= h_pk_min_u16(sv_.y, 0x00010001u) << 2; }                     \
+        if (MODE == 0) { su_ |= h_pk_min_u16(sv_.z, 0x00010001u) << 4; su_ |= h_pk_min_u16(sv_.w, 0x00010001u) << 6; }                                 \
+        af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
+        H_SB()                                                                                                                                         \
+        H_M(2, 0, S, ZERO) H_M(2, 1, S, ZERO) H_M(2, 2, S, ZERO) H_M(2, 3, S, ZERO) H_M(3, 0, S, ZERO) H_M(3, 1, S, ZERO) H_M(3, 2, S, ZERO) H_M(3, 3, S, ZERO) \
+        if (MODE == 0 && sok_ && sg_base) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
+        const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
+        H_TOUCH(DP)                                                                                                                                    \
+        const unsigned x1_ = x0_ + 65536u; af[2] = *(lds_frag_p)(uintptr_t)(x1_);                                                                      \
+        H_LW(S, 0, 0)                                                                                                                                  \
+        H_LW(S, 1, 1024)                                                                                                                               \
+        H_LW(S, 2, 2048)                                                                                                                               \
+        H_LW(S, 3, 3072)                                                                                                                               \
+        af[3] = *(lds_frag_p)(uintptr_t)(x1_ + 32768u);                                                                                                \
+        H_SB()                                                                                                                                         \
+    }
+#else
+#define H_RES_CHUNK(S, KK, ZERO, DW, DP) \
+    { \
+        const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
+        const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
+        const bool sok_ = sv_run && (m0 + srow_ < p.M);                                                                                                \
+        H_M(0, 0, S, ZERO) H_M(0, 1, S, ZERO) H_M(0, 2, S, ZERO) H_M(0, 3, S, ZERO) H_M(1, 0, S, ZERO) H_M(1, 1, S, ZERO) H_M(1, 2, S, ZERO) H_M(1, 3, S, ZERO) H_M(2, 0, S, ZERO) H_M(2, 1, S, ZERO) H_M(2, 2, S, ZERO) H_M(2, 3, S, ZERO) H_M(3, 0, S, ZERO) H_M(3, 1, S, ZERO) H_M(3, 2, S, ZERO) H_M(3, 3, S, ZERO) \
+        const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
+        af[0] = *(lds_frag_p)(uintptr_t)(x0_);                                                                                                         \
+        if (sok_) h_store16(sv_base + (size_t)(m0 + srow_) * sv_ld2 + ln * 16, sv_);                                                                   \
+        uint32_t su_ = 0; if (MODE == 0) { su_ = h_pk_min_u16(sv_.x, 0x00010001u); su_ |= h_pk_min_u16(sv_.y, 0x00010001u) << 2; }                     \
+        if (MODE == 0) { su_ |= h_pk_min_u16(sv_.z, 0x00010001u) << 4; su_ |= h_pk_min_u16(sv_.w, 0x00010001u) << 6; }                                 \
+        af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
+        if (MODE == 0 && sok_ && sg_base) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
+        const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
+        H_TOUCH(DP)                                                                                                                                    \
+        const unsigned x1_ = x0_ + 65536u; af[2] = *(lds_frag_p)(uintptr_t)(x1_);                                                                      \
+        H_LW(S, 0, 0)                                                                                                                                  \
+        H_LW(S, 1, 1024)                                                                                                                               \
+        H_LW(S, 2, 2048)                                                                                                                               \
+        H_LW(S, 3, 3072)                                                                                                                               \
+        af[3] = *(lds_frag_p)(uintptr_t)(x1_ + 32768u);                                                                                                \
+        H_SB()                                                                                                                                         \
+    }
+#endif
     // 32 resident chunks (a K = 512 operand in the A buffer): four groups of eight; the very first chunk starts the accumulators at 0
     auto resident_run = [&]() __attribute__((always_inline)) {
         H_LANE();
         const unsigned wl = w_lane();
         unsigned ag = a_lane();
+        // (a resident run starts with all 32 pieces of the previous layer's output still to stream out, or with none)
+        const bool sv_run = save_i == 0 && sv_base != nullptr;
+        save_i = 32;
         // fragments of chunk 0 (the A buffer was completed behind the epilogue's second barrier)
         af[0] = *(lds_frag_p)(uintptr_t)(ag);
         af[1] = *(lds_frag_p)(uintptr_t)(ag + 32768u);
@@ -343,19 +594,20 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
         for (int g = 0; g < 4; ++g) {
+            H_LANE();
             if (g == 0) {
-                H_RES_CHUNK(0, 0, true, e0)
+                H_RES_CHUNK(0, 0, true, e0, dnv.x)
             } else {
-                H_RES_CHUNK(0, 0, false, e0)
+                H_RES_CHUNK(0, 0, false, e0, dnv.x)
             }
-            H_RES_CHUNK(1, 1, false, e1)
-            H_RES_CHUNK(2, 2, false, e2)
-            H_RES_CHUNK(3, 3, false, e3)
+            H_RES_CHUNK(1, 1, false, e1, dnv.y)
+            H_RES_CHUNK(2, 2, false, e2, dnv.z)
+            H_RES_CHUNK(3, 3, false, e3, dnv.w)
             H_GROUP_TOP()
-            H_RES_CHUNK(0, 4, false, e0)
-            H_RES_CHUNK(1, 5, false, e1)
-            H_RES_CHUNK(2, 6, false, e2)
-            H_RES_CHUNK(3, 7, false, e3)
+            H_RES_CHUNK(0, 4, false, e0, dnv.x)
+            H_RES_CHUNK(1, 5, false, e1, dnv.y)
+            H_RES_CHUNK(2, 6, false, e2, dnv.z)
+            H_RES_CHUNK(3, 7, false, e3, dnv.w)
             H_GROUP_TOP()
             ag += 256u;
         }
@@ -419,6 +671,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         }
     };
 
+    H_STAMP()   // setup done
     // ---- prologue: the weight ring (chunks 0 .. 3)
     {
         H_LANE();
@@ -436,6 +689,17 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
             resident_run();
             epilogue(std::false_type(), 1 + 2 * b);
             if (tail && !zres) dma_round(c + 32, 0, min(H_ZCAP, nzr));   // round 0 of this layer's lin_z tail: the stage is idle until then
+            if (b == 2 && p.logits) {
+                // lin_out's weights (fp32 [d_out][512]) -> the stage, which nobody reads any more: 1 KiB pieces, two per wave.  16-byte
+                // unit u of row j holds float4 (u ^ 2 ((u >> 4) & 7)) of that row: the eight threads of an activation row, which read
+                // units 16 apart at the same time, then hit eight different bank groups.  Retired (in issue order) long before the tail.
+                H_LANE();
+                for (int k = wvu; k < p.d_out * 2; k += 4) {
+                    const int u = (k & 1) * 64 + ln;
+                    h_glds16((const char*)p.w_out + (k >> 1) * 2048, (unsigned)((u ^ (2 * ((u >> 4) & 7))) << 4),
+                             __builtin_amdgcn_readfirstlane(lds0 + H_ZS + k * 1024));
+                }
+            }
             resident_run();
             if (tail) staged_run(nz, nzr, H_ZCAP, zres ? 2 : 1, false);
             epilogue(std::true_type(), 2 + 2 * b);
@@ -466,6 +730,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
                         hp[i][j][2 * q + 1] = v.y;
                     }
         }
+        H_STAMP()   // incoming gradient tile staged
 #pragma unroll 1
         for (int l = 0; l < 6; l += 2) {
             resident_run();
@@ -477,49 +742,82 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
 #undef H_STG_CHUNK
 #undef H_STG_ROW
 #undef H_RES_CHUNK
-#undef H_RES_ROW
+#undef H_M
+#undef H_SB
+#undef H_TOUCH
+#undef H_LW
 #undef H_GROUP_TOP
 #undef H_WPTR
     H_LANE();
-    while (save_i < 32) save_piece();
-    if (MODE == 0 && p.logits) {
-        // lin_out on the rectified H3 tile still resident in the A buffer (all waves are past the last epilogue's second barrier):
-        // w_out (fp32, <= 8 KiB) is copied into the now idle stage, then 8 threads per row take 64 columns each, a butterfly adds the
-        // partials; 32 rows per pass (same summation order as fused.hip)
-        float* wl = (float*)(lds + H_ZS);
-        for (int i = wvu * 64 + ln; i < p.d_out * (SCENERF_D_HIDDEN / 4); i += H_THREADS) *(float4*)(wl + i * 4) = *(const float4*)(p.w_out + i * 4);
-        __syncthreads();
-#pragma unroll 1
-        for (int rb = 0; rb < 4; ++rb) {
-            const int t = wvu * 64 + ln;
-            const int row = rb * 32 + (t >> 3), part = t & 7;
-            float o[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-            for (int s8 = 0; s8 < 8; ++s8) {
-                const int slot = part * 8 + s8;
-                const uint4 v = *(const uint4*)(Abuf + row * F_AROW + ((slot ^ (row & 15)) << 4));
-                const float f[8] = {bf16lo(v.x), bf16hi(v.x), bf16lo(v.y), bf16hi(v.y), bf16lo(v.z), bf16hi(v.z), bf16lo(v.w), bf16hi(v.w)};
+    // ---- tail: the last layer's output goes out four pieces at a time (four LDS reads in flight, then four stores)
+    const bool do_out = MODE == 0 && p.logits;
+    while (save_i < 32) {
+        uint4 pv[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j < p.d_out) {
-                        const float4 w0 = *(const float4*)(wl + j * SCENERF_D_HIDDEN + slot * 8);
-                        const float4 w1 = *(const float4*)(wl + j * SCENERF_D_HIDDEN + slot * 8 + 4);
-                        o[j] = fmaf(f[0], w0.x, o[j]); o[j] = fmaf(f[1], w0.y, o[j]); o[j] = fmaf(f[2], w0.z, o[j]); o[j] = fmaf(f[3], w0.w, o[j]);
-                        o[j] = fmaf(f[4], w1.x, o[j]); o[j] = fmaf(f[5], w1.y, o[j]); o[j] = fmaf(f[6], w1.z, o[j]); o[j] = fmaf(f[7], w1.w, o[j]);
-                    }
+        for (int r = 0; r < 4; ++r) {
+            const int row = (4 * (save_i + r) + wvu) & (H_BM - 1);
+            pv[r] = *(const uint4*)(Abuf + row * F_AROW + ((ln ^ (row & 15)) << 4));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) save_write(pv[r]);
+    }
+    H_STAMP()   // last layer streamed out
+    if (do_out) {
+        // lin_out on the rectified H3 tile still resident in the A buffer (all waves are past the last epilogue's second barrier, and
+        // w_out has been in the stage since the last layer began): 8 threads per row take 64 columns each, a butterfly adds the partials
+        // (same summation order as fused.hip); a thread keeps its 64 columns of w_out in registers across its four rows
+        const float* wl = (const float*)(lds + H_ZS);
+        const int t = wvu * 64 + ln;
+        const int part = t & 7;
+        float o[4][4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[rb][j] = 0.f;
+#pragma unroll 1
+        for (int s8 = 0; s8 < 8; ++s8) {
+            const int slot = part * 8 + s8;
+            float4 w0[4], w1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < p.d_out) {   // (units 2 slot, 2 slot + 1 of row j, swizzled as staged)
+                    w0[j] = *(const float4*)(wl + j * 512 + (((2 * slot) ^ (2 * part)) << 2));
+                    w1[j] = *(const float4*)(wl + j * 512 + (((2 * slot + 1) ^ (2 * part)) << 2));
+                } else {
+                    w0[j] = w1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const int row = rb * 32 + (t >> 3);
+                const uint4 v = *(const uint4*)(Abuf + row * F_AROW + ((slot ^ (row & 15)) << 4));
+                const float f[8] = {bf16lo(v.x), bf16hi(v.x), bf16lo(v.y), bf16hi(v.y), bf16lo(v.z), bf16hi(v.z), bf16lo(v.w), bf16hi(v.w)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {   // (same summation order as fused.hip: slot by slot, element by element)
+                    o[rb][j] = fmaf(f[0], w0[j].x, o[rb][j]); o[rb][j] = fmaf(f[1], w0[j].y, o[rb][j]);
+                    o[rb][j] = fmaf(f[2], w0[j].z, o[rb][j]); o[rb][j] = fmaf(f[3], w0[j].w, o[rb][j]);
+                    o[rb][j] = fmaf(f[4], w1[j].x, o[rb][j]); o[rb][j] = fmaf(f[5], w1[j].y, o[rb][j]);
+                    o[rb][j] = fmaf(f[6], w1[j].z, o[rb][j]); o[rb][j] = fmaf(f[7], w1[j].w, o[rb][j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const int row = rb * 32 + (t >> 3);
+#pragma unroll
             for (int j = 0; j < 4; ++j) {
-                o[j] += __shfl_xor(o[j], 1);
-                o[j] += __shfl_xor(o[j], 2);
-                o[j] += __shfl_xor(o[j], 4);
+                o[rb][j] += __shfl_xor(o[rb][j], 1);
+                o[rb][j] += __shfl_xor(o[rb][j], 2);
+                o[rb][j] += __shfl_xor(o[rb][j], 4);
             }
             if (part == 0 && m0 + row < p.M) {
-                for (int j = 0; j < p.d_out; ++j) p.logits[(size_t)(m0 + row) * p.d_out + j] = o[j] + p.b_out[j];
+                #pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < p.d_out) p.logits[(size_t)(m0 + row) * p.d_out + j] = o[rb][j] + bo[j];
             }
         }
     }
+    H_STAMP()   // end
 }
 
 // ---- host: tables for the 32 scale masks of the forward (sets 0..31) and the backward chain (set 32)

@@ -5,7 +5,8 @@ f=$1
 cd /root/repo/scenerf_amd/csrc || exit 1
 extra=""
 [ "$f" = "wide" ] && extra="-mllvm -amdgpu-spill-vgpr-to-agpr=0"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics $extra -c $f.hip -o /tmp/$f.o -save-temps=obj 2>&1 | grep -E "error|warning" | head -20
+rm -f /tmp/$f.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics $extra -c $f.hip -o /tmp/$f.o -save-temps=obj 2>&1 | grep -E "error|warning" | head -20; [ -s /tmp/$f.o ] || { echo "COMPILE FAILED"; exit 1; }
 grep -E "^\s+\.(name|vgpr_count|vgpr_spill_count|sgpr_count|agpr_count|group_segment_fixed_size|private_segment_fixed_size):" /tmp/$f-hip-amdgcn-amd-amdhsa-gfx950.s | paste - - - - - - - | sed 's/  */ /g'
 python3 - "$f" <<'PY'
 import sys
