@@ -74,6 +74,8 @@ static inline bool srf_use_fused(const scenerf_cfg* cfg, int M) {
     return th > 0 && M >= th;
 }
 
+// row blocks from which the 128-row fused kernels (wide.hip) replace the 64-row ones when selected: three quarters of the CUs busy
+#define SRF_WIDE_MIN_BLOCKS 192
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline hipStream_t as_stream(scenerf_stream_t s) { return (hipStream_t)s; }
 

@@ -327,7 +327,10 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
         if (srf_use_fused(cfg, M) && w->w_stream) {
             // two kernels with identical results: fused.hip's LDS-ring pipeline and stream.hip's register-streamed one (scenerf_cfg.fwd_kernel)
             SRF_CHECK(cfg->fwd_kernel >= 0 && cfg->fwd_kernel <= 2, "mlp_forward: unknown fwd_kernel %d", cfg->fwd_kernel);
-            if (cfg->fwd_kernel == 2) return launch_mlp_fwd_wide(cfg, w, Z, tile_mask, M, a, s);
+            // (128-row blocks need enough of them to fill the chip: the gaussian head's 4,800 rows are 38 blocks on 256 CUs -- 156 us against
+            // the 64-row ring kernel's 109 us)
+            if (cfg->fwd_kernel == 2 && (cdiv(M, 128) >= SRF_WIDE_MIN_BLOCKS || (cfg->flags & SCENERF_FLAG_WIDE_ANY_M))) return launch_mlp_fwd_wide(cfg, w, Z, tile_mask, M, a, s);
+            if (cfg->fwd_kernel == 2) return launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s);
             return cfg->fwd_kernel == 1 ? launch_mlp_fwd_stream(cfg, w, Z, tile_mask, M, a, s) : launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s);
         }
         SRF_CHECK(a->H[3], "mlp_forward: acts->H[3] is NULL");
@@ -412,7 +415,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     const bool fused_chain = prec && w->w_stream && a->sign_bits && srf_use_fused(cfg, M) && !(cfg->flags & SCENERF_FLAG_NO_FUSED_BWD);
     const int allow_tr = (cfg->flags & SCENERF_FLAG_NO_WGRAD_TR) ? 0 : 1;
     if (fused_chain) {
-        if (int e = (cfg->flags & SCENERF_FLAG_WIDE_BWD) ? launch_mlp_bwd_wide(cfg, w, M, a, dH, dN, s) : launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
+        if (int e = ((cfg->flags & SCENERF_FLAG_WIDE_BWD) && (cdiv(M, 128) >= SRF_WIDE_MIN_BLOCKS || (cfg->flags & SCENERF_FLAG_WIDE_ANY_M))) ? launch_mlp_bwd_wide(cfg, w, M, a, dH, dN, s) : launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
         if (int e = fork()) return e;
     }
     GemmTN wg[8];   // the six fc weight gradients (+ lin_z, below): batched into one launch when the chain kernel already produced every dH / dN

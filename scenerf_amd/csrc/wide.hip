@@ -388,7 +388,17 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     // The stream-out piece of chunk k of a resident run is piece k (a run has exactly 32 chunks and a layer 32 pieces); its stores sit
     // behind ONE not-taken scalar branch (EXEC-masking them instead was measured: every write to EXEC drains the MFMA pipe, +400 cycles
     // per chunk).
+// (the ring loads of the resident loop are inline asm: the compiler's own count merges conservatively at the loop's back edge and
+// asked for vmcnt(11) in front of a chunk's first MFMA -- two chunks of slack, not four.  By hand: behind load j of chunk c at least
+// 15 - j vector-memory operations are younger -- the rest of its chunk and the next three chunks' loads; stores and DMA in between
+// only add to that -- and loads retire in order, so vmcnt(15 - j) in front of the first MFMA that reads fragment j is safe.)
+#ifdef H_VAR_CLD
+#define H_WAITW(I, J)
+#else
+#define H_WAITW(I, J) if ((I) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(15 - (J)));
+#endif
 #define H_M(I, J, S, ZERO)                                                          \
+    H_WAITW(I, J)                                                                   \
     if (ZERO) h_mfma0<16 * (4 * (I) + (J))>(wr[S][J], af[I]);                       \
     else h_mfma<16 * (4 * (I) + (J))>(wr[S][J], af[I]);
 #define H_SB() __builtin_amdgcn_sched_barrier(0);
@@ -401,8 +411,10 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
 #define H_LW(S, J, OFF)
 #elif defined(H_VAR_HALF)     // (development: half the weight loads)
 #define H_LW(S, J, OFF) if ((J) < 2) wr[S][J] = *(glb_frag_p)(uintptr_t)(wp_ + OFF);
-#else
+#elif defined(H_VAR_CLD)    // (development: the ring loads as plain loads, waits placed by the compiler)
 #define H_LW(S, J, OFF) wr[S][J] = *(glb_frag_p)(uintptr_t)(wp_ + OFF);
+#else
+#define H_LW(S, J, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(wr[S][J]) : "v"(wp_));
 #endif
 #define H_TOUCH(DP)
 #if H_PLACE == 1
@@ -645,6 +657,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         }                                                                           \
         const bool skip_ = HD_SKIP(DC) != 0;                                        \
         const unsigned xn_ = lds0 + slot_off(min(k + 1 - rbeg, cap - 1)) + sl;      \
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   /* (this chunk's weights may come from the resident loop's asm loads) */ \
         H_STG_ROW(0, S, ZERO, skip_, xn_) H_STG_ROW(1, S, ZERO, skip_, xn_) H_STG_ROW(2, S, ZERO, skip_, xn_) H_STG_ROW(3, S, ZERO, skip_, xn_) \
         h_load_w(wr[S], H_WPTR(DW), wl);                                            \
         if (save_i < 32) save_piece();                                              \

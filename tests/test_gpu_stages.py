@@ -602,7 +602,7 @@ def test_mlp_forward_wide_kernel_matches_ring_kernel(case, M, lean):
     reps = (M + nz - 1) // nz
     runs = {}
     for name in ("ring", "wide"):
-        cc = dataclasses.replace(rcfg, fused_min_rows=1, fwd_kernel=name).to_c()
+        cc = dataclasses.replace(rcfg, fused_min_rows=1, fwd_kernel=name, wide_any_m=True).to_c()   # (SCENERF_FLAG_WIDE_ANY_M: also at small M)
         run = _MlpRun(M, d_out, 1, torch.device(DEV), lean=lean)
         run.Z.fill_(float("nan"))      # columns of scales a tile does not touch must never be read (beyond the dense first 256)
         run.Z[:, :256] = 0
@@ -666,7 +666,7 @@ def test_mlp_backward_fused_matches_layer_path(case, M):
     res = {}
     for name in ("layers", "fused", "wide"):
         # scenerf_cfg.flags: SCENERF_FLAG_NO_FUSED_BWD (per-layer dgrad GEMMs) / SCENERF_FLAG_WIDE_BWD (wide.hip's 128-row chain)
-        cc = dataclasses.replace(rcfg, fused_backward=(name != "layers"), bwd_kernel="wide" if name == "wide" else "ring").to_c()
+        cc = dataclasses.replace(rcfg, fused_backward=(name != "layers"), bwd_kernel="wide" if name == "wide" else "ring", wide_any_m=True).to_c()
         gs = pk.grad_sink()
         pk.gflat.zero_()
         dH = torch.zeros((M, 2048), dtype=torch.bfloat16, device=DEV)

@@ -18,7 +18,7 @@ pk = PackedMLP([torch.as_tensor(state[n]).to(dev) for n in MLP_PARAM_NAMES], 4, 
 gen = torch.Generator().manual_seed(1)
 ntile = (M + 127) // 128
 masks = torch.tensor(pat, dtype=torch.uint8)[torch.arange(ntile) % len(pat)]
-cfg = dataclasses.replace(rcfg, fused_min_rows=1, fwd_kernel="wide", bwd_kernel="wide")
+cfg = dataclasses.replace(rcfg, fused_min_rows=1, fwd_kernel="wide", bwd_kernel="wide", wide_any_m=True)
 cc = cfg.to_c()
 run = _MlpRun(M, 4, 1, dev)
 run.Z.copy_((torch.randn(ntile * 128, 2480, generator=gen) * 0.5).to(torch.bfloat16).to(dev))

@@ -45,7 +45,7 @@ def timed(rows, name):
 
 res = {}
 for name in ("ring", "wide"):
-    cfg = dataclasses.replace(rcfg, fused_min_rows=1, fwd_kernel=name, bwd_kernel=name)
+    cfg = dataclasses.replace(rcfg, fused_min_rows=1, fwd_kernel=name, bwd_kernel=name, wide_any_m=True)
     cc = cfg.to_c()
     run = _MlpRun(M, 4, 1, dev)
     run.Z.copy_(Z); run.xenc.copy_(X); run.tile_mask[:ntile] = masks.to(dev)
@@ -81,7 +81,7 @@ msg.append("sign bits equal %.6f" % (a.sign_bits[:6, :M] == b.sign_bits[:6, :M])
 print("forward  wide vs ring: " + "; ".join(msg))
 # the chains ran on different forward states (last-ulp differences): rerun the wide chain on the ring's state for a bit-exact check
 run = a
-cc = dataclasses.replace(rcfg, fused_min_rows=1, bwd_kernel="wide").to_c()
+cc = dataclasses.replace(rcfg, fused_min_rows=1, bwd_kernel="wide", wide_any_m=True).to_c()
 gs = pk.grad_sink()
 dH2 = torch.zeros_like(dHa); dN2 = torch.zeros_like(dNa)
 _capi.check(lib.scenerf_hip_mlp_backward(C.byref(cc), C.byref(pk.c), C.byref(gs), run.Z.data_ptr(), run.xenc.data_ptr(), run.tile_mask.data_ptr(),
