@@ -80,6 +80,7 @@ typedef struct scenerf_cfg {
 #define SCENERF_FLAG_NO_WGRAD_TR     2u  /* weight gradients through gemm_tn only (no transposing-read batched kernel) */
 #define SCENERF_FLAG_DFEAT_PER_SCALE 4u  /* feature-gradient GEMM + scatter as one launch per pyramid level (A/B runs) */
 #define SCENERF_FLAG_WGRAD_OVERLAP   8u  /* per-layer backward: weight-gradient GEMMs on an internal side stream */
+#define SCENERF_FLAG_DFEAT_GEMM     64u  /* bf16 feature-map gradients through the GEMM family's scatter epilogue (gemm.hip) instead of dfeat.hip (A/B runs) */
 #define SCENERF_FLAG_WIDE_ANY_M     32u  /* the 128-row kernels also below 192 row blocks (where the 64-row ones are faster): tests, probes */
 #define SCENERF_FLAG_WIDE_BWD       16u  /* fused dgrad chain on 128-row blocks, one wave per SIMD (wide.hip) instead of fused.hip's 64-row ring */
 

@@ -52,6 +52,7 @@ class RenderConfig:
     fwd_kernel: str = "wide"          # fused forward variant: "ring" (fused.hip), "stream" (stream.hip; bit-identical), "wide" (wide.hip: 128-row blocks)
     fused_backward: bool = True       # False: the dgrad chain as six per-layer GEMMs even where the fused chain applies
     wgrad_tr: bool = True             # False: weight gradients through gemm_tn only
+    dfeat_gemm: bool = False          # True: bf16 feature-map gradients through gemm.hip's scatter epilogue instead of dfeat.hip
     dfeat_per_scale: bool = False     # True: feature-gradient GEMM + scatter as one launch per pyramid level
     wgrad_overlap: bool = False       # True: per-layer backward runs the weight-gradient GEMMs on an internal side stream
     wide_any_m: bool = False          # True: the 128-row kernels also for launches of fewer than 192 row blocks (tests, probes)
@@ -132,7 +133,7 @@ class RenderConfig:
         c.fwd_kernel = {"ring": 0, "stream": 1, "wide": 2}[self.fwd_kernel]
         c.flags = ((0 if self.fused_backward else _capi.FLAG_NO_FUSED_BWD) | (0 if self.wgrad_tr else _capi.FLAG_NO_WGRAD_TR)
                    | (_capi.FLAG_DFEAT_PER_SCALE if self.dfeat_per_scale else 0) | (_capi.FLAG_WGRAD_OVERLAP if self.wgrad_overlap else 0)
-                   | (_capi.FLAG_WIDE_BWD if self.bwd_kernel == "wide" else 0) | (_capi.FLAG_WIDE_ANY_M if self.wide_any_m else 0))
+                   | (_capi.FLAG_WIDE_BWD if self.bwd_kernel == "wide" else 0) | (_capi.FLAG_WIDE_ANY_M if self.wide_any_m else 0) | (_capi.FLAG_DFEAT_GEMM if self.dfeat_gemm else 0))
         return c
 
     @staticmethod

@@ -1,0 +1,338 @@
+// Feature-map gradient of one ResnetFC pass for gfx950 (bf16): dZ = dH[:, 0:1536] @ Wz (the three lin_z layers read the same gathered
+// features z, so dz = sum_b dH_b Wz_b^T = one K = 1536 product), scattered straight into the (H,W,C) map gradients through the
+// bilinear taps the forward gather recorded = grid_sampler_2d_backward of reference scenerf/models/utils.py:232-247 (sample_feats_2d),
+// per pyramid level of scenerf.py:522-527.
+//
+// Why its own kernel (it was gemm_nt_kernel with a scatter epilogue: 397 us at the bench shape, 162 us of it the GEMM alone):
+//   * the product is HBM-bound by construction -- 472 MB of dH for 61 GFLOP at KITTI's scale mix -- so the goal is to read dH exactly
+//     once at memory speed and to keep everything else out of its way.  One workgroup = one 128-row tile (one ray at N = 128) and ALL
+//     the scales that tile touches: the accumulators of up to 8 column tiles (256 channels) live in registers, dH streams through once.
+//     Tiles that touch only the finest level (80 channels: 3 column tiles) run in a 3-tile instantiation with a third of the registers
+//     and four workgroups per CU; the host launches both, each workgroup leaves at once if the tile is the other kernel's;
+//   * the K loop stages dH and the weight rows through LDS by DMA (global_load_lds), 128 bytes of K per row and step, two stages:
+//     a 1-KiB piece is 8 whole row segments.  (A first version loaded the MFMA fragments straight into registers -- 32 rows x 32 B
+//     per wave instruction, i.e. 32 different pages per load, dH rows being 4 KiB apart -- and ran 2.3x SLOWER than the old kernel:
+//     address translation, not bandwidth.)  The 16-byte slots of a row are XOR-swizzled on the source side of the DMA;
+//   * the scatter: a ray's samples walk along an epipolar curve, so the 512 (sample, tap) pairs of a tile hit only ~90 distinct texels.
+//     Per tap the texel is constant over runs of consecutive samples, so a wave sums its rows per (tap, run) in registers and sends one
+//     atomic per (run, channel) -- see the epilogue.  (Measured dead ends, same results: a hash table texel -> slot with a counting
+//     sort and a segmented sum -- exact de-duplication, but three dependent LDS reads per entry: 31k cycles per round; LDS float
+//     atomics into a per-texel table -- rows that share a texel serialise on one address: 278k cycles per round.)
+#include "gemm.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_d;
+typedef __attribute__((ext_vector_type(16))) float f32x16_d;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_d;
+
+#define DF_BM 128
+#define DF_THREADS 256
+#define DF_K (3 * SCENERF_D_HIDDEN)        // 1536
+#define DF_NCH (DF_K / 16)                 // 96 chunks
+#define DF_PA 4                            // dH fragments in flight per wave
+#define DF_CG 96                           // channels per epilogue round: up to three column tiles (a lane takes channel l and l + 64)
+#define DF_CLD (DF_CG + 4)                 // staged row stride in floats
+// LDS (epilogue only): staged tile, taps of the level
+#define DF_L_CS 0
+#define DF_L_TX (DF_L_CS + DF_BM * DF_CLD * 4)        // 51200: [128 rows][4 taps] texel
+#define DF_L_TW (DF_L_TX + 512 * 4)                   //        [128 rows][4 taps] weight
+#define DF_L_MISC (DF_L_TW + 512 * 4)
+#ifndef DF_KSB
+#define DF_KSB 128                                    // bytes of K per row per K-loop step
+#endif
+#ifndef DF_NTB
+#define DF_NTB 4                                       // column tiles per pass of the general instantiation
+#endif
+// LDS of an instantiation: two K-loop stages of (128 + 32 NTP) rows, or the epilogue tables
+constexpr int df_lds(int ntp) { return 2 * (DF_BM + ntp * 32) * DF_KSB > DF_L_MISC + 32 ? 2 * (DF_BM + ntp * 32) * DF_KSB : DF_L_MISC + 32; }
+
+// 16 bytes per lane, global -> LDS: per-lane 64-bit source address, destination = M0 (wave-uniform LDS address) + 16 * lane
+__device__ static inline void df_glds16(const void* src, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_wave_base)
+                 : "memory");
+}
+
+struct DfeatArgs {
+    const void* dH;          // [M][ldh] bf16, the first DF_K columns are read
+    int ldh, M;
+    const uint8_t* tile_mask;
+    const int32_t* tap_texel;   // [M][5][4]
+    const float* tap_weight;    // [M][5][4]
+    const void* W[SCENERF_N_SCALES];   // per level: [C_s][DF_K] bf16 (lin_z weights of the three blocks side by side, transposed)
+    float* gmap[SCENERF_N_SCALES];     // NULL: that level needs no gradient
+    long st[SCENERF_N_SCALES], sc[SCENERF_N_SCALES];   // element strides of gmap per texel / per channel
+    int C[SCENERF_N_SCALES];
+};
+
+#ifdef H_CYC   // development build: per-workgroup time stamps of wave 0 (tools/dfeat_probe.py)
+__device__ unsigned long long* g_df_cyc = nullptr;
+extern "C" int scenerf_hip_test_dfeat_cyc(unsigned long long* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_df_cyc), &ptr, sizeof(ptr)); }
+#define DF_STAMP()                                                                                  \
+    if (wv == 0 && g_df_cyc && ci < 16) {                                                           \
+        if (lane == 0) g_df_cyc[(size_t)blockIdx.x * 16 + ci] = __builtin_amdgcn_s_memtime();       \
+        ++ci;                                                                                       \
+    }
+#else
+#define DF_STAMP()
+#endif
+
+// NTP = column tiles (32 channels each) whose accumulators a pass keeps in registers
+template <int NTP>
+__global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x, m0 = tile * DF_BM;
+    const unsigned mask = __builtin_amdgcn_readfirstlane((unsigned)p.tile_mask[tile] & 31u);
+    // this tile's column tiles, level by level (wave-uniform, a few scalar registers): (level, first channel)
+    int nt = 0;
+#pragma unroll
+    for (int s = 0; s < SCENERF_N_SCALES; ++s)
+        if (((mask >> s) & 1u) && p.gmap[s]) nt += (p.C[s] + 31) >> 5;
+    if (nt == 0) return;
+    // (the 3-tile instantiation takes the tiles it can hold in one pass, the 8-tile one everything else)
+    if (NTP <= 3 ? nt > NTP : nt <= 3) return;   // (3-tile kernel: nt <= 3; the other one: everything else, in passes)
+    auto tile_level = [&](int t, int& s_out, int& c0_out) __attribute__((always_inline)) {
+        int acc = 0;
+        s_out = 0; c0_out = 0;
+#pragma unroll
+        for (int s = 0; s < SCENERF_N_SCALES; ++s) {
+            const int n = (((mask >> s) & 1u) && p.gmap[s]) ? (p.C[s] + 31) >> 5 : 0;
+            if (t >= acc && t < acc + n) { s_out = s; c0_out = (t - acc) * 32; }
+            acc += n;
+        }
+    };
+
+    float* const Cs = (float*)(lds + DF_L_CS);
+    int* const s_tx = (int*)(lds + DF_L_TX);
+    float* const s_tw = (float*)(lds + DF_L_TW);
+#ifdef H_CYC
+    int ci = 0;
+#endif
+    DF_STAMP()   // 0: start
+
+    for (int t0 = 0; t0 < nt; t0 += NTP) {   // passes (one, except for tiles that touch more than 256 channels)
+        const int np = min(NTP, nt - t0);
+        // ---- K loop: acc[t] (C^T tiles: rows = channels, columns = this wave's 32 rows) += W_t[:, step] x dH[rows, step]
+        // stage = [128 rows of dH][KSB] ++ [NTP x 32 weight rows][KSB]; 16-byte slot q of row r sits at q ^ swz(r)
+        constexpr int KSB = DF_KSB;                       // bytes of K per row per step
+        constexpr int SL = KSB / 16;                      // slots per row
+        constexpr int RPP = 1024 / KSB;                   // rows per 1-KiB DMA piece
+        constexpr int NPA_ = DF_BM / RPP / 4;             // dH pieces per wave per step
+        constexpr int NWP = NTP * 32 / RPP;               // weight pieces per step
+        constexpr int NPW_ = (NWP + 3) / 4;               // ... per wave (the last wave may have fewer)
+        constexpr int STG = (DF_BM + NTP * 32) * KSB;
+        constexpr int NSTEP = DF_K * 2 / KSB;
+        static_assert(2 * STG <= df_lds(NTP), "stages must fit the workgroup's LDS");
+        auto swz = [](int r) { return KSB == 128 ? (r >> 1) & 7 : (r >> 2) & 3; };
+        static_assert(KSB == 128 || KSB == 64, "swizzle is written for 8 or 4 slots per row");
+        f32x16_d acc[NTP];
+#pragma unroll
+        for (int t = 0; t < NTP; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        // DMA sources of this wave's pieces: lane -> (row of the piece, physical slot), fetching logical slot physical ^ swz(row)
+        const char* srcA[NPA_];
+        const char* srcW[NPW_];
+        bool okW[NPW_];
+        {
+            const int rp = lane / SL, ps = lane % SL;
+#pragma unroll
+            for (int i = 0; i < NPA_; ++i) {
+                const int r = (wv * NPA_ + i) * RPP + rp;
+                srcA[i] = (const char*)p.dH + (size_t)min(m0 + r, p.M - 1) * (p.ldh * 2) + ((ps ^ swz(r)) << 4);
+            }
+#pragma unroll
+            for (int i = 0; i < NPW_; ++i) {
+                const int r = (wv * NPW_ + i) * RPP + rp;     // row of the weight stage: tile r / 32, channel r % 32 of it
+                const int t = r >> 5;
+                int sl, c0;
+                tile_level(t0 + min(t, np - 1), sl, c0);
+                okW[i] = wv * NPW_ + i < NWP && (((wv * NPW_ + i) * RPP) >> 5) < np;   // (wave-uniform; a piece never straddles tiles)
+                srcW[i] = (const char*)p.W[sl] + (size_t)min(c0 + (r & 31), p.C[sl] - 1) * (DF_K * 2) + ((ps ^ swz(r)) << 4);
+            }
+        }
+        const unsigned lds0 = (unsigned)(uintptr_t)lds;
+        auto issue = [&](const int step) __attribute__((always_inline)) {
+            const unsigned sb = lds0 + (step & 1) * STG;
+            const unsigned ko = (unsigned)step * KSB;
+            // (weights first: the dH pieces are then the youngest operations of the step)
+#pragma unroll
+            for (int i = 0; i < NPW_; ++i)
+                if (okW[i]) df_glds16(srcW[i] + ko, __builtin_amdgcn_readfirstlane(sb + DF_BM * KSB + (wv * NPW_ + i) * 1024));
+#pragma unroll
+            for (int i = 0; i < NPA_; ++i)
+                df_glds16(srcA[i] + ko, __builtin_amdgcn_readfirstlane(sb + (wv * NPA_ + i) * 1024));
+        };
+        __syncthreads();   // (the previous pass's epilogue is done with the LDS the stages live in)
+        issue(0);
+        const int frow = 32 * wv + (lane & 31), fh = lane >> 5;
+#pragma unroll 1
+        for (int step = 0; step < NSTEP; ++step) {
+            if (step + 1 < NSTEP) {
+                issue(step + 1);
+                // this step's pieces landed: at most the next step's dH pieces -- the youngest NPA_ operations -- may be outstanding
+                // (issued in order, retired in order; the next step's weight pieces, fewer on some waves, are waited for too)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPA_) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            const char* const sa = lds + (step & 1) * STG;
+            const char* const sw = sa + DF_BM * KSB;
+#pragma unroll
+            for (int j = 0; j < KSB / 32; ++j) {
+                const bf16x8_d av = *(const bf16x8_d*)(sa + frow * KSB + (((2 * j + fh) ^ swz(frow)) << 4));
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) {
+                    if (t < np) {
+                        const int wr = t * 32 + (lane & 31);
+                        const bf16x8_d bv = *(const bf16x8_d*)(sw + wr * KSB + (((2 * j + fh) ^ swz(wr)) << 4));
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();   // everyone is done with this stage before the step after next overwrites it
+        }
+
+        DF_STAMP()   // K loop done
+        // ---- epilogue: level by level, up to three column tiles (96 channels) per round
+        int tb = 0;
+        int taps_level = -1;
+        while (tb < np) {
+            int s, c0;
+            tile_level(t0 + tb, s, c0);
+            int te = tb;
+            {
+                int s2, c2;
+                while (te < np) {
+                    tile_level(t0 + te, s2, c2);
+                    if (s2 != s) break;
+                    ++te;
+                }
+            }
+            float* const g = p.gmap[s];
+            const long gst = p.st[s], gsc = p.sc[s];
+            for (int tr = tb; tr < te; tr += 3) {
+                __syncthreads();   // (the K loop / the previous round is done with this LDS)
+                if (taps_level != s) {
+                    for (int i = tid; i < 512; i += DF_THREADS) {
+                        const int m = m0 + (i >> 2);
+                        const size_t o = ((size_t)min(m, p.M - 1) * SCENERF_N_SCALES + s) * 4 + (i & 3);
+                        s_tx[i] = m < p.M ? p.tap_texel[o] : -1;
+                        s_tw[i] = m < p.M ? p.tap_weight[o] : 0.f;
+                    }
+                    taps_level = s;
+                }
+                // stage: lane = row (lane & 31) of the wave's 32, quads of 4 consecutive channels 8 q + 4 hi
+                const int row = 32 * wv + (lane & 31), hi = lane >> 5;
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) {
+                    if (t >= tr && t < tr + 3 && t < te) {
+                        const int cb = (t - tr) * 32;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *(float4*)(Cs + row * DF_CLD + cb + 8 * q + 4 * hi) =
+                                make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+                    }
+                }
+                __syncthreads();
+                // scatter.  A ray's samples are sorted along the ray and their texels advance slowly, so for each of the four taps the
+                // texel is constant over runs of consecutive rows: a wave walks its 32 rows in order (eight rows of independent LDS
+                // reads in flight: staged values, tap texels, tap weights -- no indirection), keeps one running sum per tap (lanes =
+                // channels l and l + 64) and sends ONE atomic per (run, channel) when a tap's texel changes: ~30 runs per tap and ray
+                // instead of 128 rows -- 256-byte contiguous runs of the (H,W,C) accumulator.
+                int s3, cbase;
+                tile_level(t0 + tr, s3, cbase);
+                const int nch = min(32 * (min(tr + 3, te) - tr), p.C[s] - cbase);   // valid channels of the round
+                const bool ok0 = lane < nch, ok1 = lane + 64 < nch;
+                float* const gl = g + (size_t)(cbase + lane) * gsc;
+                const long g64 = 64 * gsc;
+                int cur[4] = {-1, -1, -1, -1};
+                float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
+                const int r0 = 32 * wv;
+#pragma unroll 1
+                for (int rb = 0; rb < 32; rb += 8) {
+                    float c0v[8], c1v[8];
+                    int4 t4[8];
+                    float4 w4[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = r0 + rb + j;
+                        c0v[j] = Cs[r * DF_CLD + lane];
+                        c1v[j] = Cs[r * DF_CLD + 64 + (lane & 31)];
+                        t4[j] = *(const int4*)(s_tx + r * 4);
+                        w4[j] = *(const float4*)(s_tw + r * 4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int tk[4] = {t4[j].x, t4[j].y, t4[j].z, t4[j].w};
+                        const float wk[4] = {w4[j].x, w4[j].y, w4[j].z, w4[j].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int t_ = __builtin_amdgcn_readfirstlane(tk[k]);
+                            if (t_ != cur[k]) {   // wave-uniform
+                                if (cur[k] >= 0) {
+                                    float* const gp = gl + (size_t)cur[k] * gst;
+                                    if (ok0) unsafeAtomicAdd(gp, v0[k]);
+                                    if (ok1) unsafeAtomicAdd(gp + g64, v1[k]);
+                                }
+                                cur[k] = t_; v0[k] = 0.f; v1[k] = 0.f;
+                            }
+                            v0[k] = fmaf(wk[k], c0v[j], v0[k]);
+                            v1[k] = fmaf(wk[k], c1v[j], v1[k]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (cur[k] >= 0) {
+                        float* const gp = gl + (size_t)cur[k] * gst;
+                        if (ok0) unsafeAtomicAdd(gp, v0[k]);
+                        if (ok1) unsafeAtomicAdd(gp + g64, v1[k]);
+                    }
+                }
+                DF_STAMP()   // round scattered
+            }
+            tb = te;
+        }
+    }
+}
+
+int launch_dfeat_scatter(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const uint8_t* tile_mask, const int32_t* tap_texel,
+                         const float* tap_weight, int M, const void* dH, float* const gmaps[SCENERF_N_SCALES], hipStream_t s) {
+    SRF_ONCE_PER_DEVICE(
+        SRF_HIP(hipFuncSetAttribute((const void*)dfeat_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, df_lds(3)));
+        SRF_HIP(hipFuncSetAttribute((const void*)dfeat_kernel<DF_NTB>, hipFuncAttributeMaxDynamicSharedMemorySize, df_lds(DF_NTB))));
+    DfeatArgs p = {};
+    p.dH = dH; p.ldh = 4 * SCENERF_D_HIDDEN; p.M = M;
+    p.tile_mask = tile_mask; p.tap_texel = tap_texel; p.tap_weight = tap_weight;
+    bool any = false;
+    for (int sc = 0; sc < SCENERF_N_SCALES; ++sc) {
+        p.W[sc] = w->w_z_t[sc];
+        p.gmap[sc] = gmaps[sc];
+        p.C[sc] = cfg->map_C[sc];
+        p.st[sc] = cfg->map_C[sc]; p.sc[sc] = 1;                                                          // (H,W,C)
+        if (cfg->map_chw[sc]) { p.st[sc] = 1; p.sc[sc] = (long)cfg->map_H[sc] * cfg->map_W[sc]; }       // (C,H,W)
+        any = any || gmaps[sc];
+    }
+    if (!any) return 0;
+    const int tiles = cdiv(M, DF_BM);
+    double flops = 0;   // FLOPs issued (profile mode only; synchronises to read the scale-activity mask)
+    if (srf_prof_on()) {
+        std::vector<uint8_t> hm(tiles, 0x1f);
+        if (hipMemcpyAsync(hm.data(), tile_mask, tiles, hipMemcpyDeviceToHost, s) == hipSuccess) (void)hipStreamSynchronize(s);
+        for (int t = 0; t < tiles; ++t) {
+            const int rows = M - t * DF_BM < DF_BM ? M - t * DF_BM : DF_BM;
+            for (int sc = 0; sc < SCENERF_N_SCALES; ++sc)
+                if (((hm[t] >> sc) & 1) && gmaps[sc]) flops += 2.0 * rows * (double)cfg->map_C[sc] * DF_K;
+        }
+    }
+    SrfLaunchScope ps(s, w->d_out == 2 ? "gemm_dfeat_scatter/g" : "gemm_dfeat_scatter", flops, 0);
+    dfeat_kernel<3><<<tiles, DF_THREADS, df_lds(3), s>>>(p);
+    dfeat_kernel<DF_NTB><<<tiles, DF_THREADS, df_lds(DF_NTB), s>>>(p);
+    SRF_LAUNCH_CHECK("dfeat_kernel");
+    return 0;
+}

@@ -90,6 +90,9 @@ int launch_mlp_bwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, i
                          hipStream_t s);
 // wgrad.hip: bf16 weight-gradient GEMM on transposing LDS reads (256 x 256 output tiles, wave-specialised); launch_gemm_tn uses it
 // for the shapes it fits
+// dfeat.hip: feature-map gradients of one pass (dZ = dH[:, 0:1536] @ Wz scattered through the forward's bilinear taps), bf16
+int launch_dfeat_scatter(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const uint8_t* tile_mask, const int32_t* tap_texel,
+                         const float* tap_weight, int M, const void* dH, float* const gmaps[SCENERF_N_SCALES], hipStream_t s);
 bool wgrad_tr_applicable(const GemmTN& p);
 int launch_wgrad_tr(const GemmTN& p, hipStream_t s);
 int launch_wgrad_tr_batch(const GemmTN* probs, int count, hipStream_t s);   // same (M, N, K) for all: one launch, one atomic flush

@@ -224,6 +224,12 @@ static int feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
                          const float* tap_weight, int M, const void* dH, float* const gmaps_hwc[SCENERF_N_SCALES], hipStream_t s) {
     const bool head = w->d_out == 2;
     const bool per_scale = (cfg->flags & SCENERF_FLAG_DFEAT_PER_SCALE) != 0;   // one launch per scale (the older form), for A/B runs
+    // bf16: the dedicated kernel (dfeat.hip: dH read once, tile-level texel reduction in LDS); fp32 and the A/B flags: the GEMM family's
+    // scatter epilogue
+    // (one workgroup per 128-row tile: needs enough tiles to fill the chip, and rows whose taps run along a ray -- the gaussian
+    // head's 4,800 anchor rows are 38 tiles of unrelated texels: 270 us there against 82 us through the GEMM)
+    if (cfg->precision && !per_scale && !(cfg->flags & SCENERF_FLAG_DFEAT_GEMM) && cdiv(M, 128) >= SRF_WIDE_MIN_BLOCKS)
+        return launch_dfeat_scatter(cfg, w, tile_mask, tap_texel, tap_weight, M, dH, gmaps_hwc, s);
     GemmNT g;
     g.name = head ? "gemm_dfeat_scatter/g" : "gemm_dfeat_scatter";
     g.A1 = dH; g.lda1 = 4 * SCENERF_D_HIDDEN; g.K1 = 3 * SCENERF_D_HIDDEN;
