@@ -53,10 +53,11 @@ def pmc_traffic(logical_name):
         d = json.load(open(files[-1]))
     except Exception:
         return None
+    # (the fused passes run as wide.hip's 128-row kernels where the launch is big enough, else as fused.hip's 64-row ones)
     if logical_name.startswith("mlp_fwd_fused"):
-        fn = "mlp_fused_kernel<0>"
+        fn = "mlp_wide_kernel<0>" if any(k.startswith("mlp_wide_kernel<0>") for k in d) and not logical_name.endswith("/g") else "mlp_fused_kernel<0>"
     elif logical_name.startswith("mlp_bwd_fused"):
-        fn = "mlp_fused_kernel<1>"
+        fn = "mlp_wide_kernel<1>" if any(k.startswith("mlp_wide_kernel<1>") for k in d) and not logical_name.endswith("/g") else "mlp_fused_kernel<1>"
     elif "wgrad" in logical_name:
         fn = "gemm_tn_kernel"
     else:
