@@ -24,7 +24,8 @@
 //     layers 2 and 4 through the stage -- which at the common scale mask (finest level only: 5 chunks) still holds them from layer 0,
 //     so those layers issue no DMA at all; other masks re-fetch per round of 6 chunks, the first round issued at the layer's start;
 //   * layer epilogue: accumulators + bias (+ residual) -> bf16 -> relu -> A buffer, between two barriers (backward: gate by the
-//     forward's sign bits instead of bias / relu); the finished layer is streamed out of the A buffer (coalesced 16-byte pieces +
+//     forward's sign bits instead of bias / relu); lin_out (512 -> 4) runs on the matrix cores too, from the resident H3 tile against a
+//     three-term bf16 split of its fp32 weights; the finished layer is streamed out of the A buffer (coalesced 16-byte pieces +
 //     sign bits, as in fused.hip) one piece per chunk of the next layer.
 // Results: same rounding points as fused.hip / stream.hip; the forward adds the bias after the K sum instead of before it and sums
 // layer 0's K segments in a different order, so activations agree with those kernels to the last bf16 ulp, not bit for bit; the
@@ -302,6 +303,11 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         H_STAMP()   // everyone arrived
         char* const wr0 = Abuf + (ln & 31) * F_AROW + 8 * hi;
 #define H_GATE(I, J) (MODE == 1 ? ((J) == 0 ? gt[I].x : (J) == 1 ? gt[I].y : (J) == 2 ? gt[I].z : gt[I].w) >> (4 * hi) : 0u)
+#ifdef H_VAR_EPI4
+#define H_EPI_MIDSB
+#else
+#define H_EPI_MIDSB __builtin_amdgcn_sched_barrier(0);
+#endif
 #define H_EPI_JQ(J, Q)                                                                                          \
     {                                                                                                           \
         const float4 bq = bn;                                                                                   \
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
            residual unpacking to the top -- 256 more live registers */                                             \
         h_epi_quad<MODE, is_res, 0, J, Q>(bq, H_GATE(0, J), hp[0][J], wr0, wvu * 16 + (J) * 4, axor);           \
         h_epi_quad<MODE, is_res, 1, J, Q>(bq, H_GATE(1, J), hp[1][J], wr0 + 32 * F_AROW, wvu * 16 + (J) * 4, axor); \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        H_EPI_MIDSB                                                                                             \
         h_epi_quad<MODE, is_res, 2, J, Q>(bq, H_GATE(2, J), hp[2][J], wr0 + 64 * F_AROW, wvu * 16 + (J) * 4, axor); \
         h_epi_quad<MODE, is_res, 3, J, Q>(bq, H_GATE(3, J), hp[3][J], wr0 + 96 * F_AROW, wvu * 16 + (J) * 4, axor); \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
@@ -703,15 +709,11 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
             epilogue(std::false_type(), 1 + 2 * b);
             if (tail && !zres) dma_round(c + 32, 0, min(H_ZCAP, nzr));   // round 0 of this layer's lin_z tail: the stage is idle until then
             if (b == 2 && p.logits) {
-                // lin_out's weights (fp32 [d_out][512]) -> the stage, which nobody reads any more: 1 KiB pieces, two per wave.  16-byte
-                // unit u of row j holds float4 (u ^ 2 ((u >> 4) & 7)) of that row: the eight threads of an activation row, which read
-                // units 16 apart at the same time, then hit eight different bank groups.  Retired (in issue order) long before the tail.
+                // lin_out's weights (fp32 [d_out][512]) -> the stage, which nobody reads any more: 1 KiB pieces.  Retired (in issue
+                // order) long before the tail, which splits them into bf16 triples.
                 H_LANE();
-                for (int k = wvu; k < p.d_out * 2; k += 4) {
-                    const int u = (k & 1) * 64 + ln;
-                    h_glds16((const char*)p.w_out + (k >> 1) * 2048, (unsigned)((u ^ (2 * ((u >> 4) & 7))) << 4),
-                             __builtin_amdgcn_readfirstlane(lds0 + H_ZS + k * 1024));
-                }
+                for (int k = wvu; k < p.d_out * 2; k += 4)
+                    h_glds16((const char*)p.w_out + k * 1024, (unsigned)(ln << 4), __builtin_amdgcn_readfirstlane(lds0 + H_ZS + k * 1024));
             }
             resident_run();
             if (tail) staged_run(nz, nzr, H_ZCAP, zres ? 2 : 1, false);
@@ -776,57 +778,65 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     }
     H_STAMP()   // last layer streamed out
     if (do_out) {
-        // lin_out on the rectified H3 tile still resident in the A buffer (all waves are past the last epilogue's second barrier, and
-        // w_out has been in the stage since the last layer began): 8 threads per row take 64 columns each, a butterfly adds the partials
-        // (same summation order as fused.hip); a thread keeps its 64 columns of w_out in registers across its four rows
-        const float* wl = (const float*)(lds + H_ZS);
-        const int t = wvu * 64 + ln;
-        const int part = t & 7;
-        float o[4][4];
+        // lin_out on the rectified H3 tile still resident in the A buffer, on the matrix cores: logits^T = [w_hi ; w_mid ; w_lo] (12 of an
+        // MFMA's 32 rows) x H3^T, the fp32 weights split into three bf16 terms (w = hi + mid + lo to 24 bits; the bf16 activations times
+        // each term are exact in the fp32 accumulator), one MFMA per 16-wide K chunk and row tile -- a wave takes one row tile: 32 MFMAs.
+        // (As fp32 FMAs on the vector unit this tail took 14k cycles per block: 1,024 dependent FMAs per lane, LDS round trips, a butterfly.)
+        // Stage: raw w_out at H_ZS (8 KiB, DMA'd while the last layer ran), the 13 operand rows (4 hi, 4 mid, 4 lo, 1 zero) at
+        // H_ZS + 8 KiB in the A buffer's layout (1 KiB rows, 16-byte slot s at s ^ (row & 15)).
+        char* const wsp = lds + H_ZS + 8192;
+        {
+            const int t = wvu * 64 + ln, j = t >> 6, k8 = t & 63;   // thread: 8 consecutive k of weight row j
+            const float* const raw = (const float*)(lds + H_ZS) + j * SCENERF_D_HIDDEN + k8 * 8;
+            float w[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (j < p.d_out) {
+                const float4 lo = *(const float4*)raw, hi4 = *(const float4*)(raw + 4);
+                w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w; w[4] = hi4.x; w[5] = hi4.y; w[6] = hi4.z; w[7] = hi4.w;
+            }
+            uint32_t part[3][4];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+            for (int e = 0; e < 4; ++e) {
+                float r0 = w[2 * e], r1 = w[2 * e + 1];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[rb][j] = 0.f;
-#pragma unroll 1
-        for (int s8 = 0; s8 < 8; ++s8) {
-            const int slot = part * 8 + s8;
-            float4 w0[4], w1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j < p.d_out) {   // (units 2 slot, 2 slot + 1 of row j, swizzled as staged)
-                    w0[j] = *(const float4*)(wl + j * 512 + (((2 * slot) ^ (2 * part)) << 2));
-                    w1[j] = *(const float4*)(wl + j * 512 + (((2 * slot + 1) ^ (2 * part)) << 2));
-                } else {
-                    w0[j] = w1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int sp = 0; sp < 3; ++sp) {
+                    const uint32_t pk = pack_bf16x2(r0, r1);
+                    part[sp][e] = pk;
+                    r0 -= bf16lo(pk);
+                    r1 -= bf16hi(pk);
                 }
             }
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                const int row = rb * 32 + (t >> 3);
-                const uint4 v = *(const uint4*)(Abuf + row * F_AROW + ((slot ^ (row & 15)) << 4));
-                const float f[8] = {bf16lo(v.x), bf16hi(v.x), bf16lo(v.y), bf16hi(v.y), bf16lo(v.z), bf16hi(v.z), bf16lo(v.w), bf16hi(v.w)};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {   // (same summation order as fused.hip: slot by slot, element by element)
-                    o[rb][j] = fmaf(f[0], w0[j].x, o[rb][j]); o[rb][j] = fmaf(f[1], w0[j].y, o[rb][j]);
-                    o[rb][j] = fmaf(f[2], w0[j].z, o[rb][j]); o[rb][j] = fmaf(f[3], w0[j].w, o[rb][j]);
-                    o[rb][j] = fmaf(f[4], w1[j].x, o[rb][j]); o[rb][j] = fmaf(f[5], w1[j].y, o[rb][j]);
-                    o[rb][j] = fmaf(f[6], w1[j].z, o[rb][j]); o[rb][j] = fmaf(f[7], w1[j].w, o[rb][j]);
-                }
+            for (int sp = 0; sp < 3; ++sp) {
+                const int row = 4 * sp + j;
+                *(uint4*)(wsp + row * F_AROW + ((k8 ^ (row & 15)) << 4)) = make_uint4(part[sp][0], part[sp][1], part[sp][2], part[sp][3]);
             }
+            if (t < 64) *(uint4*)(wsp + 12 * F_AROW + ((t ^ 12) << 4)) = make_uint4(0u, 0u, 0u, 0u);   // the zero row every other output row reads
         }
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            const int row = rb * 32 + (t >> 3);
+        __syncthreads();
+        {
+            const int n = min(ln & 31, 12), hi = ln >> 5;
+            const unsigned wb = lds0 + H_ZS + 8192 + (unsigned)(n * F_AROW);
+            const unsigned ab = lds0 + (unsigned)((32 * wvu + (ln & 31)) * F_AROW);
+            const int ax = ln & 15, wx = n & 15;
+            hfrag wf = *(lds_frag_p)(uintptr_t)(wb + ((hi ^ wx) << 4));
+            hfrag xf = *(lds_frag_p)(uintptr_t)(ab + ((hi ^ ax) << 4));
+            h_mfma0<0>(wf, xf);
+#pragma unroll 4
+            for (int cc = 1; cc < SCENERF_D_HIDDEN / F_BK; ++cc) {
+                wf = *(lds_frag_p)(uintptr_t)(wb + (((2 * cc + hi) ^ wx) << 4));
+                xf = *(lds_frag_p)(uintptr_t)(ab + (((2 * cc + hi) ^ ax) << 4));
+                h_mfma<0>(wf, xf);
+            }
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (MFMA results -> v_accvgpr_read)
+            // C^T tile: lane = activation row (ln & 31), output rows 8 (r >> 2) + (r & 3) + 4 hi: hi = 0 holds the hi term (r = j) and the lo
+            // term (r = 4 + j), hi = 1 the mid term (r = j)
+            const float a0[4] = {h_acc<0>(), h_acc<1>(), h_acc<2>(), h_acc<3>()};
+            const float a1[4] = {h_acc<4>(), h_acc<5>(), h_acc<6>(), h_acc<7>()};
+            const int row = 32 * wvu + (ln & 31);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                o[rb][j] += __shfl_xor(o[rb][j], 1);
-                o[rb][j] += __shfl_xor(o[rb][j], 2);
-                o[rb][j] += __shfl_xor(o[rb][j], 4);
-            }
-            if (part == 0 && m0 + row < p.M) {
-                #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < p.d_out) p.logits[(size_t)(m0 + row) * p.d_out + j] = o[rb][j] + bo[j];
+                const float mid = __shfl_xor(a0[j], 32, 64);
+                if (hi == 0 && j < p.d_out && m0 + row < p.M) p.logits[(size_t)(m0 + row) * p.d_out + j] = (a0[j] + mid) + a1[j] + bo[j];
             }
         }
     }
