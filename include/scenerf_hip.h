@@ -259,6 +259,21 @@ int scenerf_hip_sampler_backward(const scenerf_cfg* cfg, const float* offsets, c
                                  const float* g_gmeans, const float* g_gstds, int R, float* d_offsets /*[R][G][2]*/,
                                  scenerf_stream_t stream);
 
+/* ---- loss-side gathers fused with the renderer's per-ray outputs ------------------------------------------ */
+/* scenerf.py:302-307 (colour L1 against sample_pix_features of the source image, utils.py:250-266) and compute_reprojection_loss,
+ * scenerf.py:349-386 (unproject at the rendered depth, transform, project utils.py:298-315, sample the target image, min(L1, identity
+ * L1 + noise), mean over the rays whose target point has z > 0), one thread per ray.  Everything is device memory, fp32: cam_K /
+ * inv_K row-major 3x3, T_source2target row-major 4x4.  noise [R] may be NULL.  Outputs: loss_color [R][3],
+ * loss_reprojection [1]; ray_term / valid / dterm_ddepth [R], col_src [R][3], acc2 [2] are kept for the backward. */
+int scenerf_hip_loss_side_forward(const float* pix, const float* color, const float* depth, const float* img_source,
+                                  const float* img_target, const float* noise, const float* cam_K, const float* inv_K,
+                                  const float* T_source2target, int R, int H, int W, float* loss_color, float* ray_term, float* valid,
+                                  float* dterm_ddepth, float* col_src, float* acc2, float* loss_reprojection, scenerf_stream_t stream);
+/* its autograd w.r.t. the rendered colour and depth (the images carry no gradient in the reference).  Upstream NULL = 0. */
+int scenerf_hip_loss_side_backward(const float* color, const float* col_src, const float* valid, const float* dterm_ddepth,
+                                   const float* acc2, const float* g_loss_color, const float* g_loss_reprojection, int R,
+                                   float* g_color, float* g_depth, scenerf_stream_t stream);
+
 /* ---- generic building blocks exported for unit tests ------------------------------------------------------- */
 /* C[M][N] = relu?(A[M][K]) @ W[N][K]^T (+bias); act operands per `precision`, fp32 output.
  * tile: 0 = chosen by shape, 1 = 128x128 workgroup tile, 2 = 128x512 (N must be 512). */

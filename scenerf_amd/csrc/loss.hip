@@ -1,0 +1,157 @@
+// Loss-side gathers of a training step for gfx950, fused with the renderer's per-ray outputs: for every ray the
+// source colour (sample_pix_features, reference scenerf/models/utils.py:250-266), |rendered colour - source colour|
+// (scenerf.py:302-307) and the photometric reprojection term of scenerf.py:349-386 -- back-project the pixel at the rendered depth,
+// move it into the target frame, project (utils.py:298-315), sample the target image there and at the source pixel, min(L1, L1 of the
+// identity reprojection + noise) -- plus its masked mean over the rays whose target point lies in front of the camera.  One thread per
+// ray does all of it in registers (three bilinear samples, two 4x4 transforms); the derivative of a ray's term w.r.t. its rendered
+// depth is closed-form (through the projection and the bilinear weights) and is produced by the same pass, so the backward is one
+// multiply per ray.  The reference spends ~25 eager kernels and two boolean-index host syncs on this.
+#include "common.h"
+
+struct LossArgs {
+    const float* pix;        // [R][2] source pixels
+    const float* color;      // [R][3] rendered colour
+    const float* depth;      // [R] rendered depth
+    const float* img_s;      // [3][H][W]
+    const float* img_t;      // [3][H][W]
+    const float* noise;      // [R] or NULL: added to the identity term (the reference draws randn * 1e-5 there)
+    const float *K, *invK, *T;    // device: row-major 3x3, 3x3, and the 4x4 source->target transform (top three rows are read)
+    int R, H, W;
+    float* loss_color;       // [R][3]
+    float* ray_term;         // [R] min(reprojection, identity)
+    float* valid;            // [R] 1 if the target point is in front of the camera
+    float* dterm_ddepth;     // [R] derivative of ray_term w.r.t. depth (0 where the identity term wins or the projection is clamped)
+    float* col_src;          // [R][3] (kept: the colour loss's sign in the backward)
+    float* loss_rep;         // [1] masked mean of ray_term (atomically accumulated numerator / denominator in acc[0..1])
+    float* acc;              // [2] zeroed by the caller
+};
+
+// bilinear sample of one channel plane at pixel coords (px, py), grid_sample(align_corners=False, padding zeros) of utils.py:250-266:
+// x = px / (W - 1) * W - 0.5.  Returns the value and its derivatives w.r.t. px, py.
+__device__ static inline void bilin3(const float* img, int H, int W, float px, float py, float (&v)[3], float (&dx)[3], float (&dy)[3]) {
+    const float sx = (float)W / (float)(W - 1), sy = (float)H / (float)(H - 1);
+    // the reference's operation order: g = (p / (W - 1) - 0.5) * 2 ; x = ((g + 1) * W - 1) / 2
+    const float gx = (px / (float)(W - 1) - 0.5f) * 2.f, gy = (py / (float)(H - 1) - 0.5f) * 2.f;
+    const float x = ((gx + 1.f) * (float)W - 1.f) * 0.5f, y = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    const float x0f = floorf(x), y0f = floorf(y);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float fx = x - x0f, fy = y - y0f;
+    const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W, oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
+    const size_t plane = (size_t)H * W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* p = img + c * plane;
+        const float a = (okx0 && oky0) ? p[(size_t)y0 * W + x0] : 0.f, b = (okx1 && oky0) ? p[(size_t)y0 * W + x0 + 1] : 0.f;
+        const float d = (okx0 && oky1) ? p[(size_t)(y0 + 1) * W + x0] : 0.f, e = (okx1 && oky1) ? p[(size_t)(y0 + 1) * W + x0 + 1] : 0.f;
+        v[c] = a * (1.f - fx) * (1.f - fy) + b * fx * (1.f - fy) + d * (1.f - fx) * fy + e * fx * fy;
+        dx[c] = ((b - a) * (1.f - fy) + (e - d) * fy) * sx;
+        dy[c] = ((d - a) * (1.f - fx) + (e - b) * fx) * sy;
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_side_fwd_kernel(LossArgs p) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    float term = 0.f, val = 0.f;
+    if (r < p.R) {
+        const float px = p.pix[2 * r], py = p.pix[2 * r + 1], depth = p.depth[r];
+        float cs[3], ci[3], ct[3], d0[3], d1[3], tx[3], ty[3];
+        bilin3(p.img_s, p.H, p.W, px, py, cs, d0, d1);
+        bilin3(p.img_t, p.H, p.W, px, py, ci, d0, d1);
+        // back-project, transform, project (scenerf.py:355-368)
+        const float vx = p.invK[0] * px + p.invK[1] * py + p.invK[2], vy = p.invK[3] * px + p.invK[4] * py + p.invK[5],
+                    vz = p.invK[6] * px + p.invK[7] * py + p.invK[8];
+        const float sxp = depth * vx, syp = depth * vy, szp = depth * vz;
+        const float cx = p.T[0] * sxp + p.T[1] * syp + p.T[2] * szp + p.T[3], cy = p.T[4] * sxp + p.T[5] * syp + p.T[6] * szp + p.T[7],
+                    cz = p.T[8] * sxp + p.T[9] * syp + p.T[10] * szp + p.T[11];
+        // d(cam_tgt) / d(depth) = R v
+        const float rx = p.T[0] * vx + p.T[1] * vy + p.T[2] * vz, ry = p.T[4] * vx + p.T[5] * vy + p.T[6] * vz,
+                    rz = p.T[8] * vx + p.T[9] * vy + p.T[10] * vz;
+        const float hx = p.K[0] * cx + p.K[1] * cy + p.K[2] * cz, hy = p.K[3] * cx + p.K[4] * cy + p.K[5] * cz,
+                    hz = p.K[6] * cx + p.K[7] * cy + p.K[8] * cz;
+        const float gx = p.K[0] * rx + p.K[1] * ry + p.K[2] * rz, gy = p.K[3] * rx + p.K[4] * ry + p.K[5] * rz,
+                    gz = p.K[6] * rx + p.K[7] * ry + p.K[8] * rz;
+        val = cz > 0.f ? 1.f : 0.f;
+        const bool front = hz > 0.f;
+        const float qx = front ? hx / hz : -1.f, qy = front ? hy / hz : -1.f;
+        const float dqx = front ? (gx * hz - hx * gz) / (hz * hz) : 0.f, dqy = front ? (gy * hz - hy * gz) / (hz * hz) : 0.f;
+        bilin3(p.img_t, p.H, p.W, qx, qy, ct, tx, ty);
+        float l_rep = 0.f, l_id = 0.f, dl = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float e = ct[c] - cs[c];
+            l_rep += fabsf(e);
+            dl += (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * (tx[c] * dqx + ty[c] * dqy);
+            l_id += fabsf(ci[c] - cs[c]);
+            const float col = p.color[3 * r + c];
+            p.loss_color[3 * r + c] = fabsf(col - cs[c]);
+            p.col_src[3 * r + c] = cs[c];
+        }
+        l_rep *= (1.f / 3.f);
+        l_id = l_id * (1.f / 3.f) + (p.noise ? p.noise[r] : 0.f);
+        const bool rep = l_rep <= l_id;   // torch.minimum: the gradient goes to the reprojection term where it is the smaller (or equal)
+        term = rep ? l_rep : l_id;
+        p.ray_term[r] = term;
+        p.valid[r] = val;
+        p.dterm_ddepth[r] = rep ? dl * (1.f / 3.f) : 0.f;
+    }
+    // masked mean: numerator / denominator per wave, then two atomics per wave; the last block to arrive divides
+    float num = wave_sum(term * val), den = wave_sum(val);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(p.acc, num);
+        atomicAdd(p.acc + 1, den);
+    }
+}
+__global__ void loss_side_mean_kernel(const float* acc, float* out) { out[0] = acc[0] / fmaxf(acc[1], 1.f); }
+
+// backward: g_color = g_loss_color * sign(color - col_src); g_depth = g_loss_rep * valid / max(n_valid, 1) * dterm/ddepth
+__global__ __launch_bounds__(256) void loss_side_bwd_kernel(const float* color, const float* col_src, const float* valid, const float* dterm,
+                                                            const float* acc, const float* g_lc, const float* g_lr, int R, float* g_color,
+                                                            float* g_depth) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float gl = g_lr ? g_lr[0] / fmaxf(acc[1], 1.f) : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float e = color[3 * r + c] - col_src[3 * r + c];
+        g_color[3 * r + c] = g_lc ? g_lc[3 * r + c] * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) : 0.f;
+    }
+    g_depth[r] = gl * valid[r] * dterm[r];
+}
+
+extern "C" {
+
+int scenerf_hip_loss_side_forward(const float* pix, const float* color, const float* depth, const float* img_source,
+                                  const float* img_target, const float* noise, const float* cam_K, const float* inv_K,
+                                  const float* T_source2target, int R, int H, int W, float* loss_color, float* ray_term, float* valid,
+                                  float* dterm_ddepth, float* col_src, float* acc2, float* loss_reprojection, scenerf_stream_t stream) {
+    SRF_CHECK(pix && color && depth && img_source && img_target && cam_K && inv_K && T_source2target && loss_color && ray_term && valid &&
+                  dterm_ddepth && col_src && acc2 && loss_reprojection && R > 0 && H > 1 && W > 1,
+              "loss_side_forward: NULL / empty argument");
+    LossArgs p = {};
+    p.pix = pix; p.color = color; p.depth = depth; p.img_s = img_source; p.img_t = img_target; p.noise = noise;
+    p.K = cam_K; p.invK = inv_K; p.T = T_source2target;   // device memory (wave-uniform scalar loads): no host round trip per call
+    p.R = R; p.H = H; p.W = W;
+    p.loss_color = loss_color; p.ray_term = ray_term; p.valid = valid; p.dterm_ddepth = dterm_ddepth; p.col_src = col_src;
+    p.loss_rep = loss_reprojection; p.acc = acc2;
+    hipStream_t s = as_stream(stream);
+    SRF_HIP(hipMemsetAsync(acc2, 0, 2 * sizeof(float), s));
+    SrfLaunchScope ps(s, "loss_side_fwd", 0, 0);
+    loss_side_fwd_kernel<<<cdiv(R, 256), 256, 0, s>>>(p);
+    loss_side_mean_kernel<<<1, 1, 0, s>>>(acc2, loss_reprojection);
+    SRF_LAUNCH_CHECK("loss_side_fwd_kernel");
+    return 0;
+}
+
+int scenerf_hip_loss_side_backward(const float* color, const float* col_src, const float* valid, const float* dterm_ddepth,
+                                   const float* acc2, const float* g_loss_color, const float* g_loss_reprojection, int R,
+                                   float* g_color, float* g_depth, scenerf_stream_t stream) {
+    SRF_CHECK(color && col_src && valid && dterm_ddepth && acc2 && g_color && g_depth && R > 0, "loss_side_backward: NULL / empty argument");
+    hipStream_t s = as_stream(stream);
+    SrfLaunchScope ps(s, "loss_side_bwd", 0, 0);
+    loss_side_bwd_kernel<<<cdiv(R, 256), 256, 0, s>>>(color, col_src, valid, dterm_ddepth, acc2, g_loss_color, g_loss_reprojection, R, g_color,
+                                                       g_depth);
+    SRF_LAUNCH_CHECK("loss_side_bwd_kernel");
+    return 0;
+}
+
+}  // extern "C"

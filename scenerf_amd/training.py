@@ -100,9 +100,16 @@ class TrainingMixin:
         min_som_vars = torch.gather(out["som_vars"], 1, gi.unsqueeze(-1))
         self.log(step_type + "_som/dist_2_closest_gaussian", min_diff.mean().detach(), on_epoch=True, sync_dist=True)
         self.log(step_type + "_som/closest_std", min_stds.mean().detach(), on_epoch=True, sync_dist=True)
-        col_src = sample_pix_features(pix_source, img_source)
-        loss_color = torch.abs(color - col_src.T)
-        loss_rep = self.compute_reprojection_loss(pix_source, col_src, depth, img_target, inv_K, cam_K, T_source2target)
+        if color.is_cuda and getattr(self, "fused_loss_side", True):
+            # the three image gathers, the reprojection and both L1 terms in ONE kernel per direction (scenerf_amd/loss_side.py ->
+            # csrc/loss.hip), consuming the renderer's depth / colour where they lie; the noise is drawn like the reference's
+            from .loss_side import loss_side
+            noise = torch.randn(depth.shape[0], device=dev) * 0.00001
+            loss_color, loss_rep = loss_side(color, depth, pix_source, img_source, img_target, cam_K, inv_K, T_source2target, noise)
+        else:   # CPU tensors (host-logic tests): the stock-PyTorch restatement, pinned on the reference's own functions
+            col_src = sample_pix_features(pix_source, img_source)
+            loss_color = torch.abs(color - col_src.T)
+            loss_rep = self.compute_reprojection_loss(pix_source, col_src, depth, img_target, inv_K, cam_K, T_source2target)
         return dict(loss_kl=out["loss_kl"], loss_dist2closest_gauss=min_diff, loss_reprojection=loss_rep, loss_color=loss_color,
                     min_som_vars=min_som_vars, min_stds=min_stds, depth_source_rendered=depth, pix_source=pix_source)
 
