@@ -58,6 +58,8 @@ def pmc_traffic(logical_name):
         fn = "mlp_wide_kernel<0>" if any(k.startswith("mlp_wide_kernel<0>") for k in d) and not logical_name.endswith("/g") else "mlp_fused_kernel<0>"
     elif logical_name.startswith("mlp_bwd_fused"):
         fn = "mlp_wide_kernel<1>" if any(k.startswith("mlp_wide_kernel<1>") for k in d) and not logical_name.endswith("/g") else "mlp_fused_kernel<1>"
+    elif logical_name == "gemm_wgrad_fc":
+        fn = "wgrad_tr_kernel"       # the batched transposing-read launch (wgrad.hip)
     elif "wgrad" in logical_name:
         fn = "gemm_tn_kernel"
     else:
@@ -66,7 +68,7 @@ def pmc_traffic(logical_name):
         return None
     # the dominant launch of a logical kernel is the largest grid of its function (main MLP, not the 4-point gaussian head)
     sized = [(int(k.split("@grid=")[1]), k, v) for k, v in d.items() if k.startswith(fn) and "@grid=" in k]
-    if sized and logical_name.startswith("mlp_"):
+    if sized and (logical_name.startswith("mlp_") or logical_name == "gemm_wgrad_fc"):
         _, k, v = max(sized)
         return {"bytes_per_launch": round(v["hbm_bytes_per_launch"]), "kernel_fn": k, "source": os.path.basename(files[-1]),
                 "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, average over the launches of this grid size"}

@@ -40,7 +40,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_d;
 #define DF_KSB 128                                    // bytes of K per row per K-loop step
 #endif
 #ifndef DF_NTB
-#define DF_NTB 4                                       // column tiles per pass of the general instantiation
+#define DF_NTB 5                                       // column tiles per pass of the second instantiation (KITTI's 1/2 level: 160 channels)
 #endif
 // LDS of an instantiation: two K-loop stages of (128 + 32 NTP) rows, or the epilogue tables
 constexpr int df_lds(int ntp) { return 2 * (DF_BM + ntp * 32) * DF_KSB > DF_L_MISC + 32 ? 2 * (DF_BM + ntp * 32) * DF_KSB : DF_L_MISC + 32; }
@@ -64,6 +64,7 @@ struct DfeatArgs {
     float* gmap[SCENERF_N_SCALES];     // NULL: that level needs no gradient
     long st[SCENERF_N_SCALES], sc[SCENERF_N_SCALES];   // element strides of gmap per texel / per channel
     int C[SCENERF_N_SCALES];
+    unsigned levels;          // pyramid levels this launch handles (bit s)
 };
 
 #ifdef H_CYC   // development build: per-workgroup time stamps of wave 0 (tools/dfeat_probe.py)
@@ -85,15 +86,13 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x, m0 = tile * DF_BM;
-    const unsigned mask = __builtin_amdgcn_readfirstlane((unsigned)p.tile_mask[tile] & 31u);
+    const unsigned mask = __builtin_amdgcn_readfirstlane((unsigned)p.tile_mask[tile] & 31u) & p.levels;
     // this tile's column tiles, level by level (wave-uniform, a few scalar registers): (level, first channel)
     int nt = 0;
 #pragma unroll
     for (int s = 0; s < SCENERF_N_SCALES; ++s)
         if (((mask >> s) & 1u) && p.gmap[s]) nt += (p.C[s] + 31) >> 5;
     if (nt == 0) return;
-    // (the 3-tile instantiation takes the tiles it can hold in one pass, the 8-tile one everything else)
-    if (NTP <= 3 ? nt > NTP : nt <= 3) return;   // (3-tile kernel: nt <= 3; the other one: everything else, in passes)
     auto tile_level = [&](int t, int& s_out, int& c0_out) __attribute__((always_inline)) {
         int acc = 0;
         s_out = 0; c0_out = 0;
@@ -331,8 +330,17 @@ int launch_dfeat_scatter(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
         }
     }
     SrfLaunchScope ps(s, w->d_out == 2 ? "gemm_dfeat_scatter/g" : "gemm_dfeat_scatter", flops, 0);
-    dfeat_kernel<3><<<tiles, DF_THREADS, df_lds(3), s>>>(p);
-    dfeat_kernel<DF_NTB><<<tiles, DF_THREADS, df_lds(DF_NTB), s>>>(p);
+    // the finest level (every tile has it: 80 channels = 3 column tiles, one pass) and the coarser ones (a quarter of the tiles at
+    // KITTI's geometry; 5 column tiles per pass) as two launches: a tile's dH rows are read once per launch that touches it
+    const bool fine3 = gmaps[0] && cfg->map_C[0] <= 96;
+    if (fine3) {
+        p.levels = 1u;
+        dfeat_kernel<3><<<tiles, DF_THREADS, df_lds(3), s>>>(p);
+    }
+    p.levels = fine3 ? 30u : 31u;
+    bool rest = false;
+    for (int sc = 0; sc < SCENERF_N_SCALES; ++sc) rest = rest || (((p.levels >> sc) & 1u) && gmaps[sc]);
+    if (rest) dfeat_kernel<DF_NTB><<<tiles, DF_THREADS, df_lds(DF_NTB), s>>>(p);
     SRF_LAUNCH_CHECK("dfeat_kernel");
     return 0;
 }

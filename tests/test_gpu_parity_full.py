@@ -1,7 +1,7 @@
 """Direct parity of the TIMED path against the CPU oracle at the sizes bench.py and BASELINE.json name.
 
-What bench.py times is: bf16 operands, the fused forward trunk (fused.hip), the fused dgrad chain, the batched transposing-read
-weight-gradient launch (wgrad.hip, >= 32768 rows) and the multi-scale feature-gradient GEMM + scatter, at KITTI 1500x452, R = 1200
+What bench.py times is: bf16 operands, the fused forward trunk and dgrad chain (wide.hip: 128-row blocks), the batched transposing-read
+weight-gradient launch (wgrad.hip, >= 32768 rows) and the feature-gradient kernel (dfeat.hip), at KITTI 1500x452, R = 1200
 rays x N = 128 samples in ONE chunk.  The reference-minted golden vectors run R <= 64 rays; this file closes the gap: the very
 configurations of BASELINE.json configs[1] (KITTI, as benched), configs[3] (BundleFusion, R = 1080 x N = 96) and one
 configs[4]-sized chunk (N = 512, 16,384 rows) are rendered + back-propagated on the GPU and compared, output by output and
