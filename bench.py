@@ -341,7 +341,47 @@ def _rooflines(kernels, args, nprof, value_per_gpu, world):
                   "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                   "avg_launch_us": round(sum(k["total_ms"] for k in comp) * 1e3 / sum(k["launches"] for k in comp), 2),
                   "bytes_per_ray": (80 * args.samples + 64) if len(comp) == 2 else (32 * args.samples + 24)}
+        # the same two kernels at an inference-sized chunk (65,536 rays): at the training chunk (1,200 rays = 1,200 waves) the pass is
+        # launch latency, not bandwidth; this is the number the HBM roofline applies to (tools/composite_probe.py, profiles/*composite*)
+        try:
+            roof_c["at_inference_chunk"] = _composite_probe(65536, args.samples)
+        except Exception as e:   # never let the extra leg break the bench line
+            roof_c["at_inference_chunk"] = {"error": str(e)}
     return roof, roof_c
+
+
+def _composite_probe(R, N, reps=20):
+    """composite_fwd / composite_bwd through the C ABI on synthetic [R][N] inputs, HIP-event timed on the launch stream."""
+    lib = _capi.load()
+    dev = "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    logits = torch.randn(R * N, 4, device=dev)
+    logits[:, 3] -= 2
+    dist = torch.sort(torch.rand(R, N, device=dev) * 100 + 0.1, dim=1).values
+    z = dist * 0.97
+    f = lambda *s: torch.empty(s, device=dev)
+    dens, al, w, dep, col, clo, wat = f(R, N), f(R, N), f(R, N), f(R), f(R, 3), f(R), f(R)
+    ci = torch.empty(R, dtype=torch.int32, device=dev)
+    gd, gc = torch.randn(R, device=dev), torch.randn(R, 3, device=dev)
+    dl, dd, dz = f(R * N, 4), f(R, N), f(R, N)
+    fwd = lambda: lib.scenerf_hip_composite_forward(logits.data_ptr(), dist.data_ptr(), z.data_ptr(), R, N, dens.data_ptr(), al.data_ptr(),
+                                                    w.data_ptr(), dep.data_ptr(), col.data_ptr(), clo.data_ptr(), wat.data_ptr(), ci.data_ptr(), st)
+    bwd = lambda: lib.scenerf_hip_composite_backward(logits.data_ptr(), dist.data_ptr(), z.data_ptr(), R, N, gd.data_ptr(), gc.data_ptr(), None,
+                                                     None, None, None, dl.data_ptr(), dd.data_ptr(), dz.data_ptr(), st)
+    out = {"rays": R, "samples": N}
+    for name, fn, bpr in (("fwd", fwd, 32 * N + 24), ("bwd", bwd, 48 * N + 40)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        gbs = R * bpr / us / 1e3
+        out[name] = {"avg_launch_us": round(us, 1), "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+    return out
 
 
 def main():

@@ -124,7 +124,7 @@ class PrepareMaps(torch.autograd.Function):
     def forward(ctx, holder: MapHolder, *chw):
         holder.convert(chw)
         ctx.holder = holder
-        return torch.zeros(1, device=chw[0].device)
+        return torch.empty(1, device=chw[0].device)   # autograd token: its value is never read (no fill launch)
 
     @staticmethod
     def backward(ctx, _g):
@@ -280,7 +280,7 @@ class PackMLP(torch.autograd.Function):
     def forward(ctx, holder: MlpHolder, d_out: int, cfg: RenderConfig, *params):
         holder.packed = PackedMLP(params, d_out, cfg)
         ctx.holder = holder
-        return torch.zeros(1, device=params[0].device)
+        return torch.empty(1, device=params[0].device)   # autograd token: its value is never read (no fill launch)
 
     @staticmethod
     def backward(ctx, _g):

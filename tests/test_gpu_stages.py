@@ -13,7 +13,7 @@ import torch
 
 import scenerf_oracle as orc
 from golden_util import Golden
-from scenerf_amd import _capi
+from scenerf_amd import _capi, synth
 from scenerf_amd.config import RenderConfig
 
 pytestmark = pytest.mark.gpu
@@ -762,3 +762,56 @@ def test_direct_chw_scales_match_the_converted_path(case, precision):
         assert float(x.abs().max()) > 0, "scale %d received no gradient" % i
         rel = float((x - y).norm() / x.norm())
         assert rel <= (1e-5 if prec == 0 else 2e-2), "scale %d: relative L2 %.3e" % (i, rel)
+
+
+@pytest.mark.parametrize("M", [193 * 128 - 41, 40000])
+def test_feature_gradient_kernel_matches_gemm_scatter_epilogue(M):
+    """dfeat.hip (one workgroup per 128-row tile, dH staged once, per-tap run sums before the atomics) against the GEMM family's scatter
+    epilogue (scenerf_cfg.flags & SCENERF_FLAG_DFEAT_GEMM) on the same dH and taps: every level's (H,W,C) gradient map equal up to fp32
+    summation order.  Ragged last tile, all 32 tile masks, taps that repeat along a ray / differ from row to row / are absent (-1),
+    zero weights."""
+    import dataclasses
+    from scenerf_amd.renderer import MLP_PARAM_NAMES, PackedMLP
+    lib = _capi.load()
+    rcfg = RenderConfig.kitti(precision="bf16", sphere_W=376, sphere_H=114)
+    state = synth.mlp_state(5, 4)
+    pk = PackedMLP([torch.as_tensor(state[n]).to(DEV) for n in MLP_PARAM_NAMES], 4, rcfg)
+    gen = torch.Generator().manual_seed(M)
+    ntile = (M + 127) // 128
+    masks = (torch.arange(ntile) % 32).to(torch.uint8)
+    masks[::5] = 1                                                     # plenty of finest-level-only tiles, like the real geometry
+    dH = dv((torch.randn(M, 2048, generator=gen) * 0.1), torch.bfloat16)
+    shapes = rcfg.map_shapes()
+    tex = torch.full((M, 5, 4), -1, dtype=torch.int32)
+    tw = torch.zeros((M, 5, 4))
+    r = torch.arange(M)
+    for s_, (c, h, w) in enumerate(shapes):
+        act = ((masks.long() >> s_) & 1).bool().repeat_interleave(128)[:M]
+        walk = torch.randint(0, max(w - 12, 1), (ntile,), generator=gen).repeat_interleave(128)[:M] + (r % 128) * 9 // 128
+        jump = torch.randint(0, w - 1, (M,), generator=gen)
+        x0 = torch.where((r // 128) % 3 == 0, jump, walk).clamp(0, w - 2)   # every third tile: unrelated texels row by row
+        y0 = torch.randint(0, max(h - 1, 1), (ntile,), generator=gen).repeat_interleave(128)[:M].clamp(0, h - 2)
+        for k, (dx, dy) in enumerate(((0, 0), (1, 0), (0, 1), (1, 1))):
+            t = ((y0 + dy) * w + x0 + dx).int()
+            drop = (t.long() * 7919 + k) % 10 == 0                      # out-of-range taps (again a function of the position)
+            tex[:, s_, k] = torch.where(act & ~drop, t, torch.full_like(t, -1))
+            # (a row's weights are a function of its sample position, like the forward gather's: rows with the same taps have the same
+            # weights -- the GEMM epilogue's run merging relies on that; ~6 % of the positions get weight 0)
+            wv = ((t.long() * 2654435761 + k * 40503) % 1000).float() / 1000.0
+            tw[:, s_, k] = torch.where(wv < 0.06, torch.zeros(M), wv)
+    tex, tw, masks_d = dv(tex), dv(tw), dv(masks)
+    res = {}
+    for name in ("gemm", "dfeat"):
+        cc = dataclasses.replace(rcfg, dfeat_gemm=(name == "gemm")).to_c()
+        gm = [torch.zeros((h, w, c), device=DEV) for (c, h, w) in shapes]
+        arr = (C.c_void_p * 5)(*[g.data_ptr() for g in gm])
+        _capi.check(lib.scenerf_hip_mlp_feature_grads(C.byref(cc), C.byref(pk.c), masks_d.data_ptr(), tex.data_ptr(), tw.data_ptr(), M,
+                                                      dH.data_ptr(), arr, _st()), "mlp_feature_grads")
+        torch.cuda.synchronize()
+        res[name] = gm
+    for i, (a, b) in enumerate(zip(res["gemm"], res["dfeat"])):
+        scale = float(a.abs().max())
+        assert scale > 0, "level %d must be exercised" % i
+        err = float((a - b).abs().max())
+        print("level %d: max |diff| %.2e of %.2e" % (i, err, scale))
+        assert err <= 4e-6 * scale, (i, err, scale)   # measured <= 6.4e-7 (fp32 summation order)
