@@ -448,6 +448,7 @@ def main():
             step()
         allreduce = _allreduce_report(world, 3)
         sdist.TIMING = None
+        sdist.verify_step_collectives()   # every rank issued the same number of gradient collectives (an error, not a hang, if not)
 
     roof = roof_c = None
     kernels = []

@@ -50,6 +50,32 @@ def shard_rays(n_rays_total: int, rank: int, world: int) -> Tuple[int, int]:
 TIMING = None
 
 
+# Number of gradient collectives this process has issued through the two hooks below since the last verify_step_collectives().
+_ISSUED = 0
+
+
+def verify_step_collectives() -> int:
+    """The per-session hooks (``model.grad_sync`` / ``model.grad_sync_async``) issue ONE pair of all-reduces per render_rays_batch
+    session whose gradients reach autograd, so every rank must open the same number of sessions per step, in the same order, and
+    use each session's output in its loss -- a rank with one source frame fewer deadlocks the others.  Call this once per step
+    (after backward) to turn that deadlock into an error: it compares the number of hook collectives issued since the last call
+    across ranks (one 2-element all-reduce) and raises on every rank when they differ.  Returns the count.  The hooks must not be
+    combined with DistributedDataParallel / Lightning gradient hooks on the same parameters (the gradients would be averaged
+    twice); for a step whose session count varies between ranks leave both hooks None and reduce once per step with
+    ``GradBucket(model.parameters()).allreduce_mean()`` after backward."""
+    global _ISSUED
+    n, _ISSUED = _ISSUED, 0
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([n, -n], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        hi, lo = int(t[0]), -int(t[1])
+        if hi != lo:
+            raise RuntimeError("scenerf_amd.dist: ranks issued different numbers of gradient collectives this step (min %d, max %d, "
+                               "this rank %d): every rank must open the same render_rays_batch sessions per step" % (lo, hi, n))
+    return n
+
+
 def _mark():
     e = torch.cuda.Event(enable_timing=True)
     e.record()
@@ -59,7 +85,9 @@ def _mark():
 def allreduce_mean_(flat: torch.Tensor) -> None:
     """In-place mean over ranks of a flat gradient buffer (no-op for a single process).  Installed as
     ``model.grad_sync``: the renderer calls it once per MLP on the packed fp32 gradient sink (21.7 MB)."""
+    global _ISSUED
     if dist.is_initialized() and dist.get_world_size() > 1:
+        _ISSUED += 1
         t0 = _mark() if (TIMING is not None and flat.is_cuda) else None
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(dist.get_world_size())
@@ -70,8 +98,10 @@ def allreduce_mean_(flat: torch.Tensor) -> None:
 def allreduce_mean_async(flat: torch.Tensor):
     """Start the same reduction without blocking the calling stream; returns ``finish()`` -- call it (on the stream that will read
     ``flat``) before the gradients are used -- or None for a single process.  Installed as ``model.grad_sync_async``."""
+    global _ISSUED
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return None
+    _ISSUED += 1
     work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
     world = dist.get_world_size()
 

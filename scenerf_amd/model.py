@@ -193,7 +193,9 @@ class SceneRF(TrainingMixin, _Base):
             som_sigma=float(som_sigma), gauss_floor=1.5 if self._VARIANT == "kitti" else 0.5,
             precision=precision, device_rng=device_rng, **fov)
         self.render_cfg.validate()
-        # optional data-parallel hook (scenerf_amd.dist.allreduce_mean_): called on each MLP's packed gradient buffer
+        # optional data-parallel hook (scenerf_amd.dist.allreduce_mean_): called on each MLP's packed gradient buffer, once per
+        # render_rays_batch session -- every rank must then open the same sessions per step (dist.verify_step_collectives checks it)
+        # and the parameters must not also carry DDP gradient hooks; the once-per-step alternative is dist.GradBucket after backward
         self.grad_sync = None
         # optional early form of the same hook (scenerf_amd.dist.allreduce_mean_async): the radiance MLP's collective then starts
         # before the feature-gradient scatter of a single-chunk (training) step instead of after it

@@ -45,6 +45,11 @@ def _worker(rank, world, port, out):
     assert callable(finish)
     finish()
     assert torch.allclose(flat2, torch.full((5,), 10 * (1 + world) / 2.0))
+    assert sdist.verify_step_collectives() == 2       # both ranks issued the same two hook collectives this "step"
+    if rank == 0:                                     # a rank that opens one session more: an error on every rank, not a hang
+        sdist._ISSUED += 1
+    with pytest.raises(RuntimeError, match="different numbers of gradient collectives"):
+        sdist.verify_step_collectives()
     torch.save(dict(local=local, reduced=[p.grad.clone() for p in lin.parameters()], shard=(b, e)), out % rank)
     dist.destroy_process_group()
 
