@@ -93,6 +93,11 @@ int launch_mlp_bwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, i
 // dfeat.hip: feature-map gradients of one pass (dZ = dH[:, 0:1536] @ Wz scattered through the forward's bilinear taps), bf16
 int launch_dfeat_scatter(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const uint8_t* tile_mask, const int32_t* tap_texel,
                          const float* tap_weight, int M, const void* dH, float* const gmaps[SCENERF_N_SCALES], hipStream_t s);
-bool wgrad_tr_applicable(const GemmTN& p);
+#define W_SINGLE_MIN_ROWS 32768   // a launch of its own pays the 42-us atomic flush alone
+#ifndef W_BATCH_MIN_ROWS
+#define W_BATCH_MIN_ROWS 4096     // the batched launch of a backward pass (seven problems, one flush): also the gaussian head's 4,800
+                                  // rows -- 65 us instead of eleven per-layer launches of 20-30 us each (r02_d)
+#endif
+bool wgrad_tr_applicable(const GemmTN& p, int min_rows = W_SINGLE_MIN_ROWS);
 int launch_wgrad_tr(const GemmTN& p, hipStream_t s);
 int launch_wgrad_tr_batch(const GemmTN* probs, int count, hipStream_t s);   // same (M, N, K) for all: one launch, one atomic flush

@@ -440,7 +440,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc1[b]; t.ldo = SCENERF_D_HIDDEN;
             t.colsum = g_->b_fc1[b];  // fc_1.b.bias gradient = column sums of dH_{b+1}
             t.allow_tr = allow_tr;
-            if (fused_chain && wgrad_tr_applicable(t)) { t.name = "gemm_wgrad_fc"; wg[nwg++] = t; }
+            if (fused_chain && wgrad_tr_applicable(t, W_BATCH_MIN_ROWS)) { t.name = head ? "gemm_wgrad_fc/g" : "gemm_wgrad_fc"; wg[nwg++] = t; }
             else if (int e = launch_gemm_tn(prec, t, s2)) return e;
         }
         if (!fused_chain) {   // dN_b = (dH_{b+1} @ W1_b) * [N_b > 0]
@@ -461,7 +461,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_HIDDEN; t.out = g_->w_fc0[b]; t.ldo = SCENERF_D_HIDDEN;
             t.colsum = g_->b_fc0[b];
             t.allow_tr = allow_tr;
-            if (fused_chain && wgrad_tr_applicable(t)) { t.name = "gemm_wgrad_fc"; wg[nwg++] = t; }
+            if (fused_chain && wgrad_tr_applicable(t, W_BATCH_MIN_ROWS)) { t.name = head ? "gemm_wgrad_fc/g" : "gemm_wgrad_fc"; wg[nwg++] = t; }
             else if (int e = launch_gemm_tn(prec, t, s2)) return e;
         }
         if (!fused_chain) {   // dH_b = dH_{b+1} + (dN_b @ W0_b) * [H_b > 0]
@@ -484,13 +484,13 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     int linz_done = 0;
     if (nwg && SCENERF_Z_DENSE_COLS % 256 == 0) {
         GemmTN t;
-        t.name = "gemm_wgrad_fc";
+        t.name = head ? "gemm_wgrad_fc/g" : "gemm_wgrad_fc";
         t.D = dH; t.ldd = LDH;
         t.A = Z; t.lda = SCENERF_D_LATENT;
         t.M = M; t.N = 3 * SCENERF_D_HIDDEN; t.K = SCENERF_Z_DENSE_COLS;
         t.out = g_->w_z; t.ldo = SCENERF_D_LATENT;
         t.allow_tr = allow_tr;
-        if (wgrad_tr_applicable(t)) { wg[nwg++] = t; linz_done = SCENERF_Z_DENSE_COLS; }
+        if (wgrad_tr_applicable(t, W_BATCH_MIN_ROWS)) { wg[nwg++] = t; linz_done = SCENERF_Z_DENSE_COLS; }
     }
     if (nwg) {
         if (int e = launch_wgrad_tr_batch(wg, nwg, s2)) return e;

@@ -46,7 +46,7 @@ struct WgradProblem {
 struct WgradArgs {
     WgradProblem prob[W_MAXPROB];   // same M for all; N and K (multiples of 256) may differ.  The weight gradients of a backward pass
                                     // share one launch: one atomic flush per workgroup for all of them instead of one per GEMM
-    unsigned short tiles_n[W_MAXPROB];
+    unsigned short tiles_n[W_MAXPROB], tiles_k[W_MAXPROB];
     // workgroup id -> problem (bits 12..15) | tile (bits 6..11) | split (bits 0..5); 0xffff = idle.  Host-built so that the tiles
     // of one (problem, split) get ids on the same XCD, back to back
     unsigned short map[W_MAXWG];
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
     const WgradProblem& P = p.prob[pi];
     const int tn = p.tiles_n[pi];
     const int n0 = (tile % tn) * W_TILE, k0 = (tile / tn) * W_TILE;
-    const int first_k_tile = tile / tn == 0;
+    const int kt = tile / tn, tk = p.tiles_k[pi];   // this tile's k index, k tiles of the problem
     const int mb = split * p.rows_per_split;
     const int me = min(p.M, mb + p.rows_per_split);
     const int steps = (me - mb + W_BM - 1) / W_BM;
@@ -172,7 +172,13 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of D for column n0 + 128 wn + 32 i + (lane & 31), this lane's 8 rows
-    const bool do_cs = P.colsum != nullptr && first_k_tile && wk == 0;
+    // bias gradient (column sums of D): every k tile of a column block sees the same D fragments, so they take turns, step by step.
+    // The tiles of one (problem, M split) then do the SAME work per step: with the sums on the first k tile only, that tile fell
+    // behind the ones it shares its operand rows with, out of reach of the XCD's L2 (4 MiB hold about nine steps of an XCD's operand
+    // stream), and every shared row was fetched twice: 3.39 GB per launch instead of 2.40 GB, 712-740 us instead of 637-650 us
+    // (r02_d).  Holding the tiles together by force instead (a progress record per tile, producers waiting for the slowest) also
+    // brings the fetch to 2.4 GB but costs more in stalls than it saves: 1.0-1.1 ms.
+    const bool do_cs = P.colsum != nullptr && wk == 0;
     const bool relu_a = P.relu_a != 0;
 
 #pragma unroll 1
@@ -211,11 +217,14 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, A4[i]), __builtin_bit_cast(bf16x8_w, B4[j]),
                                                                         acc[i][j], 0, 0, 0);
-            if (do_cs) {
+            if (do_cs && (c % tk) == kt) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    cs[i] += (bf16lo(A4[i].x) + bf16hi(A4[i].x)) + (bf16lo(A4[i].y) + bf16hi(A4[i].y)) + (bf16lo(A4[i].z) + bf16hi(A4[i].z)) +
-                             (bf16lo(A4[i].w) + bf16hi(A4[i].w));
+                for (int i = 0; i < 4; ++i) {   // cs += lo + hi of each bf16 pair (v_dot2c with a pair of ones)
+                    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[i]) : "v"(A4[i].x), "v"(0x3f803f80u));
+                    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[i]) : "v"(A4[i].y), "v"(0x3f803f80u));
+                    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[i]) : "v"(A4[i].z), "v"(0x3f803f80u));
+                    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[i]) : "v"(A4[i].w), "v"(0x3f803f80u));
+                }
             }
         }
     }
@@ -238,8 +247,8 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
 }
 
 // Used by launch_gemm_tn for the shapes it fits (bf16, N and K multiples of 256, no tile skipping, enough rows).
-bool wgrad_tr_applicable(const GemmTN& p) {
-    return p.allow_tr && p.N % W_TILE == 0 && p.K % W_TILE == 0 && !p.tile_mask && p.M >= 32768 && p.ldd % 8 == 0 && p.lda % 8 == 0;
+bool wgrad_tr_applicable(const GemmTN& p, int min_rows) {
+    return p.allow_tr && p.N % W_TILE == 0 && p.K % W_TILE == 0 && !p.tile_mask && p.M >= min_rows && p.ldd % 8 == 0 && p.lda % 8 == 0;
 }
 
 int wgrad_prepare() {
@@ -260,9 +269,10 @@ int launch_wgrad_tr_batch(const GemmTN* probs, int count, hipStream_t s) {
     double flops = 0;
     for (int i = 0; i < count; ++i) {
         const GemmTN& p = probs[i];
-        SRF_CHECK(p.M == p0.M && wgrad_tr_applicable(p), "wgrad batch: problems must share M and fit the kernel");
+        SRF_CHECK(p.M == p0.M && wgrad_tr_applicable(p, 1), "wgrad batch: problems must share M and fit the kernel");
         a.prob[i] = {(const char*)p.D, (const char*)p.A, p.out, p.colsum, p.ldd * 2, p.lda * 2, p.ldo, p.relu_a};
         a.tiles_n[i] = (unsigned short)(p.N / W_TILE);
+        a.tiles_k[i] = (unsigned short)(p.K / W_TILE);
         SRF_CHECK((p.N / W_TILE) * (p.K / W_TILE) <= 64, "wgrad batch: at most 64 tiles per problem");
         tile_units += (p.N / W_TILE) * (p.K / W_TILE);
         flops += 2.0 * p.M * (double)p.N * p.K;
@@ -272,6 +282,7 @@ int launch_wgrad_tr_batch(const GemmTN* probs, int count, hipStream_t s) {
     const int wg_target = 256;   // one workgroup per CU (128 KiB of LDS)
     int splits = wg_target / tile_units > 1 ? wg_target / tile_units : 1;
     if (splits > 64) splits = 64;
+    if (splits > p0.M / 1024) splits = p0.M / 1024 > 1 ? p0.M / 1024 : 1;   // few rows: fewer, longer splits (each split flushes 256 KiB per tile)
     int rows = cdiv(cdiv(p0.M, splits), W_BM) * W_BM;   // (a multiple of the step)
     splits = cdiv(p0.M, rows);
     a.rows_per_split = rows;
@@ -281,7 +292,8 @@ int launch_wgrad_tr_batch(const GemmTN* probs, int count, hipStream_t s) {
     int g = 0, grid = 0;
     for (int sp = 0; sp < splits; ++sp)
         for (int i = 0; i < count; ++i, ++g) {
-            const int x = g & 7, nt = (probs[i].N / W_TILE) * (probs[i].K / W_TILE);
+            // eight splits: a split per XCD, so that problems sharing an operand (dH_b is D of fc_1.(b-1) and of lin_z.b) can share it in L2
+            const int x = splits == 8 ? sp : (g & 7), nt = (probs[i].N / W_TILE) * (probs[i].K / W_TILE);
             for (int t = 0; t < nt; ++t) {
                 const int b = (len[x]++) * 8 + x;
                 SRF_CHECK(b < W_MAXWG, "wgrad batch: workgroup map overflow");

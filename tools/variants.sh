@@ -19,6 +19,8 @@ def us(n):
 print("variant %-6r  %.3f ms/step  %7.0f rays/s | fwd_fused %.1f us  bwd_fused %.1f us  fwd_fused/g %.1f  bwd_fused/g %.1f  wgrad batch %.1f us"
       % (sys.argv[1], b["ms_per_step"], b["value"], us("mlp_fwd_fused"), us("mlp_bwd_fused"), us("mlp_fwd_fused/g"), us("mlp_bwd_fused/g"),
          us("gemm_wgrad_fc")))
+print("               head (side stream) kernels per step: %.0f us  [wgrad batch/g %.1f us]" % (
+    sum(r["total_ms"] * 1e3 for n, r in k.items() if n.endswith("/g")) / 20.0, us("gemm_wgrad_fc/g")))
 PY
     done
 done
