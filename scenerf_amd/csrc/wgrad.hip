@@ -32,6 +32,9 @@ typedef unsigned u32x2_w __attribute__((ext_vector_type(2)));
 #define W_LDS (W_NST * W_STAGE)    // 131072
 #define W_PPP (W_BM / 8)           // pieces per producer per operand per stage (a piece = two rows; four producers)
 #define W_THREADS 768
+#ifndef W_STAGGER
+#define W_STAGGER 1
+#endif
 
 #define W_MAXPROB 8
 struct WgradProblem {
@@ -52,6 +55,9 @@ struct WgradArgs {
     unsigned short map[W_MAXWG];
     int M, rows_per_split;
     const char* zero;    // >= 1 KiB of zeros (rows past M)
+#ifdef W_CYC
+    unsigned long long* cyc;
+#endif
 };
 
 __device__ static inline void w_glds16(const void* sbase, unsigned voff, unsigned lds_wave_base) {
@@ -73,6 +79,11 @@ __device__ static inline u32x2_w w_tr_read(unsigned addr) {
     u32x2_w v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
+}
+
+__device__ static inline uint32_t w_max16(uint32_t w, uint32_t f) {
+    typedef short w_short2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(w_short2, w), __builtin_bit_cast(w_short2, f)));
 }
 
 __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
@@ -112,7 +123,11 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
             offA[u] = (unsigned)row * P.lda2 + k0 * 2 + chunk * 64 + (lane & 3) * 16;
         }
         auto issue = [&](int c) {
+#ifdef W_VAR_SAMEROWS
+            const int m = (c & 7) * W_BM;      // timing experiment: every step re-reads the same 256 rows (L2-resident)
+#else
             const int m = mb + c * W_BM;
+#endif
             const unsigned sb = lds0 + (c % W_NST) * W_STAGE;
             if (m + W_BM <= p.M) {
                 const char* dD = P.D + (size_t)m * P.ldd2;
@@ -179,55 +194,113 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
     // (r02_d).  Holding the tiles together by force instead (a progress record per tile, producers waiting for the slowest) also
     // brings the fetch to 2.4 GB but costs more in stalls than it saves: 1.0-1.1 ms.
     const bool do_cs = P.colsum != nullptr && wk == 0;
-    const bool relu_a = P.relu_a != 0;
+    const uint32_t floor2 = P.relu_a ? 0u : 0x80008000u;
 
-#pragma unroll 1
-    for (int c = 0; c < steps; ++c) {
-        __builtin_amdgcn_s_barrier();
-        const unsigned S = lds0 + (c % W_NST) * W_STAGE;
+    // One step = two k-steps of [12 transposing reads -> 8 MFMAs].  All consumer waves leave the barrier together, so without further
+    // arrangement the two waves of a SIMD read at the same time (matrix pipe idle) and then multiply at the same time (LDS idle):
+    // 2,200 cycles per step against 1,024 of MFMA work, also with every operand L2-resident (r02_d).  The second wave of each SIMD
+    // (waves 4..7: wn = 1) therefore runs half a phase late: it carries the fragments of a step's second k-step across the barrier
+    // and multiplies them while the first wave reads -- same registers, same barrier, complementary phases.
+    uint4 A4[4], B4[2];
+    auto rd = [&](unsigned Sk) {
+        u32x2_w fa[4][2], fb[2][2];
 #pragma unroll
-        for (int ks = 0; ks < W_BM / 16; ++ks) {
-            const unsigned Sk = S + ks * 16 * W_ROW;
-            u32x2_w fa[4][2], fb[2][2];
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = w_tr_read(Sk + adD[i]);
+            fa[i][1] = w_tr_read(Sk + adD[i] + 4 * W_ROW);
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i][0] = w_tr_read(Sk + adD[i]);
-                fa[i][1] = w_tr_read(Sk + adD[i] + 4 * W_ROW);
-            }
+        for (int j = 0; j < 2; ++j) {
+            fb[j][0] = w_tr_read(Sk + adA[j]);
+            fb[j][1] = w_tr_read(Sk + adA[j] + 4 * W_ROW);
+        }
+        // the wait carries the fragments as operands: nothing that uses them may be scheduled above it
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]),
+                       "+v"(fa[3][1]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1])
+                     :
+                     : "memory");
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                fb[j][0] = w_tr_read(Sk + adA[j]);
-                fb[j][1] = w_tr_read(Sk + adA[j] + 4 * W_ROW);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            uint4 A4[4], B4[2];
+        for (int i = 0; i < 4; ++i) A4[i] = make_uint4(fa[i][0][0], fa[i][0][1], fa[i][1][0], fa[i][1][1]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) A4[i] = make_uint4(fa[i][0][0], fa[i][0][1], fa[i][1][0], fa[i][1][1]);
+        for (int j = 0; j < 2; ++j) {
+            // ReLU as a 16-bit integer max with 0 -- or with the most negative value, which changes nothing (no branch in the loop)
+            B4[j] = make_uint4(w_max16(fb[j][0][0], floor2), w_max16(fb[j][0][1], floor2), w_max16(fb[j][1][0], floor2),
+                               w_max16(fb[j][1][1], floor2));
+        }
+    };
+    auto mm = [&](int c) {   // c: the step the fragments belong to
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                B4[j] = make_uint4(fb[j][0][0], fb[j][0][1], fb[j][1][0], fb[j][1][1]);
-                if (relu_a) {
-                    B4[j].x = relu_bf16x2(B4[j].x); B4[j].y = relu_bf16x2(B4[j].y);
-                    B4[j].z = relu_bf16x2(B4[j].z); B4[j].w = relu_bf16x2(B4[j].w);
-                }
-            }
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, A4[i]), __builtin_bit_cast(bf16x8_w, B4[j]),
+                                                                    acc[i][j], 0, 0, 0);
+        if (do_cs && (c % tk) == kt) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, A4[i]), __builtin_bit_cast(bf16x8_w, B4[j]),
-                                                                        acc[i][j], 0, 0, 0);
-            if (do_cs && (c % tk) == kt) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {   // cs += lo + hi of each bf16 pair (v_dot2c with a pair of ones)
-                    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[i]) : "v"(A4[i].x), "v"(0x3f803f80u));
-                    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[i]) : "v"(A4[i].y), "v"(0x3f803f80u));
-                    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[i]) : "v"(A4[i].z), "v"(0x3f803f80u));
-                    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[i]) : "v"(A4[i].w), "v"(0x3f803f80u));
-                }
+            for (int i = 0; i < 4; ++i) {   // cs += lo + hi of each bf16 pair (v_dot2c with a pair of ones)
+                asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[i]) : "v"(A4[i].x), "v"(0x3f803f80u));
+                asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[i]) : "v"(A4[i].y), "v"(0x3f803f80u));
+                asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[i]) : "v"(A4[i].z), "v"(0x3f803f80u));
+                asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[i]) : "v"(A4[i].w), "v"(0x3f803f80u));
             }
         }
+    };
+    static_assert(W_BM == 32, "the staggered loop is written for two k-steps per step");
+#ifdef W_CYC
+    unsigned long long tb = 0, tr0 = 0, tm0 = 0, tr1 = 0, tm1 = 0, t0, t1;
+#define W_T(acc_) do { t1 = __builtin_readcyclecounter(); acc_ += t1 - t0; t0 = t1; } while (0)
+#else
+#define W_T(acc_) do { } while (0)
+#endif
+    if (W_STAGGER && wn == 1) {
+#pragma unroll 1
+        for (int c = 0; c < steps; ++c) {
+#ifdef W_CYC
+            t0 = __builtin_readcyclecounter();
+#endif
+            __builtin_amdgcn_s_barrier();
+            W_T(tb);
+            const unsigned S = lds0 + (c % W_NST) * W_STAGE;
+            if (c > 0) mm(c - 1);          // second k-step of the previous step (fragments read before the barrier)
+            W_T(tm1);
+            rd(S);
+            W_T(tr0);
+            mm(c);
+            W_T(tm0);
+            rd(S + 16 * W_ROW);            // in registers before the next barrier releases this stage
+            W_T(tr1);
+        }
+        mm(steps - 1);
+    } else {
+#pragma unroll 1
+        for (int c = 0; c < steps; ++c) {
+#ifndef W_CYC
+            __builtin_amdgcn_s_barrier();
+#endif
+            const unsigned S = lds0 + (c % W_NST) * W_STAGE;
+#ifdef W_CYC
+            t0 = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_barrier();
+            W_T(tb);
+            rd(S); W_T(tr0);
+            mm(c); W_T(tm0);
+            rd(S + 16 * W_ROW); W_T(tr1);
+            mm(c); W_T(tm1);
+#else
+            rd(S);
+            mm(c);
+            rd(S + 16 * W_ROW);
+            mm(c);
+#endif
+        }
     }
+#ifdef W_CYC
+    if (lane == 0 && (wv == 0 || wv == 4) && blockIdx.x < 64) {
+        unsigned long long* o = p.cyc + (blockIdx.x * 2 + (wv >> 2)) * 8;
+        o[0] = tb; o[1] = tr0; o[2] = tm0; o[3] = tr1; o[4] = tm1; o[5] = steps;
+    }
+#endif
     // ---- partial tile -> out (fp32 atomics; C tile layout: row (e & 3) + 8 (e >> 2) + 4 (lane >> 5), column lane & 31)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -251,6 +324,13 @@ bool wgrad_tr_applicable(const GemmTN& p, int min_rows) {
     return p.allow_tr && p.N % W_TILE == 0 && p.K % W_TILE == 0 && !p.tile_mask && p.M >= min_rows && p.ldd % 8 == 0 && p.lda % 8 == 0;
 }
 
+#ifdef W_CYC
+static unsigned long long* g_w_cyc = nullptr;
+extern "C" int scenerf_hip_test_wgrad_cyc(unsigned long long* out, int n) {
+    if (!g_w_cyc || hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpy(out, g_w_cyc, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess;
+}
+#endif
 int wgrad_prepare() {
     SRF_ONCE_PER_DEVICE(SRF_HIP(hipFuncSetAttribute((const void*)wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS)));
     SRF_CHECK(srf_zero_page(), "wgrad: cannot allocate the zero page");
@@ -301,6 +381,12 @@ int launch_wgrad_tr_batch(const GemmTN* probs, int count, hipStream_t s) {
                 if (b + 1 > grid) grid = b + 1;
             }
         }
+#ifdef W_CYC
+    static unsigned long long* d_cyc = nullptr;
+    if (!d_cyc) SRF_HIP(hipMalloc((void**)&d_cyc, 64 * 2 * 8 * 8));
+    a.cyc = d_cyc;
+    g_w_cyc = d_cyc;
+#endif
     SrfLaunchScope ps(s, p0.name, flops, 0);
     wgrad_tr_kernel<<<grid, W_THREADS, W_LDS, s>>>(a);
     SRF_LAUNCH_CHECK("wgrad_tr_kernel");

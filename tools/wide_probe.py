@@ -69,6 +69,15 @@ for name in ("ring", "wide"):
     print("%-5s M=%d masks=%s: forward %.1f us = %.0f TFLOP/s issued (%.1f %% of 2.5 PF) | dgrad chain %.1f us = %.0f TFLOP/s (%.1f %%)" % (
         name, M, pat, tf, fl_f / tf / 1e6, fl_f / tf / 1e6 / 25, tb, fl_b / tb / 1e6, fl_b / tb / 1e6 / 25), flush=True)
     print("      batched weight gradients %.1f us, feature gradient %.1f us" % (timed(rows, "gemm_wgrad_fc"), timed(rows, "gemm_dfeat_scatter")), flush=True)
+    if name == "wide" and hasattr(lib, "scenerf_hip_test_wgrad_cyc"):
+        buf = (C.c_ulonglong * (64 * 16))()
+        lib.scenerf_hip_test_wgrad_cyc(buf, 64 * 16)
+        import numpy as np
+        a_ = np.array(buf[:], dtype=np.float64).reshape(64, 2, 8)
+        for w_ in (0, 1):
+            m_ = a_[:, w_, :].mean(0)
+            print("      wgrad wave %d: per step: barrier %.0f  read0 %.0f  mma0 %.0f  read1 %.0f  mma1 %.0f  (steps %.0f) cycles" % (
+                4 * w_, m_[0] / m_[5], m_[1] / m_[5], m_[2] / m_[5], m_[3] / m_[5], m_[4] / m_[5], m_[5]))
     res[name] = (run, dH, dN)
 (a, dHa, dNa), (b, dHb, dNb) = res["ring"], res["wide"]
 msg = ["logits max diff %.2e (scale %.2f)" % ((a.logits - b.logits).abs().max().item(), a.logits.abs().max().item())]
