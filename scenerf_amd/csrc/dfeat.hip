@@ -57,6 +57,7 @@ __device__ static inline void df_glds16(const void* src, unsigned lds_wave_base)
 struct DfeatArgs {
     const void* dH;          // [M][ldh] bf16, the first DF_K columns are read
     int ldh, M;
+    unsigned live;           // levels of this launch that have a gradient map
     const uint8_t* tile_mask;
     const int32_t* tap_texel;   // [M][5][4]
     const float* tap_weight;    // [M][5][4]
@@ -85,14 +86,88 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x, m0 = tile * DF_BM;
+    // Work item = (tile, pass): workgroup b takes the b-th pass (NTP column tiles) of the tiles that have work in this launch (a level
+    // of this launch's set with a gradient map), found by a prefix scan over the mask bytes.  With one workgroup per tile, the four
+    // tiles of a KITTI frame that also touch the 1/4 level (15 column tiles = three passes, ~150 us) set the duration of the whole
+    // coarser-level launch (162 us for the 322 tiles that have a coarser level; r02_d); and with blockIdx = tile a launch whose
+    // active tiles are every fourth one (tools/dfeat_probe.py's periodic masks) ran on two of the eight XCDs.
+    // (a launch has one workgroup per tile; the passes beyond that -- tiles with more than NTP column tiles -- go to the first
+    // workgroups as second items)
+#ifdef H_CYC
+    int ci = 0;
+#endif
+    // The scan: thread i owns tiles i, i + 256, ...; per group of 256 tiles a wave-level prefix of the pass counts (shuffles), the
+    // per-(group, wave) totals through LDS, one barrier; every workgroup also learns the number of items, so only the few that have a
+    // second item look again.
+    constexpr int DF_SCAN_G = 8;       // groups of DF_THREADS tiles per sweep
+    int n_items = 0x7fffffff;
+    for (int want = blockIdx.x; want < n_items; want += gridDim.x) {
+    int tile = -1, pass0 = 0;
+    {
+        int* const s_wc = (int*)lds;   // [4 g + w] pass count of wave w's tiles in group g; [4 DF_SCAN_G ..] the item found: tile, pass
+        const int ntile = (p.M + DF_BM - 1) / DF_BM;
+        int base = 0;
+        for (int sweep0 = 0; sweep0 < ntile; sweep0 += DF_SCAN_G * DF_THREADS) {
+            __syncthreads();           // (previous sweep / previous item: its reads of this memory are done)
+            if (tid == 0) s_wc[4 * DF_SCAN_G] = -1;
+            int cnt[DF_SCAN_G], incl[DF_SCAN_G];
+#pragma unroll
+            for (int g = 0; g < DF_SCAN_G; ++g) {
+                const int t = sweep0 + g * DF_THREADS + tid;
+                cnt[g] = 0;
+                if (t < ntile) {
+                    const unsigned m = (unsigned)p.tile_mask[t] & p.live;
+                    int n = 0;
+#pragma unroll
+                    for (int sc = 0; sc < SCENERF_N_SCALES; ++sc) n += ((m >> sc) & 1u) ? (p.C[sc] + 31) >> 5 : 0;
+                    cnt[g] = (n + NTP - 1) / NTP;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < DF_SCAN_G; ++g) {
+                incl[g] = cnt[g];
+                if (sweep0 + g * DF_THREADS < ntile) {   // (uniform: groups past the last tile cost nothing)
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const int o = __shfl_up(incl[g], d);
+                        if (lane >= d) incl[g] += o;
+                    }
+                }
+                if (lane == 63) s_wc[4 * g + wv] = incl[g];
+            }
+            __syncthreads();
+            int run = base;            // items before (group g, wave 0)
+#pragma unroll
+            for (int g = 0; g < DF_SCAN_G; ++g) {
+                if (sweep0 + g * DF_THREADS >= ntile) break;
+                int before = run;
+                for (int i = 0; i < wv; ++i) before += s_wc[4 * g + i];
+                const int excl = before + incl[g] - cnt[g];
+                if (cnt[g] > 0 && want >= excl && want < excl + cnt[g]) {
+                    s_wc[4 * DF_SCAN_G] = sweep0 + g * DF_THREADS + tid;
+                    s_wc[4 * DF_SCAN_G + 1] = want - excl;
+                }
+                run += s_wc[4 * g] + s_wc[4 * g + 1] + s_wc[4 * g + 2] + s_wc[4 * g + 3];
+            }
+            base = run;
+            __syncthreads();
+            if (s_wc[4 * DF_SCAN_G] >= 0) { tile = s_wc[4 * DF_SCAN_G]; pass0 = s_wc[4 * DF_SCAN_G + 1]; }
+            // (keep sweeping: the item count decides whether this workgroup comes back)
+        }
+        n_items = base;
+        __syncthreads();              // the scratch words are part of the first K-loop stage
+        if (tile < 0) return;         // no such item: done
+    }
+    pass0 = __builtin_amdgcn_readfirstlane(pass0);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    const int m0 = tile * DF_BM;
     const unsigned mask = __builtin_amdgcn_readfirstlane((unsigned)p.tile_mask[tile] & 31u) & p.levels;
     // this tile's column tiles, level by level (wave-uniform, a few scalar registers): (level, first channel)
     int nt = 0;
 #pragma unroll
     for (int s = 0; s < SCENERF_N_SCALES; ++s)
         if (((mask >> s) & 1u) && p.gmap[s]) nt += (p.C[s] + 31) >> 5;
-    if (nt == 0) return;
+    if (nt == 0) continue;
     auto tile_level = [&](int t, int& s_out, int& c0_out) __attribute__((always_inline)) {
         int acc = 0;
         s_out = 0; c0_out = 0;
@@ -107,12 +182,10 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
     float* const Cs = (float*)(lds + DF_L_CS);
     int* const s_tx = (int*)(lds + DF_L_TX);
     float* const s_tw = (float*)(lds + DF_L_TW);
-#ifdef H_CYC
-    int ci = 0;
-#endif
     DF_STAMP()   // 0: start
 
-    for (int t0 = 0; t0 < nt; t0 += NTP) {   // passes (one, except for tiles that touch more than 256 channels)
+    {   // this workgroup's pass: column tiles [t0, t0 + np)
+        const int t0 = pass0 * NTP;
         const int np = min(NTP, nt - t0);
         // ---- K loop: acc[t] (C^T tiles: rows = channels, columns = this wave's 32 rows) += W_t[:, step] x dH[rows, step]
         // stage = [128 rows of dH][KSB] ++ [NTP x 32 weight rows][KSB]; 16-byte slot q of row r sits at q ^ swz(r)
@@ -298,6 +371,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
             tb = te;
         }
     }
+    }   // items
 }
 
 int launch_dfeat_scatter(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const uint8_t* tile_mask, const int32_t* tap_texel,
@@ -333,14 +407,23 @@ int launch_dfeat_scatter(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
     // the finest level (every tile has it: 80 channels = 3 column tiles, one pass) and the coarser ones (a quarter of the tiles at
     // KITTI's geometry; 5 column tiles per pass) as two launches: a tile's dH rows are read once per launch that touches it
     const bool fine3 = gmaps[0] && cfg->map_C[0] <= 96;
+    unsigned have = 0;
+    for (int sc = 0; sc < SCENERF_N_SCALES; ++sc) have |= gmaps[sc] ? 1u << sc : 0u;
     if (fine3) {
         p.levels = 1u;
+        p.live = p.levels & have;
         dfeat_kernel<3><<<tiles, DF_THREADS, df_lds(3), s>>>(p);
     }
     p.levels = fine3 ? 30u : 31u;
     bool rest = false;
     for (int sc = 0; sc < SCENERF_N_SCALES; ++sc) rest = rest || (((p.levels >> sc) & 1u) && gmaps[sc]);
-    if (rest) dfeat_kernel<DF_NTB><<<tiles, DF_THREADS, df_lds(DF_NTB), s>>>(p);
+    p.live = p.levels & have;
+    // the coarser levels: a quarter of the tiles at KITTI's geometry, so two workgroups per CU take the items in turn (a workgroup
+    // that finds no item still pays the scan: 15 us per launch with one workgroup per tile and nothing to do)
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, srf_device());
+    const int grid2 = tiles < 2 * cus ? tiles : 2 * cus;
+    if (rest) dfeat_kernel<DF_NTB><<<grid2, DF_THREADS, df_lds(DF_NTB), s>>>(p);
     SRF_LAUNCH_CHECK("dfeat_kernel");
     return 0;
 }

@@ -130,17 +130,26 @@ __global__ void linout_reduce_kernel(const float* __restrict__ partial, int nblo
 // lo = bf16(x - hi) (16 significant bits: raw xyz reaches ~100 m), and the weight is split the same way on the host;
 // x_hi.w_hi + x_lo.w_hi + x_hi.w_lo reproduces the fp32 product to ~2^-16.  Row layout: [hi(48) | lo(48) | hi(48)].
 __global__ void split_xenc_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int M) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)M * SCENERF_D_XENC) return;
-    const size_t m = i / SCENERF_D_XENC;
-    const int c = (int)(i - m * SCENERF_D_XENC);
-    const float x = in[i];
-    const bf16_t hi = f32_to_bf16(x);
-    const bf16_t lo = f32_to_bf16(x - bf16_to_f32(hi));
-    bf16_t* o = out + m * (3 * SCENERF_D_XENC);
-    o[c] = hi;
-    o[SCENERF_D_XENC + c] = lo;
-    o[2 * SCENERF_D_XENC + c] = hi;
+    // one thread per 8 consecutive encodings of a row: two 16-byte loads, three 16-byte stores
+    static_assert(SCENERF_D_XENC % 8 == 0, "8 encodings per thread");
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * (SCENERF_D_XENC / 8)) return;
+    const size_t m = i / (SCENERF_D_XENC / 8);
+    const int c = (int)(i - m * (SCENERF_D_XENC / 8)) * 8;
+    const float4 x0 = *(const float4*)(in + m * SCENERF_D_XENC + c), x1 = *(const float4*)(in + m * SCENERF_D_XENC + c + 4);
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bf16_t h0 = f32_to_bf16(x[2 * e]), h1 = f32_to_bf16(x[2 * e + 1]);
+        const bf16_t l0 = f32_to_bf16(x[2 * e] - bf16_to_f32(h0)), l1 = f32_to_bf16(x[2 * e + 1] - bf16_to_f32(h1));
+        hi[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        lo[e] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+    }
+    bf16_t* o = out + m * (3 * SCENERF_D_XENC) + c;
+    *(uint4*)o = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *(uint4*)(o + SCENERF_D_XENC) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    *(uint4*)(o + 2 * SCENERF_D_XENC) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
 }
 
 template <typename T>
@@ -331,7 +340,7 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
         bf16_t* x3 = (bf16_t*)a->h0pre;
         {
             SrfLaunchScope ps(s, "split_xenc", 0, (double)M * SCENERF_D_XENC * 10);
-            size_t n = (size_t)M * SCENERF_D_XENC;
+            size_t n = (size_t)M * (SCENERF_D_XENC / 8);
             split_xenc_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(xenc, x3, M);
             SRF_LAUNCH_CHECK("split_xenc_kernel");
         }

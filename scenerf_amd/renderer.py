@@ -182,7 +182,7 @@ class PrepareMaps(torch.autograd.Function):
 class PackedMLP:
     """ResnetFC parameters in the operand layout of include/scenerf_hip.h::scenerf_mlp_weights."""
 
-    def __init__(self, params: Sequence[torch.Tensor], d_out: int, cfg: RenderConfig):
+    def __init__(self, params: Sequence[torch.Tensor], d_out: int, cfg: RenderConfig, pack_stream=None):
         p = dict(zip(MLP_PARAM_NAMES, [_f32c(t) for t in params]))
         for n, t in p.items():
             _require_cuda(t, n)
@@ -235,13 +235,27 @@ class PackedMLP:
             raw.fc1_w[i], raw.fc1_b[i] = p["blocks.%d.fc_1.weight" % i].data_ptr(), p["blocks.%d.fc_1.bias" % i].data_ptr()
             raw.linz_w[i], raw.linz_b[i] = p["lin_z.%d.weight" % i].data_ptr(), p["lin_z.%d.bias" % i].data_ptr()
         ccfg = cfg.to_c()
-        _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(raw), C.byref(s), _stream(dev)), "mlp_pack")
+        # pack_stream: launch the pack there instead of on the current stream (the radiance MLP's operands are first read ~0.3 ms into
+        # a training step, after the gaussian head's chain: its pack runs beside that chain); wait_ready() orders the consumer
+        self._ready = None
+        if pack_stream is not None:
+            pack_stream.wait_stream(torch.cuda.current_stream(dev))   # the parameters were last written on the current stream
+            _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(raw), C.byref(s), pack_stream.cuda_stream), "mlp_pack")
+            self._ready = pack_stream.record_event()
+        else:
+            _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(raw), C.byref(s), _stream(dev)), "mlp_pack")
         # gradient sink (flat fp32 buffer carved into the scenerf_mlp_grads fields), allocated on first backward
         self.gflat: Optional[torch.Tensor] = None
         self.gviews: Dict[str, torch.Tensor] = {}
         self.gc: Optional[_capi.MlpGrads] = None
 
     _GRAD_FIELDS = None
+
+    def wait_ready(self) -> None:
+        """Order the current stream after a pack that was launched on another stream (no-op otherwise, and after the first call)."""
+        ev, self._ready = self._ready, None
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
 
     def grad_sink(self) -> "_capi.MlpGrads":
         if self.gc is not None:
@@ -296,12 +310,15 @@ class MlpHolder:
         self.pending = None          # finisher of a collective in flight on the sink
         self.synced = False          # the sink was already reduced (early, on the side stream: RenderChunk.backward)
         self.single_chunk = False    # set by render_rays_batch when the whole call is one chunk
+        self.defer_pack = False      # pack on the side stream (the radiance MLP: first used after the gaussian head's chain)
 
 
 class PackMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, holder: MlpHolder, d_out: int, cfg: RenderConfig, *params):
-        holder.packed = PackedMLP(params, d_out, cfg)
+        # training sessions (a parameter gradient will be asked for): the radiance MLP is packed on the side stream
+        side = _side_stream(params[0].device) if (holder.defer_pack and any(ctx.needs_input_grad[3:])) else None
+        holder.packed = PackedMLP(params, d_out, cfg, pack_stream=side)
         ctx.holder = holder
         return torch.empty(1, device=params[0].device)   # autograd token: its value is never read (no fill launch)
 
@@ -371,6 +388,7 @@ def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dis
               K, inv_K, T, M, keep_acts: bool = True) -> _MlpRun:
     lib = _capi.load()
     st = _stream(dist.device)
+    pk.wait_ready()
     run = _MlpRun(M, pk.d_out, cfg.precision_code, dist.device, lean=(not keep_acts) and cfg.uses_fused(M))
     _capi.check(lib.scenerf_hip_encode_points(C.byref(ccfg), dist.data_ptr(), dist_ray_stride, ppr, unit_dir.data_ptr(),
                                               viewdir.data_ptr(), K.data_ptr(), inv_K.data_ptr(), T.data_ptr(), M, None,
@@ -389,6 +407,7 @@ def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: 
     gradient GEMMs are queued, so their all-reduce is started there and the feature-gradient GEMM + scatter (0.5 ms) runs while
     the collective is in flight; returns the collective's finisher (or None)."""
     lib = _capi.load()
+    pk.wait_ready()
     act = _act_dtype(cfg.precision_code)
     dev = d_logits.device
     dH = torch.empty((run.M, 4 * D_H), dtype=act, device=dev)
@@ -594,6 +613,7 @@ class RenderSession:
         # autograd runs ready nodes newest-first: the MLP tokens are created BEFORE the map token so that in backward the map
         # transposes (PrepareMaps.backward) are queued before PackMLP.backward waits for a gradient all-reduce in flight
         self.mlp, self.mlpg = MlpHolder(grad_sync, grad_sync_async), MlpHolder(grad_sync)
+        self.mlp.defer_pack = True
         self.tok_mlp = PackMLP.apply(self.mlp, 4, cfg, *mlp_params)
         self.tok_mlpg = PackMLP.apply(self.mlpg, 2, cfg, *mlpg_params)
         self.maps = MapHolder(cfg)

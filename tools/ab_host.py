@@ -1,0 +1,18 @@
+"""A/B of host-side scheduling choices on one GPU box (box-to-box spread is +-4 %, more than what is being measured): runs bench.py in
+this process with parts of the renderer's stream plumbing switched off.
+usage: ab_host.py <mode> [bench.py arguments]     mode: comma list of  base | nopre (map-gradient accumulators zeroed in the backward)
+                                                                         | nodefer (radiance-MLP pack on the main stream)"""
+import os, runpy, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+mode = sys.argv[1].split(",")
+sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[2:]
+import scenerf_amd.renderer as r
+if "nopre" in mode:
+    r.MapHolder.prefill_grad_accumulators = lambda self: None
+if "nodefer" in mode:
+    _init = r.PackedMLP.__init__
+    def init(self, params, d_out, cfg, pack_stream=None):
+        _init(self, params, d_out, cfg, pack_stream=None)
+    r.PackedMLP.__init__ = init
+runpy.run_path(sys.argv[0], run_name="__main__")
