@@ -1,7 +1,8 @@
 """A/B of host-side scheduling choices on one GPU box (box-to-box spread is +-4 %, more than what is being measured): runs bench.py in
 this process with parts of the renderer's stream plumbing switched off.
 usage: ab_host.py <mode> [bench.py arguments]     mode: comma list of  base | nopre (map-gradient accumulators zeroed in the backward)
-                                                                         | nodefer (radiance-MLP pack on the main stream)"""
+                                                                         | nodefer (radiance-MLP pack on the main stream)
+                                                                         | overlap (scenerf_cfg flag WGRAD_OVERLAP: weight gradients on the library's side stream)"""
 import os, runpy, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,4 +16,12 @@ if "nodefer" in mode:
     def init(self, params, d_out, cfg, pack_stream=None):
         _init(self, params, d_out, cfg, pack_stream=None)
     r.PackedMLP.__init__ = init
+if "overlap" in mode:
+    from scenerf_amd import _capi, config
+    _to_c = config.RenderConfig.to_c
+    def to_c(self):
+        c = _to_c(self)
+        c.flags |= _capi.FLAG_WGRAD_OVERLAP
+        return c
+    config.RenderConfig.to_c = to_c
 runpy.run_path(sys.argv[0], run_name="__main__")
