@@ -246,7 +246,7 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
             }
         }
     };
-    static_assert(W_BM == 32, "the staggered loop is written for two k-steps per step");
+    static_assert(W_BM == 32 || !W_STAGGER, "the staggered loop is written for two k-steps per step");
 #ifdef W_CYC
     unsigned long long tb = 0, tr0 = 0, tm0 = 0, tr1 = 0, tm1 = 0, t0, t1;
 #define W_T(acc_) do { t1 = __builtin_readcyclecounter(); acc_ += t1 - t0; t0 = t1; } while (0)
@@ -288,10 +288,11 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
             rd(S + 16 * W_ROW); W_T(tr1);
             mm(c); W_T(tm1);
 #else
-            rd(S);
-            mm(c);
-            rd(S + 16 * W_ROW);
-            mm(c);
+#pragma unroll
+            for (int ks = 0; ks < W_BM / 16; ++ks) {
+                rd(S + ks * 16 * W_ROW);
+                mm(c);
+            }
 #endif
         }
     }
@@ -318,6 +319,14 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_tr_kernel(WgradArgs p) {
         }
     }
 }
+
+
+// Measured alternative (r02_e, not kept): the same kernel without producer waves -- eight waves with 256 registers each, two sets of
+// fragments per wave so that the reads of the next k-step are in flight while the current one multiplies (also across the barrier),
+// every wave moving its own four 1-KiB pieces per step by DMA.  Correct, and 5 % SLOWER than the twelve-wave form (615-622 us
+// against 588 us for the batch): the step is not bound by a wave's own read -> multiply chain.  tools/ubench/mfma_lds.hip has the
+// single-wave picture (12 LDS reads around 8 MFMAs: 248 ns against 134 ns for the MFMAs alone with one wave per SIMD, 304 against 251
+// with two).
 
 // Used by launch_gemm_tn for the shapes it fits (bf16, N and K multiples of 256, no tile skipping, enough rows).
 bool wgrad_tr_applicable(const GemmTN& p, int min_rows) {
