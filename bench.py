@@ -91,6 +91,10 @@ def parse():
     ap.add_argument("--stride", type=int, default=1, help="infer: pixel stride of the rendered frame (1 = all 451,400 px)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: run the control flow (collectives, timing, JSON) around a stub step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--maps", default="hwc", choices=["hwc", "chw"],
+                    help="memory layout of the feature maps handed to render_rays_batch: hwc = (C,H,W) tensors with channels-last strides (what a "
+                         "torch.channels_last decoder or SphereResampler(layout='hwc') emits; read in place), chw = contiguous (C,H,W) as the "
+                         "reference's decoder emits (converted per call).  The other one is timed too and reported as 'other_entry'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=0, help="rays of the CPU-baseline sample (0 = the bench's own --rays)")
@@ -182,6 +186,20 @@ def eager_gpu_baseline(args, dev):
     dt = (time.perf_counter() - t0) / n
     return {"value": round(R / dt, 1), "unit": "rays/s", "kind": "eager PyTorch-ROCm port of the reference hot path, fp32",
             "ms_per_step": round(dt * 1e3, 2), "sample": "%d rays x %d samples fwd+bwd, 3 steps" % (R, args.samples)}
+
+
+def _make_maps(layout, dev, rank):
+    """The five pyramid levels as leaf (C,H,W) fp32 tensors: contiguous ('chw') or with channels-last strides ('hwc': memory (H,W,C))."""
+    maps = {}
+    for k, v in synth.feature_maps(1500, 452, 3 + rank).items():
+        if layout == "hwc":
+            c, h, w = v.shape
+            t = torch.empty_strided((c, h, w), (1, w * c, c), dtype=torch.float32, device=dev)
+            t.copy_(v.to(dev))
+            maps[k] = t.requires_grad_(True)
+        else:
+            maps[k] = v.to(dev).requires_grad_(True)
+    return maps
 
 
 def _timed(step, args, world, dev, sync):
@@ -411,7 +429,7 @@ def main():
         model = make_model(args, dev)
         params = list(model.mlp.parameters()) + list(model.mlp_gaussian.parameters())
         opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, fused=True)
-        maps = {k: v.to(dev).requires_grad_(True) for k, v in synth.feature_maps(1500, 452, 3 + rank).items()}
+        maps = _make_maps(args.maps, dev, rank)
         K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
         pix = synth.stride2_pixels((1220, 370), R, 100 + rank).to(dev)
     # N > 1: each MLP's packed gradient sink is all-reduced (RCCL) right before it is handed to autograd: 2 x 21.7 MB
@@ -440,6 +458,16 @@ def main():
     if dry:   # every rank holds the mean over ranks of both buffers
         want = 3.0 * sum(r + 1.0 for r in range(world)) / world
         assert abs(float(last) - want) < 1e-6, (float(last), want)
+
+    other = None
+    if world == 1 and not dry and not args.no_roofline:   # the same step with the other map layout at the boundary (side measurement)
+        main_maps = maps
+        maps = _make_maps("chw" if args.maps == "hwc" else "hwc", dev, rank)
+        dt2, _ = _timed(step, args, world, dev, sync)
+        other = {"maps": "chw" if args.maps == "hwc" else "hwc", "value": round(R * args.steps / dt2, 1), "unit": "rays/s",
+                 "ms_per_step": round(dt2 / args.steps * 1e3, 3)}
+        maps = main_maps
+        torch.cuda.empty_cache()
 
     allreduce = None
     if world > 1:   # three more steps with the collectives bracketed by events; every rank takes part, then the group is done
@@ -518,10 +546,15 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "KITTI 370x1220, sphere 1500x452, %d samples/ray (U=%d,G=4,P=%d), %d rays/GPU/step, "
-                                   "render_rays_batch fwd+bwd incl. map layout conversion, MLP packing, feature-map + MLP "
-                                   "gradients, grad all-reduce (N>1), fused AdamW on both MLPs" % (args.samples, U, P, R),
+                                   "render_rays_batch fwd+bwd, %s, MLP packing, feature-map + MLP "
+                                   "gradients, grad all-reduce (N>1), fused AdamW on both MLPs" % (
+                                       args.samples, U, P, R,
+                                       "feature maps handed over channels-last ((C,H,W) tensors with (H,W,C) memory, read in place; the "
+                                       "contiguous-(C,H,W) entry with its per-call layout conversion is timed as other_entry)"
+                                       if args.maps == "hwc" else "incl. map layout conversion (contiguous (C,H,W) maps)"),
                        "rays_per_gpu": R, "samples_per_ray": args.samples, "parallelism": "dp%d" % world,
-                       "precision": args.precision},
+                       "precision": args.precision, "maps": args.maps},
+            "other_entry": other,
             "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager, "fp32_mode": fp32,
             "allreduce": allreduce,
         }

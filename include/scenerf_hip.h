@@ -63,10 +63,13 @@ typedef struct scenerf_cfg {
     int32_t map_H[SCENERF_N_SCALES], map_W[SCENERF_N_SCALES]; /* round(H/s), round(W/s): unet2d_sphere.py:139 */
     int32_t div_H[SCENERF_N_SCALES], div_W[SCENERF_N_SCALES]; /* H//s, W//s: scenerf.py:525 */
     int32_t precision;              /* 0 fp32, 1 bf16 operands */
-    int32_t map_chw[SCENERF_N_SCALES]; /* 1: scale s is NOT converted -- gather_features reads the caller's fp32 (C,H,W) map and the
-                                          feature gradient is scattered into an fp32 (C,H,W) buffer (slow per access, meant for the coarse
-                                          scales that quirk Q1 keeps out of range for all but <= 1/s^2 of the sphere) ; 0: (H,W,C) act copy
-                                          and (H,W,C) fp32 gradient accumulator */
+    int32_t map_chw[SCENERF_N_SCALES]; /* layout of the map handed to gather_features / of the gradient buffer handed to mlp_backward:
+                                          0: (H,W,C) copy in the activation type (maps_chw_to_hwc), (H,W,C) fp32 gradient accumulator;
+                                          1: scale s is NOT converted -- gather_features reads the caller's fp32 (C,H,W) map and the
+                                             feature gradient is scattered into an fp32 (C,H,W) buffer (slow per access, meant for the
+                                             coarse scales that quirk Q1 keeps out of range for all but <= 1/s^2 of the sphere);
+                                          2: the caller's fp32 (H,W,C) map read in place, (H,W,C) fp32 gradient accumulator: no layout
+                                             conversion in either direction (the entry for a producer that emits (H,W,C)) */
     /* kernel-path selection (explicit state of the call, never ambient: no environment variable changes what a call computes) */
     int32_t fused_min_rows;         /* bf16: row count M from which the ResnetFC trunk (forward) and the dgrad chain (backward) each run as
                                        ONE fused kernel; below it the per-layer GEMM path runs.  0 = library default (4096); < 0 = never */
@@ -331,6 +334,12 @@ int scenerf_hip_sphere_resample_forward(const float* x, int64_t planes, int H, i
                                         float* out, scenerf_stream_t stream);
 int scenerf_hip_sphere_resample_backward(const float* dout, int64_t planes, int H, int W, const int32_t* row_ptr, const int32_t* cells,
                                          int out_w, int out_h, float* dx, scenerf_stream_t stream);
+/* The same two with a channels-last sphere side: out / dout are fp32 [B][out_h][out_w][C] (planes = B*C, a multiple of C) -- the layout
+ * the renderer reads in place (scenerf_cfg.map_chw == 2), so that no layout conversion sits between the decoder and gather_features. */
+int scenerf_hip_sphere_resample_forward_nhwc(const float* x, int64_t planes, int C, int H, int W, const int32_t* src, int out_w, int out_h,
+                                             float* out, scenerf_stream_t stream);
+int scenerf_hip_sphere_resample_backward_nhwc(const float* dout, int64_t planes, int C, int H, int W, const int32_t* row_ptr,
+                                              const int32_t* cells, int out_w, int out_h, float* dx, scenerf_stream_t stream);
 
 #ifdef __cplusplus
 }

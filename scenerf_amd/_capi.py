@@ -101,6 +101,8 @@ _PROTOS = {
     "scenerf_hip_sphere_map_build": (C.c_int, [vp, vp, C.c_int64, i32, i32, i32, vp, vp, vp]),
     "scenerf_hip_sphere_resample_forward": (C.c_int, [vp, C.c_int64, i32, i32, vp, i32, i32, vp, vp]),
     "scenerf_hip_sphere_resample_backward": (C.c_int, [vp, C.c_int64, i32, i32, vp, vp, i32, i32, vp, vp]),
+    "scenerf_hip_sphere_resample_forward_nhwc": (C.c_int, [vp, C.c_int64, i32, i32, i32, vp, i32, i32, vp, vp]),
+    "scenerf_hip_sphere_resample_backward_nhwc": (C.c_int, [vp, C.c_int64, i32, i32, i32, vp, vp, i32, i32, vp, vp]),
     "scenerf_hip_loss_side_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_loss_side_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "scenerf_hip_mlp_feature_grads": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpWeights), vp, vp, vp, i32, vp,

@@ -47,6 +47,9 @@ class RenderConfig:
     # adding level 2 saves 80 us more in conversions but its 0.14 % of samples cluster in a few row tiles whose 1280 strided
     # cache-line reads per sample stretch the gather by 100 us.
     direct_scales: Tuple[int, ...] = (3, 4)
+    # pyramid levels handed over as fp32 (H,W,C) tensors (renderer.HWC): read in place, gradient returned in (H,W,C) -- no layout
+    # conversion in either direction (scenerf_cfg.map_chw == 2).  Set per call by RenderSession from the maps it is given.
+    hwc_scales: Tuple[int, ...] = ()
     # kernel-path selection (scenerf_cfg.fused_min_rows / fwd_kernel / flags): explicit per-call state, no environment variables
     fused_min_rows: int = _capi.FUSED_MIN_ROWS_DEFAULT   # bf16: rows from which the ResnetFC trunk / dgrad chain run as one fused kernel; < 0 never
     fwd_kernel: str = "wide"          # fused forward variant: "ring" (fused.hip), "stream" (stream.hip; bit-identical), "wide" (wide.hip: 128-row blocks)
@@ -128,7 +131,7 @@ class RenderConfig:
             c.div_H[i], c.div_W[i] = self.sphere_H // s, self.sphere_W // s   # scenerf.py:525
         c.precision = self.precision_code
         for i in range(5):
-            c.map_chw[i] = 1 if i in self.direct_scales else 0
+            c.map_chw[i] = 2 if i in self.hwc_scales else (1 if i in self.direct_scales else 0)
         c.fused_min_rows = int(self.fused_min_rows)
         c.fwd_kernel = {"ring": 0, "stream": 1, "wide": 2}[self.fwd_kernel]
         c.flags = ((0 if self.fused_backward else _capi.FLAG_NO_FUSED_BWD) | (0 if self.wgrad_tr else _capi.FLAG_NO_WGRAD_TR)

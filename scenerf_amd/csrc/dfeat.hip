@@ -388,7 +388,7 @@ int launch_dfeat_scatter(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
         p.gmap[sc] = gmaps[sc];
         p.C[sc] = cfg->map_C[sc];
         p.st[sc] = cfg->map_C[sc]; p.sc[sc] = 1;                                                          // (H,W,C)
-        if (cfg->map_chw[sc]) { p.st[sc] = 1; p.sc[sc] = (long)cfg->map_H[sc] * cfg->map_W[sc]; }       // (C,H,W)
+        if (cfg->map_chw[sc] == 1) { p.st[sc] = 1; p.sc[sc] = (long)cfg->map_H[sc] * cfg->map_W[sc]; }       // (C,H,W)
         any = any || gmaps[sc];
     }
     if (!any) return 0;

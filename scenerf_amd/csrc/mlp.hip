@@ -256,7 +256,7 @@ static int feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
             g.ms_C[sc] = cfg->map_C[sc];
             g.ms_W[sc] = w->w_z_t[sc];
             g.ms_gmap[sc] = gmaps_hwc[sc];
-            if (cfg->map_chw[sc]) { g.ms_st[sc] = 1; g.ms_sc[sc] = (long)cfg->map_H[sc] * cfg->map_W[sc]; }   // (C,H,W) gradient buffer
+            if (cfg->map_chw[sc] == 1) { g.ms_st[sc] = 1; g.ms_sc[sc] = (long)cfg->map_H[sc] * cfg->map_W[sc]; }   // (C,H,W) gradient buffer
             any = any || gmaps_hwc[sc];
             t += cdiv(cfg->map_C[sc], 128);
         }
@@ -274,7 +274,7 @@ static int feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
         g.skip_bit = sc;
         g.gmap = gmaps_hwc[sc]; g.scatter_scale = sc;
         g.gmap_st = 0; g.gmap_sc = 1;
-        if (cfg->map_chw[sc]) { g.gmap_st = 1; g.gmap_sc = (long)cfg->map_H[sc] * cfg->map_W[sc]; }   // (C,H,W) gradient buffer
+        if (cfg->map_chw[sc] == 1) { g.gmap_st = 1; g.gmap_sc = (long)cfg->map_H[sc] * cfg->map_W[sc]; }   // (C,H,W) gradient buffer
         if (int e = launch_gemm_nt(cfg->precision, g, s)) return e;
     }
     return 0;

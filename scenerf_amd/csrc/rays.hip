@@ -122,7 +122,7 @@ __global__ void encode_points_kernel(const float* __restrict__ dist, int dist_ra
 // ------------------------------------------------------------------------------------------------ gather
 struct GatherConsts {
     int C[5], Hm[5], Wm[5], Hd[5], Wd[5], off[5];
-    int chw[5];   // scale read from the caller's fp32 (C,H,W) map instead of an (H,W,C) copy (scenerf_cfg.map_chw)
+    int chw[5];   // scenerf_cfg.map_chw: 1 = read from the caller's fp32 (C,H,W) map, 2 = from the caller's fp32 (H,W,C) map, 0 = (H,W,C) act copy
 };
 
 template <typename T> struct Vec16;  // 16-byte vector of T
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
         }
         s_rowbits[tid] = (uint8_t)bits;
         for (int sc = 0; sc < 5; ++sc)
-            if (gc.chw[sc] && ((bits >> sc) & 1u)) s_list[sc][atomicAdd(&s_cnt[sc], 1)] = (uint8_t)tid;
+            if (gc.chw[sc] == 1 && ((bits >> sc) & 1u)) s_list[sc][atomicAdd(&s_cnt[sc], 1)] = (uint8_t)tid;
         if (bits) atomicOr(&s_mask, bits);
     }
     __syncthreads();
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
         }
         const int C = gc.C[s];
         const int chunks = C / VN;
-        if (gc.chw[s]) {
+        if (gc.chw[s] == 1) {
             // this scale was not converted: blend straight from the caller's fp32 (C,H,W) map.  Rows without a tap (nearly all of
             // them at the coarse scales) get their zeros from the vector loop; a row with taps spreads its C x 4 strided loads
             // over the whole workgroup -- they are independent cache lines, so parallelism is what hides them
@@ -277,6 +277,43 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
             }
             continue;
         }
+        if (gc.chw[s] == 2 && sizeof(T) != 4) {
+            // the caller's fp32 (H,W,C) map read in place (scenerf_cfg.map_chw == 2): same loop as below with fp32 taps -- the blend
+            // sees the unrounded features, Z is rounded once
+            const float* mapf = (const float*)maps.p[s];
+            const int items = SCENERF_TILE_ROWS * chunks;
+            for (int it = tid; it < items; it += 256) {
+                const int row = it / chunks, ch = it - row * chunks;
+                float acc[VN];
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+                bool first = true;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int tx = s_tex[row][s][t];
+                    if (tx >= 0) {
+                        float v[VN];
+#pragma unroll
+                        for (int q = 0; q < VN / 4; ++q) {
+                            const float4 f = *(const float4*)(mapf + (size_t)tx * C + ch * VN + 4 * q);
+                            v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+                        }
+                        const float w = s_w[row][s][t];
+                        if (first) {
+#pragma unroll
+                            for (int e = 0; e < VN; ++e) acc[e] = v[e] * w;
+                            first = false;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < VN; ++e) acc[e] = fmaf(v[e], w, acc[e]);
+                        }
+                    }
+                }
+                Vec16<T>::store(Z + ((size_t)tile * SCENERF_TILE_ROWS + row) * SCENERF_D_LATENT + gc.off[s] + ch * VN, acc);
+            }
+            continue;
+        }
+        // (fp32 mode: an (H,W,C) fp32 map read in place is exactly what this loop reads)
         const T* map = (const T*)maps.p[s];
         const int items = SCENERF_TILE_ROWS * chunks;
         for (int it = tid; it < items; it += 256) {

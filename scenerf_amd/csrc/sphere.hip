@@ -55,8 +55,15 @@ __device__ static inline float sphere_coord(int s, float size) {
     return t / 2.0f;
 }
 
+// element (plane, cell) of the sphere-side tensor: planar (B*C, out_h, out_w) when out_C == 0, channels-last (B, out_h, out_w, out_C)
+// otherwise (plane = b * out_C + c)
+__device__ static inline long long sph_idx(long long plane, int cell, int ncell, int out_C) {
+    return out_C ? ((plane / out_C) * ncell + cell) * out_C + plane % out_C : plane * ncell + cell;
+}
+
 __global__ void __launch_bounds__(SPH_THREADS)
-sphere_fwd_kernel(const float* __restrict__ x, long long planes, int H, int W, const int* __restrict__ src, int ncell, float* __restrict__ out) {
+sphere_fwd_kernel(const float* __restrict__ x, long long planes, int H, int W, const int* __restrict__ src, int ncell, int out_C,
+                  float* __restrict__ out) {
     const int cell = blockIdx.x * SPH_THREADS + threadIdx.x;
     if (cell >= ncell) return;
     const long long c0 = (long long)blockIdx.y * SPH_CG;
@@ -65,7 +72,7 @@ sphere_fwd_kernel(const float* __restrict__ x, long long planes, int H, int W, c
     if (s < 0) {
 #pragma unroll
         for (int j = 0; j < SPH_CG; ++j)
-            if (c0 + j < planes) out[(c0 + j) * ncell + cell] = 0.0f;
+            if (c0 + j < planes) out[sph_idx(c0 + j, cell, ncell, out_C)] = 0.0f;
         return;
     }
     const float ix = sphere_coord(s & 0xFFFF, (float)W), iy = sphere_coord(s >> 16, (float)H);
@@ -87,13 +94,13 @@ sphere_fwd_kernel(const float* __restrict__ x, long long planes, int H, int W, c
         acc = acc + b * w_ne;
         acc = acc + c * w_sw;
         acc = acc + d * w_se;
-        out[(c0 + j) * ncell + cell] = acc;
+        out[sph_idx(c0 + j, cell, ncell, out_C)] = acc;
     }
 }
 
 __global__ void __launch_bounds__(SPH_THREADS)
 sphere_bwd_kernel(const float* __restrict__ dout, long long planes, int H, int W, const int* __restrict__ row_ptr,
-                  const int* __restrict__ cells, int ncell, float* __restrict__ dx) {
+                  const int* __restrict__ cells, int ncell, int out_C, float* __restrict__ dx) {
     const long long p = (long long)blockIdx.x * SPH_THREADS + threadIdx.x;
     const long long hw = (long long)H * W;
     if (p >= hw) return;
@@ -122,7 +129,7 @@ sphere_bwd_kernel(const float* __restrict__ dout, long long planes, int H, int W
                 const int cell = cells[e];
 #pragma unroll
                 for (int j = 0; j < SPH_CG; ++j)
-                    if (c0 + j < planes) acc[j] = acc[j] + dout[(c0 + j) * ncell + cell] * w;
+                    if (c0 + j < planes) acc[j] = acc[j] + dout[sph_idx(c0 + j, cell, ncell, out_C)] * w;
             }
         }
     }
@@ -152,29 +159,52 @@ static bool sphere_dims_ok(int64_t planes, int H, int W, int out_w, int out_h) {
            (long long)out_w * out_h < (1ll << 31) && (long long)H * W < (1ll << 31);
 }
 
-extern "C" int scenerf_hip_sphere_resample_forward(const float* x, int64_t planes, int H, int W, const int32_t* src, int out_w, int out_h,
-                                                   float* out, scenerf_stream_t stream) {
+static int sphere_forward(const float* x, int64_t planes, int H, int W, const int32_t* src, int out_w, int out_h, int out_C, float* out,
+                          scenerf_stream_t stream) {
     SRF_CHECK(x && src && out, "sphere_resample_forward: NULL argument");
+    SRF_CHECK(out_C >= 0 && (out_C == 0 || planes % out_C == 0), "sphere_resample_forward: planes must be a multiple of the channel count");
     SRF_CHECK(sphere_dims_ok(planes, H, W, out_w, out_h), "sphere_resample_forward: bad sizes");
     hipStream_t s = as_stream(stream);
     const int ncell = out_w * out_h;
     SrfLaunchScope ps(s, "sphere_resample_fwd", 0, (double)planes * ((double)H * W + ncell) * 4.0 + ncell * 4.0);
     dim3 grid((unsigned)((ncell + SPH_THREADS - 1) / SPH_THREADS), (unsigned)((planes + SPH_CG - 1) / SPH_CG));
-    sphere_fwd_kernel<<<grid, SPH_THREADS, 0, s>>>(x, (long long)planes, H, W, src, ncell, out);
+    sphere_fwd_kernel<<<grid, SPH_THREADS, 0, s>>>(x, (long long)planes, H, W, src, ncell, out_C, out);
     SRF_LAUNCH_CHECK("sphere_resample_forward");
     return 0;
 }
 
-extern "C" int scenerf_hip_sphere_resample_backward(const float* dout, int64_t planes, int H, int W, const int32_t* row_ptr,
-                                                    const int32_t* cells, int out_w, int out_h, float* dx, scenerf_stream_t stream) {
+static int sphere_backward(const float* dout, int64_t planes, int H, int W, const int32_t* row_ptr, const int32_t* cells, int out_w, int out_h,
+                           int out_C, float* dx, scenerf_stream_t stream) {
     SRF_CHECK(dout && row_ptr && cells && dx, "sphere_resample_backward: NULL argument");
+    SRF_CHECK(out_C >= 0 && (out_C == 0 || planes % out_C == 0), "sphere_resample_backward: planes must be a multiple of the channel count");
     SRF_CHECK(sphere_dims_ok(planes, H, W, out_w, out_h), "sphere_resample_backward: bad sizes");
     hipStream_t s = as_stream(stream);
     const int ncell = out_w * out_h;
     const long long hw = (long long)H * W;
     SrfLaunchScope ps(s, "sphere_resample_bwd", 0, (double)planes * ((double)hw + ncell) * 4.0 + hw * 4.0);
     dim3 grid((unsigned)((hw + SPH_THREADS - 1) / SPH_THREADS), (unsigned)((planes + SPH_CG - 1) / SPH_CG));
-    sphere_bwd_kernel<<<grid, SPH_THREADS, 0, s>>>(dout, (long long)planes, H, W, row_ptr, cells, ncell, dx);
+    sphere_bwd_kernel<<<grid, SPH_THREADS, 0, s>>>(dout, (long long)planes, H, W, row_ptr, cells, ncell, out_C, dx);
     SRF_LAUNCH_CHECK("sphere_resample_backward");
     return 0;
+}
+
+extern "C" int scenerf_hip_sphere_resample_forward(const float* x, int64_t planes, int H, int W, const int32_t* src, int out_w, int out_h,
+                                                   float* out, scenerf_stream_t stream) {
+    return sphere_forward(x, planes, H, W, src, out_w, out_h, 0, out, stream);
+}
+extern "C" int scenerf_hip_sphere_resample_backward(const float* dout, int64_t planes, int H, int W, const int32_t* row_ptr,
+                                                    const int32_t* cells, int out_w, int out_h, float* dx, scenerf_stream_t stream) {
+    return sphere_backward(dout, planes, H, W, row_ptr, cells, out_w, out_h, 0, dx, stream);
+}
+// channels-last sphere side: out / dout are (B, out_h, out_w, C) with planes = B * C -- the layout the renderer reads in place
+// (scenerf_cfg.map_chw == 2), so that no conversion sits between the decoder and the gather
+extern "C" int scenerf_hip_sphere_resample_forward_nhwc(const float* x, int64_t planes, int C, int H, int W, const int32_t* src, int out_w,
+                                                        int out_h, float* out, scenerf_stream_t stream) {
+    SRF_CHECK(C > 0, "sphere_resample_forward_nhwc: C must be positive");
+    return sphere_forward(x, planes, H, W, src, out_w, out_h, C, out, stream);
+}
+extern "C" int scenerf_hip_sphere_resample_backward_nhwc(const float* dout, int64_t planes, int C, int H, int W, const int32_t* row_ptr,
+                                                         const int32_t* cells, int out_w, int out_h, float* dx, scenerf_stream_t stream) {
+    SRF_CHECK(C > 0, "sphere_resample_backward_nhwc: C must be positive");
+    return sphere_backward(dout, planes, H, W, row_ptr, cells, out_w, out_h, C, dx, stream);
 }

@@ -68,17 +68,22 @@ def build_map(pix: torch.Tensor, pix_sphere: torch.Tensor, scale: int, out_w: in
 
 class _Resample(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: torch.Tensor, m: SphereMap) -> torch.Tensor:
+    def forward(ctx, x: torch.Tensor, m: SphereMap, hwc: bool = False) -> torch.Tensor:
         if not x.is_cuda or x.dtype != torch.float32:
             raise RuntimeError("sphere resampling needs a float32 CUDA tensor (got %s on %s); no CPU / eager fallback" % (x.dtype, x.device))
         B, C, H, W = x.shape
         assert (H, W) == (m.H, m.W), "map was built for a %dx%d plane, got %dx%d" % (m.H, m.W, H, W)
         x = x.contiguous()
-        out = torch.empty((B, C, m.out_h, m.out_w), dtype=torch.float32, device=x.device)
-        _capi.check(_capi.load().scenerf_hip_sphere_resample_forward(x.data_ptr(), B * C, H, W, m.src.data_ptr(), m.out_w, m.out_h,
-                                                                     out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
-                    "sphere_resample_forward")
-        ctx.m, ctx.shape = m, (B, C, H, W)
+        lib, st = _capi.load(), torch.cuda.current_stream(x.device).cuda_stream
+        if hwc:   # channels-last sphere side: what the renderer reads in place (renderer.HWC)
+            out = torch.empty((B, m.out_h, m.out_w, C), dtype=torch.float32, device=x.device)
+            _capi.check(lib.scenerf_hip_sphere_resample_forward_nhwc(x.data_ptr(), B * C, C, H, W, m.src.data_ptr(), m.out_w, m.out_h,
+                                                                     out.data_ptr(), st), "sphere_resample_forward_nhwc")
+        else:
+            out = torch.empty((B, C, m.out_h, m.out_w), dtype=torch.float32, device=x.device)
+            _capi.check(lib.scenerf_hip_sphere_resample_forward(x.data_ptr(), B * C, H, W, m.src.data_ptr(), m.out_w, m.out_h,
+                                                                out.data_ptr(), st), "sphere_resample_forward")
+        ctx.m, ctx.shape, ctx.hwc = m, (B, C, H, W), hwc
         return out
 
     @staticmethod
@@ -87,15 +92,18 @@ class _Resample(torch.autograd.Function):
         row_ptr, cells = m.csr()
         dout = dout.contiguous().float()
         dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dout.device)
-        _capi.check(_capi.load().scenerf_hip_sphere_resample_backward(dout.data_ptr(), B * C, H, W, row_ptr.data_ptr(), cells.data_ptr(),
-                                                                      m.out_w, m.out_h, dx.data_ptr(),
-                                                                      torch.cuda.current_stream(dout.device).cuda_stream),
-                    "sphere_resample_backward")
-        return dx, None
+        lib, st = _capi.load(), torch.cuda.current_stream(dout.device).cuda_stream
+        if ctx.hwc:
+            _capi.check(lib.scenerf_hip_sphere_resample_backward_nhwc(dout.data_ptr(), B * C, C, H, W, row_ptr.data_ptr(), cells.data_ptr(),
+                                                                      m.out_w, m.out_h, dx.data_ptr(), st), "sphere_resample_backward_nhwc")
+        else:
+            _capi.check(lib.scenerf_hip_sphere_resample_backward(dout.data_ptr(), B * C, H, W, row_ptr.data_ptr(), cells.data_ptr(),
+                                                                 m.out_w, m.out_h, dx.data_ptr(), st), "sphere_resample_backward")
+        return dx, None, None
 
 
-def resample(x: torch.Tensor, m: SphereMap) -> torch.Tensor:
-    return _Resample.apply(x, m)
+def resample(x: torch.Tensor, m: SphereMap, hwc: bool = False) -> torch.Tensor:
+    return _Resample.apply(x, m, hwc)
 
 
 class SphereResampler:
@@ -103,7 +111,10 @@ class SphereResampler:
     the identity and version of ``pix`` / ``pix_sphere`` (the encoder grid of ``SphericalMapping.from_pixels``), the level and the
     plane size, with the few most recent geometries kept."""
 
-    def __init__(self, out_img_W: int, out_img_H: int, max_cached: int = 16):
+    def __init__(self, out_img_W: int, out_img_H: int, max_cached: int = 16, layout: str = "chw"):
+        if layout not in ("chw", "hwc"):
+            raise ValueError("layout must be 'chw' (the reference's (B, C, h, w)) or 'hwc' ((B, h, w, C), for renderer.HWC)")
+        self.layout = layout
         self.out_img_W, self.out_img_H, self.max_cached = out_img_W, out_img_H, max_cached
         self._maps: Dict[tuple, tuple] = {}
 
@@ -120,5 +131,7 @@ class SphereResampler:
         return m
 
     def get_sphere_feature(self, x: torch.Tensor, pix: torch.Tensor, pix_sphere: torch.Tensor, scale: int) -> torch.Tensor:
-        """unet2d_sphere.py:138-165.  x (B, C, H, W) float32 -> (B, C, round(out_img_H/scale), round(out_img_W/scale))."""
-        return resample(x, self.map_for(pix, pix_sphere, scale, x.shape[2], x.shape[3]))
+        """unet2d_sphere.py:138-165.  x (B, C, H, W) float32 -> (B, C, round(out_img_H/scale), round(out_img_W/scale)); with
+        ``layout="hwc"`` the same values as (B, h, w, C): ``x_rgb["1_%d" % scale] = HWC(out[i])`` hands level ``scale`` of batch item ``i``
+        to ``render_rays_batch`` without any layout conversion."""
+        return resample(x, self.map_for(pix, pix_sphere, scale, x.shape[2], x.shape[3]), self.layout == "hwc")

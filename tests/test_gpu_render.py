@@ -516,6 +516,72 @@ def test_chunked_call_equals_single_chunk_on_the_fused_path():
         assert r <= 2e-3, "%s: chunked vs single relative L2 %.3e" % (n, r)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_hwc_entry_equals_the_chw_entry(precision):
+    """x_rgb handed over as fp32 (H, W, C) tensors (renderer.HWC: read in place, gradient returned in (H, W, C)) against the reference's
+    (C, H, W) entry on the same values: fp32 mode reads the same numbers through the same arithmetic -- outputs bit-identical, gradients
+    to atomic-ordering noise; bf16 mode blends unrounded taps (the (C, H, W) entry rounds the maps to bf16 first): bf16-level agreement.
+    Levels can be mixed (here the 1/16 level stays (C, H, W))."""
+    from scenerf_amd import synth
+    from scenerf_amd.renderer import HWC
+    kw = dict(sphere_W=376, sphere_H=114, n_pts_uni=32, n_pts_per_gaussian=8)
+    R = 160
+    mlp, mlpg = synth.mlp_state(91, 4), synth.mlp_state(92, 2, out_scale=4.0)
+    maps = synth.feature_maps(376, 114, 93, smooth=True)
+    pix = synth.stride2_pixels((1220, 370), R, 94).to(DEV)
+    nu, ng = synth.sampling_noise(R, 32, 32, 95)
+    nu, ng = nu.to(DEV), ng.to(DEV)
+    K, T = synth.kitti_cam_K().to(DEV), synth.rel_pose(2.0, 10.0).to(DEV)
+    res = {}
+    for entry in ("chw", "hwc", "cl"):
+        m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision=precision, **kw).to(DEV)
+        m.mlp.load_state_dict(mlp)
+        m.mlp_gaussian.load_state_dict(mlpg)
+        leaves = {}
+        x = {}
+        for k, v in maps.items():
+            if entry == "hwc" and k != "1_16":
+                leaves[k] = v.permute(1, 2, 0).contiguous().to(DEV).requires_grad_(True)
+                x[k] = HWC(leaves[k])
+            elif entry == "cl" and k != "1_16":   # no wrapper: a (C,H,W) tensor with channels-last strides (a torch.channels_last slice)
+                c, h, w = v.shape
+                leaves[k] = torch.empty_strided((c, h, w), (1, w * c, c), device=DEV).copy_(v.to(DEV)).requires_grad_(True)
+                x[k] = leaves[k]
+            else:
+                leaves[k] = v.to(DEV).requires_grad_(True)
+                x[k] = leaves[k]
+        out = m.render_rays_batch(K, T, x, sampled_pixels=pix, ray_batch_size=R, noise=(nu, ng))
+        (out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()).backward()
+        g = {"mlp." + n: p.grad for n, p in m.mlp.named_parameters()}
+        g.update({"mlpg." + n: p.grad for n, p in m.mlp_gaussian.named_parameters()})
+        for k, v in leaves.items():
+            assert v.grad is not None and v.grad.shape == v.shape
+            g["map." + k] = v.grad.permute(2, 0, 1) if (entry == "hwc" and k != "1_16") else v.grad
+        res[entry] = ({k: v.detach() for k, v in out.items()}, g)
+    (oh, gh), (oc, gc) = res["hwc"], res["cl"]
+    for k in oh:       # the wrapper and the stride detection are the same path
+        assert torch.equal(oh[k], oc[k]), k
+    for n in gh:
+        assert float((gh[n].double() - gc[n].double()).norm()) <= 2e-5 * float(gh[n].double().norm()) + 1e-30, n
+    (o1, g1), (o2, g2) = res["chw"], res["hwc"]
+    for k in ("depth", "color", "loss_kl", "gaussian_means", "weights"):
+        if precision == "fp32":
+            assert torch.equal(o2[k], o1[k]), k
+        else:
+            torch.testing.assert_close(o2[k], o1[k], rtol=2e-2, atol=2e-2, msg=lambda s_, k=k: "%s: %s" % (k, s_))
+    tol = 2e-5 if precision == "fp32" else 6e-2
+    for n in g1:
+        a, b = g1[n].double(), g2[n].double()
+        if float(a.norm()) == 0.0:
+            assert float(b.norm()) == 0.0, n
+            continue
+        r = float((a - b).norm() / a.norm())
+        assert r <= tol, "%s: HWC vs CHW entry relative L2 %.3e" % (n, r)
+    with pytest.raises(RuntimeError, match="HWC"):   # a (C, H, W) tensor inside the wrapper is refused, not reinterpreted
+        m.render_rays_batch(K, T, {k: HWC(v.to(DEV)) for k, v in maps.items()}, sampled_pixels=pix, ray_batch_size=R, noise=(nu, ng))
+
+
 # ------------------------------------------------------------------------------------------------ full-frame inference (C5)
 @pytest.mark.gpu
 def test_render_image_static_chunks_and_graph_replay():

@@ -164,6 +164,12 @@ def test_hip_odd_maps_and_plane_tails():
         assert np.array_equal(out.detach().cpu().numpy(), orc.resample_forward(x, src))
         row_ptr, cells = orc.csr_of(src, H, W)
         assert np.array_equal(xt.grad.cpu().numpy(), orc.resample_backward_gather(dout, row_ptr, cells, H, W))
+        # channels-last sphere side (SphereResampler(layout="hwc"), what renderer.HWC reads in place): the same numbers, permuted
+        xh = _dev(x).requires_grad_(True)
+        outh = resample(xh, m, True)
+        assert outh.shape == (B, oh, ow, C) and torch.equal(outh.detach(), out.detach().permute(0, 2, 3, 1))
+        outh.backward(_dev(dout).permute(0, 2, 3, 1).contiguous())
+        assert torch.equal(xh.grad, xt.grad)
     with pytest.raises(RuntimeError, match="float32 CUDA"):
         resample(torch.zeros(1, 1, 9, 13, dtype=torch.float64).cuda(), m)
     assert _capi.load().scenerf_hip_sphere_resample_forward(None, 1, 4, 4, None, 4, 4, None, None) != 0     # NULL arguments are refused
