@@ -184,6 +184,16 @@ def _compare(tag, o, out, grads, loss, R, rep, out_gate, grad_gate, loss_gate):
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", list(CASES))
 def test_timed_path_matches_oracle_outputs_and_every_gradient(name, precision):
+    _run_case(name, precision, "chw")
+
+
+def test_timed_path_channels_last_entry_matches_oracle():
+    """The configuration bench.py times by default: the feature maps arrive as (C,H,W) tensors with channels-last memory and are read in
+    place (fp32 taps in the gather, gradients accumulated straight into the returned (H,W,C) memory) -- same oracle, same gates."""
+    _run_case("kitti_c2_r1200_n128", "bf16", "hwc")
+
+
+def _run_case(name, precision, entry):
     spec = CASES[name]
     mlp, mlpg, maps, pix, nu, ng, K, T = _inputs(spec)
     cls, kw = _ctor(spec)
@@ -194,7 +204,11 @@ def test_timed_path_matches_oracle_outputs_and_every_gradient(name, precision):
     R, N = spec["R"], spec["U"] + 4 * spec["P"]
     if precision == "bf16":   # the path bench.py times: fused forward + fused dgrad chain (+ the batched wgrad launch from 32768 rows)
         assert m.render_cfg.uses_fused(R * N) and m.render_cfg.fused_backward and m.render_cfg.wgrad_tr
-    x = {k: v.to(DEV).requires_grad_(True) for k, v in maps.items()}
+    if entry == "hwc":
+        x = {k: torch.empty_strided(tuple(v.shape), (1, v.shape[2] * v.shape[0], v.shape[0]), device=DEV).copy_(v.to(DEV)).requires_grad_(True)
+             for k, v in maps.items()}
+    else:
+        x = {k: v.to(DEV).requires_grad_(True) for k, v in maps.items()}
     out = m.render_rays_batch(K.to(DEV), T.to(DEV), x, sampled_pixels=pix.to(DEV), ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
     loss = out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
     loss.backward()
@@ -203,7 +217,7 @@ def test_timed_path_matches_oracle_outputs_and_every_gradient(name, precision):
     grads = {"mlp." + n: p.grad for n, p in zip(MLP_PARAM_NAMES, m.mlp.ordered_params())}
     grads.update({"mlp_gaussian." + n: p.grad for n, p in zip(MLP_PARAM_NAMES, m.mlp_gaussian.ordered_params())})
     grads.update({"x_rgb." + k: v.grad for k, v in x.items()})
-    rep = {"case": name, "precision": precision, "rows": R * N}
+    rep = {"case": name, "precision": precision, "rows": R * N, "maps": entry}
     fails = []
 
     # ---- the oracle at the GPU's head offsets and sphere indices -------------------------------------------------------------------
@@ -271,6 +285,6 @@ def test_timed_path_matches_oracle_outputs_and_every_gradient(name, precision):
             if v > FREE_BF16_GATE[k]:
                 fails.append("free-running bf16 %s = %.2e > %.1e" % (k, v, FREE_BF16_GATE[k]))
     if os.path.isdir("gpurun_out"):
-        with open(os.path.join("gpurun_out", "parity_full_%s_%s.json" % (name, precision)), "w") as f:
+        with open(os.path.join("gpurun_out", "parity_full_%s_%s%s.json" % (name, precision, "" if entry == "chw" else "_" + entry)), "w") as f:
             json.dump(rep, f, indent=1)
     assert not fails, "\n".join(fails)
