@@ -60,6 +60,22 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     return _SIDE[key]
 
 
+_CONSTS = {}
+
+
+def _sampler_constants(dev, U: int, G: int, max_depth: float):
+    """The two linspace vectors of the samplers (utils.py:79-81, scenerf.py:556-560): functions of the configuration only, so they are
+    built once per (device, configuration) -- on the host, copied synchronously -- instead of with two launches per chunk."""
+    key = (torch.device(dev).index, U, G, max_depth)
+    hit = _CONSTS.get(key)
+    if hit is None:
+        lin_u = torch.linspace(0.2, max_depth, steps=U, dtype=torch.float32).to(dev) if U > 0 else None
+        step = max_depth * 1.0 / G
+        anchors = torch.linspace(step / 2, max_depth - step / 2, steps=G, dtype=torch.float32).to(dev)
+        hit = _CONSTS[key] = (lin_u, anchors)
+    return hit
+
+
 def _require_cuda(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise RuntimeError("%s must live on the GPU (got %s): the SceneRF hot path has no CPU fallback" % (name, t.device))
@@ -153,8 +169,7 @@ class MapHolder:
         self._alloc_gmaps(torch.empty)
         side.wait_stream(main)    # the blocks may have just been freed by work still queued on the main stream
         with torch.cuda.stream(side):
-            for g in self.gmaps:
-                g.zero_()
+            torch._foreach_zero_(self.gmaps)   # one launch for the five accumulators
             self._gmaps_ready = side.record_event()
 
     def grad_accumulators(self) -> List[torch.Tensor]:
@@ -484,9 +499,7 @@ class RenderChunk(torch.autograd.Function):
         noise_u = _f32c(noise_u).reshape(R, max(U, 0)) if U > 0 else None
         noise_g = _f32c(noise_g).reshape(R, G * P)
         # constants the reference builds with torch.linspace (utils.py:79-81, scenerf.py:556-560)
-        lin_u = torch.linspace(0.2, cfg.max_sample_depth, steps=U, **f32) if U > 0 else None
-        step = cfg.max_sample_depth * 1.0 / G
-        anchors = torch.linspace(step / 2, cfg.max_sample_depth - step / 2, steps=G, **f32)
+        lin_u, anchors = _sampler_constants(dev, U, G, float(cfg.max_sample_depth))
 
         unit_dir = torch.empty((R, 3), **f32)
         viewdir = torch.empty((R, 3), **f32)

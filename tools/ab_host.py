@@ -16,6 +16,12 @@ if "nodefer" in mode:
     def init(self, params, d_out, cfg, pack_stream=None):
         _init(self, params, d_out, cfg, pack_stream=None)
     r.PackedMLP.__init__ = init
+if "fillloop" in mode:     # the map-gradient accumulators zeroed one fill per tensor instead of one multi-tensor launch
+    import torch
+    def _loop_zero(ts):
+        for t in ts:
+            t.zero_()
+    torch._foreach_zero_ = _loop_zero
 if "overlap" in mode:
     from scenerf_amd import _capi, config
     _to_c = config.RenderConfig.to_c
