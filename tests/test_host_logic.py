@@ -101,6 +101,32 @@ def test_hot_path_refuses_cpu_tensors():
         m.render_rays_batch(synth.kitti_cam_K(), torch.eye(4), maps)
 
 
+def test_channels_last_maps_are_recognised_and_carried_in_the_call_config():
+    """The in-place channels-last entry (renderer.HWC / a (C,H,W) tensor with (H,W,C) memory): detection and the per-call
+    scenerf_cfg.map_chw state are host logic -- checked here without a GPU (the session stops at the first device requirement)."""
+    from scenerf_amd.config import RenderConfig
+    from scenerf_amd.renderer import HWC, RenderSession
+    cfg = RenderConfig.kitti(sphere_W=376, sphere_H=114)
+    assert list(cfg.to_c().map_chw) == [0, 0, 0, 1, 1]                        # (3, 4): read from the caller's (C,H,W) tensor
+    import dataclasses
+    c2 = dataclasses.replace(cfg, hwc_scales=(0, 1, 3), direct_scales=(4,))
+    assert list(c2.to_c().map_chw) == [2, 2, 0, 2, 1]
+    with pytest.raises(ValueError, match="HWC expects"):
+        HWC(torch.zeros(2, 3, 4, 5))
+    w = HWC(torch.zeros(5, 7, 3))
+    assert w.shape == (5, 7, 3) and w.device.type == "cpu" and w.detach().t.shape == (5, 7, 3)
+    shapes = synth.feature_map_shapes(376, 114)
+    maps = {}
+    for k, (c, h, wd) in shapes.items():
+        maps[k] = torch.empty_strided((c, h, wd), (1, wd * c, c))             # what a torch.channels_last batch slice looks like
+    b4 = torch.zeros(1, *shapes["1_1"]).to(memory_format=torch.channels_last)[0]
+    assert b4.stride() == maps["1_1"].stride()
+    with pytest.raises(RuntimeError, match="GPU"):                            # recognised as channels-last, then refused for being on the CPU
+        RenderSession(cfg, maps, [], [])
+    with pytest.raises(RuntimeError, match="GPU"):
+        RenderSession(cfg, {k: HWC(v.permute(1, 2, 0)) for k, v in maps.items()}, [], [])
+
+
 def test_split_bf16_linin_arithmetic():
     """The bf16-mode lin_in split (x_hi.w_hi + x_lo.w_hi + x_hi.w_lo) reproduces fp32 to ~2^-15 relative."""
     g = torch.Generator().manual_seed(0)
