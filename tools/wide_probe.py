@@ -68,7 +68,7 @@ for name in ("ring", "wide"):
     lib.scenerf_hip_profile_enable(0)
     print("%-5s M=%d masks=%s: forward %.1f us = %.0f TFLOP/s issued (%.1f %% of 2.5 PF) | dgrad chain %.1f us = %.0f TFLOP/s (%.1f %%)" % (
         name, M, pat, tf, fl_f / tf / 1e6, fl_f / tf / 1e6 / 25, tb, fl_b / tb / 1e6, fl_b / tb / 1e6 / 25), flush=True)
-    print("      batched weight gradients %.1f us, feature gradient %.1f us" % (timed(rows, "gemm_wgrad_fc"), timed(rows, "gemm_dfeat_scatter")), flush=True)
+    print("      batched weight gradients %.1f us" % timed(rows, "gemm_wgrad_fc"), flush=True)
     if name == "wide" and hasattr(lib, "scenerf_hip_test_wgrad_cyc"):
         buf = (C.c_ulonglong * (64 * 16))()
         lib.scenerf_hip_test_wgrad_cyc(buf, 64 * 16)
