@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--stride", type=int, default=1, help="infer: pixel stride of the rendered frame (1 = all 451,400 px)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: run the control flow (collectives, timing, JSON) around a stub step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--host-rng", action="store_true",
+                    help="draw the gaussian sampler's normal noise on the host like the reference (utils.py:208-211: torch.normal on the CPU generator + "
+                         "upload; the module's default, RenderConfig.device_rng=False) instead of on the device: ~0.25 ms of host time per 1,200 rays")
     ap.add_argument("--maps", default="hwc", choices=["hwc", "chw"],
                     help="memory layout of the feature maps handed to render_rays_batch: hwc = (C,H,W) tensors with channels-last strides (what a "
                          "torch.channels_last decoder or SphereResampler(layout='hwc') emits; read in place), chw = contiguous (C,H,W) as the "
@@ -122,7 +125,7 @@ def sample_split(n):
 def make_model(args, dev, precision=None):
     U, P = sample_split(args.samples)
     m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, n_pts_uni=U, n_pts_per_gaussian=P,
-                precision=precision or args.precision, device_rng=False).to(dev)
+                precision=precision or args.precision, device_rng=not getattr(args, "host_rng", False)).to(dev)
     m.mlp.load_state_dict(synth.mlp_state(1, 4))
     m.mlp_gaussian.load_state_dict(synth.mlp_state(2, 2, out_scale=4.0))
     return m
@@ -553,7 +556,9 @@ def main():
                                        "contiguous-(C,H,W) entry with its per-call layout conversion is timed as other_entry)"
                                        if args.maps == "hwc" else "incl. map layout conversion (contiguous (C,H,W) maps)"),
                        "rays_per_gpu": R, "samples_per_ray": args.samples, "parallelism": "dp%d" % world,
-                       "precision": args.precision, "maps": args.maps},
+                       "precision": args.precision, "maps": args.maps,
+                       "sampling_noise": "host generator + upload, like the reference" if args.host_rng else
+                                         "device generator (RenderConfig.device_rng=True; --host-rng gives the reference's host-side draw: +0.1-0.25 ms per step)"},
             "other_entry": other,
             "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager, "fp32_mode": fp32,
             "allreduce": allreduce,

@@ -114,6 +114,16 @@ class HWC:
         return HWC(self.t.detach())
 
 
+def draw_noise_g(cfg: RenderConfig, R: int, device) -> torch.Tensor:
+    """N(0,1) noise of the probabilistic sampler, (R, G*P).  utils.py:208-211 draws it on the CPU generator: same stream here
+    (bit-identical to torch.normal(zeros, ones)), into pinned memory so that the H2D copy does not stall the host; with
+    ``cfg.device_rng`` on the device generator instead."""
+    GP = cfg.n_gaussians * cfg.n_pts_per_gaussian
+    if cfg.device_rng:
+        return torch.randn((R, GP), dtype=torch.float32, device=device)
+    return torch.empty((R, GP), dtype=torch.float32, pin_memory=True).normal_().to(device, non_blocking=True)
+
+
 class MapHolder:
     """(H,W,C) copies of the 5 encoder maps + lazily allocated fp32 gradient accumulators."""
 
@@ -497,7 +507,6 @@ class RenderChunk(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         pixels, K, iK, T = _f32c(pixels), _f32c(cam_K), _f32c(inv_K), _f32c(T_s2i)
         noise_u = _f32c(noise_u).reshape(R, max(U, 0)) if U > 0 else None
-        noise_g = _f32c(noise_g).reshape(R, G * P)
         # constants the reference builds with torch.linspace (utils.py:79-81, scenerf.py:556-560)
         lin_u, anchors = _sampler_constants(dev, U, G, float(cfg.max_sample_depth))
 
@@ -511,6 +520,12 @@ class RenderChunk(torch.autograd.Function):
         # (grad mode is off inside Function.forward: whether a backward can follow is what needs_input_grad says)
         keep = any(ctx.needs_input_grad)
         run_g = _mlp_eval(ccfg, cfg, maps, mlpg.packed, anchors, 0, G, unit_dir, viewdir, K, iK, T, R * G, keep)
+        # the gaussian sampler's normal noise, if the caller did not inject it: drawn HERE, with the gaussian head's chain already queued
+        # -- the reference's host-side draw (utils.py:208-211) takes ~0.25 ms of host time per 1,200 rays, which at the top of the
+        # chunk left the GPU without work (3.29 -> 3.04 ms per KITTI step, tools/ab_host.py devrng); same generator, same call order
+        if noise_g is None:
+            noise_g = draw_noise_g(cfg, R, dev)
+        noise_g = _f32c(noise_g).reshape(R, G * P)
         gmeans = torch.empty((R, G), **f32)
         gstds = torch.empty((R, G), **f32)
         dist_s = torch.empty((R, N), **f32)
@@ -689,24 +704,18 @@ class RenderSession:
         return self.maps.debug_aux
 
     def draw_noise(self, R: int, device):
-        """The reference's in-path RNG calls, same generators and order (SURVEY §5 RNG row)."""
+        """The reference's in-path RNG calls, same generators and order (SURVEY §5 RNG row): (uniform noise, gaussian noise)."""
         cfg = self.cfg
-        U, GP = cfg.n_pts_uni, cfg.n_gaussians * cfg.n_pts_per_gaussian
+        U = cfg.n_pts_uni
         nu = torch.rand((R, U, 1), dtype=torch.float32, device=device) if U > 0 else torch.empty((R, 0, 1), device=device)
-        if cfg.device_rng:
-            ng = torch.randn((R, GP), dtype=torch.float32, device=device)
-        else:
-            # utils.py:208-211 draws N(0,1) on the CPU generator.  Same stream here (bit-identical to
-            # torch.normal(zeros, ones)), but into pinned memory so the H2D copy does not stall the host.
-            ng = torch.empty((R, GP), dtype=torch.float32, pin_memory=True).normal_().to(device, non_blocking=True)
-        return nu, ng
+        return nu, draw_noise_g(cfg, R, device)
 
     def render_chunk(self, pixels, cam_K, inv_K, T_s2i, noise_u=None, noise_g=None) -> Dict[str, torch.Tensor]:
         _require_cuda(pixels, "sampled_pixels")
-        if noise_u is None or noise_g is None:
-            nu, ng = self.draw_noise(pixels.shape[0], pixels.device)
-            noise_u = nu if noise_u is None else noise_u
-            noise_g = ng if noise_g is None else noise_g
+        if noise_u is None:   # (the gaussian noise, if not injected, is drawn inside the chunk: RenderChunk._forward)
+            U = self.cfg.n_pts_uni
+            noise_u = (torch.rand((pixels.shape[0], U, 1), dtype=torch.float32, device=pixels.device) if U > 0
+                       else torch.empty((pixels.shape[0], 0, 1), device=pixels.device))
         outs = RenderChunk.apply(self.cfg, self.maps, self.mlp, self.mlpg, pixels, cam_K, inv_K, T_s2i, noise_u, noise_g,
                                  self.tok_maps, self.tok_mlp, self.tok_mlpg)
         ret = dict(zip(OUTPUT_KEYS + ["som_means"], outs))

@@ -2,6 +2,7 @@
 this process with parts of the renderer's stream plumbing switched off.
 usage: ab_host.py <mode> [bench.py arguments]     mode: comma list of  base | nopre (map-gradient accumulators zeroed in the backward)
                                                                          | nodefer (radiance-MLP pack on the main stream)
+                                                                         | devrng (sampling noise drawn on the device)
                                                                          | overlap (scenerf_cfg flag WGRAD_OVERLAP: weight gradients on the library's side stream)"""
 import os, runpy, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +17,14 @@ if "nodefer" in mode:
     def init(self, params, d_out, cfg, pack_stream=None):
         _init(self, params, d_out, cfg, pack_stream=None)
     r.PackedMLP.__init__ = init
+if "devrng" in mode:       # the samplers' normal noise drawn on the device instead of on the host like the reference (RenderConfig.device_rng)
+    from scenerf_amd import config
+    config.RenderConfig.__init__.__kwdefaults__ and None
+    _orig_init = config.RenderConfig.__init__
+    def _init(self, *a, **k):
+        k["device_rng"] = True
+        _orig_init(self, *a, **k)
+    config.RenderConfig.__init__ = _init
 if "fillloop" in mode:     # the map-gradient accumulators zeroed one fill per tensor instead of one multi-tensor launch
     import torch
     def _loop_zero(ts):
