@@ -2,6 +2,7 @@
 """bench.py -- rays/sec of the SceneRF training hot path (render_rays_batch fwd+bwd) on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 ...            # starts its own 8 ranks (re-executes itself under torch.distributed.run), or:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -98,6 +99,10 @@ def parse():
                     help="memory layout of the feature maps handed to render_rays_batch: hwc = (C,H,W) tensors with channels-last strides (what a "
                          "torch.channels_last decoder or SphereResampler(layout='hwc') emits; read in place), chw = contiguous (C,H,W) as the "
                          "reference's decoder emits (converted per call).  The other one is timed too and reported as 'other_entry'")
+    ap.add_argument("--sync", default="session", choices=["session", "step"],
+                    help="N>1: 'session' = the renderer's per-session hooks (two 21.7 MB all-reduces started inside the backward, overlapped); "
+                         "'step' = dist.StepGradSync, one 43.3 MB all-reduce at the end of backward (safe when ranks render different numbers "
+                         "of source frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=0, help="rays of the CPU-baseline sample (0 = the bench's own --rays)")
@@ -268,7 +273,7 @@ class _StubModel:
         return self.head[0] + self.main[0]
 
 
-def infer_main(args, rank, world, dev):
+def infer_main(args, rank, world, dev, census=None):
     """BASELINE.json configs[4]: novel-view inference, full frame, 512 samples/ray (U=256, G=4, P=64), no_grad, static chunks of
     --chunk rays with the tail padded, one captured hipGraph per frame replayed per chunk, device RNG (scenerf_amd/inference.py).
     A step = one full frame of one pose.  N > 1 = N independent replicas (inference does not shard)."""
@@ -317,7 +322,7 @@ def infer_main(args, rank, world, dev):
                                    "N>1 = independent replicas" % (n, args.stride, args.samples, U, P, args.chunk),
                        "rays_per_frame": n, "samples_per_ray": args.samples, "chunk": args.chunk, "parallelism": "replicas%d" % world,
                        "precision": args.precision, "mode": "infer"},
-            "roofline": roof, "roofline_composite": roof_c, "eager_launch": eager}), flush=True)
+            "roofline": roof, "roofline_composite": roof_c, "eager_launch": eager, "ranks": census}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -405,25 +410,84 @@ def _composite_probe(R, N, reps=20):
     return out
 
 
+def _self_launch(n):
+    """``python bench.py --gpus N`` outside torchrun: start the N ranks here, one process per GPU, the way the reference's trainer
+    spawns its own DDP workers (scripts/train_kitti.py:127-156, Trainer(accelerator='ddp', gpus=n_gpus)) -- same command line,
+    re-executed under torch.distributed.run on a free local port.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SRF_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _rank_census(rank, world, local, dev, dry):
+    """Who is actually in the job: every rank contributes its id through the backend the gradients travel on (a one-hot all-reduce:
+    on GPUs that is RCCL) and its device through an object gather.  ``ranks_seen`` must equal --gpus, and no two ranks may sit on
+    one GPU -- otherwise no line is printed."""
+    dinfo = {"rank": rank, "local_rank": local, "device": str(dev), "pid": os.getpid()}
+    if not dry:
+        pr = torch.cuda.get_device_properties(dev)
+        dinfo.update(name=pr.name, cus=pr.multi_processor_count, hbm_gb=round(pr.total_memory / 2 ** 30, 1))
+        for k in ("pci_bus_id", "pci_device_id", "uuid"):
+            if hasattr(pr, k):
+                dinfo[k] = str(getattr(pr, k))
+    if world == 1:
+        return {"ranks_seen": 1, "backend": None, "launched_by": "python", "devices": [dinfo]}
+    onehot = torch.zeros(world, dtype=torch.int32, device=dev)
+    onehot[rank] = 1
+    torch.distributed.all_reduce(onehot)
+    seen = int((onehot == 1).sum().item())
+    devs = [None] * world
+    torch.distributed.all_gather_object(devs, dinfo)
+    if seen != world:
+        raise SystemExit("bench.py: %d of %d ranks answered the census all-reduce" % (seen, world))
+    if not dry:
+        ids = [d.get("uuid") or d.get("pci_bus_id") or d["device"] for d in devs]
+        if len(set(ids)) != world:
+            raise SystemExit("bench.py: %d ranks share %d GPUs (%s): one process per GPU is the contract" % (world, len(set(ids)), ids))
+    return {"ranks_seen": seen, "backend": torch.distributed.get_backend(),
+            "launched_by": "bench.py (self-launch)" if os.environ.get("SRF_BENCH_SELF_LAUNCHED") else "torch.distributed.run",
+            "devices": devs}
+
+
 def main():
     args = parse()
     if args.dry_run:
         os.environ.setdefault("SRF_DIST_BACKEND", "gloo")
-    rank, world, local = sdist.init_from_env()
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args.gpus))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        # fail loud: a line that says n_gpus = WORLD_SIZE under a command that asked for --gpus N would be read as an N-GPU number
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to measure (launch with --nproc-per-node %d, or unset "
+                         "WORLD_SIZE and let bench.py start its own ranks)" % (args.gpus, env_world, args.gpus))
     dry = args.dry_run
     if not dry:
         assert torch.cuda.is_available(), "bench.py needs a GPU"
-        dev = torch.device("cuda", local % torch.cuda.device_count())   # (modulo only matters for the 1-GPU gloo self-test)
+        if torch.cuda.device_count() < env_world:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible: one process per GPU is the contract" % (
+                env_world, torch.cuda.device_count()))
+    rank, world, local = sdist.init_from_env()
+    assert world == args.gpus
+    if not dry:
+        dev = torch.device("cuda", local)
         torch.cuda.set_device(dev)
         _capi.load()
         sync = torch.cuda.synchronize
     else:
         dev, sync = torch.device("cpu"), (lambda: None)
+    census = _rank_census(rank, world, local, dev, dry)
     torch.manual_seed(42 + rank)  # train_kitti.py:11 seed_everything(42), decorrelated per rank
     if args.mode == "infer" and not dry:
-        return infer_main(args, rank, world, dev)
+        return infer_main(args, rank, world, dev, census)
 
     R = args.rays
     if dry:
@@ -436,8 +500,12 @@ def main():
         K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
         pix = synth.stride2_pixels((1220, 370), R, 100 + rank).to(dev)
     # N > 1: each MLP's packed gradient sink is all-reduced (RCCL) right before it is handed to autograd: 2 x 21.7 MB
-    model.grad_sync = sdist.allreduce_mean_ if world > 1 else None
-    model.grad_sync_async = sdist.allreduce_mean_async if world > 1 else None   # radiance MLP: started before the feature scatter
+    step_sync = None
+    if world > 1 and args.sync == "step" and not dry:
+        step_sync = sdist.StepGradSync(params)
+    else:
+        model.grad_sync = sdist.allreduce_mean_ if world > 1 else None
+        model.grad_sync_async = sdist.allreduce_mean_async if world > 1 else None   # radiance MLP: started before the feature scatter
 
     def make_step(model, opt):
         if dry:
@@ -485,6 +553,8 @@ def main():
     kernels = []
     # everything below is rank-0-only side measurement: no collective may be issued from here on (the other ranks are done)
     model.grad_sync = model.grad_sync_async = None
+    if step_sync is not None:
+        step_sync.close()
     if rank == 0 and not args.no_roofline:
         nprof = 3
         if dry:
@@ -555,13 +625,13 @@ def main():
                                        "feature maps handed over channels-last ((C,H,W) tensors with (H,W,C) memory, read in place; the "
                                        "contiguous-(C,H,W) entry with its per-call layout conversion is timed as other_entry)"
                                        if args.maps == "hwc" else "incl. map layout conversion (contiguous (C,H,W) maps)"),
-                       "rays_per_gpu": R, "samples_per_ray": args.samples, "parallelism": "dp%d" % world,
+                       "rays_per_gpu": R, "samples_per_ray": args.samples, "parallelism": "dp%d" % world, "grad_sync": (args.sync if world > 1 else None),
                        "precision": args.precision, "maps": args.maps,
                        "sampling_noise": "host generator + upload, like the reference" if args.host_rng else
                                          "device generator (RenderConfig.device_rng=True; --host-rng gives the reference's host-side draw: +0.1-0.25 ms per step)"},
             "other_entry": other,
             "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager, "fp32_mode": fp32,
-            "allreduce": allreduce,
+            "allreduce": allreduce, "ranks": census,
         }
         if dry:
             line.update(metric="dry-run (control flow only, stub step over gloo)", dtype="none", data="none")

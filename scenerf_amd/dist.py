@@ -156,3 +156,41 @@ class GradBucket:
     def finish(self) -> None:
         self.flat.div_(dist.get_world_size())
         self.unpack()
+
+
+class StepGradSync:
+    """Once-per-backward gradient averaging that does not care how many ``render_rays_batch`` sessions a rank opened.
+
+    The per-session hooks above are the fast path for a step with ONE session per rank (bench.py: the collectives overlap the
+    backward).  A real KITTI batch renders ``len(T_source2infers)`` source frames per image (scenerf.py:266-272) and that count differs
+    between images, hence between ranks: with per-session collectives a rank with one frame fewer would leave the others waiting.
+    This object is the safe default for such trainers when DistributedDataParallel is not used: the gradients of all sessions
+    accumulate locally in ``.grad`` as usual; the first parameter gradient of a backward arms ONE end-of-backward callback (the
+    mechanism DDP itself uses), which averages both MLPs' gradients in a single flat all-reduce (43.3 MB over RCCL).  Every rank
+    that runs a backward issues exactly one collective, whatever its session count.
+
+        sync = StepGradSync(list(model.mlp.parameters()) + list(model.mlp_gaussian.parameters()))
+        ... loss.backward()      # reduced when backward returns
+        sync.close()             # remove the hooks
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.bucket = GradBucket(params)
+        self._armed = False
+        self.reductions = 0
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.bucket.params]
+
+    def _on_grad(self, _p) -> None:
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+
+    def _finish(self) -> None:
+        self._armed = False
+        self.reductions += 1
+        self.bucket.allreduce_mean()
+
+    def close(self) -> None:
+        for h in self._handles:
+            h.remove()
+        self._handles = []

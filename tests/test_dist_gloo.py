@@ -67,6 +67,39 @@ def test_two_process_gloo_allreduce(tmp_path):
     assert not torch.equal(res[0]["local"][0], res[1]["local"][0])
 
 
+def _worker_step_sync(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from scenerf_amd import dist as sdist
+    sdist.init_from_env(backend="gloo")
+    lin = torch.nn.Linear(3, 2)
+    with torch.no_grad():
+        for p in lin.parameters():
+            p.fill_(0.5)
+    sync = sdist.StepGradSync(lin.parameters())
+    # rank 0 renders two "source frames" this step, rank 1 one (KITTI batches differ in len(T_source2infers)): the per-session hooks
+    # would hang here; StepGradSync reduces once per backward on every rank
+    n_sessions = 2 if rank == 0 else 1
+    loss = sum(lin(torch.full((4, 3), float(rank + 1 + s))).sum() for s in range(n_sessions))
+    local = torch.autograd.grad(loss, list(lin.parameters()), retain_graph=True)
+    loss.backward()
+    assert sync.reductions == 1
+    sync.close()
+    torch.save(dict(local=[g.clone() for g in local], reduced=[p.grad.clone() for p in lin.parameters()]), out % rank)
+    dist.destroy_process_group()
+
+
+def test_step_sync_with_unequal_session_counts(tmp_path):
+    world = 2
+    out = str(tmp_path / "s%d.pt")
+    mp.spawn(_worker_step_sync, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = [torch.load(out % r) for r in range(world)]
+    for i in range(2):
+        mean = (res[0]["local"][i] + res[1]["local"][i]) / 2
+        for r in range(world):
+            torch.testing.assert_close(res[r]["reduced"][i], mean)
+
+
 def test_shard_rays_covers_everything():
     from scenerf_amd.dist import shard_rays
     for n in (1, 7, 1200, 1201):
@@ -92,3 +125,38 @@ def test_bench_control_flow_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert len(d["allreduce"]["per_rank_ms_per_step"]) == 2
+
+
+def _bench(*argv, env=None, timeout=240):
+    import subprocess
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, timeout=timeout,
+                          cwd=ROOT, env=e)
+
+
+def test_bench_starts_its_own_ranks():
+    """Plain ``python bench.py --gpus 2`` (no torchrun, no WORLD_SIZE): bench.py must start two ranks itself, like the reference's
+    trainer does (train_kitti.py:127-156), and say who took part."""
+    import json
+    r = _bench("--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2
+    assert d["ranks"]["ranks_seen"] == 2 and d["ranks"]["backend"] == "gloo"
+    assert sorted(x["rank"] for x in d["ranks"]["devices"]) == [0, 1]
+    assert len({x["pid"] for x in d["ranks"]["devices"]}) == 2
+    assert "self-launch" in d["ranks"]["launched_by"]
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """--gpus N under a launcher that started M != N ranks: no JSON line, non-zero exit (a line saying n_gpus = M would be read as an
+    N-GPU measurement)."""
+    r = _bench("--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "refusing to measure" in r.stderr
