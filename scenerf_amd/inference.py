@@ -6,8 +6,14 @@ scripts do with ``render_rays_batch`` under ``no_grad`` -- 50k-450k rays per pos
   * every chunk has the SAME static shape: the ragged tail is padded (its rays repeat the last pixel and are dropped from the result),
     so one chunk of the hot path -- ~25 kernel launches, no host synchronisation -- is captured into a hipGraph once per frame and
     replayed for every chunk of every pose of that frame (21 x 3 poses per frame in generate_novel_depths.py);
-  * sampling noise is drawn on the device (the reference draws the gaussian noise on the CPU and uploads it, utils.py:208-211: a host
-    serialisation per chunk); ``noise=`` injects explicit noise for parity tests.
+  * sampling noise follows ``RenderConfig.device_rng`` exactly like the chunk loop of ``render_rays_batch``: by default the gaussian
+    noise of each chunk is drawn on the CPU generator with the reference's shapes and call order (utils.py:208-211) into pinned
+    memory and copied into the static buffer before the replay (seeded evaluation runs reproduce the reference's samples whether or
+    not a call takes this route); ``device_rng=True`` draws it on the device; ``noise=`` injects explicit noise for parity tests;
+  * the engine never serves stale inputs: every ``render`` call re-converts the maps and re-packs both MLPs INTO THE SAME BUFFERS
+    (0.2 ms per call against >= 10 ms of chunks), so weights or maps rewritten in place by any route -- including ``p.data.copy_``,
+    which no version counter sees -- are picked up, while the addresses baked into the graph stay valid; tensors that MOVED are
+    caught by ``matches`` (storage addresses), and the engine keeps strong references so that no id/address can be recycled.
 
 Inference uses the lean activation path of the fused kernels (only the logits leave the MLP pass).
 """
@@ -24,7 +30,7 @@ class ImageRenderer:
     """One input frame's renderer: static chunk shape, optional hipGraph replay.  Build once per input frame (``x_rgb``) and call
     ``render`` for every pose / pixel set."""
 
-    def __init__(self, model, x_rgb: Dict[str, torch.Tensor], chunk: int = 4096, use_graph: bool = True,
+    def __init__(self, model, x_rgb: Dict[str, torch.Tensor], chunk: int = 4096, use_graph=True,
                  keys: Optional[Sequence[str]] = None):
         if chunk < 1:
             raise ValueError("chunk must be positive")
@@ -38,6 +44,10 @@ class ImageRenderer:
                 raise KeyError("unknown output %r" % (k,))
         dev = x_rgb["1_1"].device
         self.device = dev
+        self.min_graph_chunks = 4     # calls with fewer chunks than this run eagerly until a graph exists (capture = 2 extra chunk passes)
+        # strong references: the identity of these objects is part of what ``matches`` compares
+        self._x_rgb = {k: x_rgb[k] for k in ("1_1", "1_2", "1_4", "1_8", "1_16")}
+        self._params = list(model.mlp.ordered_params()) + list(model.mlp_gaussian.ordered_params())
         U, GP = self.cfg.n_pts_uni, self.cfg.n_gaussians * self.cfg.n_pts_per_gaussian
         with torch.no_grad(), _on(dev):
             self.session = RenderSession(self.cfg, {k: v.detach() for k, v in x_rgb.items()}, [p.detach() for p in model.mlp.ordered_params()],
@@ -50,12 +60,43 @@ class ImageRenderer:
             self.T = torch.zeros((4, 4), **f32)
             self.noise_u = torch.zeros((self.chunk, max(U, 0), 1), **f32)
             self.noise_g = torch.zeros((self.chunk, GP), **f32)
+        self._map_ptrs = {k: v.data_ptr() for k, v in self._x_rgb.items()}
+        self._fresh = True    # the session was just built from the current values
         self.graph = None
         self.static_out = None
         self.use_graph = bool(use_graph)
+        if use_graph != "auto":
+            self.min_graph_chunks = 0
         self.replays = 0
 
     # -------------------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _addr(v):
+        return (id(v), v.data_ptr(), tuple(v.shape))
+
+    def matches(self, model, x_rgb) -> bool:
+        """True if this engine's captured addresses are still the caller's tensors: same map objects at the same addresses, same
+        parameter objects at the same addresses.  (Values are refreshed per call, see ``refresh``.)"""
+        try:
+            if any(x_rgb[k] is not v or self._addr(x_rgb[k])[1] != self._map_ptrs[k] for k, v in self._x_rgb.items()):
+                return False
+        except KeyError:
+            return False
+        now = list(model.mlp.ordered_params()) + list(model.mlp_gaussian.ordered_params())
+        return all(a is b for a, b in zip(now, self._params)) and self.session.mlp.packed.same_storage(now[:len(now) // 2]) \
+            and self.session.mlpg.packed.same_storage(now[len(now) // 2:])
+
+    def refresh(self) -> None:
+        """Re-convert the maps and re-pack both MLPs into the buffers the session (and its graph) already uses."""
+        sess = self.session
+        hwc, vals = RenderSession.classify_maps(self._x_rgb)
+        if hwc != tuple(sess.cfg.hwc_scales):
+            raise RuntimeError("a feature map changed its memory layout under a live inference engine")
+        vals = [v.detach() for v in vals]
+        sess.maps.convert(vals)
+        sess.mlp.packed.repack(sess.cfg)
+        sess.mlpg.packed.repack(sess.cfg)
+
     def _run_chunk(self):
         return self.session.render_chunk(self.pix, self.K, self.invK, self.T, self.noise_u, self.noise_g)
 
@@ -81,6 +122,9 @@ class ImageRenderer:
         dev = self.device
         C = self.chunk
         with torch.no_grad(), _on(dev):
+            if not self._fresh:
+                self.refresh()
+            self._fresh = False
             self.K.copy_(cam_K)
             self.invK.copy_(self.model._inv_K(cam_K))
             self.T.copy_(T_source2infer)
@@ -96,10 +140,18 @@ class ImageRenderer:
                     self.noise_u[:m].copy_(noise[0][s:e])
                     self.noise_g[:m].copy_(noise[1][s:e])
                 else:
+                    # the reference's draws, same generators, shapes and order as the chunk loop (scenerf.py:437-455): rand on the device
+                    # for the m rays of this chunk (utils.py:84), then the normal noise (utils.py:208-211)
                     if self.noise_u.numel():
-                        self.noise_u.uniform_()                                 # utils.py:84 (device RNG there too)
-                    self.noise_g.normal_()                                      # utils.py:208-211, on the device instead of CPU + H2D
-                if self.use_graph:
+                        self.noise_u[:m].copy_(torch.rand((m,) + tuple(self.noise_u.shape[1:]), dtype=torch.float32, device=dev))
+                    if self.cfg.device_rng:
+                        self.noise_g[:m].copy_(torch.randn((m, self.noise_g.shape[1]), dtype=torch.float32, device=dev))
+                    else:
+                        self.noise_g[:m].copy_(torch.empty((m, self.noise_g.shape[1]), dtype=torch.float32, pin_memory=True).normal_(),
+                                               non_blocking=True)
+                if self.use_graph and self.graph is None and (n + C - 1) // C < self.min_graph_chunks:
+                    out = self._run_chunk()     # a short call does not pay for a capture
+                elif self.use_graph:
                     if self.graph is None:
                         self._capture()
                     self.graph.replay()

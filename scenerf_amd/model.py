@@ -265,22 +265,28 @@ class SceneRF(TrainingMixin, _Base):
         """Render a whole pixel set of one pose under ``no_grad``: every ``stride``-th pixel of the image in the reference scripts'
         order when ``sampled_pixels`` is None (render_colors.py:102-111).  The tail chunk is padded to ``ray_batch_size`` rays so that
         every chunk has one static shape; one chunk is captured into a hipGraph per input frame and replayed for all chunks and all
-        poses rendered from that frame.  Sampling noise is drawn on the device.  Returns the dict of ``render_rays_batch``
+        poses rendered from that frame.  Sampling noise follows ``device_rng`` as in the chunk loop.  Returns the dict of ``render_rays_batch``
         (``keys`` selects a subset: the (n, N) outputs of a 451,400-ray frame at N = 512 are 0.9 GB each)."""
         from .inference import ImageRenderer, pixel_grid
         if sampled_pixels is None:
             sampled_pixels = pixel_grid(tuple(self.img_size), stride, x_rgb["1_1"].device)
         if sampled_pixels.shape[0] == 0:
             raise ValueError("sampled_pixels is empty")
-        graph = self.inference_graph if use_graph is None else bool(use_graph)
-        key = (tuple((id(x_rgb[k]), x_rgb[k]._version, x_rgb[k].data_ptr()) for k in sorted(x_rgb)),
-               tuple(p._version for p in list(self.mlp.parameters()) + list(self.mlp_gaussian.parameters())),
-               int(ray_batch_size), graph, tuple(keys) if keys is not None else None, repr(self.render_cfg), float(self.ray_som.som_sigma))
+        # default: a graph once a call is long enough to pay for the capture ("auto"); use_graph=True/False forces either way
+        graph = ("auto" if self.inference_graph else False) if use_graph is None else bool(use_graph)
+        key = (int(ray_batch_size), graph, tuple(keys) if keys is not None else None, repr(self.render_cfg), float(self.ray_som.som_sigma))
         eng = getattr(self, "_image_renderer", None)
-        if eng is None or eng[0] != key:
+        # an engine is reused only for the SAME map and parameter objects at the same addresses (it holds strong references, so neither
+        # ids nor addresses can be recycled under it); their VALUES are re-read on every call (ImageRenderer.refresh), so writes that
+        # no version counter sees (p.data.copy_(ema), load_state_dict) cannot be served stale
+        if eng is None or eng[0] != key or not eng[1].matches(self, x_rgb):
             eng = (key, ImageRenderer(self, x_rgb, chunk=int(ray_batch_size), use_graph=graph, keys=keys))
             object.__setattr__(self, "_image_renderer", eng)     # one frame's engine at a time (its graph pins a chunk's buffers)
         return eng[1].render(cam_K, T_source2infer, sampled_pixels, noise=noise)
+
+    def release_inference_engine(self) -> None:
+        """Drop the cached full-frame engine (its hipGraph pins one chunk's buffers and the converted maps of the last frame)."""
+        object.__setattr__(self, "_image_renderer", None)
 
     def configure_optimizers(self):
         optimizer = torch.optim.AdamW(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)

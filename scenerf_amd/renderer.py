@@ -135,9 +135,12 @@ class MapHolder:
         self.debug_aux: Optional[Dict[str, torch.Tensor]] = None   # dict when the session was opened with debug_aux=True
 
     def convert(self, chw: Sequence[torch.Tensor]) -> None:
+        """Also serves as the refresh of a long-lived session (inference.ImageRenderer): a second call writes into the SAME converted
+        buffers, so device addresses captured in a hipGraph stay valid while the contents follow the caller's maps."""
         lib = _capi.load()
         prec = self.cfg.precision_code
         want = self.cfg.map_shapes()
+        old = self.hwc if len(self.hwc) == len(chw) else None
         self.hwc, self.shapes = [], []
         for i, t in enumerate(chw):
             _require_cuda(t, "x_rgb map %d" % i)
@@ -149,19 +152,29 @@ class MapHolder:
                 c, h, w = want[i]
                 if tuple(t.shape) != (h, w, c):
                     raise RuntimeError("feature map %d (HWC) has shape %s, expected %s" % (i, tuple(t.shape), (h, w, c)))
-                self.hwc.append(_f32c(t))
+                self.hwc.append(self._in_place(_f32c(t), old, i))
                 self.shapes.append((c, h, w))
                 continue
             src = _f32c(t)
             c, h, w = src.shape
             if i in self.cfg.direct_scales:
-                dst = src   # read in place, (C,H,W) fp32 (RenderConfig.direct_scales)
+                dst = self._in_place(src, old, i)   # read in place, (C,H,W) fp32 (RenderConfig.direct_scales)
             else:
-                dst = torch.empty((h, w, c), dtype=_act_dtype(prec), device=src.device)
+                dst = old[i] if old is not None else torch.empty((h, w, c), dtype=_act_dtype(prec), device=src.device)
                 _capi.check(lib.scenerf_hip_maps_chw_to_hwc(src.data_ptr(), dst.data_ptr(), c, h, w, prec, _stream(src.device)),
                             "maps_chw_to_hwc")
             self.hwc.append(dst)
             self.shapes.append((c, h, w))
+
+    @staticmethod
+    def _in_place(src: torch.Tensor, old, i: int) -> torch.Tensor:
+        """A level that is read where the caller keeps it.  On a refresh the address already handed out must stay the one that is
+        read: same memory -> nothing to do; a temporary (the caller's map was not fp32-contiguous) or a moved map -> copy into the
+        buffer of the first call."""
+        if old is None or old[i].data_ptr() == src.data_ptr():
+            return src
+        old[i].copy_(src)
+        return old[i]
 
     def _alloc_gmaps(self, fill) -> None:
         dev = self.hwc[0].device
@@ -181,6 +194,8 @@ class MapHolder:
         with torch.cuda.stream(side):
             torch._foreach_zero_(self.gmaps)   # one launch for the five accumulators
             self._gmaps_ready = side.record_event()
+        for t in self.gmaps:     # if no backward ever waits on the event (graph dropped, exception): the allocator must not hand
+            t.record_stream(side)  # these blocks to a main-stream tenant while the side-stream fill is still pending
 
     def grad_accumulators(self) -> List[torch.Tensor]:
         if self.gmaps is None:
@@ -292,6 +307,7 @@ class PackedMLP:
             raw.fc0_w[i], raw.fc0_b[i] = p["blocks.%d.fc_0.weight" % i].data_ptr(), p["blocks.%d.fc_0.bias" % i].data_ptr()
             raw.fc1_w[i], raw.fc1_b[i] = p["blocks.%d.fc_1.weight" % i].data_ptr(), p["blocks.%d.fc_1.bias" % i].data_ptr()
             raw.linz_w[i], raw.linz_b[i] = p["lin_z.%d.weight" % i].data_ptr(), p["lin_z.%d.bias" % i].data_ptr()
+        self._raw = raw
         ccfg = cfg.to_c()
         # pack_stream: launch the pack there instead of on the current stream (the radiance MLP's operands are first read ~0.3 ms into
         # a training step, after the gaussian head's chain: its pack runs beside that chain); wait_ready() orders the consumer
@@ -300,6 +316,8 @@ class PackedMLP:
             pack_stream.wait_stream(torch.cuda.current_stream(dev))   # the parameters were last written on the current stream
             _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(raw), C.byref(s), pack_stream.cuda_stream), "mlp_pack")
             self._ready = pack_stream.record_event()
+            self.act_buf.record_stream(pack_stream)   # (same hazard as the map accumulators if the consumer never waits)
+            self.f32_buf.record_stream(pack_stream)
         else:
             _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(raw), C.byref(s), _stream(dev)), "mlp_pack")
         # gradient sink (flat fp32 buffer carved into the scenerf_mlp_grads fields), allocated on first backward
@@ -308,6 +326,17 @@ class PackedMLP:
         self.gc: Optional[_capi.MlpGrads] = None
 
     _GRAD_FIELDS = None
+
+    def same_storage(self, params: Sequence[torch.Tensor]) -> bool:
+        """Whether ``params`` are still the tensors (addresses) this object's operand pointers alias."""
+        return all(_f32c(t).data_ptr() == self.params[n].data_ptr() for n, t in zip(MLP_PARAM_NAMES, params))
+
+    def repack(self, cfg: RenderConfig) -> None:
+        """Run the pack again into the same operand buffers (current stream): the packed operands follow parameter VALUES that
+        changed in place since construction, whatever way they were written (optimizer step, ``p.data.copy_``, ``load_state_dict``),
+        while every device address a captured hipGraph holds stays valid.  Requires ``same_storage``."""
+        self.wait_ready()
+        _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(cfg.to_c()), C.byref(self._raw), C.byref(self.c), _stream(self.device)), "mlp_pack")
 
     def wait_ready(self) -> None:
         """Order the current stream after a pack that was launched on another stream (no-op otherwise, and after the first call)."""
@@ -658,10 +687,21 @@ class RenderSession:
 
     def __init__(self, cfg: RenderConfig, x_rgb: Dict[str, torch.Tensor], mlp_params: Sequence[torch.Tensor],
                  mlpg_params: Sequence[torch.Tensor], grad_sync=None, grad_sync_async=None, debug_aux: bool = False):
+        hwc, chw = self.classify_maps(x_rgb)
+        if hwc or cfg.hwc_scales:   # per-call layout state (scenerf_cfg.map_chw): a copy, the model's config is not touched
+            cfg = dataclasses.replace(cfg, hwc_scales=hwc, direct_scales=tuple(i for i in cfg.direct_scales if i not in hwc))
+        _require_cuda(chw[0], "x_rgb map 0")
+        self.device = chw[0].device
+        with _on(self.device):
+            self._open(cfg, chw, mlp_params, mlpg_params, grad_sync, grad_sync_async, debug_aux)
+
+    @staticmethod
+    def classify_maps(x_rgb):
+        """(indices of the levels that are read in place as (H,W,C), the five tensors as handed to PrepareMaps).  Channels-last maps
+        are read in place: either wrapped (HWC: an (H,W,C) tensor) or a (C,H,W) tensor whose MEMORY is (H,W,C) -- a slice of a
+        torch.channels_last (B,C,H,W) batch has exactly these strides -- which enters as its (H,W,C) view: autograd carries the
+        gradient back through the permute, no copy in either direction."""
         vals = [x_rgb["1_%d" % s] for s in (1, 2, 4, 8, 16)]
-        # channels-last maps are read in place: either wrapped (HWC: an (H,W,C) tensor) or a (C,H,W) tensor whose MEMORY is (H,W,C) --
-        # a slice of a torch.channels_last (B,C,H,W) batch has exactly these strides -- which enters as its (H,W,C) view: autograd
-        # carries the gradient back through the permute, no copy in either direction
         hwc, chw = [], []
         for i, v in enumerate(vals):
             if isinstance(v, HWC):
@@ -670,13 +710,7 @@ class RenderSession:
                 hwc.append(i); chw.append(v.permute(1, 2, 0))
             else:
                 chw.append(v)
-        hwc = tuple(hwc)
-        if hwc or cfg.hwc_scales:   # per-call layout state (scenerf_cfg.map_chw): a copy, the model's config is not touched
-            cfg = dataclasses.replace(cfg, hwc_scales=hwc, direct_scales=tuple(i for i in cfg.direct_scales if i not in hwc))
-        _require_cuda(chw[0], "x_rgb map 0")
-        self.device = chw[0].device
-        with _on(self.device):
-            self._open(cfg, chw, mlp_params, mlpg_params, grad_sync, grad_sync_async, debug_aux)
+        return tuple(hwc), chw
 
     def _open(self, cfg, chw, mlp_params, mlpg_params, grad_sync, grad_sync_async, debug_aux):
         lib = _capi.load()

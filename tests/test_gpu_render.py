@@ -627,6 +627,80 @@ def test_render_image_static_chunks_and_graph_replay():
 
 
 @pytest.mark.gpu
+def test_render_image_follows_in_place_writes_no_version_counter_sees():
+    """The cached full-frame engine (packed weights, converted maps, a captured graph) must not serve stale inputs: ``p.data.copy_``
+    and in-place map writes through ``.data`` bump no version counter, moving a parameter (``p.data = ...``) changes its address."""
+    from scenerf_amd import synth
+    kw = dict(sphere_W=376, sphere_H=114, n_pts_uni=32, n_pts_per_gaussian=8)
+    R, CH = 300, 128
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="bf16", **kw).to(DEV).eval()
+    m.mlp.load_state_dict(synth.mlp_state(91, 4))
+    m.mlp_gaussian.load_state_dict(synth.mlp_state(92, 2, out_scale=4.0))
+    maps = {k: v.to(DEV) for k, v in synth.feature_maps(376, 114, 93, smooth=True).items()}
+    K, T = synth.kitti_cam_K().to(DEV), synth.rel_pose(2.0, 10.0).to(DEV)
+    pix = synth.stride2_pixels((1220, 370), R, 94).to(DEV)
+    nu, ng = synth.sampling_noise(R, 32, 32, 95)
+    noise = (nu.to(DEV), ng.to(DEV))
+
+    def render():
+        with torch.no_grad():
+            return m.render_image(K, T, maps, sampled_pixels=pix, ray_batch_size=CH, noise=noise, use_graph=True, keys=("depth", "color"))
+
+    def fresh():
+        m.release_inference_engine()
+        return render()
+
+    a = render()
+    eng = m._image_renderer[1]
+    new_w = synth.mlp_state(191, 4)
+    for n, p_ in m.mlp.named_parameters():
+        v0 = p_._version
+        p_.data.copy_(new_w[n].to(DEV))            # e.g. an EMA swap: no version bump, same address
+        assert p_._version == v0
+    b = render()
+    assert m._image_renderer[1] is eng              # same engine, same graph ...
+    assert not torch.equal(a["depth"], b["depth"])  # ... new weights
+    b_ref = fresh()
+    assert torch.equal(b["depth"], b_ref["depth"]) and torch.equal(b["color"], b_ref["color"])
+    eng = m._image_renderer[1]
+    maps["1_1"].data.mul_(0.5)                      # a map rewritten in place through .data
+    c = render()
+    assert m._image_renderer[1] is eng
+    c_ref = fresh()
+    assert not torch.equal(b["color"], c["color"]) and torch.equal(c["color"], c_ref["color"]) and torch.equal(c["depth"], c_ref["depth"])
+    eng = m._image_renderer[1]
+    m.mlp.lin_out.weight.data = m.mlp.lin_out.weight.data.clone() * 2.0   # a parameter that MOVED: the engine is rebuilt
+    d = render()
+    assert m._image_renderer[1] is not eng
+    assert not torch.equal(c["color"], d["color"])
+
+
+@pytest.mark.gpu
+def test_no_grad_multi_chunk_call_keeps_the_reference_rng_stream():
+    """A seeded evaluation run must see the same samples whether or not render_rays_batch routes through the static-chunk engine:
+    with device_rng=False (default) the gaussian noise comes from the CPU generator chunk by chunk, shapes and order as in
+    scenerf.py:437-455 / utils.py:208-211; the uniform noise from the device generator (utils.py:84)."""
+    from scenerf_amd import synth
+    kw = dict(sphere_W=376, sphere_H=114, n_pts_uni=32, n_pts_per_gaussian=8)
+    R, CH = 300, 128
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="fp32", **kw).to(DEV).eval()
+    m.mlp.load_state_dict(synth.mlp_state(91, 4))
+    m.mlp_gaussian.load_state_dict(synth.mlp_state(92, 2, out_scale=4.0))
+    maps = {k: v.to(DEV) for k, v in synth.feature_maps(376, 114, 93, smooth=True).items()}
+    K, T = synth.kitti_cam_K().to(DEV), synth.rel_pose(2.0, 10.0).to(DEV)
+    pix = synth.stride2_pixels((1220, 370), R, 94).to(DEV)
+    outs = []
+    for static in (True, False, True):
+        m.static_inference = static
+        torch.manual_seed(1234)   # CPU and device generators
+        with torch.no_grad():
+            outs.append(m.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=CH))
+    for k in OUT_KEYS:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+        assert torch.equal(outs[0][k], outs[2][k]), k
+
+
+@pytest.mark.gpu
 def test_render_image_n512_bf16_against_position_matched_oracle():
     """BASELINE.json configs[4] sampling (N = 512: U=256, G=4, P=64), bf16, one padded chunk of 32 rays = 16,384 rows on the fused
     lean-inference path, replayed from the captured graph, white-noise maps at the full KITTI sphere: depth and colour of every ray
