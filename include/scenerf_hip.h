@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SCENERF_HIP_ABI_VERSION 4
+#define SCENERF_HIP_ABI_VERSION 5
 #define SCENERF_N_SCALES 5          /* feature maps "1_1","1_2","1_4","1_8","1_16" */
 #define SCENERF_D_LATENT 2480       /* 80+160+320+640+1280 (resnetfc d_latent, scenerf.py:100-114) */
 #define SCENERF_D_HIDDEN 512
@@ -249,10 +249,13 @@ int scenerf_hip_composite_backward(const float* logits, const float* dist_sorted
                                    scenerf_stream_t stream);
 
 /* ---- RaySOM KL ---------------------------------------------------------------------------------------------- */
-/* RaySOM.forward + kl_gauss, ray_som_kl.py:10-87.  kl_saved [R][G][3] = {som mean, clamped som std, mask}. */
+/* RaySOM.forward + kl_gauss, ray_som_kl.py:10-87.  kl_saved [R][G][3] = {som mean, clamped som std, mask}.
+ * bmu_out (nullable, [R][N] bytes): the best-matching unit chosen per sample (ray_som_kl.py:52, the argmax) -- a discrete choice
+ * exported so that a parity test can compare it on its own and evaluate its checker at the same choice. */
 int scenerf_hip_raysom_forward(const scenerf_cfg* cfg, const float* gmeans, const float* gstds, const float* dist_sorted,
                                const float* alphas, int R, float* loss_kl /*[R]*/, float* som_means /*[R][G]*/,
-                               float* som_vars /*[R][G]*/, float* kl_saved /*[R][G][3]*/, scenerf_stream_t stream);
+                               float* som_vars /*[R][G]*/, float* kl_saved /*[R][G][3]*/, uint8_t* bmu_out,
+                               scenerf_stream_t stream);
 
 /* autograd of the sampler + KL w.r.t. the gaussian-head outputs: reparameterisation (utils.py:213, not
  * through the 0.1 clamp), z = dist*unit.z, relu of scenerf.py:591-594, kl_gauss(m1,s1).  Upstream NULL = 0. */

@@ -221,8 +221,15 @@ def composite(density, dist, z, colors):
 
 
 # ----------------------------------------------------------------------------- RaySOM
-def ray_som_kl(means, stds, dist, alphas, som_sigma: float, kl_std_floor: float = 1.5):
-    """ray_som_kl.py:10-87: SOM update of G gaussians per ray from (sorted dist, alphas) -> KL(pred || SOM)."""
+def ray_som_kl(means, stds, dist, alphas, som_sigma: float, kl_std_floor: float = 1.5, bmu_use=None, mask_use=None, info=None):
+    """ray_som_kl.py:10-87: SOM update of G gaussians per ray from (sorted dist, alphas) -> KL(pred || SOM).
+
+    ``bmu_use`` (R, N) / ``mask_use`` (R, G), parity tests only: the two DISCRETE choices of this function -- the best-matching unit
+    per sample (an argmax over values that tie at the additive floors, :46-52) and the thresholded update mask (:66-70) -- are taken
+    from the argument instead of computed here; the ones computed here are still returned / recorded.  ``info`` (dict) receives how
+    close each of those choices was: ``bmu_margin`` (R, N) = (best - second best) / best of the argmax, ``mask_margin`` (R, G) =
+    distance of the closest thresholded quantity from its threshold, and the own ``mask``.  None / None is the reference's
+    arithmetic, unchanged."""
     m = means.detach()
     s = stds.detach()
     d = dist.detach()
@@ -241,6 +248,13 @@ def ray_som_kl(means, stds, dist, alphas, som_sigma: float, kl_std_floor: float 
     tmp = pz1.reshape(R, Np, 1, G) * p12.unsqueeze(1) + 1e-8
     pz2 = tmp.sum(-1)
     pbest, bmu = pz2.max(dim=2)
+    bmu_own = bmu
+    if info is not None:
+        top2 = torch.topk(pz2, 2, dim=2).values
+        info["bmu_margin"] = (top2[:, :, 0] - top2[:, :, 1]) / top2[:, :, 0]
+    if bmu_use is not None:
+        bmu = bmu_use.to(bmu.dtype).reshape(bmu.shape)
+        pbest = torch.gather(pz2, 2, bmu.unsqueeze(-1)).squeeze(-1)
     new_m = torch.zeros_like(m)
     new_v = torch.zeros_like(s)
     for r in range(G):
@@ -251,12 +265,17 @@ def ray_som_kl(means, stds, dist, alphas, som_sigma: float, kl_std_floor: float 
     mean_diff = torch.abs(m - new_m)
     std_diff = torch.abs(torch.sqrt(var) - torch.sqrt(new_v))
     mask = ((mean_diff > 0.1) & (new_v > 0)) * ((std_diff > 0.1) & (new_v > 0))
+    if info is not None:
+        info["mask"] = mask.clone()
+        info["mask_margin"] = torch.minimum(torch.minimum((mean_diff - 0.1).abs(), (std_diff - 0.1).abs()), new_v.abs())
+    if mask_use is not None:
+        mask = mask_use.to(mask.dtype).reshape(mask.shape)
     s2 = torch.sqrt(new_v).detach()
     m2 = new_m.detach()
     s2[s2 < kl_std_floor] = kl_std_floor
     kl = torch.log(s2 / stds + 1e-8) + (stds ** 2 + (means - m2) ** 2) / (2 * s2 ** 2) - 0.5
     loss = (kl * mask).mean(1)
-    return loss, new_m, new_v, bmu
+    return loss, new_m, new_v, bmu_own
 
 
 # ----------------------------------------------------------------------------- the chunk
@@ -264,7 +283,8 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
                  cam_K: torch.Tensor, T_source2infer: torch.Tensor, x_rgb: Dict[str, torch.Tensor],
                  pixels: torch.Tensor, noise_u: torch.Tensor, noise_g: torch.Tensor,
                  keep_intermediates: bool = False, head_offsets: Optional[torch.Tensor] = None,
-                 sphere_idx: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+                 sphere_idx: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                 som_choices: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]] = None) -> Dict[str, torch.Tensor]:
     """scenerf.py:598-700 (batchify_depth_and_color) for one chunk of R rays.
 
     Returns the 12 tensors of ``render_rays_batch`` (scenerf.py:456-469) under the same keys,
@@ -281,6 +301,8 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
     whose last ulp differs between libm implementations; a test first checks that the other implementation's indices equal the
     ones computed here except within rounding noise of a .5 boundary, then evaluates the oracle AT those indices so that the
     remaining comparison is arithmetic only.
+
+    ``som_choices = (bmu (R, N), mask (R, G))``, parity tests only: RaySOM's two discrete choices, see ``ray_som_kl``.
     """
     inv_K = torch.inverse(cam_K)
     R = pixels.shape[0]
@@ -342,8 +364,10 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
     density = density_activation(out[..., 3:4]).reshape(R, N)
 
     comp = composite(density, dist, zz, color_s)
+    som_info = {} if keep_intermediates else None
     loss_kl, som_means, som_vars, bmu = ray_som_kl(g_means, g_stds, dist, comp["alphas"], cfg.som_sigma,
-                                                   cfg.kl_std_floor)
+                                                   cfg.kl_std_floor, bmu_use=None if som_choices is None else som_choices[0],
+                                                   mask_use=None if som_choices is None else som_choices[1], info=som_info)
     ret = {
         "depth": comp["depth"], "color": comp["color"], "gaussian_means": g_means, "gaussian_stds": g_stds,
         "weights_at_depth": comp["weights_at_depth"], "closest_pts_to_depths": comp["closest"],
@@ -356,7 +380,7 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
             "_idx_g": idx_g, "_xin_g": xin_g, "_offsets": off, "_offsets_own": off_own, "_dist_g": dist_g, "_perm": perm,
             "_dist_sorted": dist, "_pts_sorted": pts, "_idx": idx, "_xin": xin, "_mlp_out": out,
             "_colors": color_s, "_closest_idx": comp["closest_idx"], "_bmu": bmu,
-            "_keep_mlp": keep_m, "_keep_gauss": keep_g,
+            "_keep_mlp": keep_m, "_keep_gauss": keep_g, "_som_info": som_info,
         })
     return ret
 

@@ -23,7 +23,7 @@ D_HIDDEN = 512
 D_XENC = 48
 TILE_ROWS = 128
 W_STREAM_BLOCKS = (3 * D_XENC + D_LATENT) // 16 + 2 * ((512 + D_LATENT) // 16) + 10 * (512 // 16)   # scenerf_hip.h
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 vp = C.c_void_p
 
@@ -110,7 +110,7 @@ _PROTOS = {
     "scenerf_hip_gaussian_sample_sort": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_composite_forward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_composite_backward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "scenerf_hip_raysom_forward": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "scenerf_hip_raysom_forward": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_sampler_backward": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
     "scenerf_hip_test_gemm_nt": (C.c_int, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "scenerf_hip_test_chunk_table": (C.c_int, [C.POINTER(Cfg), i32, vp, i32]),

@@ -624,7 +624,8 @@ __global__ __launch_bounds__(256) void raysom_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ dist, const float* __restrict__ alphas,
                                                          int R, int N, int G, float som_sigma, float kl_floor,
                                                          float* __restrict__ loss_kl, float* __restrict__ som_means,
-                                                         float* __restrict__ som_vars, float* __restrict__ kl_saved) {
+                                                         float* __restrict__ som_vars, float* __restrict__ kl_saved,
+                                                         uint8_t* __restrict__ bmu_out) {
     __shared__ float s_nb[4][MAXG][MAXG], s_p12[4][MAXG][MAXG];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + wv;
@@ -722,6 +723,7 @@ __global__ __launch_bounds__(256) void raysom_fwd_kernel(const float* __restrict
                 if (c1 < G) acc += pz1[c1] * s_p12[wv][c2][c1] + 1e-8f;
             if (acc > pbest) { pbest = acc; bmu = c2; }
         }
+        if (bmu_out) bmu_out[(size_t)r * N + i] = (uint8_t)bmu;   // parity tests: the discrete choice of ray_som_kl.py:52
 #pragma unroll
         for (int g = 0; g < MAXG; ++g) {
             if (g < G) {
@@ -1060,14 +1062,14 @@ int scenerf_hip_composite_backward(const float* logits, const float* dist_sorted
 
 int scenerf_hip_raysom_forward(const scenerf_cfg* cfg, const float* gmeans, const float* gstds, const float* dist_sorted,
                                const float* alphas, int R, float* loss_kl, float* som_means, float* som_vars, float* kl_saved,
-                               scenerf_stream_t stream) {
+                               uint8_t* bmu_out, scenerf_stream_t stream) {
     if (check_cfg(cfg)) return 1;
     SRF_CHECK(gmeans && gstds && dist_sorted && alphas && loss_kl && som_means && som_vars && kl_saved && R > 0,
               "raysom_forward: NULL argument");
     hipStream_t s = as_stream(stream);
     SrfLaunchScope ps(s, "raysom_fwd", 0, (double)R * cfg->n_samples * 16);
     raysom_fwd_kernel<<<cdiv(R, 4), 256, 0, s>>>(gmeans, gstds, dist_sorted, alphas, R, cfg->n_samples, cfg->n_gaussians,
-                                                 cfg->som_sigma, cfg->kl_std_floor, loss_kl, som_means, som_vars, kl_saved);
+                                                 cfg->som_sigma, cfg->kl_std_floor, loss_kl, som_means, som_vars, kl_saved, bmu_out);
     SRF_LAUNCH_CHECK("raysom_fwd_kernel");
     return 0;
 }

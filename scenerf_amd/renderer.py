@@ -582,9 +582,10 @@ class RenderChunk(torch.autograd.Function):
         som_means = torch.empty((R, G), **f32)
         som_vars = torch.empty((R, G), **f32)
         kl_saved = torch.empty((R, G, 3), **f32)
+        bmu = torch.empty((R, N), dtype=torch.uint8, device=dev) if maps.debug_aux is not None else None
         _capi.check(lib.scenerf_hip_raysom_forward(C.byref(ccfg), gmeans.data_ptr(), gstds.data_ptr(), dist_s.data_ptr(),
                                                    alphas.data_ptr(), R, loss_kl.data_ptr(), som_means.data_ptr(),
-                                                   som_vars.data_ptr(), kl_saved.data_ptr(), st), "raysom_forward")
+                                                   som_vars.data_ptr(), kl_saved.data_ptr(), _capi.ptr(bmu), st), "raysom_forward")
         # keep what backward needs (plain attributes: these are internal buffers, not graph tensors)
         ctx.cfg, ctx.ccfg, ctx.maps, ctx.mlp, ctx.mlpg = cfg, ccfg, maps, mlp, mlpg
         ctx.keep = dict(R=R, anchors=anchors, noise_g=noise_g, unit_dir=unit_dir, gmeans=gmeans, gstds=gstds, perm=perm,
@@ -598,7 +599,7 @@ class RenderChunk(torch.autograd.Function):
             maps.debug_aux.update(perm=perm, sphere_idx=run_m.sphere_idx, closest_idx=closest_idx, tile_mask=run_m.tile_mask,
                                   offsets=run_g.logits, logits=run_m.logits, dist_sorted=dist_s, xenc=run_m.xenc,
                                   sphere_idx_g=run_g.sphere_idx, unit_dir=unit_dir, viewdir=viewdir, dist_u=dist_u,
-                                  tile_mask_g=run_g.tile_mask)
+                                  tile_mask_g=run_g.tile_mask, bmu=bmu, kl_mask=kl_saved[:, :, 2], som_means=som_means)
         # order = OUTPUT_KEYS + som_means
         return depth, color, gmeans, gstds, w_at, closest, loss_kl, alphas, som_vars, dens, weights, z_s, som_means
 

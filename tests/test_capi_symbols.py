@@ -90,7 +90,7 @@ def test_bad_arguments_are_reported_not_fatal():
     from scenerf_amd.config import RenderConfig
     cc = RenderConfig.kitti().to_c()
     cc.n_samples = 999
-    rc = lib.scenerf_hip_raysom_forward(ctypes.byref(cc), None, None, None, None, 1, None, None, None, None, None)
+    rc = lib.scenerf_hip_raysom_forward(ctypes.byref(cc), None, None, None, None, 1, None, None, None, None, None, None)
     assert rc != 0 and b"n_samples" in lib.scenerf_hip_last_error()
 
 

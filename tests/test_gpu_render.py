@@ -582,6 +582,95 @@ def test_hwc_entry_equals_the_chw_entry(precision):
         m.render_rays_batch(K, T, {k: HWC(v.to(DEV)) for k, v in maps.items()}, sampled_pixels=pix, ray_batch_size=R, noise=(nu, ng))
 
 
+class _BasicBlock(torch.nn.Module):
+    """Shape of the reference's residual block (unet2d_sphere.py:9-34): conv-BN-LeakyReLU, conv-BN, + residual, LeakyReLU."""
+
+    def __init__(self, c, d):
+        super().__init__()
+        nn = torch.nn
+        self.b1 = nn.Sequential(nn.Conv2d(c, c, 3, padding=d, dilation=d), nn.BatchNorm2d(c), nn.LeakyReLU())
+        self.b2 = nn.Sequential(nn.Conv2d(c, c, 3, padding=d, dilation=d), nn.BatchNorm2d(c))
+        self.act = nn.LeakyReLU()
+
+    def forward(self, x):
+        return self.act(self.b2(self.b1(x)) + x)
+
+
+def _upsample_bn_like(c_in, c_out):
+    """The tail of the decoder that emits x_rgb (UpSampleBN._net, unet2d_sphere.py:37-56): 3x3 conv + three dilated residual blocks."""
+    return torch.nn.Sequential(torch.nn.Conv2d(c_in, c_out, 3, padding=1), _BasicBlock(c_out, 1), _BasicBlock(c_out, 2), _BasicBlock(c_out, 3))
+
+
+@pytest.mark.gpu
+def test_channels_last_decoder_stack_is_read_in_place():
+    """What bench.py's default entry assumes: a stock conv stack run in torch.channels_last (MIOpen convolutions, BatchNorm, LeakyReLU,
+    residual adds -- the layers of the reference's UpSampleBN) emits channels-last memory, a slice ``out[k][i]`` of its (B,C,H,W) output
+    is a (C,H,W) tensor whose memory is (H,W,C), and render_rays_batch reads it in place: layout code 2 for the levels it converts
+    otherwise, no layout-conversion kernel in the step (in-library launch table), outputs bit-identical to the contiguous entry in fp32
+    and the gradients that reach the decoder's parameters equal to atomic-ordering noise."""
+    from scenerf_amd import _capi, synth
+    from scenerf_amd.config import FEAT_CHANNELS
+    from scenerf_amd.renderer import RenderSession
+    kw = dict(sphere_W=376, sphere_H=114, n_pts_uni=32, n_pts_per_gaussian=8)
+    R, B = 160, 2
+    mlp, mlpg = synth.mlp_state(91, 4), synth.mlp_state(92, 2, out_scale=4.0)
+    pix = synth.stride2_pixels((1220, 370), R, 94).to(DEV)
+    nu, ng = synth.sampling_noise(R, 32, 32, 95)
+    nu, ng = nu.to(DEV), ng.to(DEV)
+    K, T = synth.kitti_cam_K().to(DEV), synth.rel_pose(2.0, 10.0).to(DEV)
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="fp32", **kw).to(DEV)
+    m.mlp.load_state_dict(mlp)
+    m.mlp_gaussian.load_state_dict(mlpg)
+    shapes = m.render_cfg.map_shapes()
+    torch.manual_seed(5)
+    nets = {s: _upsample_bn_like(8, c).to(DEV) for s, c in zip((1, 2, 4, 8, 16), FEAT_CHANNELS)}
+    ins = {s: torch.randn(B, 8, h, w, device=DEV) for s, (c, h, w) in zip((1, 2, 4, 8, 16), shapes)}
+    lib = _capi.load()
+    res = {}
+    for entry in ("channels_last", "contiguous"):
+        for net in nets.values():
+            net.zero_grad(set_to_none=True)
+            net.to(memory_format=torch.channels_last if entry == "channels_last" else torch.contiguous_format)
+        outs = {}
+        for s, net in nets.items():
+            x = ins[s].to(memory_format=torch.channels_last) if entry == "channels_last" else ins[s].contiguous()
+            outs[s] = net(x)
+        x_rgb = {"1_%d" % s: (o[1] if entry == "channels_last" else o[1].contiguous()) for s, o in outs.items()}
+        if entry == "channels_last":
+            for s, o in outs.items():
+                assert o.is_contiguous(memory_format=torch.channels_last), "level 1/%d: the conv stack did not keep channels_last" % s
+                c, h, w = x_rgb["1_%d" % s].shape
+                assert x_rgb["1_%d" % s].stride() == (1, w * c, c)
+            assert RenderSession.classify_maps(x_rgb)[0] == (0, 1, 2, 3, 4)
+        torch.cuda.synchronize()
+        lib.scenerf_hip_profile_enable(1)
+        out = m.render_rays_batch(K, T, x_rgb, sampled_pixels=pix, ray_batch_size=R, noise=(nu, ng))
+        (out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()).backward()
+        torch.cuda.synchronize()
+        names = {k["name"] for k in _capi.profile_collect()}
+        lib.scenerf_hip_profile_enable(0)
+        if entry == "channels_last":
+            assert not (names & {"maps_chw_to_hwc", "grads_hwc_to_chw"}), names
+        else:
+            assert {"maps_chw_to_hwc", "grads_hwc_to_chw"} <= names
+        grads = {"%d.%s" % (s, n): p.grad.detach().clone().contiguous() for s, net in nets.items() for n, p in net.named_parameters()}
+        res[entry] = ({k: v.detach().clone() for k, v in out.items()}, grads)
+    (o1, g1), (o2, g2) = res["channels_last"], res["contiguous"]
+    # the conv stack itself may pick different MIOpen kernels per layout: compare what the renderer was GIVEN first
+    for k in ("depth", "color", "loss_kl", "gaussian_means", "weights"):
+        torch.testing.assert_close(o1[k], o2[k], rtol=1e-4, atol=1e-5, msg=lambda s_, k=k: "%s: %s" % (k, s_))
+    n_checked = 0
+    for n in g1:
+        a, b = g1[n].double(), g2[n].double()
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, n
+            continue
+        r = float((a - b).norm() / b.norm())
+        assert r <= 2e-3, "%s: decoder-parameter gradient through the channels-last entry vs the contiguous one: rel L2 %.3e" % (n, r)
+        n_checked += 1
+    assert n_checked >= 20
+
+
 # ------------------------------------------------------------------------------------------------ full-frame inference (C5)
 @pytest.mark.gpu
 def test_render_image_static_chunks_and_graph_replay():

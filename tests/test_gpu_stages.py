@@ -358,8 +358,17 @@ def test_raysom_forward_and_sampler_backward(case):
     dist, al = o["_dist_sorted"].detach(), o["alphas"].detach()
     f = lambda *s: torch.empty(s, device=DEV)
     lk, sm, sv, ks = f(R), f(R, G), f(R, G), f(R, G, 3)
+    bmu = torch.empty((R, N), dtype=torch.uint8, device=DEV)
     _capi.check(lib.scenerf_hip_raysom_forward(C.byref(cc), dv(gm).data_ptr(), dv(gs).data_ptr(), dv(dist).data_ptr(), dv(al).data_ptr(), R,
-                                               lk.data_ptr(), sm.data_ptr(), sv.data_ptr(), ks.data_ptr(), _st()), "raysom_forward")
+                                               lk.data_ptr(), sm.data_ptr(), sv.data_ptr(), ks.data_ptr(), bmu.data_ptr(), _st()), "raysom_forward")
+    # the two discrete choices on their own (BMU indices bit-exact): equal to the oracle's wherever the oracle's choice
+    # is not a tie at rounding level (argmax margin > 1e-5 relative; a thresholded quantity > 1e-4 from its threshold)
+    info = {}
+    orc.ray_som_kl(gm, gs, dist.clone(), al, ocfg.som_sigma, ocfg.kl_std_floor, info=info)
+    clear = info["bmu_margin"] > 1e-5
+    assert bool((bmu.cpu().long()[clear] == o["_bmu"][clear]).all()) and float(clear.float().mean()) > 0.5
+    clear_m = info["mask_margin"] > 1e-4
+    assert bool((ks[:, :, 2].cpu()[clear_m] == info["mask"].float()[clear_m]).all())
     torch.testing.assert_close(sm.cpu(), o["som_means"].detach(), rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(sv.cpu(), o["som_vars"].detach(), rtol=2e-4, atol=2e-4)
     torch.testing.assert_close(lk.cpu(), o["loss_kl"].detach(), rtol=2e-4, atol=2e-5)
