@@ -103,6 +103,7 @@ def parse():
                     help="N>1: 'session' = the renderer's per-session hooks (two 21.7 MB all-reduces started inside the backward, overlapped); "
                          "'step' = dist.StepGradSync, one 43.3 MB all-reduce at the end of backward (safe when ranks render different numbers "
                          "of source frames)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the short BASELINE configs[3] (BundleFusion) and configs[4] (inference) legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=0, help="rays of the CPU-baseline sample (0 = the bench's own --rays)")
@@ -224,6 +225,7 @@ def _timed(step, args, world, dev, sync):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
+    _timed.host_s = time.perf_counter() - t0     # the host's share: all K steps issued (nothing waited for yet)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -458,6 +460,113 @@ def _rank_census(rank, world, local, dev, dry):
             "devices": devs}
 
 
+def _leg_roofline(run, nprof, args, samples, value_per_gpu):
+    """roofline objects of a side leg: ``run`` under the in-library HIP-event profiler."""
+    import copy
+    lib = _capi.load()
+    torch.cuda.synchronize()
+    lib.scenerf_hip_profile_enable(1)
+    for _ in range(nprof):
+        run()
+    torch.cuda.synchronize()
+    kernels = _capi.profile_collect()
+    lib.scenerf_hip_profile_enable(0)
+    a2 = copy.copy(args)
+    a2.samples = samples
+    roof, roof_c = _rooflines(kernels, a2, nprof, value_per_gpu, 1)
+    if roof_c:
+        roof_c.pop("at_inference_chunk", None)
+    return roof, roof_c
+
+
+def bundlefusion_leg(args, dev, steps=10, warmup=3):
+    """BASELINE.json configs[3]: BundleFusion indoor scene, 640x480, sphere 960x720 (train_bundlefusion.py:46-47), 96 samples/ray
+    (U=64, G=4, P=8), R = 1080 rays per step (train_bundlefusion.py:32), D = 12 m -- the same training step as the headline."""
+    from scenerf_amd.model import SceneRFBundleFusion
+    R, U, P = 1080, 64, 8
+    m = SceneRFBundleFusion(som_sigma=0.02, std=0.1, add_fov_hor=14, add_fov_ver=11, sphere_W=960, sphere_H=720, n_pts_uni=U, n_pts_per_gaussian=P,
+                            max_sample_depth=12, precision=args.precision, device_rng=not args.host_rng).to(dev)
+    m.mlp.load_state_dict(synth.mlp_state(11, 4))
+    m.mlp_gaussian.load_state_dict(synth.mlp_state(12, 2, out_scale=0.5))
+    opt = torch.optim.AdamW(list(m.mlp.parameters()) + list(m.mlp_gaussian.parameters()), lr=1e-5, weight_decay=0.0, fused=True)
+    maps = {}
+    for k, v in synth.feature_maps(960, 720, 13).items():
+        if args.maps == "hwc":
+            c, h, w = v.shape
+            maps[k] = torch.empty_strided((c, h, w), (1, w * c, c), dtype=torch.float32, device=dev).copy_(v.to(dev)).requires_grad_(True)
+        else:
+            maps[k] = v.to(dev).requires_grad_(True)
+    K, T = synth.bundlefusion_cam_K().to(dev), synth.rel_pose(0.3, 8.0).to(dev)
+    pix = synth.stride2_pixels((640, 480), R, 14).to(dev)
+
+    def step():
+        for v in maps.values():
+            v.grad = None
+        out = m.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=R)
+        loss = out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(last).item()
+    value = R / dt
+    roof, roof_c = _leg_roofline(step, 2, args, U + 4 * P, value)
+    if roof:
+        roof.pop("dense_equivalent", None)
+    return {"metric": "rays/sec (training fwd+bwd), BundleFusion 640x480, 96 samples/ray", "value": round(value, 1), "unit": "rays/s",
+            "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup,
+            "config": {"workload": "BundleFusion 640x480, sphere 960x720, 96 samples/ray (U=64,G=4,P=8), 1080 rays/step, D=12 m, same step as the headline",
+                       "rays_per_gpu": R, "samples_per_ray": U + 4 * P, "precision": args.precision, "maps": args.maps},
+            "roofline": roof, "roofline_composite": roof_c}
+
+
+def inference_leg(args, dev, frames=2, stride=2, chunk=4096, samples=512):
+    """BASELINE.json configs[4]: KITTI novel-view inference, one stride-2 frame (112,850 px, generate_novel_depths.py:103-112), 512
+    samples/ray (U=256, G=4, P=64), static chunks of 4,096 rays replayed from one captured hipGraph (scenerf_amd/inference.py)."""
+    import copy
+    from scenerf_amd.inference import pixel_grid
+    a2 = copy.copy(args)
+    a2.samples = samples
+    model = make_model(a2, dev).eval()
+    maps = {k: v.to(dev) for k, v in synth.feature_maps(1500, 452, 3).items()}
+    K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
+    grid = pixel_grid((1220, 370), stride, dev)
+    n = grid.shape[0]
+
+    def frame(graph=True):
+        with torch.no_grad():
+            return model.render_image(K, T, maps, sampled_pixels=grid, ray_batch_size=chunk, keys=("depth", "color"), use_graph=graph)
+
+    frame()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        last = frame()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / frames
+    assert bool(torch.isfinite(last["depth"]).all())
+    value = n / dt
+    roof, roof_c = _leg_roofline(lambda: frame(False), 1, a2, samples, None)
+    model.release_inference_engine()
+    U, P = sample_split(samples)
+    return {"metric": "rays/sec (novel-view inference, %d samples/ray, hipGraph-replayed static chunks)" % samples, "value": round(value, 1),
+            "unit": "rays/s", "ms_per_frame": round(dt * 1e3, 2), "frames": frames,
+            "config": {"workload": "KITTI 370x1220 novel-view render, sphere 1500x452, %d px per frame (stride %d), %d samples/ray (U=%d,G=4,P=%d), "
+                                   "chunks of %d rays (tail padded), no_grad, one hipGraph replayed per chunk" % (n, stride, samples, U, P, chunk),
+                       "rays_per_frame": n, "samples_per_ray": samples, "chunk": chunk, "precision": args.precision,
+                       "sampling_noise": "host generator per chunk" if args.host_rng else "device generator"},
+            "roofline": roof, "roofline_composite": roof_c}
+
+
 def main():
     args = parse()
     if args.dry_run:
@@ -523,6 +632,7 @@ def main():
 
     step = make_step(model, opt)
     dt, last = _timed(step, args, world, dev, sync)
+    host_ms = _timed.host_s / args.steps * 1e3
     ms = dt / args.steps * 1e3
     value = world * R * args.steps / dt
     assert torch.isfinite(last).item(), "loss is not finite"
@@ -608,6 +718,20 @@ def main():
         except Exception as e:  # never let the side measurement break the bench line
             eager = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
+    bf_leg = inf_leg = None
+    if rank == 0 and world == 1 and not dry and not args.no_extra_legs:
+        for name in ("bf", "infer"):
+            try:
+                if name == "bf":
+                    bf_leg = bundlefusion_leg(args, dev)
+                else:
+                    inf_leg = inference_leg(args, dev)
+            except Exception as e:  # never let a side leg break the bench line
+                if name == "bf":
+                    bf_leg = {"error": repr(e)[:300]}
+                else:
+                    inf_leg = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
@@ -616,6 +740,7 @@ def main():
         line = {
             "metric": "rays/sec (training fwd+bwd) at KITTI 128-sample config", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "host_issue_ms_per_step": round(host_ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "KITTI 370x1220, sphere 1500x452, %d samples/ray (U=%d,G=4,P=%d), %d rays/GPU/step, "
@@ -631,6 +756,7 @@ def main():
                                          "device generator (RenderConfig.device_rng=True; --host-rng gives the reference's host-side draw: +0.1-0.25 ms per step)"},
             "other_entry": other,
             "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager, "fp32_mode": fp32,
+            "bundlefusion_c4": bf_leg, "infer_c5": inf_leg,
             "allreduce": allreduce, "ranks": census,
         }
         if dry:

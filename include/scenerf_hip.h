@@ -50,7 +50,7 @@ typedef struct scenerf_cfg {
     int32_t n_pts_uni;              /* U */
     int32_t n_gaussians;            /* G */
     int32_t n_pts_per_gaussian;     /* P */
-    int32_t n_samples;              /* N = U + G*P (U>0) or G*P */
+    int32_t n_samples;              /* N = U + G*P (U>0) or G*P; U with SCENERF_FLAG_UNIFORM_ONLY */
     int32_t sphere_W, sphere_H;     /* out_img_W/H */
     float max_sample_depth;         /* D */
     float uni_step;                 /* (D-0.2)/U, utils.py:77 */
@@ -85,6 +85,9 @@ typedef struct scenerf_cfg {
 #define SCENERF_FLAG_WGRAD_OVERLAP   8u  /* per-layer backward: weight-gradient GEMMs on an internal side stream */
 #define SCENERF_FLAG_DFEAT_GEMM     64u  /* bf16 feature-map gradients through the GEMM family's scatter epilogue (gemm.hip) instead of dfeat.hip (A/B runs) */
 #define SCENERF_FLAG_WIDE_ANY_M     32u  /* the 128-row kernels also below 192 row blocks (where the 64-row ones are faster): tests, probes */
+#define SCENERF_FLAG_UNIFORM_ONLY  128u  /* the reference's uniform-only branch (scenerf.py:647-650 / scenerf_bf.py:662-665: n_pts_uni == 0 and
+                                           * n_pts_per_gaussian == 1): the n_pts_uni uniform samples are the ONLY samples that are rendered
+                                           * (n_samples == n_pts_uni); the gaussian head is still evaluated for the KL term */
 #define SCENERF_FLAG_WIDE_BWD       16u  /* fused dgrad chain on 128-row blocks, one wave per SIMD (wide.hip) instead of fused.hip's 64-row ring */
 
 /* Packed ResnetFC operands (built by the host from the nn.Linear parameters).

@@ -5,8 +5,13 @@
 * ``libtsdf_ref.so``: the reference's pycuda TSDF kernel (scenerf/data/utils/fusion.py:72-145) compiled verbatim with hipcc for gfx950
   behind oracle/tsdf_ref_host.hip.  The kernel text is read out of the reference file at build time and written to
   ``oracle/_ref/tsdf_ref_kernel.inc``; nothing of it is committed (``oracle/_ref/`` is git-ignored, but travels to the GPU box with
-  gpurun like every other built artefact).  Compiler defaults are kept: hipcc contracts a*b+c into fma like nvcc does (--fmad=true is
-  nvcc's default, which is what pycuda's SourceModule uses) and divides with correct rounding like nvcc's -prec-div=true.
+  gpurun like every other built artefact).  Two builds of the same text:
+    - ``libtsdf_ref.so``  with ``-ffp-contract=off``: every operation of the kernel source rounded on its own (IEEE fp32, correctly
+      rounded division: hipcc's default, as nvcc's -prec-div=true).  This is the only compiler-independent reading of the source and
+      THE PIN: oracle/tsdf_oracle.py::integrate_gpu_semantics and scenerf_amd/csrc/tsdf.hip must reproduce its volumes bit for bit.
+    - ``libtsdf_ref_contract.so`` with the compiler's default contraction (a*b+c -> fma where the compiler chooses to; nvcc's default
+      --fmad=true does the same under pycuda, with ITS OWN choice of which products to fuse -- hipcc e.g. fuses two of the three
+      rotation rows completely and the third only partly).  Kept as a statistic: how many voxels a different fusion choice moves.
 """
 import os
 import re
@@ -38,10 +43,12 @@ def build(verbose: bool = True) -> str:
         f.write("// extracted from %s (SourceModule string) by oracle/build_ref.py -- DO NOT COMMIT\n" % REF)
         f.write(extract_kernel() + "\n")
     lib = os.path.join(OUT, "libtsdf_ref.so")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-I", HERE, os.path.join(HERE, "tsdf_ref_host.hip"), "-o", lib]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    for out, extra in ((lib, ["-ffp-contract=off"]), (os.path.join(OUT, "libtsdf_ref_contract.so"), [])):
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared"] + extra + ["-I", HERE, os.path.join(HERE, "tsdf_ref_host.hip"),
+                                                                                                     "-o", out]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return lib
 
 

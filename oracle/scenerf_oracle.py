@@ -54,6 +54,7 @@ class OracleConfig:
     som_sigma: float = 2.0
     gauss_floor: float = 1.5       # scenerf.py:591-594 (+1.5); scenerf_bf.py:606-608 (+0.5)
     kl_std_floor: float = 1.5      # ray_som_kl.py:83 (same in BF)
+    uni_fallback: int = 0          # uniform samples drawn when n_pts_uni == 0: scenerf_bf.py:623-626 substitutes 2; scenerf.py has no substitute
 
     @property
     def fov(self):
@@ -67,6 +68,8 @@ class OracleConfig:
     def n_samples(self):
         if self.n_pts_uni > 0:
             return self.n_pts_uni + self.n_gaussians * self.n_pts_per_gaussian
+        if self.n_pts_per_gaussian == 1:       # scenerf.py:647-650: the uniform samples alone
+            return self.uni_fallback
         return self.n_gaussians * self.n_pts_per_gaussian
 
     @staticmethod
@@ -79,7 +82,7 @@ class OracleConfig:
     def bundlefusion(**kw):
         d = dict(img_size=(640, 480), sphere_W=960, sphere_H=720, v_angle_max=112.2911, v_angle_min=67.6248,
                  h_angle_max=118.6861, h_angle_min=61.2383, add_fov_hor=14.0, add_fov_ver=11.0,
-                 max_sample_depth=12.0, std=0.1, som_sigma=0.02, gauss_floor=0.5)
+                 max_sample_depth=12.0, std=0.1, som_sigma=0.02, gauss_floor=0.5, uni_fallback=2)
         d.update(kw)
         return OracleConfig(**d)
 
@@ -306,17 +309,26 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
     """
     inv_K = torch.inverse(cam_K)
     R = pixels.shape[0]
-    U, G, P, D = cfg.n_pts_uni, cfg.n_gaussians, cfg.n_pts_per_gaussian, cfg.max_sample_depth
+    G, P, D = cfg.n_gaussians, cfg.n_pts_per_gaussian, cfg.max_sample_depth
+    # uniform samples are drawn in every configuration (scenerf.py:609-616): n_pts_uni of them, or scenerf_bf.py:623-626's substitute of 2
+    # when that is 0; the KITTI model has no substitute and divides by zero in uniform_sampling (utils.py:77)
+    U = cfg.n_pts_uni if cfg.n_pts_uni > 0 else cfg.uni_fallback
+    if U == 0 and P == 1:
+        raise ZeroDivisionError("float division by zero (utils.py:77: step = (d_max - d_min) / n_pts_per_ray with n_pts_uni == 0)")
+    # (U == 0 with P > 1: the KITTI reference divides by zero here as well; the product renders the gaussian samples alone -- a superset
+    # of the reference -- and this restatement follows it so that the configuration can be checked: no uniform samples are drawn)
     dirs, unit = ray_directions(pixels, inv_K)
     viewdir = (T_source2infer[:3, :3] @ dirs.T).T                                  # utils.py:170
 
-    # uniform samples (utils.py:112-173)
+    # uniform samples (utils.py:112-173); with n_pts_uni == 0 and P > 1 they are drawn and not rendered (noise_u may then be empty)
+    if noise_u.shape[1] == 0 and cfg.n_pts_uni == 0 and P != 1:
+        noise_u = torch.zeros(R, U, 1, device=pixels.device)
     if U > 0:
         dist_u = uniform_distances(R, U, D, noise_u)
         pts_u_src = dist_u.unsqueeze(-1) * unit.reshape(R, 1, 3)
         z_u = pts_u_src[:, :, 2]
         pts_u = to_frame(pts_u_src.reshape(-1, 3), T_source2infer).reshape(R, U, 3)
-    else:  # the reference would sample 0 uniform points and use the gaussian samples only (scenerf.py:647-650)
+    else:
         dist_u = z_u = torch.zeros(R, 0, device=pixels.device)
         pts_u = torch.zeros(R, 0, 3, device=pixels.device)
 
@@ -341,7 +353,7 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
     pts_g = to_frame(pts_g_src.reshape(-1, 3), T_source2infer).reshape(R, G * P, 3)
 
     # merge + sort (scenerf.py:636-659)
-    if U > 0:
+    if cfg.n_pts_uni > 0:
         pts = torch.cat([pts_u, pts_g], dim=1)
         zz = torch.cat([z_u, z_g], dim=1)
         dist = torch.cat([dist_u, dist_g], dim=1)

@@ -2,8 +2,9 @@
 
 reference: scenerf/data/utils/fusion.py.  The file holds two different update rules:
   * ``semantics="gpu"``: the pycuda kernel (fusion.py:72-145) -- what runs when pycuda imports (``use_gpu=True`` is the default of
-    every reconstruction script).  It cannot run in this container (no CUDA): this restatement follows the kernel text line by line
-    in float32 and is **parity unpinned**.
+    every reconstruction script).  The kernel text is plain CUDA C: oracle/build_ref.py compiles it verbatim with hipcc (every operation
+    rounded on its own) and tests/golden/make_golden_tsdf_gpu.py runs it on an MI355X; this restatement follows the text line by line
+    in float32 and is **pinned** bit for bit on those volumes (tests/golden/tsdf_gpu_semantics.npz, tests/test_tsdf.py).
   * ``semantics="cpu"``: the vectorised CPU path (fusion.py:236-325 with the helpers :152-203).  **Pinned** against the reference itself
     (tests/golden/make_golden_tsdf.py imports fusion.py with numba / skimage stubs and runs this path; tests/test_tsdf.py).
 Volumes are float32 [X][Y][Z]; colours are folded as floor(b*65536 + g*256 + r).
@@ -49,7 +50,11 @@ def integrate_gpu_semantics(tsdf, weight, color, origin, voxel_size, color_folde
                     P[0, 2] * tmp[:, 0] + P[1, 2] * tmp[:, 1] + P[2, 2] * tmp[:, 2]], axis=1).astype(np.float32)   # :104-106
 
     def roundf(x):
-        return np.where(x >= 0, np.floor(x + f(0.5)), -np.floor(-x + f(0.5)))
+        # C roundf: nearest integer, halves away from zero -- trunc(x) + (|x - trunc(x)| >= 0.5) with the sign of x.  (floor(x + 0.5)
+        # is NOT it in float32: the sum itself rounds, e.g. 0.49999997 + 0.5 = 1.0)
+        x = np.asarray(x, dtype=np.float32)
+        t = np.trunc(x)
+        return (t + np.copysign((np.abs(x - t) >= f(0.5)).astype(np.float32), x)).astype(np.float32)
     with np.errstate(divide="ignore", invalid="ignore"):
         u = K[0, 0] * (cam[:, 0] / cam[:, 2]) + K[0, 2]
         v = K[1, 1] * (cam[:, 1] / cam[:, 2]) + K[1, 2]

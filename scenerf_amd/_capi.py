@@ -146,6 +146,7 @@ def load() -> C.CDLL:
 
 FUSED_MIN_ROWS_DEFAULT = 4096    # SCENERF_FUSED_MIN_ROWS_DEFAULT
 FLAG_NO_FUSED_BWD, FLAG_NO_WGRAD_TR, FLAG_DFEAT_PER_SCALE, FLAG_WGRAD_OVERLAP, FLAG_WIDE_BWD, FLAG_WIDE_ANY_M, FLAG_DFEAT_GEMM = 1, 2, 4, 8, 16, 32, 64   # SCENERF_FLAG_*
+FLAG_UNIFORM_ONLY = 128
 
 
 def check(code: int, what: str) -> None:

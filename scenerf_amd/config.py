@@ -36,6 +36,9 @@ class RenderConfig:
     std: float = 2.5
     som_sigma: float = 2.0
     gauss_floor: float = 1.5     # scenerf.py:591-594; 0.5 in scenerf_bf.py:606-608
+    # uniform samples drawn when n_pts_uni == 0: the BundleFusion model substitutes 2 (scenerf_bf.py:623-626); the KITTI model has no
+    # substitute and divides by zero there (utils.py:77)
+    uni_fallback: int = 0
     kl_std_floor: float = 1.5    # ray_som_kl.py:83
     precision: str = "bf16"      # "bf16": bf16 GEMM operands / fp32 accumulate; "fp32": fp32 MFMA everywhere
     device_rng: bool = False     # False: gaussian noise drawn on CPU like the reference (utils.py:208-211)
@@ -63,7 +66,25 @@ class RenderConfig:
 
     # ---- derived -----------------------------------------------------------------------------------------
     @property
+    def uniform_only(self) -> bool:
+        """scenerf.py:647-650 / scenerf_bf.py:662-665: with n_pts_uni == 0 and n_pts_per_gaussian == 1 the reference renders the
+        uniform samples alone (the gaussian head still runs: its means / stds feed the KL term)."""
+        return self.n_pts_uni == 0 and self.n_pts_per_gaussian == 1
+
+    @property
+    def n_uni_drawn(self) -> int:
+        """Uniform samples the reference draws per ray: n_pts_uni, or the variant's substitute when that is 0."""
+        return self.n_pts_uni if self.n_pts_uni > 0 else self.uni_fallback
+
+    @property
+    def n_uni_used(self) -> int:
+        """Uniform samples that reach the renderer (0 in the gaussian-only branch, where the substitute draw is discarded)."""
+        return self.n_pts_uni if self.n_pts_uni > 0 else (self.uni_fallback if self.uniform_only else 0)
+
+    @property
     def n_samples(self) -> int:
+        if self.uniform_only:
+            return self.n_uni_drawn
         u = self.n_pts_uni if self.n_pts_uni > 0 else 0
         return u + self.n_gaussians * self.n_pts_per_gaussian
 
@@ -90,14 +111,11 @@ class RenderConfig:
             raise ValueError("n_gaussians must be in [1, 8]")
         if self.n_pts_per_gaussian < 1 or self.n_pts_uni < 0:
             raise ValueError("bad sample counts")
-        if self.n_pts_uni == 0 and self.n_pts_per_gaussian == 1:
-            # scenerf.py:647-650 / scenerf_bf.py:662-665: with n_pts_uni == 0 and n_pts_per_gaussian == 1 the reference renders the
-            # *uniform* sample set instead of the gaussian one.  In the KITTI model that set is empty and the call dies earlier with
-            # ZeroDivisionError (utils.py:77, step = (d_max - d_min) / 0 -- for ANY n_pts_per_gaussian); the BundleFusion model
-            # substitutes 2 uniform samples (scenerf_bf.py:623-626) and composites those two.  Neither is a configuration the
-            # renderer kernels implement (they merge uniform + gaussian samples); refuse it instead of computing something else.
-            raise NotImplementedError("n_pts_uni == 0 with n_pts_per_gaussian == 1 selects the reference's uniform-only branch "
-                                      "(scenerf.py:647-650), which this renderer does not implement")
+        if self.uniform_only and self.n_uni_drawn == 0:
+            # the KITTI model: sample_rays_viewdir(n_pts_per_ray=0) divides by zero (utils.py:77, step = (d_max - d_min) / 0) before the
+            # uniform-only branch is reached -- the same exception here
+            raise ZeroDivisionError("n_pts_uni == 0 with n_pts_per_gaussian == 1 renders the uniform samples alone (scenerf.py:647-650) "
+                                    "and this model draws none: float division by zero (utils.py:77)")
         if self.n_samples > 512:
             raise ValueError("n_samples = %d exceeds the 512-sample limit of the wave-per-ray kernels" % self.n_samples)
         _ = self.precision_code
@@ -114,13 +132,13 @@ class RenderConfig:
     def to_c(self) -> "_capi.Cfg":
         self.validate()
         c = _capi.Cfg()
-        c.n_pts_uni = self.n_pts_uni
+        c.n_pts_uni = self.n_uni_used
         c.n_gaussians = self.n_gaussians
         c.n_pts_per_gaussian = self.n_pts_per_gaussian
         c.n_samples = self.n_samples
         c.sphere_W, c.sphere_H = self.sphere_W, self.sphere_H
         c.max_sample_depth = self.max_sample_depth
-        c.uni_step = (self.max_sample_depth - 0.2) / self.n_pts_uni if self.n_pts_uni > 0 else 0.0
+        c.uni_step = (self.max_sample_depth - 0.2) / self.n_uni_used if self.n_uni_used > 0 else 0.0
         c.base_std = self.std
         c.som_sigma = self.som_sigma
         c.gauss_floor = self.gauss_floor
@@ -136,6 +154,7 @@ class RenderConfig:
         c.fwd_kernel = {"ring": 0, "stream": 1, "wide": 2}[self.fwd_kernel]
         c.flags = ((0 if self.fused_backward else _capi.FLAG_NO_FUSED_BWD) | (0 if self.wgrad_tr else _capi.FLAG_NO_WGRAD_TR)
                    | (_capi.FLAG_DFEAT_PER_SCALE if self.dfeat_per_scale else 0) | (_capi.FLAG_WGRAD_OVERLAP if self.wgrad_overlap else 0)
+                   | (_capi.FLAG_UNIFORM_ONLY if self.uniform_only else 0)
                    | (_capi.FLAG_WIDE_BWD if self.bwd_kernel == "wide" else 0) | (_capi.FLAG_WIDE_ANY_M if self.wide_any_m else 0) | (_capi.FLAG_DFEAT_GEMM if self.dfeat_gemm else 0))
         return c
 
@@ -148,6 +167,6 @@ class RenderConfig:
     @staticmethod
     def bundlefusion(**kw) -> "RenderConfig":
         d = dict(img_size=(640, 480), sphere_W=960, sphere_H=720, add_fov_hor=14.0, add_fov_ver=11.0,
-                 max_sample_depth=12.0, std=0.1, som_sigma=0.02, gauss_floor=0.5, **BF_FOV)
+                 max_sample_depth=12.0, std=0.1, som_sigma=0.02, gauss_floor=0.5, uni_fallback=2, **BF_FOV)
         d.update(kw)
         return RenderConfig(**d)

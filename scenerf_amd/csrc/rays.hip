@@ -913,7 +913,11 @@ static int check_cfg(const scenerf_cfg* cfg) {
               cfg->n_gaussians, SCENERF_MAX_GAUSSIANS);
     SRF_CHECK(cfg->n_pts_uni >= 0 && cfg->n_pts_per_gaussian >= 1, "bad sample counts");
     int n = (cfg->n_pts_uni > 0 ? cfg->n_pts_uni : 0) + cfg->n_gaussians * cfg->n_pts_per_gaussian;
-    SRF_CHECK(cfg->n_samples == n, "n_samples %d != U + G*P = %d", cfg->n_samples, n);
+    if (cfg->flags & SCENERF_FLAG_UNIFORM_ONLY) {   // scenerf.py:647-650: only the uniform samples are rendered
+        SRF_CHECK(cfg->n_pts_uni > 0 && cfg->n_pts_per_gaussian == 1, "uniform-only: needs n_pts_uni > 0 and n_pts_per_gaussian == 1");
+        n = cfg->n_pts_uni;
+    }
+    SRF_CHECK(cfg->n_samples == n, "n_samples %d != %d (U + G*P, or U in the uniform-only branch)", cfg->n_samples, n);
     SRF_CHECK(n <= SCENERF_MAX_SAMPLES, "n_samples %d > %d", n, SCENERF_MAX_SAMPLES);
     int csum = 0;
     for (int s = 0; s < 5; ++s) {

@@ -8,11 +8,10 @@
 // One thread per voxel, z fastest: a wavefront touches 64 consecutive floats of each of the three volumes (coalesced); voxels that
 // fall outside the frustum, on invalid depth or beyond the truncation band return before touching the volumes, as in the
 // reference.  HBM-bound: 24 B per updated voxel (3 volumes read + written) plus two cached image gathers.
-// Floating-point contraction: the library is built with -ffp-contract=off; the "gpu" rule's code sits under `#pragma clang fp
-// contract(fast)` because that is how the reference kernel is compiled (pycuda's SourceModule = nvcc defaults, --fmad=true; hipcc's
-// default contracts the same a*b+c patterns): the golden volumes of tests/golden/tsdf_gpu_semantics.npz come from the reference's
-// kernel text compiled for gfx950 with compiler defaults (oracle/build_ref.py) and this kernel reproduces them bit for bit
-// (tests/test_tsdf.py).  The "cpu" rule follows numpy (no contraction).
+// Floating point: the whole library is built with -ffp-contract=off, so every operation below is rounded on its own -- the only
+// compiler-independent reading of the reference kernel's source.  The golden volumes of tests/golden/tsdf_gpu_semantics.npz come from
+// the reference's kernel text compiled for gfx950 the same way (oracle/build_ref.py) and the "gpu" rule reproduces them bit for bit
+// (tests/test_tsdf.py); the same text under the compiler's default contraction differs in the last bit of ~1 % of the distances.
 // Differences from the reference kernel, both deliberate: voxel coordinates come from exact integer division (the reference
 // derives them from float(voxel_idx), which is inexact beyond 2^24 voxels), and the bound check is >= (the reference lets
 // voxel_idx == n through, one element past the volumes).
@@ -36,7 +35,6 @@ template <int SEM>
 __device__ static inline bool tsdf_observe(const TsdfArgs& a, int vx, int vy, int vz, float& dist, double& diff1, float& c_new) {
     int ix, iy;
     if (SEM == 0) {
-#pragma clang fp contract(fast)
         // voxel -> world (fusion.py:95-99)
         const float px = a.ox + (float)vx * a.voxel_size, py = a.oy + (float)vy * a.voxel_size, pz = a.oz + (float)vz * a.voxel_size;
         // world -> camera: R^T (p - t)   (fusion.py:100-106)
@@ -79,7 +77,6 @@ __device__ static inline void tsdf_update(const TsdfArgs& a, float dist, double 
     const float w_old = w, w_new = w_old + a.obs_weight;
     w = w_new;                                                                  // fusion.py:126-127 / 193-194, 279
     if (SEM == 0) {
-#pragma clang fp contract(fast)
         t = (t * w_old + a.obs_weight * dist) / w_new;                          // fusion.py:128-129
         // colour: running average per channel of the folded b*65536 + g*256 + r value (fusion.py:131-141)
         const float ob = floorf(c / 65536.f), og = floorf((c - ob * 65536.f) / 256.f), orr = c - ob * 65536.f - og * 256.f;

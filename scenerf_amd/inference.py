@@ -48,7 +48,7 @@ class ImageRenderer:
         # strong references: the identity of these objects is part of what ``matches`` compares
         self._x_rgb = {k: x_rgb[k] for k in ("1_1", "1_2", "1_4", "1_8", "1_16")}
         self._params = list(model.mlp.ordered_params()) + list(model.mlp_gaussian.ordered_params())
-        U, GP = self.cfg.n_pts_uni, self.cfg.n_gaussians * self.cfg.n_pts_per_gaussian
+        U, GP = self.cfg.n_uni_used, self.cfg.n_gaussians * self.cfg.n_pts_per_gaussian
         with torch.no_grad(), _on(dev):
             self.session = RenderSession(self.cfg, {k: v.detach() for k, v in x_rgb.items()}, [p.detach() for p in model.mlp.ordered_params()],
                                          [p.detach() for p in model.mlp_gaussian.ordered_params()], debug_aux=bool(getattr(model, "debug_aux", False)))
@@ -142,8 +142,9 @@ class ImageRenderer:
                 else:
                     # the reference's draws, same generators, shapes and order as the chunk loop (scenerf.py:437-455): rand on the device
                     # for the m rays of this chunk (utils.py:84), then the normal noise (utils.py:208-211)
+                    nu = self.session._draw_noise_u(m, dev)
                     if self.noise_u.numel():
-                        self.noise_u[:m].copy_(torch.rand((m,) + tuple(self.noise_u.shape[1:]), dtype=torch.float32, device=dev))
+                        self.noise_u[:m].copy_(nu)
                     if self.cfg.device_rng:
                         self.noise_g[:m].copy_(torch.randn((m, self.noise_g.shape[1]), dtype=torch.float32, device=dev))
                     else:

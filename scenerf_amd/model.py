@@ -191,6 +191,7 @@ class SceneRF(TrainingMixin, _Base):
             add_fov_ver=add_fov_ver, n_pts_uni=n_pts_uni, n_gaussians=n_gaussians,
             n_pts_per_gaussian=n_pts_per_gaussian, max_sample_depth=float(max_sample_depth), std=float(std),
             som_sigma=float(som_sigma), gauss_floor=1.5 if self._VARIANT == "kitti" else 0.5,
+            uni_fallback=0 if self._VARIANT == "kitti" else 2,
             precision=precision, device_rng=device_rng, **fov)
         self.render_cfg.validate()
         # optional data-parallel hook (scenerf_amd.dist.allreduce_mean_): called on each MLP's packed gradient buffer, once per

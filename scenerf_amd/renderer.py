@@ -532,7 +532,7 @@ class RenderChunk(torch.autograd.Function):
         st = _stream(dev)
         ccfg = cfg.to_c()
         R = pixels.shape[0]
-        U, G, P, N = cfg.n_pts_uni, cfg.n_gaussians, cfg.n_pts_per_gaussian, cfg.n_samples
+        U, G, P, N = cfg.n_uni_used, cfg.n_gaussians, cfg.n_pts_per_gaussian, cfg.n_samples
         f32 = dict(dtype=torch.float32, device=dev)
         pixels, K, iK, T = _f32c(pixels), _f32c(cam_K), _f32c(inv_K), _f32c(T_s2i)
         noise_u = _f32c(noise_u).reshape(R, max(U, 0)) if U > 0 else None
@@ -740,17 +740,23 @@ class RenderSession:
 
     def draw_noise(self, R: int, device):
         """The reference's in-path RNG calls, same generators and order (SURVEY §5 RNG row): (uniform noise, gaussian noise)."""
+        return self._draw_noise_u(R, device), draw_noise_g(self.cfg, R, device)
+
+    def _draw_noise_u(self, R: int, device):
+        """utils.py:84 (torch.rand_like on the device) for the uniform samples the reference draws: n_pts_uni of them, or the variant's
+        substitute when that is 0 (scenerf_bf.py:623-626) -- drawn even where they are not rendered (gaussian-only branch), so that the
+        device generator advances exactly as in the reference."""
         cfg = self.cfg
-        U = cfg.n_pts_uni
-        nu = torch.rand((R, U, 1), dtype=torch.float32, device=device) if U > 0 else torch.empty((R, 0, 1), device=device)
-        return nu, draw_noise_g(cfg, R, device)
+        drawn = cfg.n_uni_drawn
+        nu = torch.rand((R, drawn, 1), dtype=torch.float32, device=device) if drawn > 0 else None
+        if cfg.n_uni_used == 0 or nu is None:
+            return torch.empty((R, 0, 1), device=device)
+        return nu
 
     def render_chunk(self, pixels, cam_K, inv_K, T_s2i, noise_u=None, noise_g=None) -> Dict[str, torch.Tensor]:
         _require_cuda(pixels, "sampled_pixels")
         if noise_u is None:   # (the gaussian noise, if not injected, is drawn inside the chunk: RenderChunk._forward)
-            U = self.cfg.n_pts_uni
-            noise_u = (torch.rand((pixels.shape[0], U, 1), dtype=torch.float32, device=pixels.device) if U > 0
-                       else torch.empty((pixels.shape[0], 0, 1), device=pixels.device))
+            noise_u = self._draw_noise_u(pixels.shape[0], pixels.device)
         outs = RenderChunk.apply(self.cfg, self.maps, self.mlp, self.mlpg, pixels, cam_K, inv_K, T_s2i, noise_u, noise_g,
                                  self.tok_maps, self.tok_mlp, self.tok_mlpg)
         ret = dict(zip(OUTPUT_KEYS + ["som_means"], outs))

@@ -100,6 +100,11 @@ CASES = {
     "bf_full_n96_r48": dict(variant="bf", ctor=dict(som_sigma=0.02, std=0.1, add_fov_hor=14, add_fov_ver=11, sphere_W=960,
                             sphere_H=720, n_pts_uni=64, n_pts_per_gaussian=8, max_sample_depth=12), R=48, chunk=48,
                             pose=(0.3, 8.0), seed=707, smooth=False),
+    # the uniform-only branch (scenerf_bf.py:662-665: n_pts_uni == 0 and n_pts_per_gaussian == 1): the BundleFusion model draws 2 uniform
+    # samples per ray (:623-626) and renders those alone; the gaussian head still feeds the KL term
+    "bf_uniform_only": dict(variant="bf", ctor=dict(som_sigma=0.02, std=0.1, add_fov_hor=14, add_fov_ver=11, sphere_W=240, sphere_H=180,
+                            n_pts_uni=0, n_pts_per_gaussian=1, max_sample_depth=12), R=32, chunk=20, pose=(0.4, 10.0), seed=808,
+                            smooth=True),
     # BASELINE.json configs[0] ("4k rays x 64 samples, 4-layer 128-wide MLP, CPU forward only"): both MLPs replaced by
     # ResnetFC(d_in=42, n_blocks=1, d_hidden=128) = lin_in + (lin_z.0, fc_0, fc_1) + lin_out.  Forward only; the (R, N)
     # outputs are stored as digests to keep the fixture small.
@@ -145,6 +150,8 @@ def run_case(name, spec):
     R = spec["R"]
     pix = synth.stride2_pixels(tuple(model.img_size), R, seed + 4)
     U, G, P = model.n_pts_uni, model.n_gaussians, model.n_pts_per_gaussian
+    if U == 0 and spec["variant"] == "bf":
+        U = 2    # scenerf_bf.py:623-626
     noise_u, noise_g = synth.sampling_noise(R, U, G * P, seed + 5)
     T = synth.rel_pose(*spec["pose"])
     with InjectNoise(noise_u, noise_g):

@@ -1,6 +1,7 @@
 """Golden volumes for the TSDF "gpu" update rule from the REFERENCE's own kernel: the pycuda SourceModule string of
 scenerf/data/utils/fusion.py:72-145, extracted from the mounted reference and compiled verbatim with hipcc for gfx950 by
-oracle/build_ref.py (build container), then run HERE on an MI355X:
+oracle/build_ref.py (build container) -- once with every operation rounded on its own (-ffp-contract=off: THE PIN, keys ``*_v08`` /
+``*_v07``) and once under the compiler's default contraction (keys ``*_contract``, a statistic) -- then run HERE on an MI355X:
 
     python oracle/build_ref.py                                      # build container (needs /root/reference)
     gpurun -- python tests/golden/make_golden_tsdf_gpu.py            # GPU box: writes gpurun_out/tsdf_gpu_semantics.npz
@@ -51,15 +52,17 @@ def run_reference_kernel(sc, lib):
 
 if __name__ == "__main__":
     import tsdf_scene
-    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libtsdf_ref.so"))
-    lib.tsdf_ref_last_error.restype = C.c_char_p
     out = {}
-    for tag, vs in (("v08", 0.08), ("v07", 0.07)):
-        sc = tsdf_scene.make(seed=7)
-        sc["voxel_size"] = vs
-        t, w, c = run_reference_kernel(sc, lib)
-        out.update({"tsdf_" + tag: t, "weight_" + tag: w, "color_" + tag: c})
-        print("%s: dims %s, %d voxels observed, %d at 255" % (tag, t.shape, int((w > 0).sum()), int((t == 255).sum())))
+    # the pin (every operation rounded on its own) and the same text under the compiler's default contraction (oracle/build_ref.py)
+    for suffix, name in (("", "libtsdf_ref.so"), ("_contract", "libtsdf_ref_contract.so")):
+        lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", name))
+        lib.tsdf_ref_last_error.restype = C.c_char_p
+        for tag, vs in (("v08", 0.08), ("v07", 0.07)):
+            sc = tsdf_scene.make(seed=7)
+            sc["voxel_size"] = vs
+            t, w, c = run_reference_kernel(sc, lib)
+            out.update({"tsdf_" + tag + suffix: t, "weight_" + tag + suffix: w, "color_" + tag + suffix: c})
+            print("%s%s: dims %s, %d voxels observed, %d at 255" % (tag, suffix, t.shape, int((w > 0).sum()), int((t == 255).sum())))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     dst = os.path.join(ROOT, "gpurun_out", "tsdf_gpu_semantics.npz")
     np.savez_compressed(dst, seed=7, **out)

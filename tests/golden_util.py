@@ -9,7 +9,8 @@ from scenerf_amd import synth
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["kitti_small_n64", "kitti_full_n64", "kitti_small_n128_chunks", "bf_small_n96",
-         "kitti_full_n128_r64", "bf_full_n96_r48"]   # the last two: >= 4096 rows per chunk (fused kernels in bf16 mode)
+         "kitti_full_n128_r64", "bf_full_n96_r48",   # these two: >= 4096 rows per chunk (fused kernels in bf16 mode)
+         "bf_uniform_only"]                          # scenerf_bf.py:662-665: 2 uniform samples per ray, rendered alone
 OUT_KEYS = ["depth", "color", "gaussian_means", "gaussian_stds", "weights_at_depth", "closest_pts_to_depths",
             "loss_kl", "alphas", "som_vars", "densities", "weights", "depth_volumes"]
 

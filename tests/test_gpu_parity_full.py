@@ -80,9 +80,17 @@ HEAD_GATE = {"fp32": 2e-5, "bf16": 1.5e-2}                     # relative L2 of 
 # loss_kl (docstring: BMU ties): error of the mean over the chunk's rays (one flipped ray of 32 moves it by percents) and the fraction
 # of rays within 2e-4 (fp32) / 2e-2 (bf16).  Measured: fp32 1.5e-3 / 0.981 (R = 1200); bf16 1.8e-3 / 0.964 (R = 1200), 5.4e-2 / 0.9375 (R = 32)
 # with RaySOM's discrete choices matched (step 2) loss_kl is gated per ray, every ray: |got - ref| <= tol (1 + |ref|)
-KL_GATE = {"fp32": dict(tol=2e-4, mean_rel=2e-5), "bf16": dict(tol=2e-2, mean_rel=5e-3)}
+# measured (profiles/r03_b_parity_full_*.json): fp32 max rel 1.3e-5, mean rel 2.6e-7; bf16 max rel 9.7e-5, mean rel 2.0e-5
+KL_GATE = {"fp32": dict(tol=5e-5, mean_rel=2e-6), "bf16": dict(tol=5e-4, mean_rel=1e-4)}
 # a differing BMU / mask entry must sit on a tie: relative argmax margin / distance from the 0.1 threshold below this
-SOM_TIE = {"fp32": dict(bmu=1e-4, mask=1e-3, max_frac_bmu=2e-2, max_frac_mask=1e-2), "bf16": dict(bmu=5e-2, mask=5e-2, max_frac_bmu=5e-2, max_frac_mask=3e-2)}
+# measured: the BMU differs on 0-93 of 153,600 samples, every one at a relative argmax margin <= 1.2e-7 (one fp32 ulp: exact ties at the
+# additive floors), in both precisions; the mask never differs
+SOM_TIE = {"fp32": dict(bmu=1e-6, mask=1e-4, max_frac_bmu=2e-3, max_frac_mask=1e-3), "bf16": dict(bmu=1e-6, mask=1e-3, max_frac_bmu=4e-3, max_frac_mask=2e-3)}
+# free-running fp32 (step 3), rays without a differing discrete choice: SURVEY 8d for depth / colour; the head's own outputs carry its fp32
+# MFMA rounding (offsets rel L2 <= 2e-5 of up to 100 m) and loss_kl amplifies it -- measured max rel: means 2.7e-6, stds 3.7e-5,
+# depth_volumes 1.1e-5, loss_kl 5.9e-4
+FREE_FP32_GATE = dict(depth=1e-4, color=1e-5, alphas=1e-4, weights=2e-5, densities=1e-4, gaussian_means=1e-5, gaussian_stds=1e-4,
+                      depth_volumes=5e-5, loss_kl=2e-3)
 FREE_FP32_MAX_TOUCHED_RAYS = 0.10                              # rays with any differing discrete choice (index, order, BMU, mask) vs the free oracle
 FREE_BF16_GATE = dict(depth_rel_median=1e-3, depth_rel_p99=5e-3, color_abs_p99=2e-3, gaussian_means_rel_max=3e-3)   # measured 3.0e-4 / 2.3e-3 / 6.6e-4 / 1.5e-3
 MAX_FLIPPED_SAMPLE_FRACTION = 5e-4                             # samples whose sphere index differs from the oracle's (measured 1.2e-4)
@@ -370,7 +378,7 @@ def _run_case(name, precision, entry):
         fr = rep["free_fp32"] = dict(rays_with_a_differing_index_or_order=int(touched.sum()), rays_with_any_differing_choice=int(touched_kl.sum()), rays=R, out={})
         if int(touched_kl.sum()) > FREE_FP32_MAX_TOUCHED_RAYS * R:
             fails.append("[free fp32] %d of %d rays have a differing discrete choice" % (int(touched_kl.sum()), R))
-        for k, tol in list(OUT_GATE["fp32"].items()) + [("loss_kl", klg["tol"])]:
+        for k, tol in FREE_FP32_GATE.items():
             keep = ~(touched_kl if k == "loss_kl" else touched)
             got, ref = out[k].detach().float().cpu()[keep], free["out"][k][keep]
             ok = _within(got, ref, tol, k in ABS_KEYS)

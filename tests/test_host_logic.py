@@ -183,14 +183,24 @@ def test_spherical_mapping_from_pixels_matches_reference_formula_and_caches_the_
     assert torch.equal(sph[:, 1], py)
 
 
-def test_uniform_only_branch_is_refused_explicitly():
-    """scenerf.py:647-650: n_pts_uni == 0 and n_pts_per_gaussian == 1 would render the (empty / 2-point) uniform set; the
-    renderer refuses that configuration by name instead of silently rendering the gaussian samples."""
+def test_uniform_only_branch_configuration():
+    """scenerf.py:647-650 / scenerf_bf.py:662-665: n_pts_uni == 0 and n_pts_per_gaussian == 1 renders the uniform samples alone.  The
+    BundleFusion model substitutes 2 uniform samples (scenerf_bf.py:623-626): N = 2, the C config carries the uniform-only flag.  The
+    KITTI model has no substitute: the reference divides by zero in uniform_sampling (utils.py:77) -- same exception type here."""
     import pytest
+    from scenerf_amd import _capi
     from scenerf_amd.config import RenderConfig
-    with pytest.raises(NotImplementedError, match="uniform-only branch"):
+    with pytest.raises(ZeroDivisionError, match="division by zero"):
         RenderConfig.kitti(n_pts_uni=0, n_pts_per_gaussian=1).validate()
     RenderConfig.kitti(n_pts_uni=0, n_pts_per_gaussian=2).validate()      # gaussians only: the `else` branch (scenerf.py:651-654)
+    bf = RenderConfig.bundlefusion(n_pts_uni=0, n_pts_per_gaussian=1)
+    assert bf.uniform_only and bf.n_samples == 2 and bf.n_uni_used == 2 and bf.n_uni_drawn == 2
+    c = bf.to_c()
+    assert c.n_samples == 2 and c.n_pts_uni == 2 and c.n_pts_per_gaussian == 1 and (c.flags & _capi.FLAG_UNIFORM_ONLY)
+    assert abs(c.uni_step - (12.0 - 0.2) / 2) < 1e-6
+    go = RenderConfig.bundlefusion(n_pts_uni=0, n_pts_per_gaussian=8)      # gaussian-only: the 2 substitutes are drawn and discarded
+    assert not go.uniform_only and go.n_samples == 32 and go.n_uni_used == 0 and go.n_uni_drawn == 2
+    assert not (go.to_c().flags & _capi.FLAG_UNIFORM_ONLY) and go.to_c().n_pts_uni == 0
 
 
 def test_pixel_grid_follows_the_reference_scripts():
