@@ -155,6 +155,8 @@ typedef struct scenerf_mlp_acts {
     uint8_t* sign_bits;             /* bf16 mode, may be NULL: [7][Mpad][64] -- bit n of row m = (saved activation [m][n] > 0) for
                                      * H0, N0, H1, N1, H2, N2, H3; written by the fused forward kernel, gates the fused backward
                                      * chain (Mpad = M rounded up to SCENERF_TILE_ROWS).  NULL disables the fused backward. */
+    int32_t x3_ready;               /* bf16 mode: h0pre already holds the split encoding (scenerf_hip_encode_points wrote it): the forward
+                                     * then neither reads xenc nor launches the split */
 } scenerf_mlp_acts;
 
 int scenerf_hip_abi_version(void);
@@ -189,7 +191,10 @@ int scenerf_hip_encode_points(const scenerf_cfg* cfg, const float* dist, int dis
                               const float* unit_dir, const float* viewdir, const float* K /*[9]*/,
                               const float* inv_K /*[9]*/, const float* T_s2i /*[16]*/, int M,
                               float* pts /*[M][3] or NULL*/, int32_t* sphere_idx /*[M][2]*/,
-                              float* xenc /*[M][48]*/, scenerf_stream_t stream);
+                              float* xenc /*[M][48]; may be NULL when x3 is given*/,
+                              void* x3 /*bf16 [M][144] or NULL: the split encoding [hi | lo | hi] of scenerf_mlp_acts.h0pre, written directly
+                                         (set scenerf_mlp_acts.x3_ready)*/,
+                              scenerf_stream_t stream);
 
 /* utils.py:232-247 x5 (scenerf.py:522-527): bilinear 2x2 gather of the 5 maps at idx/div*2-1 with zeros
  * padding.  Writes Z rows only for (128-row tile, scale) pairs that have at least one in-range tap and

@@ -73,7 +73,7 @@ class MlpGrads(C.Structure):
 
 
 class MlpActs(C.Structure):
-    _fields_ = [("H", vp * 4), ("Nn", vp * 3), ("h0pre", vp), ("logits", vp), ("sign_bits", vp)]
+    _fields_ = [("H", vp * 4), ("Nn", vp * 3), ("h0pre", vp), ("logits", vp), ("sign_bits", vp), ("x3_ready", C.c_int32)]
 
 
 class ProfRec(C.Structure):
@@ -89,7 +89,7 @@ _PROTOS = {
     "scenerf_hip_maps_chw_to_hwc": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "scenerf_hip_grads_hwc_to_chw": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "scenerf_hip_ray_setup": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
-    "scenerf_hip_encode_points": (C.c_int, [C.POINTER(Cfg), vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "scenerf_hip_encode_points": (C.c_int, [C.POINTER(Cfg), vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "scenerf_hip_gather_features": (C.c_int, [C.POINTER(Cfg), C.POINTER(vp * N_SCALES), vp, i32, vp, vp, vp, vp, vp]),
     "scenerf_hip_mlp_pack": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpParams), C.POINTER(MlpWeights), vp]),
     "scenerf_hip_mlp_forward": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpWeights), vp, vp, vp, i32, C.POINTER(MlpActs), vp]),

@@ -9,8 +9,10 @@
 //     the scales that tile touches: the accumulators of up to 8 column tiles (256 channels) live in registers, dH streams through once.
 //     Tiles that touch only the finest level (80 channels: 3 column tiles) run in a 3-tile instantiation with a third of the registers
 //     and four workgroups per CU; the host launches both, each workgroup leaves at once if the tile is the other kernel's;
-//   * the K loop stages dH and the weight rows through LDS by DMA (global_load_lds), 128 bytes of K per row and step, two stages:
-//     a 1-KiB piece is 8 whole row segments.  (A first version loaded the MFMA fragments straight into registers -- 32 rows x 32 B
+//   * the K loop stages dH and the weight rows through LDS by DMA (global_load_lds), 64 bytes of K per row and step, a ring of NS
+//     stages with ONE barrier per step: NS - 1 steps are in flight while a step is multiplied, NS - 2 while its pieces are waited for (the first version had two
+//     stages of 128 bytes and two barriers per step: one step of lookahead = 28 KB in flight per workgroup, and a tile took 70 us for
+//     393 KB -- the kernel ran at 2.3 TB/s with the CUs waiting for memory latency; r02_f).  A 1-KiB piece is 16 whole row segments.  (A first version loaded the MFMA fragments straight into registers -- 32 rows x 32 B
 //     per wave instruction, i.e. 32 different pages per load, dH rows being 4 KiB apart -- and ran 2.3x SLOWER than the old kernel:
 //     address translation, not bandwidth.)  The 16-byte slots of a row are XOR-swizzled on the source side of the DMA;
 //   * the scatter: a ray's samples walk along an epipolar curve, so the 512 (sample, tap) pairs of a tile hit only ~90 distinct texels.
@@ -37,13 +39,20 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_d;
 #define DF_L_TW (DF_L_TX + 512 * 4)                   //        [128 rows][4 taps] weight
 #define DF_L_MISC (DF_L_TW + 512 * 4)
 #ifndef DF_KSB
-#define DF_KSB 128                                    // bytes of K per row per K-loop step
+#define DF_KSB 64                                     // bytes of K per row per K-loop step
 #endif
+#ifndef DF_NS3
+#define DF_NS3 5                                      // K-loop ring stages of the 3-tile instantiation (71.7 KB: two workgroups per CU)
+#endif
+#ifndef DF_NS5
+#define DF_NS5 4                                      // ... of the DF_NTB-tile one (73.7 KB at 5 tiles)
+#endif
+constexpr int df_ns(int ntp) { return ntp <= 3 ? DF_NS3 : DF_NS5; }
 #ifndef DF_NTB
 #define DF_NTB 5                                       // column tiles per pass of the second instantiation (KITTI's 1/2 level: 160 channels)
 #endif
-// LDS of an instantiation: two K-loop stages of (128 + 32 NTP) rows, or the epilogue tables
-constexpr int df_lds(int ntp) { return 2 * (DF_BM + ntp * 32) * DF_KSB > DF_L_MISC + 32 ? 2 * (DF_BM + ntp * 32) * DF_KSB : DF_L_MISC + 32; }
+// LDS of an instantiation: its K-loop ring of (128 + 32 NTP)-row stages, or the epilogue tables
+constexpr int df_lds(int ntp) { return df_ns(ntp) * (DF_BM + ntp * 32) * DF_KSB > DF_L_MISC + 32 ? df_ns(ntp) * (DF_BM + ntp * 32) * DF_KSB : DF_L_MISC + 32; }
 
 // 16 bytes per lane, global -> LDS: per-lane 64-bit source address, destination = M0 (wave-uniform LDS address) + 16 * lane
 __device__ static inline void df_glds16(const void* src, unsigned lds_wave_base) {
@@ -197,7 +206,9 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
         constexpr int NPW_ = (NWP + 3) / 4;               // ... per wave (the last wave may have fewer)
         constexpr int STG = (DF_BM + NTP * 32) * KSB;
         constexpr int NSTEP = DF_K * 2 / KSB;
-        static_assert(2 * STG <= df_lds(NTP), "stages must fit the workgroup's LDS");
+        constexpr int NS = df_ns(NTP), LA = NS - 1;       // ring stages, steps issued ahead of the one being multiplied
+        static_assert(NS * STG <= df_lds(NTP), "stages must fit the workgroup's LDS");
+        static_assert(NSTEP > LA, "the ring is shorter than the K loop");
         auto swz = [](int r) { return KSB == 128 ? (r >> 1) & 7 : (r >> 2) & 3; };
         static_assert(KSB == 128 || KSB == 64, "swizzle is written for 8 or 4 slots per row");
         f32x16_d acc[NTP];
@@ -209,6 +220,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
         const char* srcA[NPA_];
         const char* srcW[NPW_];
         bool okW[NPW_];
+        int nw = 0;        // weight pieces this wave issues per step (wave-uniform)
         {
             const int rp = lane / SL, ps = lane % SL;
 #pragma unroll
@@ -223,14 +235,15 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
                 int sl, c0;
                 tile_level(t0 + min(t, np - 1), sl, c0);
                 okW[i] = wv * NPW_ + i < NWP && (((wv * NPW_ + i) * RPP) >> 5) < np;   // (wave-uniform; a piece never straddles tiles)
+                nw += okW[i] ? 1 : 0;
                 srcW[i] = (const char*)p.W[sl] + (size_t)min(c0 + (r & 31), p.C[sl] - 1) * (DF_K * 2) + ((ps ^ swz(r)) << 4);
             }
         }
+        nw = __builtin_amdgcn_readfirstlane(nw);
         const unsigned lds0 = (unsigned)(uintptr_t)lds;
-        auto issue = [&](const int step) __attribute__((always_inline)) {
-            const unsigned sb = lds0 + (step & 1) * STG;
+        auto issue = [&](const int step, const int stage) __attribute__((always_inline)) {
+            const unsigned sb = lds0 + stage * STG;
             const unsigned ko = (unsigned)step * KSB;
-            // (weights first: the dH pieces are then the youngest operations of the step)
 #pragma unroll
             for (int i = 0; i < NPW_; ++i)
                 if (okW[i]) df_glds16(srcW[i] + ko, __builtin_amdgcn_readfirstlane(sb + DF_BM * KSB + (wv * NPW_ + i) * 1024));
@@ -238,21 +251,28 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
             for (int i = 0; i < NPA_; ++i)
                 df_glds16(srcA[i] + ko, __builtin_amdgcn_readfirstlane(sb + (wv * NPA_ + i) * 1024));
         };
+        // "step s has landed": when a wave waits for it, steps up to s + LA - 1 have been issued (step s + LA follows the barrier), so at
+        // most the pieces of the LA - 1 younger steps may be outstanding (issued in order, retired in order); the count per step is
+        // NPA_ + nw, nw wave-uniform: one immediate per possible nw
+#define DF_WAIT_K(k) if (nw == (k)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * (NPA_ + (k)) < 63 ? (LA - 1) * (NPA_ + (k)) : 63) : "memory");
+        static_assert(NPW_ <= 6, "one wait immediate per weight-piece count");
         __syncthreads();   // (the previous pass's epilogue is done with the LDS the stages live in)
-        issue(0);
+#pragma unroll
+        for (int q = 0; q < LA; ++q) issue(q, q);
         const int frow = 32 * wv + (lane & 31), fh = lane >> 5;
+        int stage = 0, stage_in = LA;      // stage of the step being multiplied / of the step being issued
 #pragma unroll 1
         for (int step = 0; step < NSTEP; ++step) {
-            if (step + 1 < NSTEP) {
-                issue(step + 1);
-                // this step's pieces landed: at most the next step's dH pieces -- the youngest NPA_ operations -- may be outstanding
-                // (issued in order, retired in order; the next step's weight pieces, fewer on some waves, are waited for too)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPA_) : "memory");
+            if (step + LA < NSTEP) {
+                DF_WAIT_K(0) DF_WAIT_K(1) DF_WAIT_K(2) DF_WAIT_K(3) DF_WAIT_K(4) DF_WAIT_K(5) DF_WAIT_K(6)
             } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last LA steps: nothing younger is issued any more)
             }
+            // one barrier per step: every wave's pieces of this step have landed, and everyone is done multiplying the previous step --
+            // whose stage the pieces issued below overwrite
             __syncthreads();
-            const char* const sa = lds + (step & 1) * STG;
+            if (step + LA < NSTEP) issue(step + LA, stage_in);
+            const char* const sa = lds + stage * STG;
             const char* const sw = sa + DF_BM * KSB;
 #pragma unroll
             for (int j = 0; j < KSB / 32; ++j) {
@@ -266,8 +286,10 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
                     }
                 }
             }
-            __syncthreads();   // everyone is done with this stage before the step after next overwrites it
+            stage = stage + 1 == NS ? 0 : stage + 1;
+            stage_in = stage_in + 1 == NS ? 0 : stage_in + 1;
         }
+#undef DF_WAIT_K
 
         DF_STAMP()   // K loop done
         // ---- epilogue: level by level, up to three column tiles (96 channels) per round

@@ -310,7 +310,7 @@ int scenerf_hip_mlp_feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weig
 
 int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const float* xenc,
                             const uint8_t* tile_mask, int M, const scenerf_mlp_acts* a, scenerf_stream_t stream) {
-    SRF_CHECK(cfg && w && Z && xenc && tile_mask && a && M > 0, "mlp_forward: NULL argument");
+    SRF_CHECK(cfg && w && Z && tile_mask && a && M > 0 && (xenc || (cfg->precision == 1 && a->x3_ready)), "mlp_forward: NULL argument");
     SRF_CHECK(w->d_out == 4 || w->d_out == 2, "mlp_forward: d_out must be 4 or 2");
     const int prec = cfg->precision;
     const bool head = w->d_out == 2;  // profile names: ".../g" = gaussian head (4 points per ray)
@@ -338,7 +338,8 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
         // bf16 mode: H0 = [x_hi | x_lo | x_hi | z] @ [w_hi | w_hi | w_lo | lin_z.0]^T + (lin_in.bias + lin_z.0.bias); the
         // split encoding lives in the (otherwise unused) h0pre scratch and is reused by the lin_in weight gradient
         bf16_t* x3 = (bf16_t*)a->h0pre;
-        {
+        if (!a->x3_ready) {   // (scenerf_hip_encode_points writes the split encoding itself when it is handed the buffer)
+            SRF_CHECK(xenc, "mlp_forward: xenc is NULL and acts->x3_ready is not set");
             SrfLaunchScope ps(s, "split_xenc", 0, (double)M * SCENERF_D_XENC * 10);
             size_t n = (size_t)M * (SCENERF_D_XENC / 8);
             split_xenc_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(xenc, x3, M);
@@ -400,7 +401,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
                              const void* Z, const float* xenc, const uint8_t* tile_mask, const int32_t* tap_texel,
                              const float* tap_weight, int M, const scenerf_mlp_acts* a, const float* d_logits, void* dH,
                              void* dN, float* const gmaps_hwc[SCENERF_N_SCALES], scenerf_stream_t stream) {
-    SRF_CHECK(cfg && w && g_ && Z && xenc && tile_mask && a && d_logits && dH && dN && M > 0, "mlp_backward: NULL argument");
+    SRF_CHECK(cfg && w && g_ && Z && tile_mask && a && d_logits && dH && dN && M > 0 && (xenc || cfg->precision == 1), "mlp_backward: NULL argument");
     SRF_CHECK(!gmaps_hwc || (tap_texel && tap_weight), "mlp_backward: taps missing");
     // the dN scratch ([3][M][512] act) doubles as the lin_out partial-sum buffer before the block loop starts
     {

@@ -50,14 +50,23 @@ struct SphereConsts {
     int W, H;
 };
 
-__global__ void encode_points_kernel(const float* __restrict__ dist, int dist_ray_stride, int ppr,
+// x3 (bf16 mode, may be NULL): the split-bf16 encoding [M][144] = [hi(48) | lo(48) | hi(48)] the first hidden GEMM consumes (mlp.hip:
+// split_xenc_kernel -- same values, bit for bit), written from here so that the fp32 encoding never makes the round trip through HBM.
+// A thread's row is 288 bytes: staged per wave in LDS and written back as 18 fully coalesced 1-KiB stores (the wave's 64 rows are
+// one contiguous 18-KiB range) instead of 64 row-strided pieces per store instruction.
+#define ENC_X3_ROW (3 * SCENERF_D_XENC * 2)          // 288 bytes
+#define ENC_X3_LD (ENC_X3_ROW + 16)                   // LDS row stride (16-byte aligned, off the 32-bank period)
+__global__ __launch_bounds__(256) void encode_points_kernel(const float* __restrict__ dist, int dist_ray_stride, int ppr,
                                      const float* __restrict__ unit_dir, const float* __restrict__ viewdir,
                                      const float* __restrict__ K, const float* __restrict__ iK,
                                      const float* __restrict__ T, SphereConsts sc, int M,
                                      float* __restrict__ pts_out, int32_t* __restrict__ sphere_idx,
-                                     float* __restrict__ xenc) {
-    int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+                                     float* __restrict__ xenc, bf16_t* __restrict__ x3) {
+    __shared__ __attribute__((aligned(16))) char s_x3[4][64 * ENC_X3_LD];
+    const int m_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = m_raw < M;
+    if (!x3 && !live) return;
+    const int m = live ? m_raw : M - 1;   // (rows past M: computed on the last row, never stored)
     int r = m / ppr, j = m - r * ppr;
     float d = dist[(size_t)r * dist_ray_stride + j];
     // source-frame point = dist * unit_dir (utils.py:87 / 217), then T @ [p,1] (utils.py:161-166)
@@ -65,7 +74,7 @@ __global__ void encode_points_kernel(const float* __restrict__ dist, int dist_ra
     float qx = dot4(T[0], T[1], T[2], T[3], px, py, pz, 1.f);
     float qy = dot4(T[4], T[5], T[6], T[7], px, py, pz, 1.f);
     float qz = dot4(T[8], T[9], T[10], T[11], px, py, pz, 1.f);
-    if (pts_out) {
+    if (pts_out && live) {
         pts_out[3 * (size_t)m] = qx;
         pts_out[3 * (size_t)m + 1] = qy;
         pts_out[3 * (size_t)m + 2] = qz;
@@ -93,30 +102,62 @@ __global__ void encode_points_kernel(const float* __restrict__ dist, int dist_ra
     oy = fminf(fmaxf(rintf(oy), -1.0e9f), 1.0e9f);
     if (!(ox == ox)) ox = -1.0e9f;
     if (!(oy == oy)) oy = -1.0e9f;
-    sphere_idx[2 * (size_t)m] = (int32_t)ox;
-    sphere_idx[2 * (size_t)m + 1] = (int32_t)oy;
+    if (live) {
+        sphere_idx[2 * (size_t)m] = (int32_t)ox;
+        sphere_idx[2 * (size_t)m + 1] = (int32_t)oy;
+    }
     // PositionalEncoding pe.py:32-43: [x, sin(f0 x), sin(f0 x + pi/2), ...] then viewdir, zero pad to 48
-    float* o = xenc + (size_t)m * SCENERF_D_XENC;
+    float e[SCENERF_D_XENC];
     float q[3] = {qx, qy, qz};
-    o[0] = qx;
-    o[1] = qy;
-    o[2] = qz;
+    e[0] = qx;
+    e[1] = qy;
+    e[2] = qz;
     float f = PI_F;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float a = q[c] * f;  // addcmul: phase + x*f, product rounded first
-            o[3 + (2 * k) * 3 + c] = sinf(a);
-            o[3 + (2 * k + 1) * 3 + c] = sinf(HALF_PI_F + a);
+            e[3 + (2 * k) * 3 + c] = sinf(a);
+            e[3 + (2 * k + 1) * 3 + c] = sinf(HALF_PI_F + a);
         }
         f *= 2.f;
     }
-    o[39] = viewdir[3 * r];
-    o[40] = viewdir[3 * r + 1];
-    o[41] = viewdir[3 * r + 2];
+    e[39] = viewdir[3 * r];
+    e[40] = viewdir[3 * r + 1];
+    e[41] = viewdir[3 * r + 2];
 #pragma unroll
-    for (int c = 42; c < SCENERF_D_XENC; ++c) o[c] = 0.f;
+    for (int c = 42; c < SCENERF_D_XENC; ++c) e[c] = 0.f;
+    if (xenc && live) {
+        float* o = xenc + (size_t)m * SCENERF_D_XENC;
+#pragma unroll
+        for (int c = 0; c < SCENERF_D_XENC; c += 4) *(float4*)(o + c) = make_float4(e[c], e[c + 1], e[c + 2], e[c + 3]);
+    }
+    if (x3) {
+        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        char* const row = s_x3[wv] + lane * ENC_X3_LD;
+#pragma unroll
+        for (int c = 0; c < SCENERF_D_XENC; c += 2) {
+            // x = hi + lo, hi = bf16(x), lo = bf16(x - hi): mlp.hip split_xenc_kernel
+            const uint32_t hi = pack_bf16x2(e[c], e[c + 1]);
+            const uint32_t lo = pack_bf16x2(e[c] - bf16lo(hi), e[c + 1] - bf16hi(hi));
+            *(uint32_t*)(row + c * 2) = hi;
+            *(uint32_t*)(row + SCENERF_D_XENC * 2 + c * 2) = lo;
+            *(uint32_t*)(row + SCENERF_D_XENC * 4 + c * 2) = hi;
+        }
+        __syncthreads();
+        const int m0 = blockIdx.x * blockDim.x + wv * 64;      // first row of this wave
+        char* const g = (char*)x3 + (size_t)m0 * ENC_X3_ROW;
+        const int nbytes = (min(M - m0, 64)) * ENC_X3_ROW;     // (<= 0 for a wave past M)
+#pragma unroll
+        for (int it = 0; it < ENC_X3_ROW * 64 / 1024; ++it) {
+            const int off = (it * 64 + lane) * 16;
+            if (off < nbytes) {
+                const int rr = off / ENC_X3_ROW, cc = off - rr * ENC_X3_ROW;
+                *(uint4*)(g + off) = *(const uint4*)(s_x3[wv] + rr * ENC_X3_LD + cc);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ gather
@@ -151,7 +192,10 @@ struct MapPtrs {
     const void* p[5];
 };
 
-// one 256-thread block per 128-row tile.  Phase 1: taps + validity per (row, scale); phase 2: blend.
+// one 256-thread block per 128-row tile (gridDim.y == 1), or per (tile, pyramid level) when gridDim.y == 5: small launches -- the
+// gaussian head's 38 tiles on 256 CUs took 42 us, each block walking all the levels its tile touches -- spread their levels over
+// five times as many blocks; every block still derives the tile's full level mask (arithmetic only), block y == 0 publishes it.
+// Phase 1: taps + validity per (row, scale); phase 2: blend.
 template <typename T>
 __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts gc, const int32_t* __restrict__ sphere_idx,
                                                      int M, T* __restrict__ Z, uint8_t* __restrict__ tile_mask,
@@ -164,6 +208,7 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
     __shared__ int s_cnt[5];
     const int tile = blockIdx.x;
     const int tid = threadIdx.x;
+    const int s_lo = gridDim.y == 1 ? 0 : (int)blockIdx.y, s_hi = gridDim.y == 1 ? 5 : (int)blockIdx.y + 1;   // levels of this block
     if (tid == 0) s_mask = 0u;
     if (tid < 5) s_cnt[tid] = 0;
     __syncthreads();
@@ -200,11 +245,13 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
                         }
                     }
                 }
-                size_t o = ((size_t)m * 5 + s) * 4;
+                if (s >= s_lo && s < s_hi) {
+                    size_t o = ((size_t)m * 5 + s) * 4;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    tap_texel[o + t] = tex[t];
-                    tap_weight[o + t] = w[t];
+                    for (int t = 0; t < 4; ++t) {
+                        tap_texel[o + t] = tex[t];
+                        tap_weight[o + t] = w[t];
+                    }
                 }
             }
 #pragma unroll
@@ -220,9 +267,9 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
     }
     __syncthreads();
     const unsigned mask = s_mask;
-    if (tid == 0) tile_mask[tile] = (uint8_t)mask;
+    if (tid == 0 && blockIdx.y == 0) tile_mask[tile] = (uint8_t)mask;
     constexpr int VN = Vec16<T>::N;
-    for (int s = 0; s < 5; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
         if (!(mask & (1u << s))) {
             // a scale this tile does not touch: its columns are normally never read (every consumer skips them by tile_mask) and stay
             // unwritten -- except the first SCENERF_Z_DENSE_COLS columns, which the batched lin_z weight gradient reads for every row
@@ -971,16 +1018,16 @@ int scenerf_hip_ray_setup(const scenerf_cfg* cfg, const float* pixels, const flo
 
 int scenerf_hip_encode_points(const scenerf_cfg* cfg, const float* dist, int dist_ray_stride, int pts_per_ray,
                               const float* unit_dir, const float* viewdir, const float* K, const float* inv_K,
-                              const float* T_s2i, int M, float* pts, int32_t* sphere_idx, float* xenc,
+                              const float* T_s2i, int M, float* pts, int32_t* sphere_idx, float* xenc, void* x3,
                               scenerf_stream_t stream) {
     if (check_cfg(cfg)) return 1;
-    SRF_CHECK(dist && unit_dir && viewdir && K && inv_K && T_s2i && sphere_idx && xenc, "encode_points: NULL argument");
+    SRF_CHECK(dist && unit_dir && viewdir && K && inv_K && T_s2i && sphere_idx && (xenc || x3), "encode_points: NULL argument");
     SRF_CHECK(M > 0 && pts_per_ray > 0 && M % pts_per_ray == 0, "encode_points: M=%d not a multiple of pts_per_ray=%d", M, pts_per_ray);
     hipStream_t s = as_stream(stream);
     SphereConsts sc{cfg->v_min, cfg->v_fov, cfg->h_min, cfg->h_fov, cfg->sphere_W, cfg->sphere_H};
-    SrfLaunchScope ps(s, "encode_points", 0, (double)M * (4 + 8 + 4.0 * SCENERF_D_XENC));
+    SrfLaunchScope ps(s, "encode_points", 0, (double)M * (4 + 8 + (xenc ? 4.0 * SCENERF_D_XENC : 0.0) + (x3 ? 6.0 * SCENERF_D_XENC : 0.0)));
     encode_points_kernel<<<cdiv(M, 256), 256, 0, s>>>(dist, dist_ray_stride, pts_per_ray, unit_dir, viewdir, K, inv_K, T_s2i,
-                                                      sc, M, pts, sphere_idx, xenc);
+                                                      sc, M, pts, sphere_idx, xenc, (bf16_t*)x3);
     SRF_LAUNCH_CHECK("encode_points_kernel");
     return 0;
 }
@@ -999,10 +1046,12 @@ int scenerf_hip_gather_features(const scenerf_cfg* cfg, const void* const maps_h
     GatherConsts gc = make_gc(cfg);
     int tiles = cdiv(M, SCENERF_TILE_ROWS);
     SrfLaunchScope ps(s, "gather_features", 0, 0);
+    // small launches (the gaussian head: R x G points): one block per (tile, level) instead of one per tile
+    const dim3 grid(tiles, tiles < 512 ? SCENERF_N_SCALES : 1);
     if (cfg->precision)
-        gather_kernel<bf16_t><<<tiles, 256, 0, s>>>(mp, gc, sphere_idx, M, (bf16_t*)Z, tile_mask, tap_texel, tap_weight);
+        gather_kernel<bf16_t><<<grid, 256, 0, s>>>(mp, gc, sphere_idx, M, (bf16_t*)Z, tile_mask, tap_texel, tap_weight);
     else
-        gather_kernel<float><<<tiles, 256, 0, s>>>(mp, gc, sphere_idx, M, (float*)Z, tile_mask, tap_texel, tap_weight);
+        gather_kernel<float><<<grid, 256, 0, s>>>(mp, gc, sphere_idx, M, (float*)Z, tile_mask, tap_texel, tap_weight);
     SRF_LAUNCH_CHECK("gather_kernel");
     return 0;
 }

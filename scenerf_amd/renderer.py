@@ -51,6 +51,7 @@ def _on(dev):
 
 
 _SIDE = {}
+DEFER_HEAD_PACK = True     # (tools/ab_step.py toggles this)
 
 
 def _side_stream(dev) -> "torch.cuda.Stream":
@@ -439,7 +440,7 @@ class PackMLP(torch.autograd.Function):
 class _MlpRun:
     """Buffers of one ResnetFC evaluation over M rows (kept for backward when grad is enabled)."""
 
-    def __init__(self, M: int, d_out: int, prec: int, dev, lean: bool = False):
+    def __init__(self, M: int, d_out: int, prec: int, dev, lean: bool = False, x3_direct: bool = False, keep_xenc: bool = False):
         act = _act_dtype(prec)
         # lean = inference (no_grad) on the fused bf16 path (RenderConfig.uses_fused): lin_out runs inside the kernel, so no activation
         # is ever read again: neither they nor the sign bits are allocated or written (NULL in scenerf_mlp_acts)
@@ -448,7 +449,12 @@ class _MlpRun:
         self.M = M
         self.Mpad = (M + _capi.TILE_ROWS - 1) // _capi.TILE_ROWS * _capi.TILE_ROWS
         self.sphere_idx = torch.empty((M, 2), dtype=torch.int32, device=dev)
-        self.xenc = torch.empty((M, D_X), dtype=torch.float32, device=dev)
+        # the fp32 encoding [M][48].  x3_direct (bf16 mode): encode_points writes the split-bf16 form straight into h0pre, the forward
+        # neither reads this buffer nor launches the split -- it then exists only if asked for (keep_xenc: stage tests)
+        if x3_direct and prec != 1:
+            raise ValueError("the split encoding exists in bf16 mode only")
+        self.x3_direct = x3_direct
+        self.xenc = torch.empty((M, D_X), dtype=torch.float32, device=dev) if (not x3_direct or keep_xenc) else None
         self.Z = torch.empty((self.Mpad, D_L), dtype=act, device=dev)
         self.tile_mask = torch.empty((self.Mpad // _capi.TILE_ROWS,), dtype=torch.uint8, device=dev)
         self.tap_texel = torch.empty((M, 5, 4), dtype=torch.int32, device=dev)
@@ -468,6 +474,7 @@ class _MlpRun:
         # sign bits of the seven saved activations (fused forward -> fused backward chain, scenerf_hip.h)
         self.sign_bits = torch.empty((7, self.Mpad, 64), dtype=torch.uint8, device=dev) if (prec and not lean) else None
         a.sign_bits = self.sign_bits.data_ptr() if self.sign_bits is not None else None
+        a.x3_ready = 1 if x3_direct else 0
         self.c = a
 
 
@@ -475,15 +482,17 @@ def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dis
               K, inv_K, T, M, keep_acts: bool = True) -> _MlpRun:
     lib = _capi.load()
     st = _stream(dist.device)
-    pk.wait_ready()
-    run = _MlpRun(M, pk.d_out, cfg.precision_code, dist.device, lean=(not keep_acts) and cfg.uses_fused(M))
+    run = _MlpRun(M, pk.d_out, cfg.precision_code, dist.device, lean=(not keep_acts) and cfg.uses_fused(M),
+                  x3_direct=cfg.precision_code == 1, keep_xenc=maps.debug_aux is not None)
     _capi.check(lib.scenerf_hip_encode_points(C.byref(ccfg), dist.data_ptr(), dist_ray_stride, ppr, unit_dir.data_ptr(),
                                               viewdir.data_ptr(), K.data_ptr(), inv_K.data_ptr(), T.data_ptr(), M, None,
-                                              run.sphere_idx.data_ptr(), run.xenc.data_ptr(), st), "encode_points")
+                                              run.sphere_idx.data_ptr(), _capi.ptr(run.xenc),
+                                              run.h0pre.data_ptr() if run.x3_direct else None, st), "encode_points")
     _capi.check(lib.scenerf_hip_gather_features(C.byref(ccfg), C.byref(maps.map_ptr_array()), run.sphere_idx.data_ptr(), M,
                                                 run.Z.data_ptr(), run.tile_mask.data_ptr(), run.tap_texel.data_ptr(),
                                                 run.tap_weight.data_ptr(), st), "gather_features")
-    _capi.check(lib.scenerf_hip_mlp_forward(C.byref(ccfg), C.byref(pk.c), run.Z.data_ptr(), run.xenc.data_ptr(),
+    pk.wait_ready()   # (the operands may have been packed on the side stream: first needed here, behind the encode and the gather)
+    _capi.check(lib.scenerf_hip_mlp_forward(C.byref(ccfg), C.byref(pk.c), run.Z.data_ptr(), _capi.ptr(run.xenc),
                                             run.tile_mask.data_ptr(), M, C.byref(run.c), st), "mlp_forward")
     return run
 
@@ -502,7 +511,7 @@ def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: 
     g = pk.grad_sink()
     gm = C.byref(maps.gmap_ptr_array()) if want_map_grads else None
     split = sync_async is not None and gm is not None
-    _capi.check(lib.scenerf_hip_mlp_backward(C.byref(ccfg), C.byref(pk.c), C.byref(g), run.Z.data_ptr(), run.xenc.data_ptr(),
+    _capi.check(lib.scenerf_hip_mlp_backward(C.byref(ccfg), C.byref(pk.c), C.byref(g), run.Z.data_ptr(), _capi.ptr(run.xenc),
                                              run.tile_mask.data_ptr(), run.tap_texel.data_ptr(), run.tap_weight.data_ptr(),
                                              run.M, C.byref(run.c), d_logits.data_ptr(), dH.data_ptr(), dN.data_ptr(),
                                              None if split else gm, _stream(dev)), "mlp_backward")
@@ -673,8 +682,9 @@ class RenderChunk(torch.autograd.Function):
             ctx.mlp.pending = _mlp_backward(ccfg, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps, sync_async=early)
         if do_head:
             main.wait_stream(side)
-            for t in (d_off, run_g.Z, run_g.xenc, run_g.logits):
-                t.record_stream(side)
+            for t in (d_off, run_g.Z, run_g.xenc, run_g.h0pre, run_g.logits):
+                if t is not None:
+                    t.record_stream(side)
         ctx.keep = None
         z1 = torch.zeros(1, **f32)
         return (None, None, None, None, None, None, None, None, None, None,
@@ -723,9 +733,13 @@ class RenderSession:
         # autograd runs ready nodes newest-first: the MLP tokens are created BEFORE the map token so that in backward the map
         # transposes (PrepareMaps.backward) are queued before PackMLP.backward waits for a gradient all-reduce in flight
         self.mlp, self.mlpg = MlpHolder(grad_sync, grad_sync_async), MlpHolder(grad_sync)
+        # training sessions pack both MLPs on the side stream: the gaussian head's operands (needed first) are packed while the main
+        # stream sets up the rays and gathers the head's features (~55 us before its first GEMM), the radiance MLP's behind them
+        # (first read ~0.3 ms into the step).  The side stream runs them in this order: head, then radiance MLP.
         self.mlp.defer_pack = True
-        self.tok_mlp = PackMLP.apply(self.mlp, 4, cfg, *mlp_params)
+        self.mlpg.defer_pack = DEFER_HEAD_PACK
         self.tok_mlpg = PackMLP.apply(self.mlpg, 2, cfg, *mlpg_params)
+        self.tok_mlp = PackMLP.apply(self.mlp, 4, cfg, *mlp_params)
         self.maps = MapHolder(cfg)
         if debug_aux:
             self.maps.debug_aux = {}

@@ -136,10 +136,22 @@ def _encode(case, rcfg, dist, stride, ppr, M):
     pts = torch.empty((M, 3), device=DEV)
     idx = torch.empty((M, 2), dtype=torch.int32, device=DEV)
     xenc = torch.empty((M, 48), device=DEV)
+    x3 = torch.zeros((M, 144), dtype=torch.bfloat16, device=DEV)
     _capi.check(lib.scenerf_hip_encode_points(C.byref(cc), dist.data_ptr(), stride, ppr, dv(o["_unit"]).data_ptr(),
                                               dv(o["_viewdir"]).data_ptr(), dv(g.cam_K).data_ptr(), dv(iK).data_ptr(),
-                                              dv(g.T).data_ptr(), M, pts.data_ptr(), idx.data_ptr(), xenc.data_ptr(), _st()),
+                                              dv(g.T).data_ptr(), M, pts.data_ptr(), idx.data_ptr(), xenc.data_ptr(), x3.data_ptr(), _st()),
                 "encode_points")
+    # the split-bf16 form written by the same launch: [hi | lo | hi] with hi = bf16(x), lo = bf16(x - hi), exactly
+    hi = xenc.to(torch.bfloat16)
+    lo = (xenc - hi.float()).to(torch.bfloat16)
+    assert torch.equal(x3, torch.cat([hi, lo, hi], dim=1)), "split encoding differs from bf16 hi / lo of the fp32 encoding"
+    # ... and alone (xenc = NULL: the product's bf16 path)
+    x3b = torch.zeros_like(x3)
+    idx2 = torch.empty_like(idx)
+    _capi.check(lib.scenerf_hip_encode_points(C.byref(cc), dist.data_ptr(), stride, ppr, dv(o["_unit"]).data_ptr(),
+                                              dv(o["_viewdir"]).data_ptr(), dv(g.cam_K).data_ptr(), dv(iK).data_ptr(),
+                                              dv(g.T).data_ptr(), M, None, idx2.data_ptr(), None, x3b.data_ptr(), _st()), "encode_points")
+    assert torch.equal(x3b, x3) and torch.equal(idx2, idx)
     return pts, idx, xenc
 
 

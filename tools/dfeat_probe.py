@@ -52,9 +52,9 @@ for name in ("gemm", "dfeat"):
     print("%-6s M=%d masks=%s: %.1f us per launch" % (name, M, pat, e0.elapsed_time(e1) * 100), flush=True)
 for i in range(2):
     a, b = res["gemm"][i], res["dfeat"][i]
-    print("level %d: max |diff| %.3e  (scale %.3e)" % (i, (a - b).abs().max().item(), a.abs().max().item()))
+    print("level %d: max |diff| %.3e  (scale %.3e)%s" % (i, (a - b).abs().max().item(), a.abs().max().item(), "" if bool(torch.isfinite(b).all()) else "  NON-FINITE"))
 
-if os.environ.get("SRF_LIB_TAG"):   # a -DH_CYC build: where a workgroup's cycles go (3-tile kernel: start, K loop, table, rounds)
+if os.environ.get("SRF_LIB_TAG") and hasattr(lib, "scenerf_hip_test_dfeat_cyc"):   # a -DH_CYC build: where a workgroup's cycles go (3-tile kernel: start, K loop, table, rounds)
     lib.scenerf_hip_test_dfeat_cyc.argtypes = [C.c_void_p]
     buf = torch.zeros((ntile, 16), dtype=torch.int64, device=dev)
     lib.scenerf_hip_test_dfeat_cyc(buf.data_ptr())
