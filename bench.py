@@ -103,6 +103,9 @@ def parse():
                     help="N>1: 'session' = the renderer's per-session hooks (two 21.7 MB all-reduces started inside the backward, overlapped); "
                          "'step' = dist.StepGradSync, one 43.3 MB all-reduce at the end of backward (safe when ranks render different numbers "
                          "of source frames)")
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
+                    help="AdamW of the step: 'fused' = scenerf_amd.optim.FusedAdamW (one HIP launch over all 40 parameter tensors), 'torch' = "
+                         "torch.optim.AdamW(fused=True)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short BASELINE configs[3] (BundleFusion) and configs[4] (inference) legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -126,6 +129,14 @@ def sample_split(n):
     if n == 96:
         return 64, 8
     return n // 2, n // 8
+
+
+def make_optimizer(args, params):
+    """AdamW(lr=1e-5, weight_decay=0) as the reference configures it (scenerf.py:756-761)."""
+    if getattr(args, "optimizer", "fused") == "torch":
+        return torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, fused=True)
+    from scenerf_amd.optim import FusedAdamW
+    return FusedAdamW(params, lr=1e-5, weight_decay=0.0)
 
 
 def make_model(args, dev, precision=None):
@@ -488,7 +499,7 @@ def bundlefusion_leg(args, dev, steps=10, warmup=3):
                             max_sample_depth=12, precision=args.precision, device_rng=not args.host_rng).to(dev)
     m.mlp.load_state_dict(synth.mlp_state(11, 4))
     m.mlp_gaussian.load_state_dict(synth.mlp_state(12, 2, out_scale=0.5))
-    opt = torch.optim.AdamW(list(m.mlp.parameters()) + list(m.mlp_gaussian.parameters()), lr=1e-5, weight_decay=0.0, fused=True)
+    opt = make_optimizer(args, list(m.mlp.parameters()) + list(m.mlp_gaussian.parameters()))
     maps = {}
     for k, v in synth.feature_maps(960, 720, 13).items():
         if args.maps == "hwc":
@@ -604,7 +615,7 @@ def main():
     else:
         model = make_model(args, dev)
         params = list(model.mlp.parameters()) + list(model.mlp_gaussian.parameters())
-        opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, fused=True)
+        opt = make_optimizer(args, params)
         maps = _make_maps(args.maps, dev, rank)
         K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
         pix = synth.stride2_pixels((1220, 370), R, 100 + rank).to(dev)
@@ -692,7 +703,7 @@ def main():
         # baseline below has a matched-precision partner
         try:
             m32 = make_model(args, dev, precision="fp32")
-            o32 = torch.optim.AdamW(list(m32.mlp.parameters()) + list(m32.mlp_gaussian.parameters()), lr=1e-5, weight_decay=0.0, fused=True)
+            o32 = make_optimizer(args, list(m32.mlp.parameters()) + list(m32.mlp_gaussian.parameters()))
             s32 = make_step(m32, o32)
             for _ in range(2):
                 s32()
@@ -751,6 +762,7 @@ def main():
                                        "contiguous-(C,H,W) entry with its per-call layout conversion is timed as other_entry)"
                                        if args.maps == "hwc" else "incl. map layout conversion (contiguous (C,H,W) maps)"),
                        "rays_per_gpu": R, "samples_per_ray": args.samples, "parallelism": "dp%d" % world, "grad_sync": (args.sync if world > 1 else None),
+                       "optimizer": "scenerf_amd.optim.FusedAdamW" if args.optimizer == "fused" else "torch.optim.AdamW(fused=True)",
                        "precision": args.precision, "maps": args.maps,
                        "sampling_noise": "host generator + upload, like the reference" if args.host_rng else
                                          "device generator (RenderConfig.device_rng=True; --host-rng gives the reference's host-side draw: +0.1-0.25 ms per step)"},

@@ -131,9 +131,11 @@ typedef struct scenerf_mlp_params {
     const float* linz_b[3];
 } scenerf_mlp_params;
 
+#define SCENERF_WIN_LD 256
 /* Gradients of the packed operands (fp32, accumulated with atomics: zero them first). */
 typedef struct scenerf_mlp_grads {
-    float* w_in;                    /* [512][48] */
+    float* w_in;                    /* [512][SCENERF_WIN_LD]: columns 0..47 hold the gradient (42 real + pad); the rest of a row is scratch
+                                     * -- the batched weight-gradient kernel works in 256-column tiles and lin_in rides along (wgrad.hip) */
     float* b_in;                    /* [512] */
     float* w_fc0[3];                /* [512][512] */
     float* b_fc0[3];
@@ -327,6 +329,22 @@ int scenerf_hip_tsdf_integrate(float* tsdf_vol, float* weight_vol, float* color_
                                const float vol_origin[3], double voxel_size, const float cam_intr[9], const float cam_pose[16],
                                const double cam_pose_inv[16], const float* color_im, const float* depth_im, int im_h, int im_w,
                                float trunc_margin, float obs_weight, int semantics, scenerf_stream_t stream);
+
+/* ---- optimizer step of the renderer's parameters --------------------------------------------------------------------
+ * torch.optim.AdamW (amsgrad = False) over `count` tensors in one launch (reference: configure_optimizers, scenerf.py:756-761).
+ * p, m (exp_avg), v (exp_avg_sq): contiguous fp32 [numel]; g: fp32, contiguous (g_cols == 0) or rows of g_cols elements at stride
+ * g_ld (a sliced view of the gradient sink); step >= 1 = this tensor's step count INCLUDING this step.  `tensors` is a HOST array. */
+typedef struct scenerf_adamw_tensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t numel;
+    int32_t g_cols, g_ld;
+    int64_t step;
+} scenerf_adamw_tensor;
+int scenerf_hip_adamw_step(int count, const scenerf_adamw_tensor* tensors, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, scenerf_stream_t stream);
 
 /* ---- image -> sphere resampling of the encoder levels --------------------------------------------------------
  * Replaces DecoderSphere.get_sphere_feature (reference scenerf/models/unet2d_sphere.py:138-165; six calls per image).

@@ -76,6 +76,11 @@ class MlpActs(C.Structure):
     _fields_ = [("H", vp * 4), ("Nn", vp * 3), ("h0pre", vp), ("logits", vp), ("sign_bits", vp), ("x3_ready", C.c_int32)]
 
 
+class AdamWTensor(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("numel", C.c_int64), ("g_cols", C.c_int32), ("g_ld", C.c_int32),
+                ("step", C.c_int64)]
+
+
 class ProfRec(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_float),
                 ("flops", C.c_double), ("bytes", C.c_double)]
@@ -98,6 +103,7 @@ _PROTOS = {
     "scenerf_hip_tsdf_integrate": (C.c_int, [vp, vp, vp, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_float * 3), C.c_double,
                                              C.POINTER(C.c_float * 9), C.POINTER(C.c_float * 16), C.POINTER(C.c_double * 16), vp, vp,
                                              i32, i32, C.c_float, C.c_float, i32, vp]),
+    "scenerf_hip_adamw_step": (C.c_int, [i32, C.POINTER(AdamWTensor), C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     "scenerf_hip_sphere_map_build": (C.c_int, [vp, vp, C.c_int64, i32, i32, i32, vp, vp, vp]),
     "scenerf_hip_sphere_resample_forward": (C.c_int, [vp, C.c_int64, i32, i32, vp, i32, i32, vp, vp]),
     "scenerf_hip_sphere_resample_backward": (C.c_int, [vp, C.c_int64, i32, i32, vp, vp, i32, i32, vp, vp]),
@@ -147,6 +153,7 @@ def load() -> C.CDLL:
 FUSED_MIN_ROWS_DEFAULT = 4096    # SCENERF_FUSED_MIN_ROWS_DEFAULT
 FLAG_NO_FUSED_BWD, FLAG_NO_WGRAD_TR, FLAG_DFEAT_PER_SCALE, FLAG_WGRAD_OVERLAP, FLAG_WIDE_BWD, FLAG_WIDE_ANY_M, FLAG_DFEAT_GEMM = 1, 2, 4, 8, 16, 32, 64   # SCENERF_FLAG_*
 FLAG_UNIFORM_ONLY = 128
+WIN_LD = 256            # SCENERF_WIN_LD: row stride of scenerf_mlp_grads.w_in
 
 
 def check(code: int, what: str) -> None:

@@ -502,6 +502,21 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         t.allow_tr = allow_tr;
         if (wgrad_tr_applicable(t, W_BATCH_MIN_ROWS)) { wg[nwg++] = t; linz_done = SCENERF_Z_DENSE_COLS; }
     }
+    // lin_in: dWin += dH0^T x as an eighth problem of the same launch (bf16): its K = 48 is padded to one 256-column tile -- the A tile
+    // reads on into the following rows of the split encoding [M][144] (finite garbage, one row of slack behind the buffer), the
+    // output tile's columns 48..255 land in the scratch part of w_in's rows (SCENERF_WIN_LD).  40 GFLOP of padding on the matrix
+    // cores against a separate skinny GEMM that ran at 2 TB/s (76-82 us, r02/r03 profiles)
+    int linin_done = 0;
+    if (nwg && nwg < 8 && prec) {
+        GemmTN t;
+        t.name = head ? "gemm_wgrad_fc/g" : "gemm_wgrad_fc";
+        t.D = dH; t.ldd = LDH;
+        t.A = a->h0pre; t.lda = 3 * SCENERF_D_XENC;
+        t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_WIN_LD; t.out = g_->w_in; t.ldo = SCENERF_WIN_LD;
+        t.colsum = g_->b_in;
+        t.allow_tr = allow_tr;
+        if (wgrad_tr_applicable(t, W_BATCH_MIN_ROWS)) { wg[nwg++] = t; linin_done = 1; }
+    }
     if (nwg) {
         if (int e = launch_wgrad_tr_batch(wg, nwg, s2)) return e;
     }
@@ -520,7 +535,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         if (int e = launch_gemm_tn(prec, t, s2)) return e;
     }
     // [side] dWin += dH0^T xenc   (bf16 mode: the hi part of the split encoding kept in h0pre is bf16(xenc))
-    {
+    if (!linin_done) {
         GemmTN t;
         t.name = head ? "gemm_wgrad_lin_in/g" : "gemm_wgrad_lin_in";
         t.D = dH; t.ldd = LDH;
@@ -529,7 +544,7 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         } else {
             t.A = xenc; t.lda = SCENERF_D_XENC;
         }
-        t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_XENC; t.out = g_->w_in; t.ldo = SCENERF_D_XENC;
+        t.M = M; t.N = SCENERF_D_HIDDEN; t.K = SCENERF_D_XENC; t.out = g_->w_in; t.ldo = SCENERF_WIN_LD;
         t.colsum = g_->b_in;  // lin_in.bias gradient = column sums of dH_0
         t.allow_tr = allow_tr;
         if (int e = launch_gemm_tn(prec, t, s2)) return e;

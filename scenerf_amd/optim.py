@@ -1,0 +1,75 @@
+"""AdamW over the renderer's parameters in one HIP launch (``scenerf_hip_adamw_step``, csrc/optim.hip).
+
+The reference trains with ``torch.optim.AdamW(self.parameters(), lr, weight_decay)`` (scenerf.py:756-761).  ``FusedAdamW`` is that
+optimizer -- same hyper-parameters, same ``param_groups`` / ``state_dict`` layout (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter),
+schedulers work on it unchanged -- with the update of ALL parameters of a group issued as one kernel that reads each gradient where
+autograd left it: the renderer hands ``lin_in.weight``'s gradient over as a sliced view of its gradient sink, which the stock fused
+optimizer first copies into a contiguous tensor.  amsgrad / maximize / capturable are not offered.  CUDA fp32 parameters only: anything
+else raises (no fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List
+
+import torch
+
+from . import _capi
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _capi.load()
+        for group in self.param_groups:
+            entries: List[_capi.AdamWTensor] = []
+            keep = []    # (temporaries must outlive the launch call)
+            dev = None
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise RuntimeError("FusedAdamW: parameters must be contiguous fp32 CUDA tensors (got %s %s)" % (p.dtype, p.device))
+                if g.is_sparse or g.dtype != torch.float32 or g.device != p.device:
+                    raise RuntimeError("FusedAdamW: gradients must be dense fp32 tensors on the parameter's device")
+                if dev is None:
+                    dev = p.device
+                elif p.device != dev:
+                    raise RuntimeError("FusedAdamW: one device per parameter group")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] = int(st["step"]) + 1
+                e = _capi.AdamWTensor()
+                e.p, e.m, e.v = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                e.numel, e.step = p.numel(), st["step"]
+                if g.is_contiguous():
+                    e.g, e.g_cols, e.g_ld = g.data_ptr(), 0, 0
+                elif g.dim() == 2 and g.stride(1) == 1 and g.stride(0) >= g.shape[1]:
+                    e.g, e.g_cols, e.g_ld = g.data_ptr(), g.shape[1], g.stride(0)     # a column slice of a wider buffer, read in place
+                else:
+                    gc = g.contiguous()
+                    keep.append(gc)
+                    e.g, e.g_cols, e.g_ld = gc.data_ptr(), 0, 0
+                entries.append(e)
+            if not entries:
+                continue
+            arr = (_capi.AdamWTensor * len(entries))(*entries)
+            b1, b2 = group["betas"]
+            with torch.cuda.device(dev):
+                _capi.check(lib.scenerf_hip_adamw_step(len(entries), arr, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                       float(group["weight_decay"]), torch.cuda.current_stream(dev).cuda_stream), "adamw_step")
+            del keep
+        return loss

@@ -349,7 +349,7 @@ class PackedMLP:
         if self.gc is not None:
             return self.gc
         d = self.d_out
-        fields = [("w_in", (D_H, D_X)), ("b_in", (D_H,))]
+        fields = [("w_in", (D_H, _capi.WIN_LD)), ("b_in", (D_H,))]   # (columns >= 48 of w_in: scratch of the batched wgrad kernel)
         for b in range(3):
             fields += [("w_fc0.%d" % b, (D_H, D_H)), ("b_fc0.%d" % b, (D_H,)),
                        ("w_fc1.%d" % b, (D_H, D_H)), ("b_fc1.%d" % b, (D_H,))]
@@ -462,7 +462,8 @@ class _MlpRun:
         self.H = [None if lean else torch.empty((M, D_H), dtype=act, device=dev) for i in range(4)]
         self.Nn = [None if lean else torch.empty((M, D_H), dtype=act, device=dev) for _ in range(3)]
         # fp32 lin_in output (fp32 mode) or the split-bf16 encoding [M][144] (bf16 mode)
-        self.h0pre = torch.empty((M, D_H) if prec == 0 else (M, 3 * D_X // 2), dtype=torch.float32, device=dev)
+        # (bf16: one row of slack -- lin_in's weight gradient reads the split encoding in 256-column tiles of its 144-column rows)
+        self.h0pre = torch.empty((M, D_H) if prec == 0 else (M + 1, 3 * D_X // 2), dtype=torch.float32, device=dev)
         self.logits = torch.empty((M, d_out), dtype=torch.float32, device=dev)
         a = _capi.MlpActs()
         for i in range(4):

@@ -17,12 +17,12 @@ mod = importlib.import_module("scenerf_amd." + modname)
 vals = [ast.literal_eval(v) for v in vals.split(",")]
 
 dev = torch.device("cuda:0")
-args = argparse.Namespace(samples=128, precision="bf16", host_rng=False)
+args = argparse.Namespace(samples=128, precision="bf16", host_rng=False, optimizer=os.environ.get("AB_OPT", "fused"))
 R = 1200
 torch.manual_seed(1)
 model = bench.make_model(args, dev)
 params = list(model.mlp.parameters()) + list(model.mlp_gaussian.parameters())
-opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, fused=True)
+opt = bench.make_optimizer(args, params)
 maps = bench._make_maps("hwc", dev, 0)
 K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
 pix = synth.stride2_pixels((1220, 370), R, 100).to(dev)
