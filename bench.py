@@ -371,7 +371,8 @@ def _rooflines(kernels, args, nprof, value_per_gpu, world):
                                         "unit": "TFLOP/s", "frac_of_peak": round(value_per_gpu * dense / 1e12 / peak, 4),
                                         "note": "rays/s x the reference's dense FLOPs per ray (it multiplies the out-of-range "
                                                 "scales' zeros); not a utilisation: the kernels skip those K blocks"}
-    comp = [k for k in kernels if k["name"] in ("composite_fwd", "composite_bwd")]
+    # (training chunks launch the fused per-ray tail: compositing + RaySOM forward, their autograd + the sampler's backward)
+    comp = [k for k in kernels if k["name"] in ("composite_fwd", "composite_bwd", "ray_tail_fwd", "ray_tail_bwd")]
     if comp:
         b = sum(k["bytes"] for k in comp)
         t = sum(k["total_ms"] for k in comp)
@@ -379,7 +380,8 @@ def _rooflines(kernels, args, nprof, value_per_gpu, world):
         roof_c = {"bound": "hbm", "kernel": "+".join(k["name"] for k in comp), "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
                   "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                   "avg_launch_us": round(sum(k["total_ms"] for k in comp) * 1e3 / sum(k["launches"] for k in comp), 2),
-                  "bytes_per_ray": (80 * args.samples + 64) if len(comp) == 2 else (32 * args.samples + 24)}
+                  "bytes_per_ray": sum({"composite_fwd": 32 * args.samples + 24, "ray_tail_fwd": 32 * args.samples + 24,
+                                        "composite_bwd": 48 * args.samples + 40, "ray_tail_bwd": 44 * args.samples + 40}[k["name"]] for k in comp)}
         # the same two kernels at an inference-sized chunk (65,536 rays): at the training chunk (1,200 rays = 1,200 waves) the pass is
         # launch latency, not bandwidth; this is the number the HBM roofline applies to (tools/composite_probe.py, profiles/*composite*)
         try:
@@ -390,27 +392,42 @@ def _rooflines(kernels, args, nprof, value_per_gpu, world):
 
 
 def _composite_probe(R, N, reps=20):
-    """composite_fwd / composite_bwd through the C ABI on synthetic [R][N] inputs, HIP-event timed on the launch stream."""
+    """The fused per-ray tail (compositing + RaySOM forward; their autograd + the sampler's backward) through the C ABI on synthetic
+    [R][N] inputs, HIP-event timed on the launch stream, against the compositing pass's algorithmic bytes."""
+    import ctypes as C
+    from scenerf_amd.config import RenderConfig
     lib = _capi.load()
     dev = "cuda"
+    U, P = sample_split(N)
+    cc = RenderConfig.kitti(n_pts_uni=U, n_pts_per_gaussian=P).to_c()
+    G = 4
     st = torch.cuda.current_stream().cuda_stream
     logits = torch.randn(R * N, 4, device=dev)
     logits[:, 3] -= 2
     dist = torch.sort(torch.rand(R, N, device=dev) * 100 + 0.1, dim=1).values
     z = dist * 0.97
+    gm = torch.sort(torch.rand(R, G, device=dev) * 80 + 2, dim=1).values
+    gs = torch.rand(R, G, device=dev) * 4 + 1.5
+    perm = torch.argsort(torch.rand(R, N, device=dev), dim=1).to(torch.int32)
+    offs, anchors = torch.randn(R, G, 2, device=dev), torch.linspace(12.5, 87.5, G, device=dev)
+    noise, unit = torch.randn(R, G * P, device=dev), torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=1)
     f = lambda *s: torch.empty(s, device=dev)
     dens, al, w, dep, col, clo, wat = f(R, N), f(R, N), f(R, N), f(R), f(R, 3), f(R), f(R)
     ci = torch.empty(R, dtype=torch.int32, device=dev)
+    lk, sm, sv, ks = f(R), f(R, G), f(R, G), f(R, G, 3)
     gd, gc = torch.randn(R, device=dev), torch.randn(R, 3, device=dev)
-    dl, dd, dz = f(R * N, 4), f(R, N), f(R, N)
-    fwd = lambda: lib.scenerf_hip_composite_forward(logits.data_ptr(), dist.data_ptr(), z.data_ptr(), R, N, dens.data_ptr(), al.data_ptr(),
-                                                    w.data_ptr(), dep.data_ptr(), col.data_ptr(), clo.data_ptr(), wat.data_ptr(), ci.data_ptr(), st)
-    bwd = lambda: lib.scenerf_hip_composite_backward(logits.data_ptr(), dist.data_ptr(), z.data_ptr(), R, N, gd.data_ptr(), gc.data_ptr(), None,
-                                                     None, None, None, dl.data_ptr(), dd.data_ptr(), dz.data_ptr(), st)
-    out = {"rays": R, "samples": N}
-    for name, fn, bpr in (("fwd", fwd, 32 * N + 24), ("bwd", bwd, 48 * N + 40)):
+    dl, do = f(R * N, 4), f(R, G, 2)
+    fwd = lambda: lib.scenerf_hip_ray_tail_forward(C.byref(cc), logits.data_ptr(), dist.data_ptr(), z.data_ptr(), gm.data_ptr(), gs.data_ptr(), R,
+                                                   dens.data_ptr(), al.data_ptr(), w.data_ptr(), dep.data_ptr(), col.data_ptr(), clo.data_ptr(),
+                                                   wat.data_ptr(), ci.data_ptr(), lk.data_ptr(), sm.data_ptr(), sv.data_ptr(), ks.data_ptr(), None, st)
+    bwd = lambda: lib.scenerf_hip_ray_tail_backward(C.byref(cc), logits.data_ptr(), dist.data_ptr(), z.data_ptr(), R, gd.data_ptr(), gc.data_ptr(),
+                                                    None, None, None, None, offs.data_ptr(), anchors.data_ptr(), noise.data_ptr(), unit.data_ptr(),
+                                                    gm.data_ptr(), gs.data_ptr(), perm.data_ptr(), ks.data_ptr(), None, None, None, dl.data_ptr(),
+                                                    do.data_ptr(), None, None, st)
+    out = {"rays": R, "samples": N, "kernels": "ray_tail_fwd (compositing + RaySOM), ray_tail_bwd (compositing + sampler / KL backward)"}
+    for name, fn, bpr in (("fwd", fwd, 32 * N + 24), ("bwd", bwd, 44 * N + 40)):
         for _ in range(3):
-            fn()
+            assert fn() == 0, lib.scenerf_hip_last_error()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):

@@ -267,6 +267,24 @@ int scenerf_hip_raysom_forward(const scenerf_cfg* cfg, const float* gmeans, cons
                                float* som_vars /*[R][G]*/, float* kl_saved /*[R][G][3]*/, uint8_t* bmu_out,
                                scenerf_stream_t stream);
 
+/* The per-ray tail of a chunk in ONE launch each way (what RenderChunk calls): compositing + RaySOM forward (scenerf.py:704-748,
+ * ray_som_kl.py:10-87 -- the sorted distances and fresh alphas stay in the wave's registers for the SOM update), and their autograd
+ * together with the sampler's (compositing backward + reparameterisation / relu / kl_gauss backward: the gradients w.r.t. the sorted
+ * distances and depths never leave the wave; d_dist / d_z are written only if non-NULL).  Results are bit-identical to the stage
+ * entries above and below, which remain for per-stage use.  Algorithmic HBM bytes per ray: 32 N + 24 forward, 44 N + 40 backward. */
+int scenerf_hip_ray_tail_forward(const scenerf_cfg* cfg, const float* logits, const float* dist_sorted, const float* z_sorted,
+                                 const float* gmeans, const float* gstds, int R, float* densities, float* alphas, float* weights,
+                                 float* depth, float* color, float* closest, float* weights_at_depth, int32_t* closest_idx,
+                                 float* loss_kl, float* som_means, float* som_vars, float* kl_saved, uint8_t* bmu_out,
+                                 scenerf_stream_t stream);
+int scenerf_hip_ray_tail_backward(const scenerf_cfg* cfg, const float* logits, const float* dist_sorted, const float* z_sorted, int R,
+                                  const float* g_depth, const float* g_color, const float* g_weights, const float* g_alphas,
+                                  const float* g_densities, const float* g_zvol, const float* offsets, const float* anchors,
+                                  const float* noise_g, const float* unit_dir, const float* gmeans, const float* gstds,
+                                  const int32_t* perm, const float* kl_saved, const float* g_loss_kl, const float* g_gmeans,
+                                  const float* g_gstds, float* d_logits /*[R*N][4]*/, float* d_offsets /*[R][G][2]*/,
+                                  float* d_dist /*[R][N] or NULL*/, float* d_z /*[R][N] or NULL*/, scenerf_stream_t stream);
+
 /* autograd of the sampler + KL w.r.t. the gaussian-head outputs: reparameterisation (utils.py:213, not
  * through the 0.1 clamp), z = dist*unit.z, relu of scenerf.py:591-594, kl_gauss(m1,s1).  Upstream NULL = 0. */
 int scenerf_hip_sampler_backward(const scenerf_cfg* cfg, const float* offsets, const float* anchors, const float* noise_g,

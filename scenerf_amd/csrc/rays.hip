@@ -806,6 +806,226 @@ __global__ __launch_bounds__(256) void raysom_fwd_kernel(const float* __restrict
     if (lane == 0) loss_kl[r] = klsum / (float)G;
 }
 
+
+// ------------------------------------------------------------------------------------------------ fused per-ray tail
+// composite_fwd_kernel + raysom_fwd_kernel in ONE launch (scenerf.py:704-748 + ray_som_kl.py:10-87): the ray's sorted distances and
+// the alphas the compositing just produced stay in the wave's registers for the SOM update -- one launch and one pass over
+// (logits, dist, z) per ray instead of two launches and a re-read of dist / alphas.  Same arithmetic, statement for statement, as
+// the two stage kernels (tests hold the outputs bit-identical to theirs).
+__device__ __forceinline__ void raysom_sample(const float d, const float dens, const float (&m)[MAXG], const float (&s)[MAXG],
+                                              const float (&var)[MAXG], const int G, const float (*p12)[MAXG], float (&pz1)[MAXG],
+                                              float& pbest, int& bmu) {
+    const float sqrt2pi = 2.5066282746310002f;
+#pragma unroll
+    for (int c = 0; c < MAXG; ++c) {
+        float gap = fabsf(m[c] - d);
+        float p = expf(-(gap * gap) / (2.f * var[c])) / (sqrt2pi * s[c]) + 1e-5f;
+        pz1[c] = (c < G) ? p * dens + 1e-8f : 0.f;
+    }
+    pbest = -1.f;
+    bmu = 0;
+    for (int c2 = 0; c2 < G; ++c2) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c1 = 0; c1 < MAXG; ++c1)
+            if (c1 < G) acc += pz1[c1] * p12[c2][c1] + 1e-8f;
+        if (acc > pbest) { pbest = acc; bmu = c2; }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ dist,
+                                                           const float* __restrict__ zv, const float* __restrict__ gmeans,
+                                                           const float* __restrict__ gstds, int R, int N, int G, float som_sigma,
+                                                           float kl_floor, float* __restrict__ densities, float* __restrict__ alphas,
+                                                           float* __restrict__ weights, float* __restrict__ depth,
+                                                           float* __restrict__ color, float* __restrict__ closest,
+                                                           float* __restrict__ w_at, int32_t* __restrict__ closest_idx,
+                                                           float* __restrict__ loss_kl, float* __restrict__ som_means,
+                                                           float* __restrict__ som_vars, float* __restrict__ kl_saved,
+                                                           uint8_t* __restrict__ bmu_out) {
+    __shared__ float s_nb[4][MAXG][MAXG], s_p12[4][MAXG][MAXG];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wv;
+    const bool active = r < R;
+    // ---- RaySOM tables of this ray (ray_som_kl.py:30-38), before anything else: the barriers are block-wide
+    float m[MAXG], s[MAXG], var[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        bool ok = active && g < G;
+        m[g] = ok ? gmeans[(size_t)r * G + g] : 0.f;
+        s[g] = ok ? gstds[(size_t)r * G + g] : 1.f;
+        var[g] = s[g] * s[g];
+    }
+    const float two_sig2 = (float)(2.0 * (double)som_sigma * (double)som_sigma);
+    if (lane < MAXG * MAXG) {
+        int c2 = lane / MAXG, c1 = lane % MAXG;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            if (g == c2) a = m[g];
+            if (g == c1) b = m[g];
+        }
+        const float dm = a - b;
+        s_nb[wv][c2][c1] = (c2 < G && c1 < G) ? expf(-(dm * dm) / two_sig2) : 0.f;
+    }
+    __syncthreads();
+    if (lane < MAXG * MAXG) {
+        int c2 = lane / MAXG, c1 = lane % MAXG;
+        float sum = 0.f;
+        for (int g = 0; g < G; ++g) sum += s_nb[wv][c2][g];
+        s_p12[wv][c2][c1] = (c2 < G && c1 < G) ? s_nb[wv][c2][c1] / sum : 0.f;
+    }
+    __syncthreads();
+    if (!active) return;
+    // ---- compositing (composite_fwd_kernel)
+    const size_t base = (size_t)r * N;
+    float z[C], w[C], d[C], al[C];
+    float4 lg[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = c * 64 + lane;
+        const bool ok = i < N;
+        lg[c] = ok ? *(const float4*)(logits + (base + i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float dd = ok ? dist[base + i] : 0.f;
+        d[c] = dd < 0.f ? 0.f : dd;  // scenerf.py:707 (in place on the sorted tensor: RaySOM sees the clamped distances too)
+        z[c] = ok ? zv[base + i] : 0.f;
+    }
+    float carryT = 1.f, carry_d = 0.f;
+    float sd = 0.f, sr = 0.f, sgc = 0.f, sb = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = c * 64 + lane;
+        const bool ok = i < N;
+        const float sg = softplus_m1(lg[c].w);
+        const float cr = sigmoidf(lg[c].x), cg = sigmoidf(lg[c].y), cb = sigmoidf(lg[c].z);
+        float before = __shfl_up(d[c], 1, WAVE);
+        if (lane == 0) before = carry_d;
+        const float delta = (i == 0) ? d[c] : d[c] - before;
+        const float a = ok ? 1.f - expf(-delta * sg) : 0.f;
+        al[c] = a;
+        const float sfac = 1.f - a + 1e-10f;
+        const float excl = wave_excl_prod(sfac, lane);
+        const float Ti = carryT * excl;
+        w[c] = a * Ti;
+        carryT *= wave_total_prod_from_excl(excl, sfac);
+        carry_d = __shfl(d[c], 63, WAVE);
+        sd += w[c] * z[c];
+        sr += w[c] * cr;
+        sgc += w[c] * cg;
+        sb += w[c] * cb;
+        if (ok) {
+            densities[base + i] = sg;
+            alphas[base + i] = a;
+            weights[base + i] = w[c];
+        }
+    }
+    sd = wave_sum(sd);
+    sr = wave_sum(sr);
+    sgc = wave_sum(sgc);
+    sb = wave_sum(sb);
+    float best = __builtin_inff();
+    int bi = 0x7fffffff;
+    float bw = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = c * 64 + lane;
+        if (i < N) {
+            const float a = fabsf(sd - z[c]);
+            if (a < best) { best = a; bi = i; bw = w[c]; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, WAVE);
+        const int oi = __shfl_xor(bi, o, WAVE);
+        const float ow = __shfl_xor(bw, o, WAVE);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; bw = ow; }
+    }
+    if (lane == 0) {
+        depth[r] = sd;
+        color[3 * r] = sr;
+        color[3 * r + 1] = sgc;
+        color[3 * r + 2] = sb;
+        closest[r] = best;
+        w_at[r] = bw;
+        closest_idx[r] = bi;
+    }
+    // ---- RaySOM update + KL (raysom_fwd_kernel) on the registers' (distance, alpha)
+    float sw[MAXG], swd[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) { sw[g] = 0.f; swd[g] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = c * 64 + lane;
+        if (i < N) {
+            float pz1[MAXG], pbest;
+            int bmu;
+            raysom_sample(d[c], al[c] + 1e-8f, m, s, var, G, s_p12[wv], pz1, pbest, bmu);
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g) {
+                if (g < G) {
+                    float wgt = s_nb[wv][g][bmu] * pz1[g] / pbest + 1e-5f;
+                    sw[g] += wgt;
+                    swd[g] += wgt * d[c];
+                }
+            }
+        }
+    }
+    float nm[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        sw[g] = wave_sum(sw[g]);
+        swd[g] = wave_sum(swd[g]);
+        nm[g] = swd[g] / sw[g];
+    }
+    float sv[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) sv[g] = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = c * 64 + lane;
+        if (i < N) {
+            float pz1[MAXG], pbest;
+            int bmu;
+            raysom_sample(d[c], al[c] + 1e-8f, m, s, var, G, s_p12[wv], pz1, pbest, bmu);
+            if (bmu_out) bmu_out[base + i] = (uint8_t)bmu;
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g) {
+                if (g < G) {
+                    float wgt = s_nb[wv][g][bmu] * pz1[g] / pbest + 1e-5f;
+                    float e = d[c] - nm[g];
+                    sv[g] += wgt * (e * e);
+                }
+            }
+        }
+    }
+    float klsum = 0.f;
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        sv[g] = wave_sum(sv[g]);
+        if (g < G) {
+            float nv = sv[g] / sw[g];
+            float mean_diff = fabsf(m[g] - nm[g]);
+            float std_diff = fabsf(sqrtf(var[g]) - sqrtf(nv));
+            float mk = ((mean_diff > 0.1f) && (nv > 0.f) && (std_diff > 0.1f)) ? 1.f : 0.f;  // ray_som_kl.py:66-70
+            float s2 = sqrtf(nv);
+            if (s2 < kl_floor) s2 = kl_floor;  // ray_som_kl.py:83
+            float dmm = m[g] - nm[g];
+            float kl = logf(s2 / s[g] + 1e-8f) + (s[g] * s[g] + dmm * dmm) / (2.f * (s2 * s2)) - 0.5f;
+            klsum += kl * mk;
+            if (lane == 0) {
+                som_means[(size_t)r * G + g] = nm[g];
+                som_vars[(size_t)r * G + g] = nv;
+                kl_saved[((size_t)r * G + g) * 3 + 0] = nm[g];
+                kl_saved[((size_t)r * G + g) * 3 + 1] = s2;
+                kl_saved[((size_t)r * G + g) * 3 + 2] = mk;
+            }
+        }
+    }
+    if (lane == 0) loss_kl[r] = klsum / (float)G;
+}
+
 // sampler + KL backward: one wave per ray, 4 rays per block.
 __global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restrict__ offsets, const float* __restrict__ anchors,
                                                           const float* __restrict__ noise_g, const float* __restrict__ unit_dir,
@@ -857,6 +1077,158 @@ __global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restric
             float s1 = s[g], m1 = m[g];
             float scale = gkl * mk / (float)G;
             // d/dm1, d/ds1 of log(s2/s1 + 1e-8) + (s1^2 + (m1-m2)^2) / (2 s2^2) - 0.5
+            float dm = (m1 - m2) / (s2 * s2) * scale;
+            float ds = (-(s2 / (s1 * s1)) / (s2 / s1 + 1e-8f) + s1 / (s2 * s2)) * scale;
+            float tm = am[g] + dm + (g_gmeans ? g_gmeans[q] : 0.f);
+            float ts = as_[g] + ds + (g_gstds ? g_gstds[q] : 0.f);
+            float o0 = offsets[q * 2], o1 = offsets[q * 2 + 1];
+            d_offsets[q * 2] = (anchors[g] + o0 > 0.f) ? tm : 0.f;       // relu of scenerf.py:591
+            d_offsets[q * 2 + 1] = (o1 + base_std > 0.f) ? ts : 0.f;    // relu of scenerf.py:593
+        }
+    }
+}
+
+// composite_bwd_kernel + sampler_bwd_kernel in ONE launch: the gradients w.r.t. the sorted distances and depths never leave the
+// wave -- they are summed per gaussian straight from the registers through the sort permutation (utils.py:213-219 backward, the relu of
+// scenerf.py:591-594, kl_gauss) -- d_dist / d_z are written only if the caller asks for them.  Same arithmetic as the two stage kernels.
+template <int C>
+__global__ __launch_bounds__(256) void ray_tail_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ dist,
+                                                           const float* __restrict__ zv, int R, int N,
+                                                           const float* __restrict__ g_depth, const float* __restrict__ g_color,
+                                                           const float* __restrict__ g_weights, const float* __restrict__ g_alphas,
+                                                           const float* __restrict__ g_dens, const float* __restrict__ g_zvol,
+                                                           float* __restrict__ d_logits, float* __restrict__ d_dist,
+                                                           float* __restrict__ d_z,
+                                                           const float* __restrict__ offsets, const float* __restrict__ anchors,
+                                                           const float* __restrict__ noise_g, const float* __restrict__ unit_dir,
+                                                           const float* __restrict__ gmeans, const float* __restrict__ gstds,
+                                                           const int32_t* __restrict__ perm, const float* __restrict__ kl_saved,
+                                                           const float* __restrict__ g_loss_kl, const float* __restrict__ g_gmeans,
+                                                           const float* __restrict__ g_gstds, int U, int G, int P, float base_std,
+                                                           float* __restrict__ d_offsets) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const size_t base = (size_t)r * N;
+    float d[C], z[C], sg[C], al[C], w[C], cr[C], cg[C], cb[C], dl[C], Ti[C], o3[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = c * 64 + lane;
+        const bool ok = i < N;
+        const float4 lg = ok ? *(const float4*)(logits + (base + i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float dd = ok ? dist[base + i] : 0.f;
+        d[c] = dd < 0.f ? 0.f : dd;
+        z[c] = ok ? zv[base + i] : 0.f;
+        o3[c] = lg.w;
+        sg[c] = softplus_m1(lg.w);
+        cr[c] = sigmoidf(lg.x);
+        cg[c] = sigmoidf(lg.y);
+        cb[c] = sigmoidf(lg.z);
+    }
+    const float gd = g_depth[r];
+    const float gcr = g_color[3 * r], gcg = g_color[3 * r + 1], gcb = g_color[3 * r + 2];
+    float carryT = 1.f, carry_d = 0.f;
+    float gw[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = c * 64 + lane;
+        const bool ok = i < N;
+        float before = __shfl_up(d[c], 1, WAVE);
+        if (lane == 0) before = carry_d;
+        dl[c] = (i == 0) ? d[c] : d[c] - before;
+        al[c] = ok ? 1.f - expf(-dl[c] * sg[c]) : 0.f;
+        const float sfac = 1.f - al[c] + 1e-10f;
+        const float excl = wave_excl_prod(sfac, lane);
+        Ti[c] = carryT * excl;
+        w[c] = al[c] * Ti[c];
+        carryT *= wave_total_prod_from_excl(excl, sfac);
+        carry_d = __shfl(d[c], 63, WAVE);
+        float g = gd * z[c] + gcr * cr[c] + gcg * cg[c] + gcb * cb[c];
+        if (g_weights && ok) g += g_weights[base + i];
+        gw[c] = ok ? g : 0.f;
+    }
+    // the sampler's part: per-gaussian sums of (dL/ddist_i + dL/dz_i * unit_z) over the samples that came from that gaussian
+    float m[MAXG], s[MAXG], am[MAXG], as_[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        bool ok = g < G;
+        m[g] = ok ? gmeans[(size_t)r * G + g] : 0.f;
+        s[g] = ok ? gstds[(size_t)r * G + g] : 1.f;
+        am[g] = 0.f;
+        as_[g] = 0.f;
+    }
+    const float uz = unit_dir[3 * r + 2];
+    float tot_c[C];            // dL/ddist_i + dL/dz_i * unit_z of this lane's sample of segment c
+    float carryS = 0.f;        // sum of gw*w over all later segments
+    float next_first = 0.f;    // gdelta of the first sample of the next segment (i + 1 for lane 63)
+#pragma unroll
+    for (int c = C - 1; c >= 0; --c) {
+        const int i = c * 64 + lane;
+        const bool ok = i < N;
+        tot_c[c] = 0.f;
+        const float v = gw[c] * w[c];
+        const float S = carryS + wave_excl_suffix_sum(v, lane);
+        carryS += wave_sum(v);
+        const float s_i = 1.f - al[c] + 1e-10f;
+        float ga = gw[c] * Ti[c] - S / s_i;
+        if (g_alphas && ok) ga += g_alphas[base + i];
+        const float one_m = expf(-dl[c] * sg[c]);  // = 1 - alpha
+        float gs = ga * dl[c] * one_m;
+        if (g_dens && ok) gs += g_dens[base + i];
+        const float gdelta = ok ? ga * sg[c] * one_m : 0.f;
+        float after = __shfl_down(gdelta, 1, WAVE);
+        if (lane == 63) after = next_first;
+        next_first = __shfl(gdelta, 0, WAVE);
+        if (ok) {
+            const float y = o3[c] - 1.f;
+            const float dsig = y > 20.f ? 1.f : sigmoidf(y);  // softplus'
+            float4 o;
+            o.x = gcr * w[c] * cr[c] * (1.f - cr[c]);
+            o.y = gcg * w[c] * cg[c] * (1.f - cg[c]);
+            o.z = gcb * w[c] * cb[c] * (1.f - cb[c]);
+            o.w = gs * dsig;
+            *(float4*)(d_logits + (base + i) * 4) = o;
+            float gz = gd * w[c];
+            if (g_zvol) gz += g_zvol[base + i];
+            const float gdist = gdelta - ((i + 1 < N) ? after : 0.f);
+            if (d_z) d_z[base + i] = gz;
+            if (d_dist) d_dist[base + i] = gdist;
+            tot_c[c] = gdist + gz * uz;
+        }
+    }
+    // (segments in ascending order, like sampler_bwd_kernel's sample loop: the per-gaussian sums are then bit-identical to the stage's)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = c * 64 + lane;
+        if (i < N) {
+            const int o_ = perm[base + i];
+            if (o_ >= U) {
+                const int jj = o_ - U, g = jj / P;
+                const float nz = noise_g[(size_t)r * G * P + jj];
+                const float tot = tot_c[c];
+#pragma unroll
+                for (int gg = 0; gg < MAXG; ++gg) {
+                    if (gg == g) {
+                        const float raw = m[gg] + nz * s[gg];
+                        if (!(raw < 0.1f)) {  // the 0.1 clamp blocks the gradient, utils.py:214
+                            am[gg] += tot;
+                            as_[gg] += tot * nz;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const float gkl = g_loss_kl ? g_loss_kl[r] : 0.f;
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        am[g] = wave_sum(am[g]);
+        as_[g] = wave_sum(as_[g]);
+        if (g < G && lane == 0) {
+            size_t q = (size_t)r * G + g;
+            float m2 = kl_saved[q * 3], s2 = kl_saved[q * 3 + 1], mk = kl_saved[q * 3 + 2];
+            float s1 = s[g], m1 = m[g];
+            float scale = gkl * mk / (float)G;
             float dm = (m1 - m2) / (s2 * s2) * scale;
             float ds = (-(s2 / (s1 * s1)) / (s2 / s1 + 1e-8f) + s1 / (s2 * s2)) * scale;
             float tm = am[g] + dm + (g_gmeans ? g_gmeans[q] : 0.f);
@@ -1140,6 +1512,52 @@ int scenerf_hip_sampler_backward(const scenerf_cfg* cfg, const float* offsets, c
                                                   g_loss_kl, g_gmeans, g_gstds, R, cfg->n_pts_uni, cfg->n_gaussians,
                                                   cfg->n_pts_per_gaussian, cfg->n_samples, cfg->base_std, d_offsets);
     SRF_LAUNCH_CHECK("sampler_bwd_kernel");
+    return 0;
+}
+
+int scenerf_hip_ray_tail_forward(const scenerf_cfg* cfg, const float* logits, const float* dist_sorted, const float* z_sorted,
+                                 const float* gmeans, const float* gstds, int R, float* densities, float* alphas, float* weights,
+                                 float* depth, float* color, float* closest, float* weights_at_depth, int32_t* closest_idx,
+                                 float* loss_kl, float* som_means, float* som_vars, float* kl_saved, uint8_t* bmu_out,
+                                 scenerf_stream_t stream) {
+    if (check_cfg(cfg)) return 1;
+    SRF_CHECK(logits && dist_sorted && z_sorted && gmeans && gstds && densities && alphas && weights && depth && color && closest &&
+                  weights_at_depth && closest_idx && loss_kl && som_means && som_vars && kl_saved && R > 0, "ray_tail_forward: NULL argument");
+    const int N = cfg->n_samples;
+    hipStream_t s = as_stream(stream);
+    dim3 grid(cdiv(R, 4));
+    SrfLaunchScope ps(s, "ray_tail_fwd", 0, (double)R * (32.0 * N + 24.0));
+#define TF(C) ray_tail_fwd_kernel<C><<<grid, 256, 0, s>>>(logits, dist_sorted, z_sorted, gmeans, gstds, R, N, cfg->n_gaussians, cfg->som_sigma, cfg->kl_std_floor, densities, alphas, weights, depth, color, closest, weights_at_depth, closest_idx, loss_kl, som_means, som_vars, kl_saved, bmu_out)
+    if (N <= 64) TF(1);
+    else if (N <= 128) TF(2);
+    else if (N <= 256) TF(4);
+    else TF(8);
+#undef TF
+    SRF_LAUNCH_CHECK("ray_tail_fwd_kernel");
+    return 0;
+}
+
+int scenerf_hip_ray_tail_backward(const scenerf_cfg* cfg, const float* logits, const float* dist_sorted, const float* z_sorted, int R,
+                                  const float* g_depth, const float* g_color, const float* g_weights, const float* g_alphas,
+                                  const float* g_densities, const float* g_zvol, const float* offsets, const float* anchors,
+                                  const float* noise_g, const float* unit_dir, const float* gmeans, const float* gstds,
+                                  const int32_t* perm, const float* kl_saved, const float* g_loss_kl, const float* g_gmeans,
+                                  const float* g_gstds, float* d_logits, float* d_offsets, float* d_dist, float* d_z,
+                                  scenerf_stream_t stream) {
+    if (check_cfg(cfg)) return 1;
+    SRF_CHECK(logits && dist_sorted && z_sorted && g_depth && g_color && d_logits && offsets && anchors && noise_g && unit_dir && gmeans &&
+                  gstds && perm && kl_saved && d_offsets && R > 0, "ray_tail_backward: NULL argument");
+    const int N = cfg->n_samples;
+    hipStream_t s = as_stream(stream);
+    dim3 grid(cdiv(R, 4));
+    SrfLaunchScope ps(s, "ray_tail_bwd", 0, (double)R * (44.0 * N + 40.0));
+#define TB(C) ray_tail_bwd_kernel<C><<<grid, 256, 0, s>>>(logits, dist_sorted, z_sorted, R, N, g_depth, g_color, g_weights, g_alphas, g_densities, g_zvol, d_logits, d_dist, d_z, offsets, anchors, noise_g, unit_dir, gmeans, gstds, perm, kl_saved, g_loss_kl, g_gmeans, g_gstds, cfg->n_pts_uni, cfg->n_gaussians, cfg->n_pts_per_gaussian, cfg->base_std, d_offsets)
+    if (N <= 64) TB(1);
+    else if (N <= 128) TB(2);
+    else if (N <= 256) TB(4);
+    else TB(8);
+#undef TB
+    SRF_LAUNCH_CHECK("ray_tail_bwd_kernel");
     return 0;
 }
 

@@ -584,18 +584,17 @@ class RenderChunk(torch.autograd.Function):
         closest = torch.empty((R,), **f32)
         w_at = torch.empty((R,), **f32)
         closest_idx = torch.empty((R,), dtype=torch.int32, device=dev)
-        _capi.check(lib.scenerf_hip_composite_forward(run_m.logits.data_ptr(), dist_s.data_ptr(), z_s.data_ptr(), R, N,
-                                                      dens.data_ptr(), alphas.data_ptr(), weights.data_ptr(), depth.data_ptr(),
-                                                      color.data_ptr(), closest.data_ptr(), w_at.data_ptr(),
-                                                      closest_idx.data_ptr(), st), "composite_forward")
         loss_kl = torch.empty((R,), **f32)
         som_means = torch.empty((R, G), **f32)
         som_vars = torch.empty((R, G), **f32)
         kl_saved = torch.empty((R, G, 3), **f32)
         bmu = torch.empty((R, N), dtype=torch.uint8, device=dev) if maps.debug_aux is not None else None
-        _capi.check(lib.scenerf_hip_raysom_forward(C.byref(ccfg), gmeans.data_ptr(), gstds.data_ptr(), dist_s.data_ptr(),
-                                                   alphas.data_ptr(), R, loss_kl.data_ptr(), som_means.data_ptr(),
-                                                   som_vars.data_ptr(), kl_saved.data_ptr(), _capi.ptr(bmu), st), "raysom_forward")
+        # compositing + RaySOM: one launch, the alphas stay in the wave's registers for the SOM update (scenerf_hip.h: ray_tail)
+        _capi.check(lib.scenerf_hip_ray_tail_forward(C.byref(ccfg), run_m.logits.data_ptr(), dist_s.data_ptr(), z_s.data_ptr(),
+                                                     gmeans.data_ptr(), gstds.data_ptr(), R, dens.data_ptr(), alphas.data_ptr(),
+                                                     weights.data_ptr(), depth.data_ptr(), color.data_ptr(), closest.data_ptr(),
+                                                     w_at.data_ptr(), closest_idx.data_ptr(), loss_kl.data_ptr(), som_means.data_ptr(),
+                                                     som_vars.data_ptr(), kl_saved.data_ptr(), _capi.ptr(bmu), st), "ray_tail_forward")
         # keep what backward needs (plain attributes: these are internal buffers, not graph tensors)
         ctx.cfg, ctx.ccfg, ctx.maps, ctx.mlp, ctx.mlpg = cfg, ccfg, maps, mlp, mlpg
         ctx.keep = dict(R=R, anchors=anchors, noise_g=noise_g, unit_dir=unit_dir, gmeans=gmeans, gstds=gstds, perm=perm,
@@ -644,20 +643,15 @@ class RenderChunk(torch.autograd.Function):
                                                                               g_weights, g_zvol))
         run_m, run_g = k["run_m"], k["run_g"]
         d_logits = torch.empty((R * N, 4), **f32)
-        d_dist = torch.empty((R, N), **f32)
-        d_z = torch.empty((R, N), **f32)
-        _capi.check(lib.scenerf_hip_composite_backward(run_m.logits.data_ptr(), k["dist_s"].data_ptr(), k["z_s"].data_ptr(), R, N,
-                                                       g_depth.data_ptr(), g_color.data_ptr(), _capi.ptr(g_weights),
-                                                       _capi.ptr(g_alphas), _capi.ptr(g_dens), _capi.ptr(g_zvol),
-                                                       d_logits.data_ptr(), d_dist.data_ptr(), d_z.data_ptr(), st),
-                    "composite_backward")
         d_off = torch.empty((R, G, 2), **f32)
-        _capi.check(lib.scenerf_hip_sampler_backward(C.byref(ccfg), run_g.logits.data_ptr(), k["anchors"].data_ptr(),
-                                                     k["noise_g"].data_ptr(), k["unit_dir"].data_ptr(), k["gmeans"].data_ptr(),
-                                                     k["gstds"].data_ptr(), k["perm"].data_ptr(), d_dist.data_ptr(),
-                                                     d_z.data_ptr(), k["kl_saved"].data_ptr(), _capi.ptr(g_kl),
-                                                     _capi.ptr(g_gmeans), _capi.ptr(g_gstds), R, d_off.data_ptr(), st),
-                    "sampler_backward")
+        # compositing backward + sampler / KL backward: one launch, d_dist / d_z never reach HBM (scenerf_hip.h: ray_tail)
+        _capi.check(lib.scenerf_hip_ray_tail_backward(C.byref(ccfg), run_m.logits.data_ptr(), k["dist_s"].data_ptr(), k["z_s"].data_ptr(), R,
+                                                      g_depth.data_ptr(), g_color.data_ptr(), _capi.ptr(g_weights), _capi.ptr(g_alphas),
+                                                      _capi.ptr(g_dens), _capi.ptr(g_zvol), run_g.logits.data_ptr(),
+                                                      k["anchors"].data_ptr(), k["noise_g"].data_ptr(), k["unit_dir"].data_ptr(),
+                                                      k["gmeans"].data_ptr(), k["gstds"].data_ptr(), k["perm"].data_ptr(),
+                                                      k["kl_saved"].data_ptr(), _capi.ptr(g_kl), _capi.ptr(g_gmeans), _capi.ptr(g_gstds),
+                                                      d_logits.data_ptr(), d_off.data_ptr(), None, None, st), "ray_tail_backward")
         want_maps = bool(ctx.needs_input_grad[10])
         # The gaussian head's backward (R*G rows: small grids) is independent of the radiance MLP's backward: run it
         # on a side stream so its workgroups fill the gaps of the big GEMMs.  Both scatter into the same map-gradient

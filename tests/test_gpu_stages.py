@@ -411,6 +411,68 @@ def test_raysom_forward_and_sampler_backward(case):
     torch.testing.assert_close(doff.cpu(), offs.grad, rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("N,U,P", [(64, 32, 8), (96, 64, 8), (128, 64, 16), (512, 256, 64), (2, 2, 1)])
+def test_fused_ray_tail_equals_the_stage_kernels(N, U, P):
+    """scenerf_hip_ray_tail_forward / _backward (what RenderChunk launches: compositing + RaySOM in one kernel, their autograd + the
+    sampler's in one kernel) against the four stage entries on the same inputs: every output bit-identical."""
+    lib = _capi.load()
+    G, R = 4, 301
+    uniform_only = (N == U)
+    rcfg = RenderConfig.bundlefusion(n_pts_uni=0, n_pts_per_gaussian=1) if uniform_only else RenderConfig.kitti(n_pts_uni=U, n_pts_per_gaussian=P)
+    cc = rcfg.to_c()
+    assert cc.n_samples == N
+    gen = torch.Generator().manual_seed(N)
+    logits = torch.randn(R * N, 4, generator=gen)
+    logits[:, 3] -= 1.5
+    dist = torch.sort(torch.rand(R, N, generator=gen) * 90 + 0.1, dim=1).values
+    dist[:, N // 2] = dist[:, N // 2 - 1] if N > 2 else dist[:, N // 2]       # a tie
+    z = dist * 0.97
+    gm = torch.sort(torch.rand(R, G, generator=gen) * 80 + 2, dim=1).values
+    gs = torch.rand(R, G, generator=gen) * 4 + 1.5
+    perm = torch.stack([torch.randperm(N, generator=gen) for _ in range(R)]).to(torch.int32)
+    offs = torch.randn(R, G, 2, generator=gen)
+    anchors = torch.linspace(12.5, 87.5, G)
+    noise = torch.randn(R, G * max(P, 1), generator=gen)
+    unit = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=1)
+    ups = [torch.randn(s, generator=gen) for s in ((R,), (R, 3), (R, N), (R, N), (R, N), (R, N), (R,), (R, G), (R, G))]
+    gd, gc, gw, ga, gden, gz, gkl, ggm, ggs = [dv(t) for t in ups]
+    L, D, Z, GM, GS, PM, OF, AN, NZ, UN = [dv(t) for t in (logits, dist, z, gm, gs, perm, offs, anchors, noise, unit)]
+    f = lambda *s_: torch.empty(s_, device=DEV)
+
+    def outs():
+        return dict(dens=f(R, N), al=f(R, N), w=f(R, N), dep=f(R), col=f(R, 3), clo=f(R), wat=f(R), ci=torch.empty(R, dtype=torch.int32, device=DEV),
+                    lk=f(R), sm=f(R, G), sv=f(R, G), ks=f(R, G, 3), bmu=torch.empty((R, N), dtype=torch.uint8, device=DEV))
+    a, b = outs(), outs()
+    _capi.check(lib.scenerf_hip_composite_forward(L.data_ptr(), D.data_ptr(), Z.data_ptr(), R, N, a["dens"].data_ptr(), a["al"].data_ptr(),
+                                                  a["w"].data_ptr(), a["dep"].data_ptr(), a["col"].data_ptr(), a["clo"].data_ptr(),
+                                                  a["wat"].data_ptr(), a["ci"].data_ptr(), _st()), "composite_forward")
+    _capi.check(lib.scenerf_hip_raysom_forward(C.byref(cc), GM.data_ptr(), GS.data_ptr(), D.data_ptr(), a["al"].data_ptr(), R, a["lk"].data_ptr(),
+                                               a["sm"].data_ptr(), a["sv"].data_ptr(), a["ks"].data_ptr(), a["bmu"].data_ptr(), _st()), "raysom_forward")
+    _capi.check(lib.scenerf_hip_ray_tail_forward(C.byref(cc), L.data_ptr(), D.data_ptr(), Z.data_ptr(), GM.data_ptr(), GS.data_ptr(), R,
+                                                 b["dens"].data_ptr(), b["al"].data_ptr(), b["w"].data_ptr(), b["dep"].data_ptr(), b["col"].data_ptr(),
+                                                 b["clo"].data_ptr(), b["wat"].data_ptr(), b["ci"].data_ptr(), b["lk"].data_ptr(), b["sm"].data_ptr(),
+                                                 b["sv"].data_ptr(), b["ks"].data_ptr(), b["bmu"].data_ptr(), _st()), "ray_tail_forward")
+    for k_ in a:
+        assert torch.equal(a[k_], b[k_]), "forward output %s differs" % k_
+    dl1, dd1, dz1, do1 = f(R * N, 4), f(R, N), f(R, N), f(R, G, 2)
+    dl2, dd2, dz2, do2, do3 = f(R * N, 4), f(R, N), f(R, N), f(R, G, 2), f(R, G, 2)
+    _capi.check(lib.scenerf_hip_composite_backward(L.data_ptr(), D.data_ptr(), Z.data_ptr(), R, N, gd.data_ptr(), gc.data_ptr(), gw.data_ptr(),
+                                                   ga.data_ptr(), gden.data_ptr(), gz.data_ptr(), dl1.data_ptr(), dd1.data_ptr(), dz1.data_ptr(), _st()),
+                "composite_backward")
+    _capi.check(lib.scenerf_hip_sampler_backward(C.byref(cc), OF.data_ptr(), AN.data_ptr(), NZ.data_ptr(), UN.data_ptr(), GM.data_ptr(), GS.data_ptr(),
+                                                 PM.data_ptr(), dd1.data_ptr(), dz1.data_ptr(), a["ks"].data_ptr(), gkl.data_ptr(), ggm.data_ptr(),
+                                                 ggs.data_ptr(), R, do1.data_ptr(), _st()), "sampler_backward")
+    for (o_, dd_, dz_) in ((do2, dd2, dz2), (do3, None, None)):
+        _capi.check(lib.scenerf_hip_ray_tail_backward(C.byref(cc), L.data_ptr(), D.data_ptr(), Z.data_ptr(), R, gd.data_ptr(), gc.data_ptr(),
+                                                      gw.data_ptr(), ga.data_ptr(), gden.data_ptr(), gz.data_ptr(), OF.data_ptr(), AN.data_ptr(),
+                                                      NZ.data_ptr(), UN.data_ptr(), GM.data_ptr(), GS.data_ptr(), PM.data_ptr(), a["ks"].data_ptr(),
+                                                      gkl.data_ptr(), ggm.data_ptr(), ggs.data_ptr(), dl2.data_ptr(), o_.data_ptr(),
+                                                      _capi.ptr(dd_), _capi.ptr(dz_), _st()), "ray_tail_backward")
+    assert torch.equal(dl1, dl2) and torch.equal(dd1, dd2) and torch.equal(dz1, dz2)
+    assert torch.equal(do1, do2) and torch.equal(do1, do3)
+    assert bool(torch.isfinite(do1).all()) and float(do1.abs().max()) > 0
+
+
 # ------------------------------------------------------------------------------------------------ MLP pass
 def _mlp_case(case, precision, which):
     """Feed the oracle's x_in to the HIP MLP pass; returns everything needed to compare."""
