@@ -31,7 +31,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_d;
 #define DF_K (3 * SCENERF_D_HIDDEN)        // 1536
 #define DF_NCH (DF_K / 16)                 // 96 chunks
 #define DF_PA 4                            // dH fragments in flight per wave
+#ifndef DF_CG
 #define DF_CG 96                           // channels per epilogue round: up to three column tiles (a lane takes channel l and l + 64)
+#endif
+#define DF_RT (DF_CG / 32)                 // column tiles per epilogue round
+#ifndef DF_WGS
+#define DF_WGS 2                           // workgroups per CU the register budget is set for
+#endif
 #define DF_CLD (DF_CG + 4)                 // staged row stride in floats
 // LDS (epilogue only): staged tile, taps of the level
 #define DF_L_CS 0
@@ -91,7 +97,7 @@ extern "C" int scenerf_hip_test_dfeat_cyc(unsigned long long* ptr) { return (int
 
 // NTP = column tiles (32 channels each) whose accumulators a pass keeps in registers
 template <int NTP>
-__global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
+__global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,6 +116,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
     // second item look again.
     constexpr int DF_SCAN_G = 8;       // groups of DF_THREADS tiles per sweep
     int n_items = 0x7fffffff;
+    DF_STAMP()   // entry (before the item scan)
     for (int want = blockIdx.x; want < n_items; want += gridDim.x) {
     int tile = -1, pass0 = 0;
     {
@@ -209,8 +216,8 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
         constexpr int NS = df_ns(NTP), LA = NS - 1;       // ring stages, steps issued ahead of the one being multiplied
         static_assert(NS * STG <= df_lds(NTP), "stages must fit the workgroup's LDS");
         static_assert(NSTEP > LA, "the ring is shorter than the K loop");
-        auto swz = [](int r) { return KSB == 128 ? (r >> 1) & 7 : (r >> 2) & 3; };
-        static_assert(KSB == 128 || KSB == 64, "swizzle is written for 8 or 4 slots per row");
+        auto swz = [](int r) { return KSB == 256 ? r & 15 : KSB == 128 ? (r >> 1) & 7 : (r >> 2) & 3; };
+        static_assert(KSB == 256 || KSB == 128 || KSB == 64, "swizzle is written for 16, 8 or 4 slots per row");
         f32x16_d acc[NTP];
 #pragma unroll
         for (int t = 0; t < NTP; ++t)
@@ -244,18 +251,27 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
         auto issue = [&](const int step, const int stage) __attribute__((always_inline)) {
             const unsigned sb = lds0 + stage * STG;
             const unsigned ko = (unsigned)step * KSB;
+            // (DF_VAR_*: development knobs -- which of the two DMA streams the K loop waits for; results are garbage with them)
 #pragma unroll
-            for (int i = 0; i < NPW_; ++i)
+            for (int i = 0; i < NPW_; ++i) {
+#ifdef DF_VAR_NOW
+                if (step >= LA) continue;
+#endif
                 if (okW[i]) df_glds16(srcW[i] + ko, __builtin_amdgcn_readfirstlane(sb + DF_BM * KSB + (wv * NPW_ + i) * 1024));
+            }
 #pragma unroll
-            for (int i = 0; i < NPA_; ++i)
+            for (int i = 0; i < NPA_; ++i) {
+#ifdef DF_VAR_NOA
+                if (step >= LA) continue;
+#endif
                 df_glds16(srcA[i] + ko, __builtin_amdgcn_readfirstlane(sb + (wv * NPA_ + i) * 1024));
+            }
         };
         // "step s has landed": when a wave waits for it, steps up to s + LA - 1 have been issued (step s + LA follows the barrier), so at
         // most the pieces of the LA - 1 younger steps may be outstanding (issued in order, retired in order); the count per step is
         // NPA_ + nw, nw wave-uniform: one immediate per possible nw
 #define DF_WAIT_K(k) if (nw == (k)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * (NPA_ + (k)) < 63 ? (LA - 1) * (NPA_ + (k)) : 63) : "memory");
-        static_assert(NPW_ <= 6, "one wait immediate per weight-piece count");
+        static_assert(NPW_ <= 10, "one wait immediate per weight-piece count");
         __syncthreads();   // (the previous pass's epilogue is done with the LDS the stages live in)
 #pragma unroll
         for (int q = 0; q < LA; ++q) issue(q, q);
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
 #pragma unroll 1
         for (int step = 0; step < NSTEP; ++step) {
             if (step + LA < NSTEP) {
-                DF_WAIT_K(0) DF_WAIT_K(1) DF_WAIT_K(2) DF_WAIT_K(3) DF_WAIT_K(4) DF_WAIT_K(5) DF_WAIT_K(6)
+                DF_WAIT_K(0) DF_WAIT_K(1) DF_WAIT_K(2) DF_WAIT_K(3) DF_WAIT_K(4) DF_WAIT_K(5) DF_WAIT_K(6) DF_WAIT_K(7) DF_WAIT_K(8) DF_WAIT_K(9) DF_WAIT_K(10)
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last LA steps: nothing younger is issued any more)
             }
@@ -274,15 +290,35 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
             if (step + LA < NSTEP) issue(step + LA, stage_in);
             const char* const sa = lds + stage * STG;
             const char* const sw = sa + DF_BM * KSB;
+            if (np == NTP) {
+                // the common case, a full pass: every fragment of the step is requested before the first MFMA (straight-line code: the
+                // guarded form below compiles to read -> wait -> MFMA six times over, ~120 cycles of LDS latency exposed per MFMA --
+                // that, not memory, was 80 % of this kernel: without any DMA at all it still took 187 of 230 us; r03)
+                bf16x8_d av[KSB / 32], bv[KSB / 32][NTP];
 #pragma unroll
-            for (int j = 0; j < KSB / 32; ++j) {
-                const bf16x8_d av = *(const bf16x8_d*)(sa + frow * KSB + (((2 * j + fh) ^ swz(frow)) << 4));
+                for (int j = 0; j < KSB / 32; ++j) {
+                    av[j] = *(const bf16x8_d*)(sa + frow * KSB + (((2 * j + fh) ^ swz(frow)) << 4));
 #pragma unroll
-                for (int t = 0; t < NTP; ++t) {
-                    if (t < np) {
+                    for (int t = 0; t < NTP; ++t) {
                         const int wr = t * 32 + (lane & 31);
-                        const bf16x8_d bv = *(const bf16x8_d*)(sw + wr * KSB + (((2 * j + fh) ^ swz(wr)) << 4));
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[t], 0, 0, 0);
+                        bv[j][t] = *(const bf16x8_d*)(sw + wr * KSB + (((2 * j + fh) ^ swz(wr)) << 4));
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < KSB / 32; ++j)
+#pragma unroll
+                    for (int t = 0; t < NTP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][t], av[j], acc[t], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < KSB / 32; ++j) {
+                    const bf16x8_d av = *(const bf16x8_d*)(sa + frow * KSB + (((2 * j + fh) ^ swz(frow)) << 4));
+#pragma unroll
+                    for (int t = 0; t < NTP; ++t) {
+                        if (t < np) {
+                            const int wr = t * 32 + (lane & 31);
+                            const bf16x8_d bv = *(const bf16x8_d*)(sw + wr * KSB + (((2 * j + fh) ^ swz(wr)) << 4));
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[t], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -309,7 +345,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
             }
             float* const g = p.gmap[s];
             const long gst = p.st[s], gsc = p.sc[s];
-            for (int tr = tb; tr < te; tr += 3) {
+            for (int tr = tb; tr < te; tr += DF_RT) {
                 __syncthreads();   // (the K loop / the previous round is done with this LDS)
                 if (taps_level != s) {
                     for (int i = tid; i < 512; i += DF_THREADS) {
@@ -324,7 +360,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
                 const int row = 32 * wv + (lane & 31), hi = lane >> 5;
 #pragma unroll
                 for (int t = 0; t < NTP; ++t) {
-                    if (t >= tr && t < tr + 3 && t < te) {
+                    if (t >= tr && t < tr + DF_RT && t < te) {
                         const int cb = (t - tr) * 32;
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -340,7 +376,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void dfeat_kernel(DfeatArgs p) {
                 // instead of 128 rows -- 256-byte contiguous runs of the (H,W,C) accumulator.
                 int s3, cbase;
                 tile_level(t0 + tr, s3, cbase);
-                const int nch = min(32 * (min(tr + 3, te) - tr), p.C[s] - cbase);   // valid channels of the round
+                const int nch = min(32 * (min(tr + DF_RT, te) - tr), p.C[s] - cbase);   // valid channels of the round
                 const bool ok0 = lane < nch, ok1 = lane + 64 < nch;
                 float* const gl = g + (size_t)(cbase + lane) * gsc;
                 const long g64 = 64 * gsc;
