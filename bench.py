@@ -42,7 +42,7 @@ PEAK_FP32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
-def pmc_traffic(logical_name):
+def pmc_traffic(logical_name, rows=None):
     """HBM bytes per launch of the kernel FUNCTION that runs `logical_name`, from the committed rocprofv3 --pmc passes
     (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/pmc_hbm.py).  PMC counters cannot be read from inside the
     process, so this is the last profiled value of the same bench command, not a live reading; None if absent."""
@@ -69,6 +69,8 @@ def pmc_traffic(logical_name):
         return None
     # the dominant launch of a logical kernel is the largest grid of its function (main MLP, not the 4-point gaussian head)
     sized = [(int(k.split("@grid=")[1]), k, v) for k, v in d.items() if k.startswith(fn) and "@grid=" in k]
+    if sized and rows and logical_name.startswith("mlp_") and any(g == (rows + 127) // 128 * 256 for g, _, _ in sized):
+        sized = [t for t in sized if t[0] == (rows + 127) // 128 * 256]     # the 128-row kernels: one 256-thread block per 128 rows
     if sized and (logical_name.startswith("mlp_") or logical_name == "gemm_wgrad_fc"):
         _, k, v = max(sized)
         return {"bytes_per_launch": round(v["hbm_bytes_per_launch"]), "kernel_fn": k, "source": os.path.basename(files[-1]),
@@ -355,7 +357,7 @@ def _rooflines(kernels, args, nprof, value_per_gpu, world):
         tot_f = sum(k["flops"] for k in mfma)
         tot_t = sum(k["total_ms"] for k in mfma)
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom["name"]),
+                "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom["name"], getattr(args, "rows_per_launch", None)),
                 "avg_launch_us": round(dom["avg_us"], 2), "flops_per_launch": dom["flops"] / dom["launches"],
                 "all_mfma_kernels_achieved": round(tot_f / (tot_t * 1e-3) / 1e12, 2),
                 "all_mfma_kernels_frac": round(tot_f / (tot_t * 1e-3) / 1e12 / peak, 4),
@@ -424,8 +426,17 @@ def _composite_probe(R, N, reps=20):
                                                     None, None, None, None, offs.data_ptr(), anchors.data_ptr(), noise.data_ptr(), unit.data_ptr(),
                                                     gm.data_ptr(), gs.data_ptr(), perm.data_ptr(), ks.data_ptr(), None, None, None, dl.data_ptr(),
                                                     do.data_ptr(), None, None, st)
-    out = {"rays": R, "samples": N, "kernels": "ray_tail_fwd (compositing + RaySOM), ray_tail_bwd (compositing + sampler / KL backward)"}
-    for name, fn, bpr in (("fwd", fwd, 32 * N + 24), ("bwd", bwd, 44 * N + 40)):
+    dd, dz = f(R, N), f(R, N)
+    cfwd = lambda: lib.scenerf_hip_composite_forward(logits.data_ptr(), dist.data_ptr(), z.data_ptr(), R, N, dens.data_ptr(), al.data_ptr(),
+                                                     w.data_ptr(), dep.data_ptr(), col.data_ptr(), clo.data_ptr(), wat.data_ptr(), ci.data_ptr(), st)
+    cbwd = lambda: lib.scenerf_hip_composite_backward(logits.data_ptr(), dist.data_ptr(), z.data_ptr(), R, N, gd.data_ptr(), gc.data_ptr(), None,
+                                                      None, None, None, dl.data_ptr(), dd.data_ptr(), dz.data_ptr(), st)
+    out = {"rays": R, "samples": N,
+           "note": "fwd / bwd = the compositing pass proper (composite_fwd / composite_bwd stage kernels: alpha compositing only, the pass the "
+                   "HBM roofline of SURVEY 8d is defined on); tail_fwd / tail_bwd = what a training chunk launches (ray_tail_*: compositing + "
+                   "RaySOM, compositing + sampler / KL backward), priced on the same compositing bytes -- the SOM update's exp / log per "
+                   "(sample, gaussian) makes the fused forward compute-bound"}
+    for name, fn, bpr in (("fwd", cfwd, 32 * N + 24), ("bwd", cbwd, 48 * N + 40), ("tail_fwd", fwd, 32 * N + 24), ("tail_bwd", bwd, 44 * N + 40)):
         for _ in range(3):
             assert fn() == 0, lib.scenerf_hip_last_error()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -488,7 +499,7 @@ def _rank_census(rank, world, local, dev, dry):
             "devices": devs}
 
 
-def _leg_roofline(run, nprof, args, samples, value_per_gpu):
+def _leg_roofline(run, nprof, args, samples, value_per_gpu, rows_per_launch=None):
     """roofline objects of a side leg: ``run`` under the in-library HIP-event profiler."""
     import copy
     lib = _capi.load()
@@ -501,6 +512,7 @@ def _leg_roofline(run, nprof, args, samples, value_per_gpu):
     lib.scenerf_hip_profile_enable(0)
     a2 = copy.copy(args)
     a2.samples = samples
+    a2.rows_per_launch = rows_per_launch
     roof, roof_c = _rooflines(kernels, a2, nprof, value_per_gpu, 1)
     if roof_c:
         roof_c.pop("at_inference_chunk", None)
@@ -547,7 +559,7 @@ def bundlefusion_leg(args, dev, steps=10, warmup=3):
     dt = (time.perf_counter() - t0) / steps
     assert torch.isfinite(last).item()
     value = R / dt
-    roof, roof_c = _leg_roofline(step, 2, args, U + 4 * P, value)
+    roof, roof_c = _leg_roofline(step, 2, args, U + 4 * P, value, R * (U + 4 * P))
     if roof:
         roof.pop("dense_equivalent", None)
     return {"metric": "rays/sec (training fwd+bwd), BundleFusion 640x480, 96 samples/ray", "value": round(value, 1), "unit": "rays/s",
@@ -583,7 +595,7 @@ def inference_leg(args, dev, frames=2, stride=2, chunk=4096, samples=512):
     dt = (time.perf_counter() - t0) / frames
     assert bool(torch.isfinite(last["depth"]).all())
     value = n / dt
-    roof, roof_c = _leg_roofline(lambda: frame(False), 1, a2, samples, None)
+    roof, roof_c = _leg_roofline(lambda: frame(False), 1, a2, samples, None, chunk * samples)
     model.release_inference_engine()
     U, P = sample_split(samples)
     return {"metric": "rays/sec (novel-view inference, %d samples/ray, hipGraph-replayed static chunks)" % samples, "value": round(value, 1),
@@ -707,6 +719,7 @@ def main():
             torch.cuda.synchronize()
             kernels = _capi.profile_collect()
             lib.scenerf_hip_profile_enable(0)
+            args.rows_per_launch = R * args.samples
             roof, roof_c = _rooflines(kernels, args, nprof, value / world, world)
         if args.kernels_json:
             with open(args.kernels_json, "w") as f:

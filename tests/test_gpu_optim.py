@@ -48,7 +48,8 @@ def test_fused_adamw_follows_torch_adamw(wd):
     # state_dict round trip into a fresh optimizer continues the same trajectory
     pc = [torch.nn.Parameter(b.detach().clone()) for b in pb]
     oc = FusedAdamW(pc, lr=1.0)
-    oc.load_state_dict(ob.state_dict())
+    import copy
+    oc.load_state_dict(copy.deepcopy(ob.state_dict()))     # (load_state_dict itself may alias same-dtype, same-device state tensors)
     g = [torch.randn(b.shape, generator=gen).to(DEV) for b in pb]
     for b, c, gg in zip(pb, pc, g):
         b.grad, c.grad = gg.clone(), gg.clone()

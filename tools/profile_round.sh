@@ -7,7 +7,7 @@ R=$(pwd)
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eager-baseline --no-fp32-mode --no-roofline"
+CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eager-baseline --no-fp32-mode --no-roofline --no-extra-legs"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_kt -o p -- $CMD > $O/${tag}_kt.log 2>&1
 f=$(ls $O/${tag}_kt/*kernel_stats.csv 2>/dev/null | head -1)
 if [ -n "$f" ]; then
