@@ -81,6 +81,7 @@ struct DfeatArgs {
     long st[SCENERF_N_SCALES], sc[SCENERF_N_SCALES];   // element strides of gmap per texel / per channel
     int C[SCENERF_N_SCALES];
     unsigned levels;          // pyramid levels this launch handles (bit s)
+    int direct;               // 1: workgroup b IS tile b (a launch whose every active tile has exactly one pass: the finest level alone)
 };
 
 #ifdef H_CYC   // development build: per-workgroup time stamps of wave 0 (tools/dfeat_probe.py)
@@ -119,7 +120,13 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
     DF_STAMP()   // entry (before the item scan)
     for (int want = blockIdx.x; want < n_items; want += gridDim.x) {
     int tile = -1, pass0 = 0;
-    {
+    if (p.direct) {
+        // one workgroup per tile and at most one pass per tile: no item search (the scan below costs 12.8k of a tile's 120k cycles; r03)
+        n_items = 0;                   // (no second item)
+        tile = blockIdx.x;
+        if (tile >= (p.M + DF_BM - 1) / DF_BM || !((unsigned)p.tile_mask[tile] & p.live)) return;
+        __syncthreads();
+    } else {
         int* const s_wc = (int*)lds;   // [4 g + w] pass count of wave w's tiles in group g; [4 DF_SCAN_G ..] the item found: tile, pass
         const int ntile = (p.M + DF_BM - 1) / DF_BM;
         int base = 0;
@@ -470,7 +477,9 @@ int launch_dfeat_scatter(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
     if (fine3) {
         p.levels = 1u;
         p.live = p.levels & have;
+        p.direct = 1;     // level 0 alone: <= 3 column tiles = one pass per tile, one workgroup per tile
         dfeat_kernel<3><<<tiles, DF_THREADS, df_lds(3), s>>>(p);
+        p.direct = 0;
     }
     p.levels = fine3 ? 30u : 31u;
     bool rest = false;
