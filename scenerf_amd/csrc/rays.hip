@@ -952,20 +952,26 @@ __global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restri
         closest_idx[r] = bi;
     }
     // ---- RaySOM update + KL (raysom_fwd_kernel) on the registers' (distance, alpha)
-    float sw[MAXG], swd[MAXG];
+    // (the per-sample update weights of pass 1 are kept for pass 2 -- C x G registers -- instead of being recomputed: the stage kernel
+    // evaluates the same expressions twice, the values are identical)
+    float sw[MAXG], swd[MAXG], wk[C][MAXG];
 #pragma unroll
     for (int g = 0; g < MAXG; ++g) { sw[g] = 0.f; swd[g] = 0.f; }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const int i = c * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) wk[c][g] = 0.f;
         if (i < N) {
             float pz1[MAXG], pbest;
             int bmu;
             raysom_sample(d[c], al[c] + 1e-8f, m, s, var, G, s_p12[wv], pz1, pbest, bmu);
+            if (bmu_out) bmu_out[base + i] = (uint8_t)bmu;
 #pragma unroll
             for (int g = 0; g < MAXG; ++g) {
                 if (g < G) {
                     float wgt = s_nb[wv][g][bmu] * pz1[g] / pbest + 1e-5f;
+                    wk[c][g] = wgt;
                     sw[g] += wgt;
                     swd[g] += wgt * d[c];
                 }
@@ -986,16 +992,11 @@ __global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restri
     for (int c = 0; c < C; ++c) {
         const int i = c * 64 + lane;
         if (i < N) {
-            float pz1[MAXG], pbest;
-            int bmu;
-            raysom_sample(d[c], al[c] + 1e-8f, m, s, var, G, s_p12[wv], pz1, pbest, bmu);
-            if (bmu_out) bmu_out[base + i] = (uint8_t)bmu;
 #pragma unroll
             for (int g = 0; g < MAXG; ++g) {
                 if (g < G) {
-                    float wgt = s_nb[wv][g][bmu] * pz1[g] / pbest + 1e-5f;
                     float e = d[c] - nm[g];
-                    sv[g] += wgt * (e * e);
+                    sv[g] += wk[c][g] * (e * e);
                 }
             }
         }

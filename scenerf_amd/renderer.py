@@ -133,6 +133,7 @@ class MapHolder:
         self.hwc: List[torch.Tensor] = []
         self.shapes = []
         self.gmaps: Optional[List[torch.Tensor]] = None
+        self._gflat: Optional[torch.Tensor] = None      # the one allocation the five accumulators are views of
         self.debug_aux: Optional[Dict[str, torch.Tensor]] = None   # dict when the session was opened with debug_aux=True
 
     def convert(self, chw: Sequence[torch.Tensor]) -> None:
@@ -177,11 +178,20 @@ class MapHolder:
         old[i].copy_(src)
         return old[i]
 
-    def _alloc_gmaps(self, fill) -> None:
+    def _alloc_gmaps(self, zero_now: bool) -> None:
         dev = self.hwc[0].device
-        # (H,W,C) accumulators, transposed once at the end; the direct scales accumulate in the (C,H,W) result itself
-        self.gmaps = [fill((c, h, w) if i in self.cfg.direct_scales else (h, w, c), dtype=torch.float32, device=dev)
-                      for i, (c, h, w) in enumerate(self.shapes)]
+        # (H,W,C) accumulators, transposed once at the end; the direct scales accumulate in the (C,H,W) result itself.  One flat
+        # allocation carved into the five maps: ONE fill launch zeroes them all (five tensors cost five to six multi-tensor launches)
+        shapes = [(c, h, w) if i in self.cfg.direct_scales else (h, w, c) for i, (c, h, w) in enumerate(self.shapes)]
+        sizes = [a * b * c for a, b, c in shapes]
+        pad = [(n + 63) // 64 * 64 for n in sizes]          # 256-byte aligned starts
+        self._gflat = torch.empty(sum(pad), dtype=torch.float32, device=dev)
+        self.gmaps, off = [], 0
+        for shp, n, p in zip(shapes, sizes, pad):
+            self.gmaps.append(self._gflat[off:off + n].view(*shp))
+            off += p
+        if zero_now:
+            self._gflat.zero_()
 
     def prefill_grad_accumulators(self) -> None:
         """Called from the forward when a map gradient will be asked for: the accumulators (217 MB at the KITTI shapes) are zeroed on
@@ -190,17 +200,18 @@ class MapHolder:
             return
         dev = self.hwc[0].device
         main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-        self._alloc_gmaps(torch.empty)
+        self._alloc_gmaps(False)
         side.wait_stream(main)    # the blocks may have just been freed by work still queued on the main stream
         with torch.cuda.stream(side):
-            torch._foreach_zero_(self.gmaps)   # one launch for the five accumulators
+            self._gflat.zero_()
             self._gmaps_ready = side.record_event()
-        for t in self.gmaps:     # if no backward ever waits on the event (graph dropped, exception): the allocator must not hand
-            t.record_stream(side)  # these blocks to a main-stream tenant while the side-stream fill is still pending
+        # if no backward ever waits on the event (graph dropped, exception): the allocator must not hand this block to a main-stream
+        # tenant while the side-stream fill is still pending
+        self._gflat.record_stream(side)
 
     def grad_accumulators(self) -> List[torch.Tensor]:
         if self.gmaps is None:
-            self._alloc_gmaps(torch.zeros)
+            self._alloc_gmaps(True)
         ev, self._gmaps_ready = getattr(self, "_gmaps_ready", None), None
         if ev is not None:
             torch.cuda.current_stream(self.gmaps[0].device).wait_event(ev)
@@ -232,7 +243,7 @@ class PrepareMaps(torch.autograd.Function):
         holder.grad_accumulators()   # (orders this stream after the zero fills if no chunk's backward has done so)
         with _on(holder.gmaps[0].device):
             outs = PrepareMaps._transpose_back(ctx, holder, lib)
-        holder.gmaps = None
+        holder.gmaps = holder._gflat = None
         return (None,) + tuple(outs)
 
     @staticmethod
