@@ -50,14 +50,16 @@ typedef const __attribute__((address_space(4))) int* desc_ptr;   // constant add
 #define FD_STAGE(d) (((d) >> 25) & 7)
 #define F_MAXCH SCENERF_CHUNK_TABLE_STRIDE   // 704:     // 666 chunks with all five scales + header + zero padding (the pipeline reads a few entries past the end)
 
-// Per-device cache of a host-built descriptor table (one per kernel family): built once per (device, segment layout), uploaded with an
-// asynchronous copy on the caller's stream from a host image that stays alive (no stream synchronisation, no blocking copy).  A first
-// use inside a hipGraph capture is not capturable -- call scenerf_hip_prepare before capturing.
+// Per-device cache of a host-built descriptor table (one per kernel family): built once per (device, segment layout) and uploaded with
+// a blocking copy before its pointer is handed out -- the table is shared by every stream of the device.  A first use inside a
+// hipGraph capture is not capturable -- call scenerf_hip_prepare before capturing.
+#define SRF_DESC_LAYOUTS 4        // segment layouts (map channel counts) kept per device; the oldest is replaced beyond that
 struct SrfDescCache {
     std::mutex mu;
     struct Slot {
-        int seg_len[5] = {-1, -1, -1, -1, -1};
-        int* d_desc = nullptr;
+        int seg_len[SRF_DESC_LAYOUTS][5];
+        int* d_desc[SRF_DESC_LAYOUTS] = {nullptr, nullptr, nullptr, nullptr};
+        int next = 0;
     } slot[SRF_MAX_DEVICES];
 };
 int srf_desc_cache_get(SrfDescCache& C, const scenerf_cfg* cfg, hipStream_t s, int (*build)(const scenerf_cfg*, std::vector<int>&),

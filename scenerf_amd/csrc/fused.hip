@@ -365,22 +365,30 @@ int srf_desc_cache_get(SrfDescCache& C, const scenerf_cfg* cfg, hipStream_t s, i
     SRF_CHECK(dev >= 0 && dev < SRF_MAX_DEVICES, "no current HIP device");
     std::lock_guard<std::mutex> lk(C.mu);
     SrfDescCache::Slot& S = C.slot[dev];
-    bool same = S.d_desc != nullptr;
-    for (int i = 0; i < 5; ++i) same = same && S.seg_len[i] == cfg->map_C[i];
-    if (!same) {
-        // a new layout gets a NEW device buffer and a NEW host image (both live for the rest of the process: ~90 KB per layout):
-        // launches still in flight on other streams keep reading the old table, and the asynchronous upload never reads freed memory
-        std::vector<int>* tab = new std::vector<int>();
-        if (int e = build(cfg, *tab)) { delete tab; return e; }
-        int* d = nullptr;
-        SRF_HIP(hipMalloc((void**)&d, tab->size() * sizeof(int)));
-        SRF_HIP(hipMemcpyAsync(d, tab->data(), tab->size() * sizeof(int), hipMemcpyHostToDevice, s));
-        S.d_desc = d;
-        for (int i = 0; i < 5; ++i) S.seg_len[i] = cfg->map_C[i];
+    for (int k = 0; k < SRF_DESC_LAYOUTS; ++k) {
+        bool same = S.d_desc[k] != nullptr;
+        for (int i = 0; i < 5; ++i) same = same && S.seg_len[k][i] == cfg->map_C[i];
+        if (same) { *desc = S.d_desc[k]; return 0; }
     }
-    *desc = S.d_desc;
+    // a new layout: built on the host and uploaded SYNCHRONOUSLY -- the table is published to every stream of the device at once, so
+    // it must be complete before anyone can see the pointer (an asynchronous upload on the caller's stream ordered only that stream).
+    // This is first-use setup: scenerf_hip_prepare does it before any capture; inside a hipGraph capture it fails loudly instead.
+    // A small set of layouts is kept per device (alternating map layouts do not reallocate); a replaced table is NOT freed -- launches
+    // of another stream may still read it -- which bounds the leak to one table (~90 KB) per replacement beyond the set.
+    (void)s;
+    std::vector<int> tab;
+    if (int e = build(cfg, tab)) return e;
+    int* d = nullptr;
+    SRF_HIP(hipMalloc((void**)&d, tab.size() * sizeof(int)));
+    SRF_HIP(hipMemcpy(d, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+    const int k = S.next;
+    S.next = (S.next + 1) % SRF_DESC_LAYOUTS;
+    S.d_desc[k] = d;
+    for (int i = 0; i < 5; ++i) S.seg_len[k][i] = cfg->map_C[i];
+    *desc = d;
     return 0;
 }
+
 
 // host-only: the descriptor sets of the ring kernels (sets 0..31: forward per scale mask ; set 32: backward chain)
 int fused_table_build(const scenerf_cfg* cfg, std::vector<int>& tab) {

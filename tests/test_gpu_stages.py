@@ -411,6 +411,57 @@ def test_raysom_forward_and_sampler_backward(case):
     torch.testing.assert_close(doff.cpu(), offs.grad, rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("M", [4133, 40000])
+@pytest.mark.parametrize("path", ["layers", "fused"])
+def test_parameter_gradients_are_reproducible_run_to_run(M, path):
+    """Every parameter gradient of scenerf_hip_mlp_backward on identical inputs, four runs: anything beyond fp32 atomic-ordering noise
+    between two runs of the SAME path is a race.  (Regression test for the bias-gradient column sums of gemm_tn_kernel, which once came
+    back wrong for 16 columns of one workgroup in a few hundred at M = 40,000: they were re-read from a staged LDS tile; they are now
+    taken from the registers on their way into LDS.  M = 4,133: per-layer weight gradients; M = 40,000: the batched transposing-read
+    launch, lin_in's padded tile included.)"""
+    import dataclasses
+    from scenerf_amd.renderer import MLP_PARAM_NAMES, PackedMLP, _MlpRun
+    lib = _capi.load()
+    rcfg = RenderConfig.kitti(precision="bf16", sphere_W=376, sphere_H=114)
+    state = synth.mlp_state(102, 4)
+    pk = PackedMLP([state[n].to(DEV) for n in MLP_PARAM_NAMES], 4, rcfg)
+    gen = torch.Generator().manual_seed(M + 1)
+    run = _MlpRun(M, 4, 1, DEV)
+    run.Z.copy_((torch.randn(run.Z.shape, generator=gen) * 0.5).to(torch.bfloat16).to(DEV))
+    xe = torch.zeros((M, 48))
+    xe[:, :42] = torch.randn(M, 42, generator=gen).clamp(-1, 1)
+    run.xenc.copy_(xe.to(DEV))
+    run.tile_mask.fill_(31)
+    cc = rcfg.to_c()
+    _capi.check(lib.scenerf_hip_mlp_forward(C.byref(cc), C.byref(pk.c), run.Z.data_ptr(), run.xenc.data_ptr(), run.tile_mask.data_ptr(), M,
+                                            C.byref(run.c), _st()), "fwd")
+    dl = torch.randn(M, 4, generator=gen).to(DEV)
+    tex = torch.full((M, 5, 4), -1, dtype=torch.int32, device=DEV)
+    tw = torch.zeros((M, 5, 4), device=DEV)
+    cc = dataclasses.replace(rcfg, fused_backward=(path == "fused")).to_c()
+    outs = []
+    for rep in range(4):
+        gs = pk.grad_sink()
+        pk.gflat.zero_()
+        dH = torch.zeros((M, 2048), dtype=torch.bfloat16, device=DEV)
+        dN = torch.zeros((3, M, 512), dtype=torch.bfloat16, device=DEV)
+        _capi.check(lib.scenerf_hip_mlp_backward(C.byref(cc), C.byref(pk.c), C.byref(gs), run.Z.data_ptr(), run.xenc.data_ptr(),
+                                                 run.tile_mask.data_ptr(), tex.data_ptr(), tw.data_ptr(), M, C.byref(run.c), dl.data_ptr(),
+                                                 dH.data_ptr(), dN.data_ptr(), None, _st()), "bwd")
+        torch.cuda.synchronize()
+        outs.append([g.clone() for g in pk.unpack_grads()])
+    worst = {}
+    for rep in range(1, 4):
+        for n, a, b in zip(MLP_PARAM_NAMES, outs[0], outs[rep]):
+            worst[n] = max(worst.get(n, 0.0), float((a - b).norm() / max(float(a.norm()), 1e-20)))
+    bad = {k: "%.1e" % v for k, v in worst.items() if v > 1e-5}
+    assert not bad, "run-to-run differences beyond summation-order noise: %s" % bad
+    # ... and the bias gradient of lin_in is the column sum of dH0 (fp64 on the GPU) of the last run
+    ref = dH[:, :512].double().sum(0)
+    got = outs[-1][MLP_PARAM_NAMES.index("lin_in.bias")].double()
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("N,U,P", [(64, 32, 8), (96, 64, 8), (128, 64, 16), (512, 256, 64), (2, 2, 1)])
 def test_fused_ray_tail_equals_the_stage_kernels(N, U, P):
     """scenerf_hip_ray_tail_forward / _backward (what RenderChunk launches: compositing + RaySOM in one kernel, their autograd + the
