@@ -680,6 +680,19 @@ def main():
         want = 3.0 * sum(r + 1.0 for r in range(world)) / world
         assert abs(float(last) - want) < 1e-6, (float(last), want)
 
+    steady = None
+    if world == 1 and not dry and not args.no_roofline:
+        # the same step over a longer window: 20 steps after 5 warm-ups start on a GPU that idled through the setup and measure 2-4 %
+        # slower than a run of hundreds (same box); `value` stays the driver's K / W, this is the sustained rate next to it
+        n_ss = 300
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_ss):
+            step()
+        torch.cuda.synchronize()
+        d_ss = (time.perf_counter() - t0) / n_ss
+        steady = {"value": round(R / d_ss, 1), "unit": "rays/s", "ms_per_step": round(d_ss * 1e3, 3), "steps": n_ss,
+                  "note": "same step, same process, right after the timed region"}
     other = None
     if world == 1 and not dry and not args.no_roofline:   # the same step with the other map layout at the boundary (side measurement)
         main_maps = maps
@@ -796,7 +809,7 @@ def main():
                        "precision": args.precision, "maps": args.maps,
                        "sampling_noise": "host generator + upload, like the reference" if args.host_rng else
                                          "device generator (RenderConfig.device_rng=True; --host-rng gives the reference's host-side draw: +0.1-0.25 ms per step)"},
-            "other_entry": other,
+            "other_entry": other, "steady_state": steady,
             "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager, "fp32_mode": fp32,
             "bundlefusion_c4": bf_leg, "infer_c5": inf_leg,
             "allreduce": allreduce, "ranks": census,

@@ -80,7 +80,7 @@ HEAD_GATE = {"fp32": 2e-5, "bf16": 1.5e-2}                     # relative L2 of 
 # loss_kl (docstring: BMU ties): error of the mean over the chunk's rays (one flipped ray of 32 moves it by percents) and the fraction
 # of rays within 2e-4 (fp32) / 2e-2 (bf16).  Measured: fp32 1.5e-3 / 0.981 (R = 1200); bf16 1.8e-3 / 0.964 (R = 1200), 5.4e-2 / 0.9375 (R = 32)
 # with RaySOM's discrete choices matched (step 2) loss_kl is gated per ray, every ray: |got - ref| <= tol (1 + |ref|)
-# measured (profiles/r03_e_parity_full_*.json): fp32 max rel 1.3e-5, mean rel 2.6e-7; bf16 max rel 9.7e-5, mean rel 2.0e-5
+# measured (profiles/r03_f_parity_full_*.json): fp32 max rel 1.3e-5, mean rel 2.6e-7; bf16 max rel 9.7e-5, mean rel 2.0e-5
 KL_GATE = {"fp32": dict(tol=5e-5, mean_rel=2e-6), "bf16": dict(tol=5e-4, mean_rel=1e-4)}
 # a differing BMU / mask entry must sit on a tie: relative argmax margin / distance from the 0.1 threshold below this
 # measured: the BMU differs on 0-93 of 153,600 samples, every one at a relative argmax margin <= 1.2e-7 (one fp32 ulp: exact ties at the
