@@ -702,6 +702,13 @@ def main():
                  "ms_per_step": round(dt2 / args.steps * 1e3, 3)}
         maps = main_maps
         torch.cuda.empty_cache()
+    rng_other = None
+    if world == 1 and not dry and not args.no_roofline:   # ... and with the other source of the sampler's normal noise
+        model.render_cfg.device_rng = not model.render_cfg.device_rng
+        dt3, _ = _timed(step, args, world, dev, sync)
+        rng_other = {"sampling_noise": "device generator" if model.render_cfg.device_rng else "host generator + upload, like the reference (utils.py:208-211)",
+                     "value": round(R * args.steps / dt3, 1), "unit": "rays/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3)}
+        model.render_cfg.device_rng = not model.render_cfg.device_rng
 
     allreduce = None
     if world > 1:   # three more steps with the collectives bracketed by events; every rank takes part, then the group is done
@@ -809,7 +816,7 @@ def main():
                        "precision": args.precision, "maps": args.maps,
                        "sampling_noise": "host generator + upload, like the reference" if args.host_rng else
                                          "device generator (RenderConfig.device_rng=True; --host-rng gives the reference's host-side draw: +0.1-0.25 ms per step)"},
-            "other_entry": other, "steady_state": steady,
+            "other_entry": other, "other_rng": rng_other, "steady_state": steady,
             "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager, "fp32_mode": fp32,
             "bundlefusion_c4": bf_leg, "infer_c5": inf_leg,
             "allreduce": allreduce, "ranks": census,
