@@ -72,6 +72,31 @@ def _clean_rays(m, g: Golden, R):
     return clean_mask(m.last_aux, o, ocfg, g.cam_K, R)
 
 
+def _loss_kl_at_the_gpus_choices(m, g: Golden, R):
+    """loss_kl of the oracle (pinned on the reference: test_oracle_golden.py) evaluated AT the GPU's discrete choices -- gaussian-head
+    offsets, sphere indices, RaySOM's BMU per sample and mask per gaussian (render_chunk(head_offsets=, sphere_idx=, som_choices=)) --
+    after checking that every differing RaySOM choice sits on a tie of the oracle's own (argmax margin / threshold distance)."""
+    ocfg = (orc.OracleConfig.kitti if g.variant == "kitti" else orc.OracleConfig.bundlefusion)(**g.cfg_kwargs())
+    mlp, mlpg = g.mlp_states()
+    aux = m.last_aux
+    N, G = aux["bmu"].shape[1], aux["kl_mask"].shape[1]
+    out = []
+    for s in range(0, R, g.chunk):
+        e = min(s + g.chunk, R)
+        off = aux["offsets"].detach().float().cpu().reshape(R, G, 2)[s:e]
+        idx = (aux["sphere_idx"].cpu().long().reshape(R, N, 2)[s:e].reshape(-1, 2), aux["sphere_idx_g"].cpu().long().reshape(R, G, 2)[s:e].reshape(-1, 2))
+        bmu, msk = aux["bmu"].cpu().long()[s:e], aux["kl_mask"].detach().cpu()[s:e] > 0.5
+        with torch.no_grad():
+            o = orc.render_chunk(ocfg, mlp, mlpg, g.cam_K, g.T, g.feature_maps(), g.pixels[s:e], g.noise_u[s:e], g.noise_g[s:e],
+                                 keep_intermediates=True, head_offsets=off, sphere_idx=idx, som_choices=(bmu, msk))
+        si = o["_som_info"]
+        d_b, d_m = bmu != o["_bmu"], msk != si["mask"].bool()
+        assert not bool(d_b.any()) or float(si["bmu_margin"][d_b].max()) <= 1e-6, "a BMU differs from the oracle's away from a tie"
+        assert not bool(d_m.any()) or float(si["mask_margin"][d_m].max()) <= 1e-4, "a RaySOM mask term differs away from its threshold"
+        out.append(o["loss_kl"])
+    return torch.cat(out)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", CASES)
 def test_render_matches_reference_golden(name, precision):
@@ -99,8 +124,16 @@ def test_render_matches_reference_golden(name, precision):
     for k in ("depth", "color", "weights", "alphas", "densities", "gaussian_means", "gaussian_stds", "depth_volumes"):
         assert report[k] == 1.0, "%s: only %.3f of the rays within tolerance (max error %.2e)" % (k, report[k], worst[k])
     # loss_kl: RaySOM's BMU is an argmax over values that tie at the additive floors for samples far from every gaussian
-    # (ray_som_kl.py:46-52), so single rays flip under any rounding difference (tests/test_gpu_parity_full.py docstring)
+    # (ray_som_kl.py:46-52), so single rays flip against the stored vector under any rounding difference ...
     assert report["loss_kl"] >= 0.85, report["loss_kl"]
+    if m.debug_aux:
+        # ... which is why, in fp32, EVERY ray is held to the oracle evaluated at the GPU's own discrete choices, each differing
+        # choice being checked to sit on a tie (the oracle's own choices reproduce the stored vector: tests/test_oracle_golden.py)
+        kl_ref = _loss_kl_at_the_gpus_choices(m, g, R)
+        kl_got = out["loss_kl"].detach().float().cpu()
+        bad = ((kl_got - kl_ref).abs() > 5e-5 * (1.0 + kl_ref.abs()))
+        assert not bool(bad.any()), "loss_kl at matched choices: %d of %d rays off (max rel %.2e)" % (
+            int(bad.sum()), R, float(((kl_got - kl_ref).abs() / (1.0 + kl_ref.abs())).max()))
     # aggregate (the training loss proxy) must agree closely
     loss = out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
     ref_loss = float(g.z["loss"])
