@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256) void linout_bwd_kernel(const void* __restrict_
             dw[j][e] = 0.f;
         }
     }
-    constexpr int RU = 4;
+#ifndef LOB_RU
+#define LOB_RU 4
+#endif
+    constexpr int RU = LOB_RU;
     for (int mb = wave * RU; mb < M; mb += nwaves * RU) {
         float h[RU][8], dl[RU][DO];
 #pragma unroll
