@@ -58,7 +58,8 @@ constexpr int df_ns(int ntp) { return ntp <= 3 ? DF_NS3 : DF_NS5; }
 #define DF_NTB 5                                       // column tiles per pass of the second instantiation (KITTI's 1/2 level: 160 channels)
 #endif
 // LDS of an instantiation: its K-loop ring of (128 + 32 NTP)-row stages, or the epilogue tables
-constexpr int df_lds(int ntp) { return df_ns(ntp) * (DF_BM + ntp * 32) * DF_KSB > DF_L_MISC + 32 ? df_ns(ntp) * (DF_BM + ntp * 32) * DF_KSB : DF_L_MISC + 32; }
+#define DF_DUMP 4096                               // behind the ring: 1 KiB per wave where the pieces a wave issues only to keep its count uniform land
+constexpr int df_lds(int ntp) { return df_ns(ntp) * (DF_BM + ntp * 32) * DF_KSB + DF_DUMP > DF_L_MISC + 32 ? df_ns(ntp) * (DF_BM + ntp * 32) * DF_KSB + DF_DUMP : DF_L_MISC + 32; }
 
 // 16 bytes per lane, global -> LDS: per-lane 64-bit source address, destination = M0 (wave-uniform LDS address) + 16 * lane
 __device__ static inline void df_glds16(const void* src, unsigned lds_wave_base) {
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
         constexpr int STG = (DF_BM + NTP * 32) * KSB;
         constexpr int NSTEP = DF_K * 2 / KSB;
         constexpr int NS = df_ns(NTP), LA = NS - 1;       // ring stages, steps issued ahead of the one being multiplied
-        static_assert(NS * STG <= df_lds(NTP), "stages must fit the workgroup's LDS");
+        static_assert(NS * STG + DF_DUMP <= df_lds(NTP), "stages must fit the workgroup's LDS");
         static_assert(NSTEP > LA, "the ring is shorter than the K loop");
         auto swz = [](int r) { return KSB == 256 ? r & 15 : KSB == 128 ? (r >> 1) & 7 : (r >> 2) & 3; };
         static_assert(KSB == 256 || KSB == 128 || KSB == 64, "swizzle is written for 16, 8 or 4 slots per row");
@@ -233,8 +234,10 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
         // DMA sources of this wave's pieces: lane -> (row of the piece, physical slot), fetching logical slot physical ^ swz(row)
         const char* srcA[NPA_];
         const char* srcW[NPW_];
-        bool okW[NPW_];
-        int nw = 0;        // weight pieces this wave issues per step (wave-uniform)
+        bool okW[NPW_];    // (wave-uniform) a real piece; the others are issued too, into the dump area: every wave then has the SAME
+                           // number of pieces in flight per step and "step s has landed" is ONE s_waitcnt immediate -- the per-count
+                           // chain of compares and branches this replaces was a third of the loop's 11.5 scalar instructions per MFMA
+                           // (SQ counters, profiles/r03_f_pmc_sq_dfeat.txt)
         {
             const int rp = lane / SL, ps = lane % SL;
 #pragma unroll
@@ -249,12 +252,11 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
                 int sl, c0;
                 tile_level(t0 + min(t, np - 1), sl, c0);
                 okW[i] = wv * NPW_ + i < NWP && (((wv * NPW_ + i) * RPP) >> 5) < np;   // (wave-uniform; a piece never straddles tiles)
-                nw += okW[i] ? 1 : 0;
                 srcW[i] = (const char*)p.W[sl] + (size_t)min(c0 + (r & 31), p.C[sl] - 1) * (DF_K * 2) + ((ps ^ swz(r)) << 4);
             }
         }
-        nw = __builtin_amdgcn_readfirstlane(nw);
         const unsigned lds0 = (unsigned)(uintptr_t)lds;
+        const unsigned dump = lds0 + NS * STG + wv * 1024;
         auto issue = [&](const int step, const int stage) __attribute__((always_inline)) {
             const unsigned sb = lds0 + stage * STG;
             const unsigned ko = (unsigned)step * KSB;
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
 #ifdef DF_VAR_NOW
                 if (step >= LA) continue;
 #endif
-                if (okW[i]) df_glds16(srcW[i] + ko, __builtin_amdgcn_readfirstlane(sb + DF_BM * KSB + (wv * NPW_ + i) * 1024));
+                df_glds16(srcW[i] + ko, __builtin_amdgcn_readfirstlane(okW[i] ? sb + DF_BM * KSB + (wv * NPW_ + i) * 1024 : dump));
             }
 #pragma unroll
             for (int i = 0; i < NPA_; ++i) {
@@ -275,10 +277,8 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
             }
         };
         // "step s has landed": when a wave waits for it, steps up to s + LA - 1 have been issued (step s + LA follows the barrier), so at
-        // most the pieces of the LA - 1 younger steps may be outstanding (issued in order, retired in order); the count per step is
-        // NPA_ + nw, nw wave-uniform: one immediate per possible nw
-#define DF_WAIT_K(k) if (nw == (k)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * (NPA_ + (k)) < 63 ? (LA - 1) * (NPA_ + (k)) : 63) : "memory");
-        static_assert(NPW_ <= 10, "one wait immediate per weight-piece count");
+        // most the pieces of the LA - 1 younger steps may be outstanding (issued in order, retired in order): NPA_ + NPW_ per step
+#define DF_WAIT_STEP() asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * (NPA_ + NPW_) < 63 ? (LA - 1) * (NPA_ + NPW_) : 63) : "memory");
         __syncthreads();   // (the previous pass's epilogue is done with the LDS the stages live in)
 #pragma unroll
         for (int q = 0; q < LA; ++q) issue(q, q);
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
 #pragma unroll 1
         for (int step = 0; step < NSTEP; ++step) {
             if (step + LA < NSTEP) {
-                DF_WAIT_K(0) DF_WAIT_K(1) DF_WAIT_K(2) DF_WAIT_K(3) DF_WAIT_K(4) DF_WAIT_K(5) DF_WAIT_K(6) DF_WAIT_K(7) DF_WAIT_K(8) DF_WAIT_K(9) DF_WAIT_K(10)
+                DF_WAIT_STEP()
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last LA steps: nothing younger is issued any more)
             }
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
             stage = stage + 1 == NS ? 0 : stage + 1;
             stage_in = stage_in + 1 == NS ? 0 : stage_in + 1;
         }
-#undef DF_WAIT_K
+#undef DF_WAIT_STEP
 
         DF_STAMP()   // K loop done
         // ---- epilogue: level by level, up to three column tiles (96 channels) per round
