@@ -259,7 +259,11 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
         const unsigned dump = lds0 + NS * STG + wv * 1024;
         auto issue = [&](const int step, const int stage) __attribute__((always_inline)) {
             const unsigned sb = lds0 + stage * STG;
+#ifdef DF_VAR_SAME   // (development: every step fetches the first step's bytes again -- cache-resident sources)
+            const unsigned ko = 0u * (unsigned)step;
+#else
             const unsigned ko = (unsigned)step * KSB;
+#endif
             // (DF_VAR_*: development knobs -- which of the two DMA streams the K loop waits for; results are garbage with them)
 #pragma unroll
             for (int i = 0; i < NPW_; ++i) {
@@ -284,6 +288,12 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
         for (int q = 0; q < LA; ++q) issue(q, q);
         const int frow = 32 * wv + (lane & 31), fh = lane >> 5;
         int stage = 0, stage_in = LA;      // stage of the step being multiplied / of the step being issued
+#ifdef H_CYC   // where a step's cycles go (wave 0): waiting for its pieces / at the barrier / issuing the next pieces / reads + MFMAs
+        unsigned long long ph_[4] = {0, 0, 0, 0}, pt_ = __builtin_amdgcn_s_memtime();
+#define DF_PH(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_[i] += n_ - pt_; pt_ = n_; }
+#else
+#define DF_PH(i)
+#endif
 #pragma unroll 1
         for (int step = 0; step < NSTEP; ++step) {
             if (step + LA < NSTEP) {
@@ -293,8 +303,11 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
             }
             // one barrier per step: every wave's pieces of this step have landed, and everyone is done multiplying the previous step --
             // whose stage the pieces issued below overwrite
+            DF_PH(0)
             __syncthreads();
+            DF_PH(1)
             if (step + LA < NSTEP) issue(step + LA, stage_in);
+            DF_PH(2)
             const char* const sa = lds + stage * STG;
             const char* const sw = sa + DF_BM * KSB;
             if (np == NTP) {
@@ -331,8 +344,14 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
             }
             stage = stage + 1 == NS ? 0 : stage + 1;
             stage_in = stage_in + 1 == NS ? 0 : stage_in + 1;
+            DF_PH(3)
         }
 #undef DF_WAIT_STEP
+#ifdef H_CYC
+        if (wv == 0 && g_df_cyc && lane == 0)
+            for (int i = 0; i < 4; ++i) g_df_cyc[(size_t)blockIdx.x * 16 + 12 + i] = ph_[i];
+#endif
+#undef DF_PH
 
         DF_STAMP()   // K loop done
         // ---- epilogue: level by level, up to three column tiles (96 channels) per round

@@ -421,7 +421,10 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     for (int i = 0, off = 0; i < 5; ++i) { kSegOff[i] = off; off += cfg->map_C[i]; }
     auto dHcol = [&](int b) { return (void*)((char*)dH + (size_t)b * SCENERF_D_HIDDEN * es); };
 
-    // measured neutral on MI355X at R=1200 (6.89 vs 6.86 ms/step: both kernels are bandwidth-limited), so opt-in
+    // Round 1 (per-layer GEMMs, 6.9 ms/step): neutral.  Round 3 (fused chain, 2.85 ms/step): the batched weight gradients on the side
+    // stream beside the feature-map gradients on the caller's: -35 us per step in three same-process A/Bs (tools/ab_step.py
+    // renderer.MAIN_WGRAD_OVERLAP) -- the renderer sets the flag for the radiance MLP.  (Also tried there: the coarser levels'
+    // feature-gradient launch on a third stream beside the finest level's: +200 us, not kept.)
     const bool overlap = (cfg->flags & SCENERF_FLAG_WGRAD_OVERLAP) != 0;
     SideCtx* sc_ = overlap ? side_ctx(s) : nullptr;
     hipStream_t s2 = sc_ ? sc_->side : s;   // weight-gradient stream (== s when overlap is off)
@@ -466,7 +469,9 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             g.out = dNb(b); g.ldout = SCENERF_D_HIDDEN;
             if (int e = launch_gemm_nt(prec, g, s)) return e;
         }
-        if (int e = fork()) return e;
+        if (!fused_chain) {
+            if (int e = fork()) return e;
+        }
         {   // [side] dW0_b += dN_b^T relu(H_b);  db0_b = column sums of dN_b
             GemmTN t;
             t.name = head ? "gemm_wgrad_fc0/g" : "gemm_wgrad_fc0";
@@ -488,7 +493,9 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
             g.out = dHcol(b); g.ldout = LDH;
             if (int e = launch_gemm_nt(prec, g, s)) return e;
         }
-        if (int e = fork()) return e;
+        if (!fused_chain) {
+            if (int e = fork()) return e;
+        }
     }
     // lin_z: dWz[:, slice_s] += dH[:, 0:1536]^T Z[:, slice_s].  In the batched launch the first 256 columns of Z -- the two finest
     // scales, which (nearly) every row block touches, and the head of the third -- ride along as a seventh problem without row

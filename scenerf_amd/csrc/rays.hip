@@ -324,70 +324,54 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
             }
             continue;
         }
-        if (gc.chw[s] == 2 && sizeof(T) != 4) {
-            // the caller's fp32 (H,W,C) map read in place (scenerf_cfg.map_chw == 2): same loop as below with fp32 taps -- the blend
-            // sees the unrounded features, Z is rounded once
-            const float* mapf = (const float*)maps.p[s];
-            const int items = SCENERF_TILE_ROWS * chunks;
-            for (int it = tid; it < items; it += 256) {
-                const int row = it / chunks, ch = it - row * chunks;
+        // (H,W,C) maps: the act copy, or the caller's fp32 map read in place (scenerf_cfg.map_chw == 2: the blend sees the unrounded
+        // features, Z is rounded once; fp32 mode reads exactly that through the generic branch).  Item = (row, 16-byte channel chunk of
+        // Z).  The taps of GU items are requested together, branch-free -- an out-of-range tap reads texel 0 and is replaced by zeros
+        // after the load; its weight is 0 -- so a thread has 4 GU independent loads in flight instead of one dependent wait per tap
+        // (r03: the guarded form ran the main gather at 1.1 TB/s of requests, one memory latency after the other).  Same arithmetic:
+        // the first in-range tap used to be a plain product, fmaf(v, w, 0) rounds identically; a skipped tap is fmaf(0, 0, acc) = acc.
+        const int items = SCENERF_TILE_ROWS * chunks;
+        constexpr int GU = 3;
+        const bool inplace32 = gc.chw[s] == 2 && sizeof(T) != 4;
+        for (int it0 = tid; it0 < items; it0 += 256 * GU) {
+            float v[GU][4][VN], w[GU][4];
+            int row[GU], ch[GU];
+            bool ok[GU][4];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int it = min(it0 + 256 * u, items - 1);
+                row[u] = it / chunks;
+                ch[u] = it - row[u] * chunks;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int tx = s_tex[row[u]][s][t];
+                    ok[u][t] = tx >= 0;
+                    w[u][t] = s_w[row[u]][s][t];
+                    const size_t o = (size_t)max(tx, 0) * C + ch[u] * VN;
+                    if (inplace32) {
+                        const float* mapf = (const float*)maps.p[s];
+#pragma unroll
+                        for (int q = 0; q < VN / 4; ++q) {
+                            const float4 f = *(const float4*)(mapf + o + 4 * q);
+                            v[u][t][4 * q] = f.x; v[u][t][4 * q + 1] = f.y; v[u][t][4 * q + 2] = f.z; v[u][t][4 * q + 3] = f.w;
+                        }
+                    } else {
+                        Vec16<T>::load((const T*)maps.p[s] + o, v[u][t]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
                 float acc[VN];
 #pragma unroll
                 for (int e = 0; e < VN; ++e) acc[e] = 0.f;
-                bool first = true;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int tx = s_tex[row][s][t];
-                    if (tx >= 0) {
-                        float v[VN];
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                        for (int q = 0; q < VN / 4; ++q) {
-                            const float4 f = *(const float4*)(mapf + (size_t)tx * C + ch * VN + 4 * q);
-                            v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
-                        }
-                        const float w = s_w[row][s][t];
-                        if (first) {
-#pragma unroll
-                            for (int e = 0; e < VN; ++e) acc[e] = v[e] * w;
-                            first = false;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < VN; ++e) acc[e] = fmaf(v[e], w, acc[e]);
-                        }
-                    }
-                }
-                Vec16<T>::store(Z + ((size_t)tile * SCENERF_TILE_ROWS + row) * SCENERF_D_LATENT + gc.off[s] + ch * VN, acc);
+                    for (int e = 0; e < VN; ++e) acc[e] = fmaf(ok[u][t] ? v[u][t][e] : 0.f, w[u][t], acc[e]);
+                if (it0 + 256 * u < items)
+                    Vec16<T>::store(Z + ((size_t)tile * SCENERF_TILE_ROWS + row[u]) * SCENERF_D_LATENT + gc.off[s] + ch[u] * VN, acc);
             }
-            continue;
-        }
-        // (fp32 mode: an (H,W,C) fp32 map read in place is exactly what this loop reads)
-        const T* map = (const T*)maps.p[s];
-        const int items = SCENERF_TILE_ROWS * chunks;
-        for (int it = tid; it < items; it += 256) {
-            int row = it / chunks, ch = it - row * chunks;
-            float acc[VN];
-#pragma unroll
-            for (int e = 0; e < VN; ++e) acc[e] = 0.f;
-            bool first = true;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                int tx = s_tex[row][s][t];
-                if (tx >= 0) {
-                    float v[VN];
-                    Vec16<T>::load(map + (size_t)tx * C + ch * VN, v);
-                    float w = s_w[row][s][t];
-                    if (first) {
-#pragma unroll
-                        for (int e = 0; e < VN; ++e) acc[e] = v[e] * w;
-                        first = false;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < VN; ++e) acc[e] = fmaf(v[e], w, acc[e]);
-                    }
-                }
-            }
-            size_t zrow = (size_t)tile * SCENERF_TILE_ROWS + row;
-            Vec16<T>::store(Z + zrow * SCENERF_D_LATENT + gc.off[s] + ch * VN, acc);
         }
     }
 }

@@ -51,6 +51,7 @@ def _on(dev):
 
 
 _SIDE = {}
+MAIN_WGRAD_OVERLAP = True    # radiance MLP's weight gradients on the library's side stream, beside its feature-map gradients (-35 us/step)
 DEFER_HEAD_PACK = True     # (tools/ab_step.py toggles this)
 
 
@@ -685,7 +686,11 @@ class RenderChunk(torch.autograd.Function):
                     ctx.mlpg.synced = True
         if ctx.needs_input_grad[11] or want_maps:
             early = ctx.mlp.grad_sync_async if (ctx.mlpg.single_chunk and ctx.needs_input_grad[11]) else None
-            ctx.mlp.pending = _mlp_backward(ccfg, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps, sync_async=early)
+            ccm = ccfg
+            if MAIN_WGRAD_OVERLAP:
+                ccm = type(ccfg).from_buffer_copy(ccfg)
+                ccm.flags |= _capi.FLAG_WGRAD_OVERLAP
+            ctx.mlp.pending = _mlp_backward(ccm, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps, sync_async=early)
         if do_head:
             main.wait_stream(side)
             for t in (d_off, run_g.Z, run_g.xenc, run_g.h0pre, run_g.logits):

@@ -64,7 +64,9 @@ if os.environ.get("SRF_LIB_TAG") and hasattr(lib, "scenerf_hip_test_dfeat_cyc"):
     t = buf.cpu().double()
     for m_ in sorted(set(pat)):
         sel = (masks.cpu() == m_)
-        tt = t[sel]
+        tt = t[sel][:, :12]
+        ph = t[sel][:, 12:].mean(0).tolist()     # K-loop phases of wave 0, summed over the steps (the launch that ran last on this block)
+        print("mask %d: K loop of wave 0: waiting for the step's pieces %.0f, at the barrier %.0f, issuing the next pieces %.0f, reads + MFMAs %.0f cycles" % (m_, *ph))
         n = int((tt[0] != 0).sum())
         d = tt[:, 1:n] - tt[:, :n - 1]
         print("mask %d: %d stamps; mean cycles between stamps: %s ; total %.0f" % (m_, n, " ".join("%.0f" % x for x in d.mean(0).tolist()), (tt[:, n - 1] - tt[:, 0]).mean().item()))

@@ -1,6 +1,6 @@
 """Forward trunk and backward dgrad chain of the ResnetFC at the bench row count: fused.hip's 64-row ring kernels against wide.hip's
 128-row kernels.  Kernel times come from the in-library HIP-event table (per launch, on the launch stream); results are compared.
-usage: wide_probe.py [M] [reps]     env: PROBE_MASKS="1,1,1,3" (tile masks, repeated; default = the KITTI mix)"""
+usage: wide_probe.py [M] [reps]     env: PROBE_MASKS="1,1,1,3" (tile masks, repeated; default = the KITTI mix), PROBE_ZERO=1 (zero data)"""
 import ctypes as C, dataclasses, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,6 +16,9 @@ lib = _capi.load()
 rcfg = RenderConfig.kitti(precision="bf16")
 state = synth.mlp_state(1, 4)
 params = [torch.as_tensor(state[n]).to(dev) for n in MLP_PARAM_NAMES]
+ZERO = os.environ.get("PROBE_ZERO", "0") == "1"     # all-zero operands: the same instruction stream at the lowest switching power
+if ZERO:
+    params = [torch.zeros_like(t) for t in params]
 pk = PackedMLP(params, 4, rcfg)
 gen = torch.Generator().manual_seed(1)
 ntile = (M + 127) // 128
@@ -30,6 +33,8 @@ for s_ in range(5):   # the gather writes exact zeros into the dense first 256 c
 X = torch.randn(M, 48, generator=gen).clamp(-1, 1).to(dev)
 X[:, 42:] = 0
 dl = torch.randn(M, 4, generator=gen).to(dev)
+if ZERO:
+    Z.zero_(); X.zero_(); dl.zero_()
 tex = torch.full((M, 5, 4), -1, dtype=torch.int32, device=dev)
 tw = torch.zeros((M, 5, 4), device=dev)
 st = torch.cuda.current_stream().cuda_stream
