@@ -42,7 +42,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_h;
 #define H_ABUF (H_BM * F_AROW)                  // 131072
 #define H_ZCAP 6                                // streamed-operand stage: chunks of 128 rows x 32 B
 #define H_ZS H_ABUF
-#define H_LDS (H_ZS + H_ZCAP * 4096)            // 155648 of 163840
+#define H_XB (H_ZS + H_ZCAP * 4096)             // 155648: 8 KiB of epilogue operands, fetched by DMA at the start of the layer's K loop --
+                                                // forward: the layer's bias (2 KiB, two buffers), backward: the 128 rows' gate bits (8 KiB)
+#define H_LDS (H_XB + 8192)                     // 163840: all of the CU's LDS
 #define H_CAP0 (H_ZCAP + 32)                    // layer 0: stage + the A buffer (nothing resident yet)
 // table set (F_MAXCH ints per tile mask): [0] chunks in total, [1] chunks of layer 0, [2] chunks of a lin_z tail (both incl. padding,
 // multiples of H_D), [3] REAL chunks of a lin_z tail, [4 + c] descriptor of chunk c in execution order.  Descriptor bits as in fused.h,
@@ -151,8 +153,14 @@ __device__ __forceinline__ void h_epi_quad(const float4 bias, const uint32_t gat
     if (MODE == 0) {
         v0 += bias.x; v1 += bias.y; v2 += bias.z; v3 += bias.w;
     } else {
-        v0 = (gate >> (8 * Q)) & 1u ? v0 : 0.f; v1 = (gate >> (8 * Q + 1)) & 1u ? v1 : 0.f;
-        v2 = (gate >> (8 * Q + 2)) & 1u ? v2 : 0.f; v3 = (gate >> (8 * Q + 3)) & 1u ? v3 : 0.f;
+        // gate bit -> all-ones / zero mask (one v_bfe_i32), value & mask: two instructions per value and no VCC round trip
+        // (compare + select was three, plus the wait states of writing and reading VCC)
+        auto gsel = [](const float v, const uint32_t g, const int bit) __attribute__((always_inline)) {
+            uint32_t m;   // (inline asm: written in C, instcombine turns "and with a sign-extended bit" back into compare + select)
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(g), "n"(bit));
+            return __uint_as_float(__float_as_uint(v) & m);
+        };
+        v0 = gsel(v0, gate, 8 * Q); v1 = gsel(v1, gate, 8 * Q + 1); v2 = gsel(v2, gate, 8 * Q + 2); v3 = gsel(v3, gate, 8 * Q + 3);
     }
     uint32_t p0, p1;
     if (is_res) {
@@ -286,23 +294,40 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         while (save_i < 32) save_piece();
         H_LANE();
         const int hi = ln >> 5, axor = ln & 15;
-        // forward: bias of the wave's tile j, outputs 8 q + 4 hi + {0..3}; backward: the 128 gate bits of row (32 i + lane & 31)
-        const float* const bb = MODE == 0 ? L.bias + wvu * 128 + 4 * hi : nullptr;
+        // forward: bias of the wave's tile j, outputs 8 q + 4 hi + {0..3}; backward: the 128 gate bits of row (32 i + lane & 31).  Both
+        // come out of LDS (H_XB), where xb_dma() put them at the start of this layer's K loop: from global memory a bias quad cost an L2
+        // round trip every (j, q) -- 3k of an epilogue's 7-9k cycles (r03: H_VAR_NOBIAS) -- and the gate rows one exposed at the top.
+        typedef float f32x4_h __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(3))) f32x4_h* lds_f4_p;
+        typedef const __attribute__((address_space(3))) u32x4_h* lds_u4_p;
+        auto ld_f4 = [](const unsigned a) __attribute__((always_inline)) { const f32x4_h v = *(lds_f4_p)(uintptr_t)a; return make_float4(v.x, v.y, v.z, v.w); };
+        const unsigned bb = lds0 + H_XB + (MODE == 0 ? (unsigned)((layer & 1) * 2048 + (wvu * 128 + 4 * hi) * 4) : (unsigned)((ln & 31) * 64 + wvu * 16));
         // (quads in (j, q, i) order: the four row tiles of a (j, q) share one float4 of bias -- one in use, the next one on its way)
         float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
         uint4 gt[4];
-        if (MODE == 0) {
-            bn = *(const float4*)bb;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gt[i] = *(const uint4*)(L.sign + (size_t)(m0 + 32 * i + (ln & 31)) * 64 + wvu * 16);
-        }
         // (MFMA results are visible to v_accvgpr_read only after the pipeline has drained: 16 passes)
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();     // every wave has finished reading the A buffer for this layer
+        __builtin_amdgcn_s_barrier();     // every wave has finished reading the A buffer for this layer -- and its K loop's counted waits
+                                          // have retired the DMA pieces it issued at the loop's start: H_XB is complete
         H_STAMP()   // everyone arrived
+        if (MODE == 0) {
+#ifndef H_VAR_NOBIAS   // (development: what the bias reads cost the epilogue)
+            bn = ld_f4(bb);
+#endif
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4_h v = *(lds_u4_p)(uintptr_t)(bb + i * 32 * 64);
+                gt[i] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        }
         char* const wr0 = Abuf + (ln & 31) * F_AROW + 8 * hi;
 #define H_GATE(I, J) (MODE == 1 ? ((J) == 0 ? gt[I].x : (J) == 1 ? gt[I].y : (J) == 2 ? gt[I].z : gt[I].w) >> (4 * hi) : 0u)
+#ifdef H_VAR_NOBIAS
+#define H_BIAS_ON false
+#else
+#define H_BIAS_ON true
+#endif
 #ifdef H_VAR_EPI4
 #define H_EPI_MIDSB
 #else
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
 #define H_EPI_JQ(J, Q)                                                                                          \
     {                                                                                                           \
         const float4 bq = bn;                                                                                   \
-        if (MODE == 0 && (J) * 4 + (Q) < 15) bn = *(const float4*)(bb + (((J) * 4 + (Q) + 1) >> 2) * 32 + (((Q) + 1) & 3) * 8); \
+        if (MODE == 0 && (J) * 4 + (Q) < 15 && H_BIAS_ON) bn = ld_f4(bb + ((((J) * 4 + (Q) + 1) >> 2) * 32 + (((Q) + 1) & 3) * 8) * 4); \
         /* quads in pairs between scheduling barriers: two independent dependency chains to interleave (a quad alone is one serial   \
            chain of ~18 instructions with hazard nops); no barrier at all = one huge basic block whose scheduler hoists every quad's     \
            residual unpacking to the top -- 256 more live registers */                                             \
@@ -334,6 +359,23 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         sv_ld2 = L.save_ld * 2;
         sg_base = MODE == 0 ? L.sign : nullptr;
         save_i = 0;
+    };
+
+    // ---- epilogue operands of `layer` -> H_XB, issued at the start of the layer's K loop (the K loop's counted waits retire them: every
+    // wave waits, chunk after chunk, for all but its ~16 youngest vector-memory operations)
+    auto xb_dma = [&](const int layer) __attribute__((always_inline)) {
+        H_LANE();
+        const FusedLayer& L = p.layer[layer];
+        if (MODE == 0) {
+            if (wvu < 2)   // forward: 512 floats of bias = two 1-KiB pieces
+                h_glds16((const char*)L.bias + wvu * 1024, (unsigned)(ln << 4),
+                         __builtin_amdgcn_readfirstlane(lds0 + H_XB + (layer & 1) * 2048 + wvu * 1024));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)   // backward: 128 rows x 64 B of the forward's sign bits (rows past M: the buffer is padded)
+                h_glds16((const char*)L.sign + (size_t)m0 * 64 + (wvu * 2 + i) * 1024, (unsigned)(ln << 4),
+                         __builtin_amdgcn_readfirstlane(lds0 + H_XB + (wvu * 2 + i) * 1024));
+        }
     };
 
     // ---- staged chunks: DMA of chunk descriptor d (X3 / Z columns FD_Y .. +15 of the block's 128 rows) into LDS offset `off`: this
@@ -656,6 +698,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
                 __builtin_amdgcn_s_barrier();                                       \
             }                                                                       \
             rbeg = k; rend = k + cap;                                               \
+            if (first) { H_STAMP() }   /* layer 0's operand has landed */                \
             const unsigned x_ = lds0 + slot_off(0) + sl;                            \
             af[0] = *(lds_frag_p)(uintptr_t)(x_); af[1] = *(lds_frag_p)(uintptr_t)(x_ + 1024u);   \
             af[2] = *(lds_frag_p)(uintptr_t)(x_ + 2048u); af[3] = *(lds_frag_p)(uintptr_t)(x_ + 3072u); \
@@ -700,11 +743,13 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     if (MODE == 0) {
         // (the two epilogue variants never meet at a join: the residual stream's 128 registers are rewritten in one of them only, and
         // the register allocator does not coalesce such a join -- it parks the overflow in accumulator registers)
+        xb_dma(0);
         staged_run(n0, n0, H_CAP0, 0, true);
         epilogue(std::true_type(), 0);
 #pragma unroll 1
         for (int b = 0; b < 3; ++b) {
             const bool tail = b < 2 && nz > 0;
+            xb_dma(1 + 2 * b);
             resident_run();
             epilogue(std::false_type(), 1 + 2 * b);
             if (tail && !zres) dma_round(c + 32, 0, min(H_ZCAP, nzr));   // round 0 of this layer's lin_z tail: the stage is idle until then
@@ -715,6 +760,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
                 for (int k = wvu; k < p.d_out * 2; k += 4)
                     h_glds16((const char*)p.w_out + k * 1024, (unsigned)(ln << 4), __builtin_amdgcn_readfirstlane(lds0 + H_ZS + k * 1024));
             }
+            xb_dma(2 + 2 * b);
             resident_run();
             if (tail) staged_run(nz, nzr, H_ZCAP, zres ? 2 : 1, false);
             epilogue(std::true_type(), 2 + 2 * b);
@@ -748,8 +794,10 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         H_STAMP()   // incoming gradient tile staged
 #pragma unroll 1
         for (int l = 0; l < 6; l += 2) {
+            xb_dma(l);
             resident_run();
             epilogue(std::false_type(), l);       // dN_b = ...
+            xb_dma(l + 1);
             resident_run();
             epilogue(std::true_type(), l + 1);    // dH_b = dH_{b+1} + ...
         }

@@ -51,6 +51,9 @@ def _on(dev):
 
 
 _SIDE = {}
+PREFILL_AT = 2               # where a training session zeroes the map-gradient accumulators on the side stream: 0 = at the session's
+                             # start (beside the gaussian head's chain), 1 = behind the head's forward, 2 = behind the radiance MLP's
+                             # (2.635 / -- / 2.622 ms per step: the fill no longer runs beside the head's latency-bound chain)
 MAIN_WGRAD_OVERLAP = True    # radiance MLP's weight gradients on the library's side stream, beside its feature-map gradients (-35 us/step)
 DEFER_HEAD_PACK = True     # (tools/ab_step.py toggles this)
 
@@ -231,7 +234,10 @@ class PrepareMaps(torch.autograd.Function):
         holder.convert(chw)
         ctx.holder = holder
         if any(ctx.needs_input_grad[1:]):
-            holder.prefill_grad_accumulators()
+            if PREFILL_AT == 0:
+                holder.prefill_grad_accumulators()
+            else:
+                holder._want_prefill = True     # (zeroed from the first chunk's forward: RenderChunk._forward)
         return torch.empty(1, device=chw[0].device)   # autograd token: its value is never read (no fill launch)
 
     @staticmethod
@@ -571,6 +577,9 @@ class RenderChunk(torch.autograd.Function):
         # (grad mode is off inside Function.forward: whether a backward can follow is what needs_input_grad says)
         keep = any(ctx.needs_input_grad)
         run_g = _mlp_eval(ccfg, cfg, maps, mlpg.packed, anchors, 0, G, unit_dir, viewdir, K, iK, T, R * G, keep)
+        if PREFILL_AT == 1 and getattr(maps, "_want_prefill", False):
+            maps._want_prefill = False
+            maps.prefill_grad_accumulators()
         # the gaussian sampler's normal noise, if the caller did not inject it: drawn HERE, with the gaussian head's chain already queued
         # -- the reference's host-side draw (utils.py:208-211) takes ~0.25 ms of host time per 1,200 rays, which at the top of the
         # chunk left the GPU without work (3.29 -> 3.04 ms per KITTI step, tools/ab_host.py devrng); same generator, same call order
@@ -588,6 +597,9 @@ class RenderChunk(torch.autograd.Function):
                                                          perm.data_ptr(), st), "gaussian_sample_sort")
         # radiance MLP on the sorted samples (scenerf.py:661-665)
         run_m = _mlp_eval(ccfg, cfg, maps, mlp.packed, dist_s, N, N, unit_dir, viewdir, K, iK, T, R * N, keep)
+        if PREFILL_AT == 2 and getattr(maps, "_want_prefill", False):
+            maps._want_prefill = False
+            maps.prefill_grad_accumulators()
         dens = torch.empty((R, N), **f32)
         alphas = torch.empty((R, N), **f32)
         weights = torch.empty((R, N), **f32)
@@ -671,6 +683,15 @@ class RenderChunk(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
         do_head = bool(ctx.needs_input_grad[12] or want_maps)
+        def main_backward():
+            if ctx.needs_input_grad[11] or want_maps:
+                early = ctx.mlp.grad_sync_async if (ctx.mlpg.single_chunk and ctx.needs_input_grad[11]) else None
+                ccm = ccfg
+                if MAIN_WGRAD_OVERLAP:
+                    ccm = type(ccfg).from_buffer_copy(ccfg)
+                    ccm.flags |= _capi.FLAG_WGRAD_OVERLAP
+                ctx.mlp.pending = _mlp_backward(ccm, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps, sync_async=early)
+
         if do_head:
             if want_maps:
                 ctx.maps.grad_accumulators()   # allocate + zero on the main stream before the fork
@@ -684,13 +705,7 @@ class RenderChunk(torch.autograd.Function):
                 if ctx.mlpg.single_chunk and ctx.mlpg.grad_sync is not None and ctx.needs_input_grad[12]:
                     ctx.mlpg.grad_sync(ctx.mlpg.packed.gflat)
                     ctx.mlpg.synced = True
-        if ctx.needs_input_grad[11] or want_maps:
-            early = ctx.mlp.grad_sync_async if (ctx.mlpg.single_chunk and ctx.needs_input_grad[11]) else None
-            ccm = ccfg
-            if MAIN_WGRAD_OVERLAP:
-                ccm = type(ccfg).from_buffer_copy(ccfg)
-                ccm.flags |= _capi.FLAG_WGRAD_OVERLAP
-            ctx.mlp.pending = _mlp_backward(ccm, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps, sync_async=early)
+        main_backward()     # (queued before the head's instead: no difference, 2.653 / 2.659 ms per step)
         if do_head:
             main.wait_stream(side)
             for t in (d_off, run_g.Z, run_g.xenc, run_g.h0pre, run_g.logits):

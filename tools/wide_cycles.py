@@ -34,7 +34,7 @@ bwd = lambda: _capi.check(lib.scenerf_hip_mlp_backward(C.byref(cc), C.byref(pk.c
                                                        tex.data_ptr(), tw.data_ptr(), M, C.byref(run.c), dl.data_ptr(), dH.data_ptr(), dN.data_ptr(), None, st), "bwd")
 fwd(); bwd(); torch.cuda.synchronize()
 nb = ntile
-for name, call, labels in (("forward", fwd, ["setup"] + sum([["K%d" % l, "wait%d" % l, "epi%d" % l] for l in range(7)], []) + ["stream-out", "lin_out"]),
+for name, call, labels in (("forward", fwd, ["setup", "dma0"] + sum([["K%d" % l, "wait%d" % l, "epi%d" % l] for l in range(7)], []) + ["stream-out", "lin_out"]),
                            ("backward", None, ["setup", "stage dH3"] + sum([["K%d" % l, "wait%d" % l, "epi%d" % l] for l in range(6)], []) + ["stream-out", "end"])):
     buf = torch.zeros((nb, 64), dtype=torch.int64, device=dev)
     assert lib.scenerf_hip_test_wide_cyc(buf.data_ptr()) == 0
