@@ -53,9 +53,10 @@ __device__ static inline void f_glds16x4(const void* sbase, unsigned voff, unsig
                  : "memory");
 }
 
-typedef unsigned short f_ushort2 __attribute__((ext_vector_type(2)));
-__device__ static inline uint32_t pk_min_u16(uint32_t a, uint32_t b) {   // v_pk_min_u16
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(f_ushort2, a), __builtin_bit_cast(f_ushort2, b)));
+__device__ static inline uint32_t pk_min_u16(uint32_t a, uint32_t b) {   // v_pk_min_u16, by name (see wide.hip: the compiler's own form of
+    uint32_t r;                                                                   // min(x, 1) is compare + select per half)
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
 }
 
 

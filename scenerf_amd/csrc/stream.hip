@@ -54,9 +54,10 @@ __device__ static inline void g_store16(void* p, uint4 v) {
 }
 __device__ static inline void g_store1(void* p, uint32_t v) { asm volatile("global_store_byte %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 
-typedef unsigned short g_ushort2 __attribute__((ext_vector_type(2)));
-__device__ static inline uint32_t g_pk_min_u16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(g_ushort2, a), __builtin_bit_cast(g_ushort2, b)));
+__device__ static inline uint32_t g_pk_min_u16(uint32_t a, uint32_t b) {   // v_pk_min_u16, by name (see wide.hip: the compiler's own form of
+    uint32_t r;                                                                   // min(x, 1) is compare + select per half)
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
 }
 
 __global__ __launch_bounds__(G_THREADS) void mlp_stream_kernel(FusedArgs p) {
