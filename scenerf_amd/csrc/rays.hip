@@ -196,7 +196,10 @@ struct MapPtrs {
 // gaussian head's 38 tiles on 256 CUs took 42 us, each block walking all the levels its tile touches -- spread their levels over
 // five times as many blocks; every block still derives the tile's full level mask (arithmetic only), block y == 0 publishes it.
 // Phase 1: taps + validity per (row, scale); phase 2: blend.
-template <typename T>
+// GU = items (row, 16-byte channel chunk) whose taps a thread requests together in the blend: 3 for the latency-bound launches (a
+// training chunk: 1,200 tiles), 1 for the throughput-bound ones (an inference chunk's 8,192 tiles: the 96 extra registers of GU = 3 cost
+// more occupancy than the loads in flight buy: 286 -> 364 us per launch, r03)
+template <typename T, int GU>
 __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts gc, const int32_t* __restrict__ sphere_idx,
                                                      int M, T* __restrict__ Z, uint8_t* __restrict__ tile_mask,
                                                      int32_t* __restrict__ tap_texel, float* __restrict__ tap_weight) {
@@ -331,7 +334,6 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
         // (r03: the guarded form ran the main gather at 1.1 TB/s of requests, one memory latency after the other).  Same arithmetic:
         // the first in-range tap used to be a plain product, fmaf(v, w, 0) rounds identically; a skipped tap is fmaf(0, 0, acc) = acc.
         const int items = SCENERF_TILE_ROWS * chunks;
-        constexpr int GU = 3;
         const bool inplace32 = gc.chw[s] == 2 && sizeof(T) != 4;
         for (int it0 = tid; it0 < items; it0 += 256 * GU) {
             float v[GU][4][VN], w[GU][4];
@@ -1406,9 +1408,9 @@ int scenerf_hip_gather_features(const scenerf_cfg* cfg, const void* const maps_h
     // small launches (the gaussian head: R x G points): one block per (tile, level) instead of one per tile
     const dim3 grid(tiles, tiles < 512 ? SCENERF_N_SCALES : 1);
     if (cfg->precision)
-        gather_kernel<bf16_t><<<grid, 256, 0, s>>>(mp, gc, sphere_idx, M, (bf16_t*)Z, tile_mask, tap_texel, tap_weight);
+        (tiles > 3072 ? gather_kernel<bf16_t, 1> : gather_kernel<bf16_t, 3>)<<<grid, 256, 0, s>>>(mp, gc, sphere_idx, M, (bf16_t*)Z, tile_mask, tap_texel, tap_weight);
     else
-        gather_kernel<float><<<grid, 256, 0, s>>>(mp, gc, sphere_idx, M, (float*)Z, tile_mask, tap_texel, tap_weight);
+        (tiles > 3072 ? gather_kernel<float, 1> : gather_kernel<float, 3>)<<<grid, 256, 0, s>>>(mp, gc, sphere_idx, M, (float*)Z, tile_mask, tap_texel, tap_weight);
     SRF_LAUNCH_CHECK("gather_kernel");
     return 0;
 }
