@@ -83,6 +83,9 @@ struct DfeatArgs {
     int C[SCENERF_N_SCALES];
     unsigned levels;          // pyramid levels this launch handles (bit s)
     int direct;               // 1: workgroup b IS tile b (a launch whose every active tile has exactly one pass: the finest level alone)
+    // direct launches: the tiles from `split_from` on are split over `split_n` workgroups each along K (a workgroup's sum goes out
+    // through the same atomics) -- the last, partly filled round of workgroups then takes 1 / split_n of a K loop instead of a whole one
+    int split_from, split_n;
 };
 
 #ifdef H_CYC   // development build: per-workgroup time stamps of wave 0 (tools/dfeat_probe.py)
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
     if (p.direct) {
         // one workgroup per tile and at most one pass per tile: no item search (the scan below costs 12.8k of a tile's 120k cycles; r03)
         n_items = 0;                   // (no second item)
-        tile = blockIdx.x;
+        tile = (int)blockIdx.x < p.split_from ? (int)blockIdx.x : p.split_from + ((int)blockIdx.x - p.split_from) / p.split_n;
         if (tile >= (p.M + DF_BM - 1) / DF_BM || !((unsigned)p.tile_mask[tile] & p.live)) return;
         __syncthreads();
     } else {
@@ -223,7 +226,14 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
         constexpr int NSTEP = DF_K * 2 / KSB;
         constexpr int NS = df_ns(NTP), LA = NS - 1;       // ring stages, steps issued ahead of the one being multiplied
         static_assert(NS * STG + DF_DUMP <= df_lds(NTP), "stages must fit the workgroup's LDS");
-        static_assert(NSTEP > LA, "the ring is shorter than the K loop");
+        static_assert(NSTEP / 4 > LA && NSTEP % 12 == 0, "the ring is shorter than a quarter of the K loop / K splits in 2, 3, 4");
+        // this workgroup's part of the K loop (the whole of it unless the tile is split: DfeatArgs.split_from)
+        int s_beg = 0, s_end = NSTEP;
+        if (p.direct && (int)blockIdx.x >= p.split_from) {
+            const int part = ((int)blockIdx.x - p.split_from) % p.split_n;
+            s_beg = part * (NSTEP / p.split_n);
+            s_end = s_beg + NSTEP / p.split_n;
+        }
         auto swz = [](int r) { return KSB == 256 ? r & 15 : KSB == 128 ? (r >> 1) & 7 : (r >> 2) & 3; };
         static_assert(KSB == 256 || KSB == 128 || KSB == 64, "swizzle is written for 16, 8 or 4 slots per row");
         f32x16_d acc[NTP];
@@ -268,14 +278,14 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
 #pragma unroll
             for (int i = 0; i < NPW_; ++i) {
 #ifdef DF_VAR_NOW
-                if (step >= LA) continue;
+                if (step >= s_beg + LA) continue;
 #endif
                 df_glds16(srcW[i] + ko, __builtin_amdgcn_readfirstlane(okW[i] ? sb + DF_BM * KSB + (wv * NPW_ + i) * 1024 : dump));
             }
 #pragma unroll
             for (int i = 0; i < NPA_; ++i) {
 #ifdef DF_VAR_NOA
-                if (step >= LA) continue;
+                if (step >= s_beg + LA) continue;
 #endif
                 df_glds16(srcA[i] + ko, __builtin_amdgcn_readfirstlane(sb + (wv * NPA_ + i) * 1024));
             }
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
 #define DF_WAIT_STEP() asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * (NPA_ + NPW_) < 63 ? (LA - 1) * (NPA_ + NPW_) : 63) : "memory");
         __syncthreads();   // (the previous pass's epilogue is done with the LDS the stages live in)
 #pragma unroll
-        for (int q = 0; q < LA; ++q) issue(q, q);
+        for (int q = 0; q < LA; ++q) issue(s_beg + q, q);
         const int frow = 32 * wv + (lane & 31), fh = lane >> 5;
         int stage = 0, stage_in = LA;      // stage of the step being multiplied / of the step being issued
 #ifdef H_CYC   // where a step's cycles go (wave 0): waiting for its pieces / at the barrier / issuing the next pieces / reads + MFMAs
@@ -295,8 +305,8 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
 #define DF_PH(i)
 #endif
 #pragma unroll 1
-        for (int step = 0; step < NSTEP; ++step) {
-            if (step + LA < NSTEP) {
+        for (int step = s_beg; step < s_end; ++step) {
+            if (step + LA < s_end) {
                 DF_WAIT_STEP()
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last LA steps: nothing younger is issued any more)
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
             DF_PH(0)
             __syncthreads();
             DF_PH(1)
-            if (step + LA < NSTEP) issue(step + LA, stage_in);
+            if (step + LA < s_end) issue(step + LA, stage_in);
             DF_PH(2)
             const char* const sa = lds + stage * STG;
             const char* const sw = sa + DF_BM * KSB;
@@ -497,7 +507,14 @@ int launch_dfeat_scatter(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
         p.levels = 1u;
         p.live = p.levels & have;
         p.direct = 1;     // level 0 alone: <= 3 column tiles = one pass per tile, one workgroup per tile
-        dfeat_kernel<3><<<tiles, DF_THREADS, df_lds(3), s>>>(p);
+        // ... except in the last round of workgroups (two per CU): 1,200 tiles are 2.34 rounds of 512 and every tile takes the same
+        // ~50 us, so the 176 tiles of the third round are split along K over as many workgroups as fit it
+        int cus1 = 256;
+        (void)hipDeviceGetAttribute(&cus1, hipDeviceAttributeMultiprocessorCount, srf_device());
+        const int slots = DF_WGS * cus1, full = tiles / slots * slots, tail = tiles - full;
+        p.split_from = tiles; p.split_n = 1;
+        if (tail > 0 && slots / tail >= 2) { p.split_from = full; p.split_n = slots / tail > 4 ? 4 : slots / tail; }
+        dfeat_kernel<3><<<p.split_from + (tiles - p.split_from) * p.split_n, DF_THREADS, df_lds(3), s>>>(p);
         p.direct = 0;
     }
     p.levels = fine3 ? 30u : 31u;

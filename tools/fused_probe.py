@@ -1,6 +1,7 @@
 """Time the ResnetFC forward (per-layer path and the fused kernels: ring / stream / wide) on random inputs at the bench row count, and
 compare the fused variants' outputs.   usage: fused_probe.py [M] [reps] [kernels: layers,ring,stream,wide]
-env: PROBE_MASK (scale mask of every tile, default 1 = KITTI's common case), PROBE_LEAN=1 (inference buffers)"""
+env: PROBE_MASK (scale mask of every tile, default 1 = KITTI's common case), PROBE_LEAN=1 (inference buffers), PROBE_COLD=1 (also time
+calls behind a cache-flushing fill)"""
 import ctypes as C, dataclasses, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +27,7 @@ X[:, 42:] = 0
 st = torch.cuda.current_stream().cuda_stream
 res = {}
 for name in kernels:
-    cfg = dataclasses.replace(rcfg, fused_min_rows=-1) if name == "layers" else dataclasses.replace(rcfg, fused_min_rows=1, fwd_kernel=name)
+    cfg = dataclasses.replace(rcfg, fused_min_rows=-1) if name == "layers" else dataclasses.replace(rcfg, fused_min_rows=1, fwd_kernel=name, wide_any_m=True)
     cc = cfg.to_c()
     run = _MlpRun(M, 4, 1, dev, lean=lean and name != "layers")
     run.Z.copy_(Z); run.xenc.copy_(X); run.tile_mask.fill_(maskv)
@@ -42,6 +43,15 @@ for name in kernels:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
+    if os.environ.get("PROBE_COLD"):   # every call behind a 512-MB fill: weights and inputs come from HBM, as after a re-pack by another kernel
+        flush = torch.empty(128 << 20, dtype=torch.float32, device=dev)
+        tot = 0.0
+        for _ in range(reps):
+            flush.zero_()
+            e0.record(); call(); e1.record()
+            torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        print("%-7s cold: %.3f ms per forward" % (name, tot / reps), flush=True)
     nz = sum(c for i, (c, _, _) in enumerate(rcfg.map_shapes()) if (maskv >> i) & 1)
     fl = 2.0 * M * 512 * (144 + 6 * 512 + 3 * nz)
     print("%-7s M=%d mask=%d%s: %.3f ms per forward  %.0f TFLOP/s issued = %.1f %% of 2.5 PF" % (
