@@ -248,13 +248,10 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
                         }
                     }
                 }
-                if (s >= s_lo && s < s_hi) {
+                if (s >= s_lo && s < s_hi) {   // (one 16-byte store each: the four taps of a (row, level) are consecutive)
                     size_t o = ((size_t)m * 5 + s) * 4;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        tap_texel[o + t] = tex[t];
-                        tap_weight[o + t] = w[t];
-                    }
+                    *(int4*)(tap_texel + o) = make_int4(tex[0], tex[1], tex[2], tex[3]);
+                    *(float4*)(tap_weight + o) = make_float4(w[0], w[1], w[2], w[3]);
                 }
             }
 #pragma unroll
