@@ -108,6 +108,10 @@ def parse():
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
                     help="AdamW of the step: 'fused' = scenerf_amd.optim.FusedAdamW (one HIP launch over all 40 parameter tensors), 'torch' = "
                          "torch.optim.AdamW(fused=True)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="train, one GPU: issue the step as ONE hipGraph replay (scenerf_amd.graph.GraphedStep: forward, loss, backward, fused "
+                         "AdamW captured once); 'auto' = on when it can be captured (bf16, device noise, the fused optimizer, one rank), the "
+                         "eagerly issued step is then reported next to it as `eager_step`; 'off' = the eager step is the headline")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short BASELINE configs[3] (BundleFusion) and configs[4] (inference) legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -138,7 +142,7 @@ def make_optimizer(args, params):
     if getattr(args, "optimizer", "fused") == "torch":
         return torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, fused=True)
     from scenerf_amd.optim import FusedAdamW
-    return FusedAdamW(params, lr=1e-5, weight_decay=0.0)
+    return FusedAdamW(params, lr=1e-5, weight_decay=0.0, capturable=bool(getattr(args, "capturable", False)))
 
 
 def make_model(args, dev, precision=None):
@@ -671,8 +675,45 @@ def main():
         return step
 
     step = make_step(model, opt)
-    dt, last = _timed(step, args, world, dev, sync)
-    host_ms = _timed.host_s / args.steps * 1e3
+    # one GPU: the step as ONE hipGraph replay (the product's GraphedStep); the eagerly issued step is measured right after it and
+    # reported as `eager_step`.  N > 1 stays eager: a captured RCCL collective has never run here.
+    graphed = eager_leg = None
+    graph_note = "eager (one launch call per kernel)"
+    want_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    if want_graph and not dry:
+        why = None
+        if world > 1: why = "more than one rank"
+        elif args.precision != "bf16" and args.graph == "auto": why = "fp32 mode"
+        elif getattr(args, "host_rng", False): why = "--host-rng (the host-side draw cannot be captured)"
+        elif args.optimizer != "fused": why = "--optimizer torch"
+        if why is None:
+            try:
+                from scenerf_amd.graph import GraphedStep
+                args.capturable = True
+                opt_g = make_optimizer(args, params)
+                args.capturable = False
+                loss_fn = lambda out: out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
+                graphed = GraphedStep(model, opt_g, loss_fn, K, T, maps, pix, ray_batch_size=R, warmup=max(1, args.warmup))
+                graph_note = "one hipGraph replay per step (scenerf_amd.graph.GraphedStep: forward + loss + backward + fused AdamW captured once)"
+            except Exception as e:      # (a capture that fails must not cost the line: the eager step is the fallback, and the line says so)
+                graphed = None
+                graph_note = "eager (graph capture failed: %s)" % repr(e)[:200]
+                torch.cuda.synchronize()
+        else:
+            graph_note = "eager (%s)" % why
+    if graphed is not None:
+        dt, last = _timed(graphed, args, world, dev, sync)
+        host_ms = _timed.host_s / args.steps * 1e3
+        dt_e, last_e = _timed(step, args, world, dev, sync)
+        assert torch.isfinite(last_e).item(), "loss is not finite (eager step)"
+        eager_leg = {"value": round(R * args.steps / dt_e, 1), "unit": "rays/s", "ms_per_step": round(dt_e / args.steps * 1e3, 3),
+                     "host_issue_ms_per_step": round(_timed.host_s / args.steps * 1e3, 3),
+                     "note": "the same step issued eagerly (~57 launch calls per step from Python), same process, right after the timed region"}
+        step_main = graphed
+    else:
+        dt, last = _timed(step, args, world, dev, sync)
+        host_ms = _timed.host_s / args.steps * 1e3
+        step_main = step
     ms = dt / args.steps * 1e3
     value = world * R * args.steps / dt
     assert torch.isfinite(last).item(), "loss is not finite"
@@ -688,7 +729,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_ss):
-            step()
+            step_main()
         torch.cuda.synchronize()
         d_ss = (time.perf_counter() - t0) / n_ss
         steady = {"value": round(R / d_ss, 1), "unit": "rays/s", "ms_per_step": round(d_ss * 1e3, 3), "steps": n_ss,
@@ -699,7 +740,7 @@ def main():
         maps = _make_maps("chw" if args.maps == "hwc" else "hwc", dev, rank)
         dt2, _ = _timed(step, args, world, dev, sync)
         other = {"maps": "chw" if args.maps == "hwc" else "hwc", "value": round(R * args.steps / dt2, 1), "unit": "rays/s",
-                 "ms_per_step": round(dt2 / args.steps * 1e3, 3)}
+                 "ms_per_step": round(dt2 / args.steps * 1e3, 3), "issued": "eager (compare with eager_step)"}
         maps = main_maps
         torch.cuda.empty_cache()
     rng_other = None
@@ -707,7 +748,8 @@ def main():
         model.render_cfg.device_rng = not model.render_cfg.device_rng
         dt3, _ = _timed(step, args, world, dev, sync)
         rng_other = {"sampling_noise": "device generator" if model.render_cfg.device_rng else "host generator + upload, like the reference (utils.py:208-211)",
-                     "value": round(R * args.steps / dt3, 1), "unit": "rays/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3)}
+                     "value": round(R * args.steps / dt3, 1), "unit": "rays/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+                     "issued": "eager (compare with eager_step)"}
         model.render_cfg.device_rng = not model.render_cfg.device_rng
 
     allreduce = None
@@ -813,10 +855,10 @@ def main():
                                        if args.maps == "hwc" else "incl. map layout conversion (contiguous (C,H,W) maps)"),
                        "rays_per_gpu": R, "samples_per_ray": args.samples, "parallelism": "dp%d" % world, "grad_sync": (args.sync if world > 1 else None),
                        "optimizer": "scenerf_amd.optim.FusedAdamW" if args.optimizer == "fused" else "torch.optim.AdamW(fused=True)",
-                       "precision": args.precision, "maps": args.maps,
+                       "precision": args.precision, "maps": args.maps, "step_issue": graph_note,
                        "sampling_noise": "host generator + upload, like the reference" if args.host_rng else
                                          "device generator (RenderConfig.device_rng=True; --host-rng gives the reference's host-side draw: +0.1-0.25 ms per step)"},
-            "other_entry": other, "other_rng": rng_other, "steady_state": steady,
+            "eager_step": eager_leg, "other_entry": other, "other_rng": rng_other, "steady_state": steady,
             "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager, "fp32_mode": fp32,
             "bundlefusion_c4": bf_leg, "infer_c5": inf_leg,
             "allreduce": allreduce, "ranks": census,

@@ -363,6 +363,11 @@ typedef struct scenerf_adamw_tensor {
 } scenerf_adamw_tensor;
 int scenerf_hip_adamw_step(int count, const scenerf_adamw_tensor* tensors, float lr, float beta1, float beta2, float eps,
                            float weight_decay, scenerf_stream_t stream);
+/* The capturable form (torch.optim.AdamW(capturable=True)): the learning rate and the step count -- INCLUDING this step, the same for
+ * every tensor -- are read from device memory, hyper = [lr, t] (fp32), so a hipGraph that holds this launch advances when the caller's
+ * graph (or a copy in front of the replay) updates them; bias corrections are formed on the device in fp32.  tensors[i].step is ignored. */
+int scenerf_hip_adamw_step_dev(int count, const scenerf_adamw_tensor* tensors, const float* hyper, float beta1, float beta2, float eps,
+                               float weight_decay, scenerf_stream_t stream);
 
 /* ---- image -> sphere resampling of the encoder levels --------------------------------------------------------
  * Replaces DecoderSphere.get_sphere_feature (reference scenerf/models/unet2d_sphere.py:138-165; six calls per image).

@@ -106,6 +106,7 @@ _PROTOS = {
     "scenerf_hip_ray_tail_forward": (C.c_int, [C.POINTER(Cfg)] + [vp] * 5 + [i32] + [vp] * 13 + [vp]),
     "scenerf_hip_ray_tail_backward": (C.c_int, [C.POINTER(Cfg)] + [vp] * 3 + [i32] + [vp] * 21 + [vp]),
     "scenerf_hip_adamw_step": (C.c_int, [i32, C.POINTER(AdamWTensor), C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
+    "scenerf_hip_adamw_step_dev": (C.c_int, [i32, C.POINTER(AdamWTensor), vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     "scenerf_hip_sphere_map_build": (C.c_int, [vp, vp, C.c_int64, i32, i32, i32, vp, vp, vp]),
     "scenerf_hip_sphere_resample_forward": (C.c_int, [vp, C.c_int64, i32, i32, vp, i32, i32, vp, vp]),
     "scenerf_hip_sphere_resample_backward": (C.c_int, [vp, C.c_int64, i32, i32, vp, vp, i32, i32, vp, vp]),

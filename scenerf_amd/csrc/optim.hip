@@ -24,6 +24,10 @@ struct OptArgs {
     int first_chunk[OPT_MAX_TENSORS + 1];   // prefix sum of chunks per tensor
     int count;
     float decay, b1, b2, eps;     // decay = 1 - lr * weight_decay
+    // capturable form (scenerf_hip_adamw_step_dev): the learning rate and the step count live in device memory, [lr, t] -- a replayed
+    // hipGraph then advances with them; bias corrections are formed here, in fp32, the same for every tensor of the launch
+    const float* hyper;
+    float wd;
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(OptArgs a) {
@@ -37,6 +41,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(OptArgs a) {
     const OptTensor& T = a.t[lo];
     const int e0 = (b - a.first_chunk[lo]) * OPT_CHUNK;
     const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2;
+    float decay = a.decay, step_size = T.step_size, inv_sqrt_bc2 = T.inv_sqrt_bc2;
+    if (a.hyper) {
+        const float lr = a.hyper[0], t = a.hyper[1];
+        decay = 1.f - lr * a.wd;
+        step_size = lr / (1.f - powf(a.b1, t));
+        inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(a.b2, t));
+    }
 #pragma unroll
     for (int it = 0; it < OPT_CHUNK / 1024; ++it) {
         const int e = e0 + it * 1024 + threadIdx.x * 4;
@@ -60,11 +71,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(OptArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            p[q] *= a.decay;
+            p[q] *= decay;
             m[q] = m[q] + (g[q] - m[q]) * omb1;
             v[q] = a.b2 * v[q] + omb2 * g[q] * g[q];
-            const float denom = sqrtf(v[q]) * T.inv_sqrt_bc2 + a.eps;
-            p[q] -= T.step_size * (m[q] / denom);
+            const float denom = sqrtf(v[q]) * inv_sqrt_bc2 + a.eps;
+            p[q] -= step_size * (m[q] / denom);
         }
         if (full) {
             *(float4*)(T.p + e) = make_float4(p[0], p[1], p[2], p[3]);
@@ -78,21 +89,23 @@ __global__ __launch_bounds__(256) void adamw_kernel(OptArgs a) {
     }
 }
 
-extern "C" int scenerf_hip_adamw_step(int count, const scenerf_adamw_tensor* tensors, float lr, float beta1, float beta2, float eps,
-                                      float weight_decay, scenerf_stream_t stream) {
+static int adamw_launch(int count, const scenerf_adamw_tensor* tensors, const float* hyper, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, scenerf_stream_t stream) {
     SRF_CHECK(tensors && count > 0, "adamw_step: no tensors");
     hipStream_t s = as_stream(stream);
     for (int base = 0; base < count; base += OPT_MAX_TENSORS) {
         OptArgs a;
         a.count = count - base < OPT_MAX_TENSORS ? count - base : OPT_MAX_TENSORS;
         a.decay = 1.f - lr * weight_decay; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+        a.hyper = hyper; a.wd = weight_decay;
         int chunks = 0;
         double bytes = 0;
         for (int i = 0; i < a.count; ++i) {
             const scenerf_adamw_tensor& t = tensors[base + i];
-            SRF_CHECK(t.p && t.g && t.m && t.v && t.numel > 0 && t.numel < (1ll << 31) && t.step >= 1, "adamw_step: bad tensor %d", base + i);
+            SRF_CHECK(t.p && t.g && t.m && t.v && t.numel > 0 && t.numel < (1ll << 31) && (hyper || t.step >= 1), "adamw_step: bad tensor %d", base + i);
             SRF_CHECK(t.g_cols == 0 || (t.g_ld >= t.g_cols && t.numel % t.g_cols == 0), "adamw_step: bad gradient view of tensor %d", base + i);
-            const double bc1 = 1.0 - pow((double)beta1, (double)t.step), bc2 = 1.0 - pow((double)beta2, (double)t.step);
+            const double st = hyper ? 1.0 : (double)t.step;   // (unused by the kernel when `hyper` is given)
+            const double bc1 = 1.0 - pow((double)beta1, st), bc2 = 1.0 - pow((double)beta2, st);
             a.t[i] = {t.p, t.g, t.m, t.v, (int)t.numel, t.g_cols, t.g_ld, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2))};
             a.first_chunk[i] = chunks;
             chunks += (int)((t.numel + OPT_CHUNK - 1) / OPT_CHUNK);
@@ -104,4 +117,15 @@ extern "C" int scenerf_hip_adamw_step(int count, const scenerf_adamw_tensor* ten
         SRF_LAUNCH_CHECK("adamw_kernel");
     }
     return 0;
+}
+
+extern "C" int scenerf_hip_adamw_step(int count, const scenerf_adamw_tensor* tensors, float lr, float beta1, float beta2, float eps,
+                                      float weight_decay, scenerf_stream_t stream) {
+    return adamw_launch(count, tensors, nullptr, lr, beta1, beta2, eps, weight_decay, stream);
+}
+
+extern "C" int scenerf_hip_adamw_step_dev(int count, const scenerf_adamw_tensor* tensors, const float* hyper, float beta1, float beta2,
+                                          float eps, float weight_decay, scenerf_stream_t stream) {
+    SRF_CHECK(hyper, "adamw_step_dev: hyper is NULL");
+    return adamw_launch(count, tensors, hyper, 0.f, beta1, beta2, eps, weight_decay, stream);
 }

@@ -4,8 +4,14 @@ The reference trains with ``torch.optim.AdamW(self.parameters(), lr, weight_deca
 optimizer -- same hyper-parameters, same ``param_groups`` / ``state_dict`` layout (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter),
 schedulers work on it unchanged -- with the update of ALL parameters of a group issued as one kernel that reads each gradient where
 autograd left it: the renderer hands ``lin_in.weight``'s gradient over as a sliced view of its gradient sink, which the stock fused
-optimizer first copies into a contiguous tensor.  amsgrad / maximize / capturable are not offered.  CUDA fp32 parameters only: anything
-else raises (no fallback).
+optimizer first copies into a contiguous tensor.  amsgrad / maximize are not offered.  CUDA fp32 parameters only: anything else raises
+(no fallback).
+
+``capturable=True`` (like torch's): the step count and the learning rate live in a device tensor per parameter group (``hyper`` =
+[lr, t]); ``step()`` advances t with a device-side add and the kernel forms the bias corrections itself, so the call can sit inside a
+captured hipGraph (``scenerf_amd.graph.GraphedStep``) and every replay is one more optimizer step.  A learning rate changed by a
+scheduler reaches a captured graph through ``sync_hyper()`` (one small fill, outside the graph).  All parameters of a group step
+together in this mode (a parameter without a gradient raises).
 """
 from __future__ import annotations
 
@@ -18,10 +24,34 @@ from . import _capi
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 capturable: bool = False):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameters")
-        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, capturable=bool(capturable)))
+        self._hyper = {}      # id(group) -> (device tensor [lr, t], the lr it holds)
+
+    def _group_hyper(self, group, dev):
+        h = self._hyper.get(id(group))
+        if h is None:
+            steps = [int(self.state[p]["step"]) for p in group["params"] if self.state.get(p)]
+            t0 = float(max(steps)) if steps else 0.0
+            h = [torch.tensor([float(group["lr"]), t0], dtype=torch.float32, device=dev), float(group["lr"])]
+            self._hyper[id(group)] = h
+        return h
+
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)
+        self._hyper = {}      # (the step counts just loaded seed the device-side counters at the next step)
+
+    def sync_hyper(self) -> None:
+        """Write the groups' current learning rates into their device-side copies (capturable mode; call it after a scheduler step
+        and before the next graph replay -- an eager ``step()`` does it by itself)."""
+        for group in self.param_groups:
+            h = self._hyper.get(id(group))
+            if h is not None and h[1] != float(group["lr"]):
+                h[0][0:1].fill_(float(group["lr"]))
+                h[1] = float(group["lr"])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -51,10 +81,11 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] = int(st["step"]) + 1
+                if not group.get("capturable"):
+                    st["step"] = int(st["step"]) + 1
                 e = _capi.AdamWTensor()
                 e.p, e.m, e.v = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                e.numel, e.step = p.numel(), st["step"]
+                e.numel, e.step = p.numel(), (1 if group.get("capturable") else st["step"])
                 if g.is_contiguous():
                     e.g, e.g_cols, e.g_ld = g.data_ptr(), 0, 0
                 elif g.dim() == 2 and g.stride(1) == 1 and g.stride(0) >= g.shape[1]:
@@ -69,7 +100,20 @@ class FusedAdamW(torch.optim.Optimizer):
             arr = (_capi.AdamWTensor * len(entries))(*entries)
             b1, b2 = group["betas"]
             with torch.cuda.device(dev):
-                _capi.check(lib.scenerf_hip_adamw_step(len(entries), arr, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                                       float(group["weight_decay"]), torch.cuda.current_stream(dev).cuda_stream), "adamw_step")
+                if group.get("capturable"):
+                    if len(entries) != len(group["params"]):
+                        raise RuntimeError("FusedAdamW(capturable=True): every parameter of a group needs a gradient (one step count per group)")
+                    hyper, lr_held = self._group_hyper(group, dev)
+                    if not torch.cuda.is_current_stream_capturing() and lr_held != float(group["lr"]):
+                        self.sync_hyper()
+                    hyper[1:2].add_(1.0)                        # t, on the device: a replayed graph counts on
+                    for p in group["params"]:
+                        self.state[p]["step"] = hyper[1]        # (like torch's capturable optimizers: a device scalar)
+                    _capi.check(lib.scenerf_hip_adamw_step_dev(len(entries), arr, hyper.data_ptr(), float(b1), float(b2), float(group["eps"]),
+                                                               float(group["weight_decay"]), torch.cuda.current_stream(dev).cuda_stream),
+                                "adamw_step_dev")
+                else:
+                    _capi.check(lib.scenerf_hip_adamw_step(len(entries), arr, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                           float(group["weight_decay"]), torch.cuda.current_stream(dev).cuda_stream), "adamw_step")
             del keep
         return loss

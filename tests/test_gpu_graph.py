@@ -1,0 +1,132 @@
+"""scenerf_amd.graph.GraphedStep (one hipGraph per training step) and FusedAdamW(capturable=True): a replayed step is an eager step."""
+import copy
+
+import pytest
+import torch
+
+from scenerf_amd import synth
+from scenerf_amd.model import SceneRF
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_capturable_adamw_follows_the_host_counted_one():
+    from scenerf_amd.optim import FusedAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(512, 42), (512,), (4, 512), (4097,)]
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = FusedAdamW(pa, lr=3e-3, betas=(0.9, 0.99), weight_decay=0.05)
+    ob = FusedAdamW(pb, lr=3e-3, betas=(0.9, 0.99), weight_decay=0.05, capturable=True)
+    sa, sb = torch.optim.lr_scheduler.ExponentialLR(oa, gamma=0.9), torch.optim.lr_scheduler.ExponentialLR(ob, gamma=0.9)
+    for step in range(5):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+        sa.step(); sb.step()
+    for a, b in zip(pa, pb):
+        # (bias corrections in fp32 on the device against double on the host)
+        torch.testing.assert_close(b.detach(), a.detach(), rtol=2e-5, atol=2e-6)
+        assert float(ob.state[b]["step"]) == 5.0 and int(oa.state[a]["step"]) == 5
+    # a parameter without a gradient cannot lag behind in this mode
+    pb[1].grad = None
+    with pytest.raises(RuntimeError, match="every parameter"):
+        ob.step()
+    # state_dict round trip: the device-side counter restarts from the loaded steps
+    for b in pb:
+        b.grad = torch.ones_like(b)
+    pc = [torch.nn.Parameter(b.detach().clone()) for b in pb]
+    oc = FusedAdamW(pc, lr=1.0, capturable=True)
+    oc.load_state_dict(copy.deepcopy(ob.state_dict()))
+    for c in pc:
+        c.grad = torch.ones_like(c)
+    ob.step(); oc.step()
+    for b, c in zip(pb, pc):
+        assert torch.equal(b.detach(), c.detach())
+
+
+def _setup(seed):
+    torch.manual_seed(seed)
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, n_pts_uni=32, n_pts_per_gaussian=8, precision="bf16",
+                device_rng=True).to(DEV)
+    m.mlp.load_state_dict(synth.mlp_state(1, 4))
+    m.mlp_gaussian.load_state_dict(synth.mlp_state(2, 2, out_scale=4.0))
+    from scenerf_amd.optim import FusedAdamW
+    opt = FusedAdamW(list(m.mlp.parameters()) + list(m.mlp_gaussian.parameters()), lr=1e-4, weight_decay=0.0, capturable=True)
+    maps = {k: v.to(DEV).requires_grad_(True) for k, v in synth.feature_maps(1500, 452, 3).items()}
+    K, T = synth.kitti_cam_K().to(DEV), synth.rel_pose(1.0, 0.0).to(DEV)
+    pix = synth.stride2_pixels((1220, 370), 256, 100).to(DEV)
+    g = torch.Generator().manual_seed(seed + 100)
+    noise = (torch.rand(256, 32, generator=g).to(DEV), torch.randn(256, 4 * 8, generator=g).to(DEV))   # static: the same draw every step
+    return m, opt, maps, K, T, pix, noise
+
+
+def _loss(out):
+    return out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
+
+
+def _eager_run(steps):
+    m, opt, maps, K, T, pix, noise = _setup(5)
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        for v in maps.values():
+            v.grad = None
+        loss = _loss(m.render_rays_batch(K, T, maps, T_cam2velo=None, sampled_pixels=pix, ray_batch_size=256, noise=noise))
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    return [p.detach().clone() for p in opt.param_groups[0]["params"]], {k: v.grad.detach().clone() for k, v in maps.items()}, losses
+
+
+def _rel(a, b):
+    num = sum(float((x.detach() - y.detach()).norm() ** 2) for x, y in zip(a, b)) ** 0.5
+    return num / sum(float(x.detach().norm() ** 2) for x in a) ** 0.5
+
+
+def test_graphed_step_replays_the_eager_step():
+    """W warm-up steps + N replays of ONE captured step against W + N eager steps from the same start, with the sampler noise
+    injected (the same static draw in every step of every run).  Two eager runs already differ -- bf16 weights, fp32 atomics in a
+    different order, samples that land on the other side of a texel boundary -- so the yardstick is that run-to-run spread."""
+    from scenerf_amd.graph import GraphedStep
+    N, W = 3, 2
+    ref, gref, losses = _eager_run(W + N)
+    ref2, gref2, losses2 = _eager_run(W + N)
+    m2, opt2, maps2, K2, T2, pix2, noise2 = _setup(5)
+    gs = GraphedStep(m2, opt2, _loss, K2, T2, maps2, pix2, ray_batch_size=256, warmup=W, noise=noise2)
+    got = [float(gs()) for _ in range(N)]
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(torch.tensor(got)))
+    assert float(opt2.state[opt2.param_groups[0]["params"][0]]["step"]) == float(W + N)     # every replay was an optimizer step
+    m0 = _setup(5)[0]       # the starting point: the optimizer did move the parameters
+    assert _rel(ref, list(m0.mlp.parameters()) + list(m0.mlp_gaussian.parameters())) > 1e-4
+    spread_p = _rel(ref, ref2)
+    assert _rel(ref, [p.detach() for p in opt2.param_groups[0]["params"]]) <= 3 * spread_p + 1e-5, (spread_p, losses, got)
+    assert abs(got[-1] - losses[-1]) <= 3 * abs(losses2[-1] - losses[-1]) + 2e-3 * (1 + abs(losses[-1])), (losses, losses2, got)
+    for k in gref:      # map gradients of the last replay land in the captured leaves' .grad
+        spread = float((gref[k] - gref2[k]).norm())
+        assert float((gref[k] - gs.map_grads[k]).norm()) <= 3 * spread + 2e-2 * float(gref[k].norm()) + 1e-6, (k, spread)
+
+
+def test_graphed_step_with_the_device_draw_inside_the_graph():
+    from scenerf_amd.graph import GraphedStep
+    m, opt, maps, K, T, pix, _ = _setup(7)
+    gs = GraphedStep(m, opt, _loss, K, T, maps, pix, ray_batch_size=256, warmup=2)
+    got = [float(gs()) for _ in range(4)]
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(torch.tensor(got)))
+    assert len(set(round(x, 7) for x in got)) > 1, got      # a fresh draw per replay: the loss moves from step to step
+    assert float(opt.state[opt.param_groups[0]["params"][0]]["step"]) == 6.0
+
+
+def test_graphed_step_refuses_what_cannot_be_captured():
+    from scenerf_amd.graph import GraphedStep
+    from scenerf_amd.optim import FusedAdamW
+    m, opt, maps, K, T, pix, _ = _setup(1)
+    with pytest.raises(RuntimeError, match="capturable"):
+        GraphedStep(m, FusedAdamW(list(m.mlp.parameters()), lr=1e-4), _loss, K, T, maps, pix)
+    m.render_cfg.device_rng = False
+    with pytest.raises(RuntimeError, match="device"):
+        GraphedStep(m, opt, _loss, K, T, maps, pix)
