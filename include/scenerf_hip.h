@@ -73,9 +73,9 @@ typedef struct scenerf_cfg {
     /* kernel-path selection (explicit state of the call, never ambient: no environment variable changes what a call computes) */
     int32_t fused_min_rows;         /* bf16: row count M from which the ResnetFC trunk (forward) and the dgrad chain (backward) each run as
                                        ONE fused kernel; below it the per-layer GEMM path runs.  0 = library default (4096); < 0 = never */
-    int32_t fwd_kernel;             /* fused forward variant: 0 = LDS-ring pipeline, 64-row blocks (fused.hip); 1 = register-streamed, 64-row
-                                       blocks (stream.hip), bit-identical to 0; 2 = 128-row blocks, one wave per SIMD (wide.hip): same
-                                       rounding points, the bias added after the K sum instead of before it (last-ulp differences) */
+    int32_t fwd_kernel;             /* fused forward variant: 0 = LDS-ring pipeline, 64-row blocks (fused.hip); 2 = 128-row blocks, one wave
+                                       per SIMD (wide.hip): same rounding points, the bias added after the K sum instead of before it
+                                       (last-ulp differences).  (1 was a register-streamed 64-row variant, removed: refused) */
     uint32_t flags;                 /* SCENERF_FLAG_* */
 } scenerf_cfg;
 #define SCENERF_FUSED_MIN_ROWS_DEFAULT 4096
@@ -318,7 +318,7 @@ int scenerf_hip_test_gemm_tn(int precision, const void* D, const void* A, int M,
                              float* C, float* colsum, scenerf_stream_t stream);
 
 /* Host-only (no GPU needed): the chunk-descriptor tables the fused ResnetFC kernels walk -- kind 0: fused.hip (33 sets: one per
- * scale mask for the forward, set 32 = backward chain), kind 1: stream.hip (32 sets), kind 2: wide.hip (33 sets: 32 forward masks + the backward chain).  A set is SCENERF_CHUNK_TABLE_STRIDE ints:
+ * scale mask for the forward, set 32 = backward chain), kind 2: wide.hip (33 sets: 32 forward masks + the backward chain; kind 1 is refused).  A set is SCENERF_CHUNK_TABLE_STRIDE ints:
  * entry 0 = number of descriptors, then the descriptors, zero-padded.  Returns the number of ints written (<= cap) or < 0. */
 #define SCENERF_CHUNK_TABLE_STRIDE 704
 int scenerf_hip_test_chunk_table(const scenerf_cfg* cfg, int kind, int32_t* out, int cap);

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 # development knobs (kernel experiments, tools/variants.sh): extra -D flags build a separately named library next to the default one
 _TAG = os.environ.get("SRF_LIB_TAG", "")
 LIB = os.path.join(CSRC, "libscenerf_hip%s.so" % ("_" + _TAG if _TAG else ""))
-SOURCES = ["runtime.hip", "rays.hip", "gemm.hip", "wgrad.hip", "fused.hip", "stream.hip", "wide.hip", "dfeat.hip", "mlp.hip", "loss.hip", "tsdf.hip", "sphere.hip", "optim.hip"]
+SOURCES = ["runtime.hip", "rays.hip", "gemm.hip", "wgrad.hip", "fused.hip", "wide.hip", "dfeat.hip", "mlp.hip", "loss.hip", "tsdf.hip", "sphere.hip", "optim.hip"]
 # wide.hip owns the whole accumulator file (a[0:255] by name in inline-asm MFMAs): the compiler must not park spilled VGPRs there
 # (a spill then shows up as scratch usage, which tools/asmcheck.sh and the build's resource check refuse)
 EXTRA = {"wide.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}

@@ -55,7 +55,7 @@ class RenderConfig:
     hwc_scales: Tuple[int, ...] = ()
     # kernel-path selection (scenerf_cfg.fused_min_rows / fwd_kernel / flags): explicit per-call state, no environment variables
     fused_min_rows: int = _capi.FUSED_MIN_ROWS_DEFAULT   # bf16: rows from which the ResnetFC trunk / dgrad chain run as one fused kernel; < 0 never
-    fwd_kernel: str = "wide"          # fused forward variant: "ring" (fused.hip), "stream" (stream.hip; bit-identical), "wide" (wide.hip: 128-row blocks)
+    fwd_kernel: str = "wide"          # fused forward variant: "ring" (fused.hip: 64-row blocks), "wide" (wide.hip: 128-row blocks)
     fused_backward: bool = True       # False: the dgrad chain as six per-layer GEMMs even where the fused chain applies
     wgrad_tr: bool = True             # False: weight gradients through gemm_tn only
     dfeat_gemm: bool = False          # True: bf16 feature-map gradients through gemm.hip's scatter epilogue instead of dfeat.hip
@@ -119,8 +119,8 @@ class RenderConfig:
         if self.n_samples > 512:
             raise ValueError("n_samples = %d exceeds the 512-sample limit of the wave-per-ray kernels" % self.n_samples)
         _ = self.precision_code
-        if self.fwd_kernel not in ("ring", "stream", "wide"):
-            raise ValueError("fwd_kernel must be 'ring', 'stream' or 'wide', got %r" % (self.fwd_kernel,))
+        if self.fwd_kernel not in ("ring", "wide"):
+            raise ValueError("fwd_kernel must be 'ring' or 'wide', got %r" % (self.fwd_kernel,))
         if self.bwd_kernel not in ("ring", "wide"):
             raise ValueError("bwd_kernel must be 'ring' or 'wide', got %r" % (self.bwd_kernel,))
 
@@ -151,7 +151,7 @@ class RenderConfig:
         for i in range(5):
             c.map_chw[i] = 2 if i in self.hwc_scales else (1 if i in self.direct_scales else 0)
         c.fused_min_rows = int(self.fused_min_rows)
-        c.fwd_kernel = {"ring": 0, "stream": 1, "wide": 2}[self.fwd_kernel]
+        c.fwd_kernel = {"ring": 0, "wide": 2}[self.fwd_kernel]
         c.flags = ((0 if self.fused_backward else _capi.FLAG_NO_FUSED_BWD) | (0 if self.wgrad_tr else _capi.FLAG_NO_WGRAD_TR)
                    | (_capi.FLAG_DFEAT_PER_SCALE if self.dfeat_per_scale else 0) | (_capi.FLAG_WGRAD_OVERLAP if self.wgrad_overlap else 0)
                    | (_capi.FLAG_UNIFORM_ONLY if self.uniform_only else 0)

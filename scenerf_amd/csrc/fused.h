@@ -1,5 +1,4 @@
-// Shared by the fused ResnetFC kernels (fused.hip: LDS-ring pipeline, still used for the backward dgrad chain; stream.hip: the
-// register-streamed forward).
+// Shared by the fused ResnetFC kernels (fused.hip: 64-row LDS-ring pipeline; wide.hip: 128-row blocks).
 #pragma once
 #include "gemm.h"
 #include <vector>
@@ -66,12 +65,10 @@ int srf_desc_cache_get(SrfDescCache& C, const scenerf_cfg* cfg, hipStream_t s, i
                        const int** desc);
 // one-time per-device setup of each kernel family (kernel attributes, descriptor tables, the zero page)
 int fused_prepare(const scenerf_cfg* cfg, hipStream_t s);
-int stream_prepare(const scenerf_cfg* cfg, hipStream_t s);
 int wide_prepare(const scenerf_cfg* cfg, hipStream_t s);
 int wgrad_prepare();
 int gemm_prepare();
 
 // host-only builders of the chunk-descriptor tables (also reachable through scenerf_hip_test_chunk_table for the CPU tests)
 int fused_table_build(const scenerf_cfg* cfg, std::vector<int>& tab);    // fused.hip: 33 sets of F_MAXCH ints
-int stream_table_build(const scenerf_cfg* cfg, std::vector<int>& tab);   // stream.hip: 32 sets of F_MAXCH ints
 int wide_table_build(const scenerf_cfg* cfg, std::vector<int>& tab);     // wide.hip: 33 sets of F_MAXCH ints (32 forward masks + the backward chain)

@@ -77,9 +77,6 @@ int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
                          const scenerf_mlp_acts* a, hipStream_t s);
 // backward dgrad chain of the three residual blocks in one kernel (bf16): reads dH column block 3, writes dH column blocks 2..0 and
 // dN [3][M][512]; sign gates come from the saved activations a->Nn / a->H.
-// stream.hip: the register-streamed forward (same arguments and results as launch_mlp_fwd_fused, which it replaces by default)
-int launch_mlp_fwd_stream(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const uint8_t* tile_mask, int M,
-                          const scenerf_mlp_acts* a, hipStream_t s);
 // wide.hip: the same forward on 128-row blocks, one wave per SIMD (activations agree to the last bf16 ulp, not bit for bit: the bias is
 // added after the K sum), and the dgrad chain on the same kernel shape (bit-identical to launch_mlp_bwd_fused)
 int launch_mlp_fwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const uint8_t* tile_mask, int M,

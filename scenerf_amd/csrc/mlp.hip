@@ -298,7 +298,6 @@ int scenerf_hip_prepare(const scenerf_cfg* cfg, scenerf_stream_t stream) {
     if (int e = wgrad_prepare()) return e;
     if (cfg->precision) {
         if (int e = fused_prepare(cfg, s)) return e;
-        if (int e = stream_prepare(cfg, s)) return e;
         if (int e = wide_prepare(cfg, s)) return e;
     }
     return 0;
@@ -350,13 +349,13 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
         }
         // rows from which the whole trunk runs as ONE fused kernel (scenerf_cfg.fused_min_rows), lin_out included
         if (srf_use_fused(cfg, M) && w->w_stream) {
-            // two kernels with identical results: fused.hip's LDS-ring pipeline and stream.hip's register-streamed one (scenerf_cfg.fwd_kernel)
-            SRF_CHECK(cfg->fwd_kernel >= 0 && cfg->fwd_kernel <= 2, "mlp_forward: unknown fwd_kernel %d", cfg->fwd_kernel);
+            // scenerf_cfg.fwd_kernel: 0 = fused.hip's 64-row LDS-ring pipeline, 2 = wide.hip's 128-row blocks (1 was a register-streamed
+            // 64-row variant with identical results and the same speed: removed in round 3)
+            SRF_CHECK(cfg->fwd_kernel == 0 || cfg->fwd_kernel == 2, "mlp_forward: unknown fwd_kernel %d", cfg->fwd_kernel);
             // (128-row blocks need enough of them to fill the chip: the gaussian head's 4,800 rows are 38 blocks on 256 CUs -- 156 us against
             // the 64-row ring kernel's 109 us)
             if (cfg->fwd_kernel == 2 && (cdiv(M, 128) >= SRF_WIDE_MIN_BLOCKS || (cfg->flags & SCENERF_FLAG_WIDE_ANY_M))) return launch_mlp_fwd_wide(cfg, w, Z, tile_mask, M, a, s);
-            if (cfg->fwd_kernel == 2) return launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s);
-            return cfg->fwd_kernel == 1 ? launch_mlp_fwd_stream(cfg, w, Z, tile_mask, M, a, s) : launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s);
+            return launch_mlp_fwd_fused(cfg, w, Z, tile_mask, M, a, s);
         }
         SRF_CHECK(a->H[3], "mlp_forward: acts->H[3] is NULL");
         SRF_CHECK(a->H[0] && a->H[1] && a->H[2] && a->Nn[0] && a->Nn[1] && a->Nn[2],
@@ -584,9 +583,9 @@ int scenerf_hip_test_gemm_nt(int precision, const void* A, const void* W, const 
 }
 
 int scenerf_hip_test_chunk_table(const scenerf_cfg* cfg, int kind, int32_t* out, int cap) {
-    if (!(cfg && out && kind >= 0 && kind <= 2)) { srf_set_error("test_chunk_table: bad arguments"); return -1; }
+    if (!(cfg && out && (kind == 0 || kind == 2))) { srf_set_error("test_chunk_table: bad arguments (kind 0 = fused.hip, 2 = wide.hip)"); return -1; }
     std::vector<int> tab;
-    if (int e = kind == 0 ? fused_table_build(cfg, tab) : kind == 1 ? stream_table_build(cfg, tab) : wide_table_build(cfg, tab)) return -e;
+    if (int e = kind == 0 ? fused_table_build(cfg, tab) : wide_table_build(cfg, tab)) return -e;
     if ((int)tab.size() > cap) { srf_set_error("test_chunk_table: output buffer too small (%d ints needed)", (int)tab.size()); return -2; }
     for (size_t i = 0; i < tab.size(); ++i) out[i] = tab[i];
     return (int)tab.size();

@@ -4,7 +4,7 @@
 // reference scenerf/models/resnetfc.py:41-57,133-164.
 //
 // Why this shape (measured history: DESIGN.md section 5).  A 64-row block needs all 16 KiB of a K chunk's weights per 256 MFMA cycles:
-// 64 B/clk/CU, twice what a CU pulls from L2, so every 64-row design (fused.hip, stream.hip) saturates near 45 % MFMA.  A 128-row
+// 64 B/clk/CU, twice what a CU pulls from L2, so every 64-row design (fused.hip) saturates near 45 % MFMA.  A 128-row
 // block halves the weight bytes per FLOP; its 128 x 512 fp32 accumulators are 256 KiB -- HALF of the CU's register file:
 //   * 4 waves, one per SIMD, each with the whole 512-register budget: wave w owns output columns [128 w, 128 w + 128) for all 128 rows
 //     = 4 x 4 MFMA 32x32x16 tiles = 256 accumulators held in a[0:255] (the accumulator file) by inline-asm MFMAs on literal registers;
@@ -27,7 +27,7 @@
 //     forward's sign bits instead of bias / relu); lin_out (512 -> 4) runs on the matrix cores too, from the resident H3 tile against a
 //     three-term bf16 split of its fp32 weights; the finished layer is streamed out of the A buffer (coalesced 16-byte pieces +
 //     sign bits, as in fused.hip) one piece per chunk of the next layer.
-// Results: same rounding points as fused.hip / stream.hip; the forward adds the bias after the K sum instead of before it and sums
+// Results: same rounding points as fused.hip; the forward adds the bias after the K sum instead of before it and sums
 // layer 0's K segments in a different order, so activations agree with those kernels to the last bf16 ulp, not bit for bit; the
 // backward chain has no bias and the same K order: bit-identical to fused.hip's and to the per-layer dgrad GEMMs (tests/test_gpu_stages.py).
 #include "fused.h"

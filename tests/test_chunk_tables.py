@@ -1,4 +1,4 @@
-"""Host logic of the fused ResnetFC kernels: the chunk-descriptor tables they walk (csrc/fused.hip, csrc/stream.hip), read back
+"""Host logic of the fused ResnetFC kernels: the chunk-descriptor tables they walk (csrc/fused.hip, csrc/wide.hip), read back
 through the host-only C entry scenerf_hip_test_chunk_table.  No GPU needed.  For every scale mask the descriptors must cover each
 16-wide K chunk of each layer exactly once, in order, with the right operand source / column / weight block, and satisfy the
 structural rules the kernels rely on (layer ends on group boundaries, stages, padding)."""
@@ -74,35 +74,15 @@ def test_ring_kernel_tables(variant):
         assert f["end"] == (i % 32 == 31) and f["begin"] == (i % 32 == 0) and (int(d[i]) >> 25) & 7 == i % 5
 
 
-@pytest.mark.parametrize("variant", ["kitti", "bundlefusion"])
-def test_stream_kernel_tables(variant):
-    """stream.hip: one descriptor per PAIR of chunks; layers padded to groups of four steps; odd segments end in a half no-op pair."""
-    tabs, chans = _tables(1, variant)
-    for mask in range(32):
-        n, d = int(tabs[mask, 0]), [int(x) for x in tabs[mask, 1:]]
-        want, _ = _expected_chunks(mask, chans)
-        assert n % 4 == 0 and n + 20 <= STRIDE - 1                                 # the kernel copies n + 20 entries into LDS
-        got = []
-        for i in range(n):
-            f = _fields(d[i])
-            skip2, stage, skipall = (d[i] >> 25) & 1, (d[i] >> 26) & 7, (d[i] >> 29) & 1
-            assert stage == i % 8
-            if skipall:
-                assert f["src"] == 0 and f["block"] == 0                          # harmless loads, MFMAs skipped
-            else:
-                got.append((f["layer"], f["src"], f["acol"], f["block"]))
-                if not skip2:
-                    got.append((f["layer"], f["src"], f["acol"] + 1, f["block"] + 1))
-                else:
-                    assert f["src"] != 0                                           # only streamed (odd) segments end in a half pair:
-                                                                                   # their second half is staged as zeros
-            last_of_layer = i + 1 == n or _fields(d[i + 1])["layer"] != f["layer"]
-            assert f["end"] == last_of_layer
-            if last_of_layer:
-                assert i % 4 == 3                                                  # the epilogue site is the end of a group
-        assert got == [tuple(int(v) for v in w) for w in want], mask               # every chunk exactly once, in order
-        # pairs never straddle two segments: the second chunk continues the first one's column run and weight run
-        assert all(x == 0 for x in d[n:n + 20])
+def test_removed_kernel_kind_is_refused():
+    """kind 1 was stream.hip's table (a register-streamed 64-row forward with fused.hip's results and speed, removed in round 3)."""
+    import ctypes as C
+    from scenerf_amd.config import RenderConfig
+    lib = _capi.load()
+    buf = (C.c_int32 * 8)()
+    assert lib.scenerf_hip_test_chunk_table(C.byref(RenderConfig.kitti().to_c()), 1, buf, 8) < 0
+    with pytest.raises(ValueError):
+        RenderConfig.kitti(fwd_kernel="stream").to_c()
 
 
 @pytest.mark.parametrize("variant", ["kitti", "bundlefusion"])

@@ -661,56 +661,6 @@ def test_mlp_forward_fused_matches_layer_path(case, M):
     assert ef <= max(1.25 * el, 1e-2 * max(float(ref.abs().max()), 1.0))
 
 
-@pytest.mark.parametrize("M,lean", [(64, False), (4133, False), (40000, False), (40000, True), (153600, False)])
-def test_mlp_forward_stream_equals_ring_kernel(case, M, lean):
-    """stream.hip (weights streamed into a register ring, no per-chunk barrier) against fused.hip's LDS-ring kernel: the same chunk
-    order and arithmetic, so every saved activation, sign bit and logit must be IDENTICAL -- mixed tile masks, a ragged tail, the
-    lean inference buffers (nothing but the logits kept) and the full bench row count."""
-    import dataclasses
-    from scenerf_amd.renderer import _MlpRun
-    lib = _capi.load()
-    rcfg, xin0, state, d_out, pk = _mlp_case(case, "bf16", "mlp")
-    gen = torch.Generator().manual_seed(M + 1)
-    ntile = (M + 127) // 128
-    masks = torch.tensor([7, 31, 1, 5, 0, 24, 3, 16], dtype=torch.uint8)[torch.arange(ntile) % 8]
-    nz = min(M, 40000)
-    z = torch.randn(nz, 2480, generator=gen).to(torch.bfloat16)
-    xe = torch.randn(nz, 48, generator=gen).clamp(-1, 1)
-    xe[:, 42:] = 0
-    seg = [0]
-    for c, _, _ in rcfg.map_shapes():
-        seg.append(seg[-1] + c)
-    reps = (M + nz - 1) // nz
-    runs = {}
-    for name in ("ring", "stream"):
-        cc = dataclasses.replace(rcfg, fused_min_rows=1, fwd_kernel=name).to_c()
-        run = _MlpRun(M, d_out, 1, torch.device(DEV), lean=lean)
-        run.Z.fill_(float("nan"))      # columns of scales a tile does not touch must never be read (beyond the dense first 256)
-        run.Z[:, :256] = 0
-        zz = dv(z).repeat(reps, 1)[:M]
-        for s_ in range(5):
-            act = ((masks.long() >> s_) & 1).bool().repeat_interleave(128)[:M]
-            cols = slice(seg[s_], seg[s_ + 1])
-            run.Z[:M, cols] = torch.where(dv(act)[:, None], zz[:, cols], run.Z[:M, cols])
-        run.xenc.copy_(dv(xe).repeat(reps, 1)[:M])
-        run.tile_mask.zero_()
-        run.tile_mask[:ntile] = dv(masks)
-        _capi.check(lib.scenerf_hip_mlp_forward(C.byref(cc), C.byref(pk.c), run.Z.data_ptr(), run.xenc.data_ptr(), run.tile_mask.data_ptr(),
-                                                M, C.byref(run.c), _st()), "mlp_forward")
-        torch.cuda.synchronize()
-        runs[name] = run
-    a, b = runs["ring"], runs["stream"]
-    assert torch.isfinite(b.logits).all()
-    assert torch.equal(a.logits, b.logits)
-    if not lean:
-        for i in range(4):
-            assert torch.equal(a.H[i].view(torch.int16), b.H[i].view(torch.int16)), "H%d" % i
-        for i in range(3):
-            assert torch.equal(a.Nn[i].view(torch.int16), b.Nn[i].view(torch.int16)), "N%d" % i
-        for l in range(6):
-            assert torch.equal(a.sign_bits[l, :M], b.sign_bits[l, :M]), "sign bits of layer %d" % l
-
-
 @pytest.mark.parametrize("M,lean", [(64, False), (4133, False), (40000, False), (40000, True)])
 def test_mlp_forward_wide_kernel_matches_ring_kernel(case, M, lean):
     """wide.hip (128-row blocks, one wave per SIMD, accumulators in the accumulator file) against fused.hip's ring kernel: the same

@@ -1,5 +1,5 @@
-"""Time the ResnetFC forward (per-layer path and the fused kernels: ring / stream / wide) on random inputs at the bench row count, and
-compare the fused variants' outputs.   usage: fused_probe.py [M] [reps] [kernels: layers,ring,stream,wide]
+"""Time the ResnetFC forward (per-layer path and the fused kernels: ring / wide) on random inputs at the bench row count, and
+compare the fused variants' outputs.   usage: fused_probe.py [M] [reps] [kernels: layers,ring,wide]
 env: PROBE_MASK (scale mask of every tile, default 1 = KITTI's common case), PROBE_LEAN=1 (inference buffers), PROBE_COLD=1 (also time
 calls behind a cache-flushing fill)"""
 import ctypes as C, dataclasses, os, sys
@@ -11,7 +11,7 @@ from scenerf_amd.renderer import MLP_PARAM_NAMES, PackedMLP, _MlpRun
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 153600
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-kernels = (sys.argv[3] if len(sys.argv) > 3 else "ring,stream,wide").split(",")
+kernels = (sys.argv[3] if len(sys.argv) > 3 else "ring,wide").split(",")
 maskv = int(os.environ.get("PROBE_MASK", "1"))
 lean = bool(os.environ.get("PROBE_LEAN"))
 dev = torch.device("cuda:0")
@@ -57,7 +57,7 @@ for name in kernels:
     print("%-7s M=%d mask=%d%s: %.3f ms per forward  %.0f TFLOP/s issued = %.1f %% of 2.5 PF" % (
         name, M, maskv, " lean" if lean else "", ms, fl / ms / 1e9, fl / ms / 1e9 / 25), flush=True)
     res[name] = run
-ref = res.get("ring") or res.get("stream")
+ref = res.get("ring")
 for name, run in res.items():
     if run is ref or ref is None or name == "layers":
         continue
@@ -71,4 +71,4 @@ for name, run in res.items():
             a, b = ref.Nn[i].float(), run.Nn[i].float()
             msg.append("N%d: %.5f equal" % (i, (a == b).float().mean().item()))
         msg.append("sign bits equal %.6f" % (ref.sign_bits[:6, :M] == run.sign_bits[:6, :M]).float().mean().item())
-    print("%s vs %s: %s" % (name, "ring" if "ring" in res else "stream", "; ".join(msg)))
+    print("%s vs %s: %s" % (name, "ring", "; ".join(msg)))
