@@ -53,7 +53,8 @@ def _on(dev):
 _SIDE = {}
 PREFILL_AT = 2               # where a training session zeroes the map-gradient accumulators on the side stream: 0 = at the session's
                              # start (beside the gaussian head's chain), 1 = behind the head's forward, 2 = behind the radiance MLP's
-                             # (2.635 / -- / 2.622 ms per step: the fill no longer runs beside the head's latency-bound chain)
+                             # (2.635 / -- / 2.622 ms per step: the fill no longer runs beside the head's latency-bound chain;
+                             #  beside the radiance MLP's forward instead of behind it: +16 us, not offered)
 MAIN_WGRAD_OVERLAP = True    # radiance MLP's weight gradients on the library's side stream, beside its feature-map gradients (-35 us/step)
 DEFER_HEAD_PACK = True     # (tools/ab_step.py toggles this)
 
