@@ -1,5 +1,5 @@
 """Where a wide.hip block's cycles go: per-block s_memtime stamps of wave 0 (library built with SRF_LIB_TAG=cyc SRF_EXTRA_FLAGS=-DH_CYC).
-usage: SRF_LIB_TAG=cyc python tools/wide_cycles.py [M]      env PROBE_MASKS as in wide_probe.py"""
+usage: SRF_LIB_TAG=cyc python tools/wide_cycles.py [M]      env PROBE_MASKS, PROBE_ZERO as in wide_probe.py"""
 import ctypes as C, dataclasses, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,8 @@ lib = _capi.load()
 lib.scenerf_hip_test_wide_cyc.argtypes = [C.c_void_p]
 rcfg = RenderConfig.kitti(precision="bf16")
 state = synth.mlp_state(1, 4)
-pk = PackedMLP([torch.as_tensor(state[n]).to(dev) for n in MLP_PARAM_NAMES], 4, rcfg)
+ZERO = os.environ.get("PROBE_ZERO", "0") == "1"    # all-zero weights and inputs: the same instruction stream at the lowest switching power
+pk = PackedMLP([torch.zeros_like(torch.as_tensor(state[n])).to(dev) if ZERO else torch.as_tensor(state[n]).to(dev) for n in MLP_PARAM_NAMES], 4, rcfg)
 gen = torch.Generator().manual_seed(1)
 ntile = (M + 127) // 128
 masks = torch.tensor(pat, dtype=torch.uint8)[torch.arange(ntile) % len(pat)]
@@ -25,6 +26,8 @@ run.Z.copy_((torch.randn(ntile * 128, 2480, generator=gen) * 0.5).to(torch.bfloa
 X = torch.randn(M, 48, generator=gen).clamp(-1, 1); X[:, 42:] = 0
 run.xenc.copy_(X.to(dev)); run.tile_mask[:ntile] = masks.to(dev)
 dl = torch.randn(M, 4, generator=gen).to(dev)
+if ZERO:
+    run.Z.zero_(); X.zero_(); dl.zero_()
 tex = torch.full((M, 5, 4), -1, dtype=torch.int32, device=dev); tw = torch.zeros((M, 5, 4), device=dev)
 st = torch.cuda.current_stream().cuda_stream
 gs = pk.grad_sink()
