@@ -92,6 +92,10 @@ def test_bad_arguments_are_reported_not_fatal():
     cc.n_samples = 999
     rc = lib.scenerf_hip_raysom_forward(ctypes.byref(cc), None, None, None, None, 1, None, None, None, None, None, None)
     assert rc != 0 and b"n_samples" in lib.scenerf_hip_last_error()
+    # the capturable optimizer step: no device-side [lr, t], no launch
+    arr = (_capi.AdamWTensor * 1)()
+    rc = lib.scenerf_hip_adamw_step_dev(1, arr, None, 0.9, 0.999, 1e-8, 0.0, None)
+    assert rc != 0 and b"hyper" in lib.scenerf_hip_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch):
