@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SCENERF_HIP_ABI_VERSION 5
+#define SCENERF_HIP_ABI_VERSION 6
 #define SCENERF_N_SCALES 5          /* feature maps "1_1","1_2","1_4","1_8","1_16" */
 #define SCENERF_D_LATENT 2480       /* 80+160+320+640+1280 (resnetfc d_latent, scenerf.py:100-114) */
 #define SCENERF_D_HIDDEN 512
@@ -88,7 +88,10 @@ typedef struct scenerf_cfg {
 #define SCENERF_FLAG_UNIFORM_ONLY  128u  /* the reference's uniform-only branch (scenerf.py:647-650 / scenerf_bf.py:662-665: n_pts_uni == 0 and
                                            * n_pts_per_gaussian == 1): the n_pts_uni uniform samples are the ONLY samples that are rendered
                                            * (n_samples == n_pts_uni); the gaussian head is still evaluated for the KL term */
-#define SCENERF_FLAG_WIDE_BWD       16u  /* fused dgrad chain on 128-row blocks, one wave per SIMD (wide.hip) instead of fused.hip's 64-row ring */
+#define SCENERF_FLAG_WIDE_BWD       16u  /* fused dgrad chain on 128-row blocks, one wave per SIMD (wide.hip) instead of fused.hip's 64-row ring;
+                                           * the chain then also makes lin_out's input gradient (dH column block 3) from d_logits and H3's sign bits */
+#define SCENERF_FLAG_WIDE_BWD_STAGED 256u /* ... but reads dH column block 3 as linout_bwd wrote it, like fused.hip's chain (tests, A/B runs: bit-identical
+                                           * to the per-layer dgrad GEMMs) */
 
 /* Packed ResnetFC operands (built by the host from the nn.Linear parameters).
  * T = float (precision 0) or bf16 (precision 1).  reference scenerf/models/resnetfc.py:88-118,133-164 */
@@ -152,14 +155,23 @@ typedef struct scenerf_mlp_grads {
 typedef struct scenerf_mlp_acts {
     void* H[4];                     /* T [M][512]; H and Nn may be NULL for inference when the fused bf16 kernel runs (>= 4096 rows) */
     void* Nn[3];                    /* T [M][512] */
-    float* h0pre;                   /* scratch: fp32 mode [M][512] fp32 lin_in output ; bf16 mode the split-bf16 encoding [M][144] bf16 */
+    float* h0pre;                   /* scratch: fp32 mode [M][512] fp32 lin_in output ; bf16 mode the split-bf16 encoding [M + 1][144] bf16 -- ONE ROW OF
+                                     * SLACK, zero-filled by the caller: lin_in's weight gradient reads the 144-column rows in 256-column tiles, so the
+                                     * last row's tile ends 224 bytes behind [M][144] (what it reads there lands in the scratch columns of
+                                     * scenerf_mlp_grads.w_in, which are undefined but must stay finite for a caller that reduces the whole sink) */
     float* logits;                  /* fp32 [M][d_out] */
     uint8_t* sign_bits;             /* bf16 mode, may be NULL: [7][Mpad][64] -- bit n of row m = (saved activation [m][n] > 0) for
-                                     * H0, N0, H1, N1, H2, N2, H3; written by the fused forward kernel, gates the fused backward
-                                     * chain (Mpad = M rounded up to SCENERF_TILE_ROWS).  NULL disables the fused backward. */
+                                     * H0, N0, H1, N1, H2, N2, H3; written by the fused forward kernels, gates the fused backward
+                                     * chain and (H3's) lin_out's input gradient (Mpad = M rounded up to SCENERF_TILE_ROWS).  NULL disables
+                                     * the fused backward. */
     int32_t x3_ready;               /* bf16 mode: h0pre already holds the split encoding (scenerf_hip_encode_points wrote it): the forward
                                      * then neither reads xenc nor launches the split */
+    float* lin_out_scratch;         /* optional, fp32 [SCENERF_LINOUT_SCRATCH_FLOATS]: partial sums of lin_out's weight gradient.  With it (and
+                                     * SCENERF_FLAG_WGRAD_OVERLAP) that reduction runs beside the 128-row dgrad chain instead of in front of it;
+                                     * NULL: it borrows the dN scratch, in stream order */
 } scenerf_mlp_acts;
+#define SCENERF_LINOUT_SCRATCH_BLOCKS 512
+#define SCENERF_LINOUT_SCRATCH_FLOATS (SCENERF_LINOUT_SCRATCH_BLOCKS * (4 * SCENERF_D_HIDDEN + 8))
 
 int scenerf_hip_abi_version(void);
 const char* scenerf_hip_last_error(void);

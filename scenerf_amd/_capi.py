@@ -23,7 +23,7 @@ D_HIDDEN = 512
 D_XENC = 48
 TILE_ROWS = 128
 W_STREAM_BLOCKS = (3 * D_XENC + D_LATENT) // 16 + 2 * ((512 + D_LATENT) // 16) + 10 * (512 // 16)   # scenerf_hip.h
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 vp = C.c_void_p
 
@@ -73,7 +73,8 @@ class MlpGrads(C.Structure):
 
 
 class MlpActs(C.Structure):
-    _fields_ = [("H", vp * 4), ("Nn", vp * 3), ("h0pre", vp), ("logits", vp), ("sign_bits", vp), ("x3_ready", C.c_int32)]
+    _fields_ = [("H", vp * 4), ("Nn", vp * 3), ("h0pre", vp), ("logits", vp), ("sign_bits", vp), ("x3_ready", C.c_int32),
+                ("lin_out_scratch", vp)]
 
 
 class AdamWTensor(C.Structure):
@@ -156,6 +157,8 @@ def load() -> C.CDLL:
 FUSED_MIN_ROWS_DEFAULT = 4096    # SCENERF_FUSED_MIN_ROWS_DEFAULT
 FLAG_NO_FUSED_BWD, FLAG_NO_WGRAD_TR, FLAG_DFEAT_PER_SCALE, FLAG_WGRAD_OVERLAP, FLAG_WIDE_BWD, FLAG_WIDE_ANY_M, FLAG_DFEAT_GEMM = 1, 2, 4, 8, 16, 32, 64   # SCENERF_FLAG_*
 FLAG_UNIFORM_ONLY = 128
+FLAG_WIDE_BWD_STAGED = 256
+LINOUT_SCRATCH_FLOATS = 512 * (4 * 512 + 8)   # SCENERF_LINOUT_SCRATCH_FLOATS
 WIN_LD = 256            # SCENERF_WIN_LD: row stride of scenerf_mlp_grads.w_in
 
 

@@ -62,7 +62,11 @@ class RenderConfig:
     dfeat_per_scale: bool = False     # True: feature-gradient GEMM + scatter as one launch per pyramid level
     wgrad_overlap: bool = False       # True: per-layer backward runs the weight-gradient GEMMs on an internal side stream
     wide_any_m: bool = False          # True: the 128-row kernels also for launches of fewer than 192 row blocks (tests, probes)
-    bwd_kernel: str = "wide"          # fused dgrad chain: "ring" (fused.hip, 64-row blocks) or "wide" (wide.hip, 128-row blocks); bit-identical
+    # fused dgrad chain: "ring" (fused.hip, 64-row blocks), "wide" (wide.hip, 128-row blocks; lin_out's input gradient is made in the
+    # kernel's prologue from d_logits and H3's sign bits) or "wide_staged" (the 128-row chain on a dH3 tile written by linout_bwd like the
+    # ring's: tests and A/B runs).  ring and wide_staged are bit-identical to the per-layer dgrad GEMMs; wide differs from them only
+    # where the prologue's fp32-accurate K = 4 product rounds to a different bf16 than linout_bwd's FMA chain
+    bwd_kernel: str = "wide"
 
     # ---- derived -----------------------------------------------------------------------------------------
     @property
@@ -121,8 +125,8 @@ class RenderConfig:
         _ = self.precision_code
         if self.fwd_kernel not in ("ring", "wide"):
             raise ValueError("fwd_kernel must be 'ring' or 'wide', got %r" % (self.fwd_kernel,))
-        if self.bwd_kernel not in ("ring", "wide"):
-            raise ValueError("bwd_kernel must be 'ring' or 'wide', got %r" % (self.bwd_kernel,))
+        if self.bwd_kernel not in ("ring", "wide", "wide_staged"):
+            raise ValueError("bwd_kernel must be 'ring', 'wide' or 'wide_staged', got %r" % (self.bwd_kernel,))
 
     def uses_fused(self, rows: int) -> bool:
         """Whether an MLP pass over ``rows`` rows runs on the fused kernels (mirrors srf_use_fused in csrc/common.h)."""
@@ -155,7 +159,8 @@ class RenderConfig:
         c.flags = ((0 if self.fused_backward else _capi.FLAG_NO_FUSED_BWD) | (0 if self.wgrad_tr else _capi.FLAG_NO_WGRAD_TR)
                    | (_capi.FLAG_DFEAT_PER_SCALE if self.dfeat_per_scale else 0) | (_capi.FLAG_WGRAD_OVERLAP if self.wgrad_overlap else 0)
                    | (_capi.FLAG_UNIFORM_ONLY if self.uniform_only else 0)
-                   | (_capi.FLAG_WIDE_BWD if self.bwd_kernel == "wide" else 0) | (_capi.FLAG_WIDE_ANY_M if self.wide_any_m else 0) | (_capi.FLAG_DFEAT_GEMM if self.dfeat_gemm else 0))
+                   | (_capi.FLAG_WIDE_BWD if self.bwd_kernel in ("wide", "wide_staged") else 0)
+                   | (_capi.FLAG_WIDE_BWD_STAGED if self.bwd_kernel == "wide_staged" else 0) | (_capi.FLAG_WIDE_ANY_M if self.wide_any_m else 0) | (_capi.FLAG_DFEAT_GEMM if self.dfeat_gemm else 0))
         return c
 
     @staticmethod

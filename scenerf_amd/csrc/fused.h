@@ -26,6 +26,9 @@ struct FusedArgs {
     const void* Z;       // forward: [Mpad][2480] bf16
     const void* dH3;     // backward: incoming gradient rows, [M][dH_ld] bf16 (column block 3 of the dH scratch)
     int dH_ld;
+    const float* dlog;   // backward, wide.hip MODE 1: d_logits [M][d_out] fp32 -- dH3 is made from it in the kernel (layer[6] = where it is saved
+                         // and H3's sign bits) instead of read
+
     const uint8_t* tile_mask;
     const int* desc;     // [32][F_MAXCH] per tile mask: header {number of chunks}, chunk descriptors, zero padding
     int M;

@@ -478,8 +478,8 @@ int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
     p.layer[0] = {w->b_h[0], a->H[0], sign(0), 0, H};
     for (int b = 0; b < 3; ++b) {
         p.layer[1 + 2 * b] = {w->b_fc0[b], a->Nn[b], sign(1 + 2 * b), 1, H};
-        p.layer[2 + 2 * b] = {w->b_h[b + 1], a->H[b + 1], b < 2 ? sign(2 + 2 * b) : nullptr, 2, H};   // (H3's sign is not used: lin_out's
-    }                                                                                                     //  backward reads H3 itself)
+        p.layer[2 + 2 * b] = {w->b_h[b + 1], a->H[b + 1], sign(2 + 2 * b), 2, H};   // (H3's bits: wide.hip's backward makes lin_out's input
+    }                                                                                 //  gradient from them, whichever kernel ran the forward)
     p.Wst = w->w_stream;
     p.X3 = a->h0pre;
     p.Z = Z;

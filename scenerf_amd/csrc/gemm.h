@@ -81,8 +81,9 @@ int launch_mlp_fwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
 // added after the K sum), and the dgrad chain on the same kernel shape (bit-identical to launch_mlp_bwd_fused)
 int launch_mlp_fwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const void* Z, const uint8_t* tile_mask, int M,
                         const scenerf_mlp_acts* a, hipStream_t s);
+// (d_logits != NULL: dH column block 3 = lin_out's input gradient is made by the kernel itself from d_logits, w_out and H3's sign bits)
 int launch_mlp_bwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, int M, const scenerf_mlp_acts* a, void* dH, void* dN,
-                        hipStream_t s);
+                        const float* d_logits, hipStream_t s);
 int launch_mlp_bwd_fused(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, int M, const scenerf_mlp_acts* a, void* dH, void* dN,
                          hipStream_t s);
 // wgrad.hip: bf16 weight-gradient GEMM on transposing LDS reads (256 x 256 output tiles, wave-specialised); launch_gemm_tn uses it

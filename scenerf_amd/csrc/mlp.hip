@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void linout_fwd_kernel(const void* __restrict_
 
 // dH3[m][k] = [H3>0] * sum_j dl[m][j] w_out[j][k];  dw_out[j][k] += sum_m dl[m][j] relu(H3[m][k]);  db_out[j] += sum_m dl[m][j]
 // one wave per row, lane owns 8 of the 512 columns; 4 rows per iteration so 4 independent 16-byte loads are in flight
-template <typename T, int DO>
+// DH = false: the weight / bias gradients only (the 128-row dgrad chain makes dH3 itself: wide.hip MODE 1), H3 is read and nothing but
+// the partial sums is written
+template <typename T, int DO, bool DH>
 __global__ __launch_bounds__(256) void linout_bwd_kernel(const void* __restrict__ H3, const float* __restrict__ w_out,
                                                          const float* __restrict__ dlog, int M, void* __restrict__ dH3, int lddh,
                                                          float* __restrict__ partial) {
@@ -78,12 +80,12 @@ __global__ __launch_bounds__(256) void linout_bwd_kernel(const void* __restrict_
                 float a = 0.f;
 #pragma unroll
                 for (int j = 0; j < DO; ++j) {
-                    a = fmaf(dl[u][j], w[j][e], a);
+                    if (DH) a = fmaf(dl[u][j], w[j][e], a);
                     dw[j][e] = fmaf(dl[u][j], fmaxf(h[u][e], 0.f), dw[j][e]);
                 }
                 g[e] = h[u][e] > 0.f ? a : 0.f;
             }
-            if (mb + u < M) store8<T>(dH3, (size_t)(mb + u) * lddh + lane * 8, g);
+            if (DH && mb + u < M) store8<T>(dH3, (size_t)(mb + u) * lddh + lane * 8, g);
         }
     }
 #pragma unroll
@@ -165,15 +167,23 @@ static int launch_linout_fwd(int d_out, const void* H3, const float* w, const fl
     SRF_LAUNCH_CHECK("linout_fwd_kernel");
     return 0;
 }
+// dH3 == NULL: weight / bias gradients only, at most SCENERF_LINOUT_SCRATCH_BLOCKS blocks (the partial sums then fit
+// scenerf_mlp_acts.lin_out_scratch)
 template <typename T>
 static int launch_linout_bwd(int d_out, const void* H3, const float* w, const float* dlog, int M, void* dH3, int lddh, float* dw,
                              float* db, float* scratch, hipStream_t s) {
     int grid = cdiv(M, 128);   // 32 rows per wave
-    if (grid > 2048) grid = 2048;
+    const int cap = dH3 ? 2048 : SCENERF_LINOUT_SCRATCH_BLOCKS;
+    if (grid > cap) grid = cap;
     {
-        SrfLaunchScope ps(s, "linout_bwd", 0, (double)M * (1024.0 * sizeof(T) + 4.0 * d_out));
-        if (d_out == 4) linout_bwd_kernel<T, 4><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, scratch);
-        else linout_bwd_kernel<T, 2><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, scratch);
+        SrfLaunchScope ps(s, dH3 ? "linout_bwd" : "linout_wgrad", 0, (double)M * ((dH3 ? 1024.0 : 512.0) * sizeof(T) + 4.0 * d_out));
+        if (dH3) {
+            if (d_out == 4) linout_bwd_kernel<T, 4, true><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, scratch);
+            else linout_bwd_kernel<T, 2, true><<<grid, 256, 0, s>>>(H3, w, dlog, M, dH3, lddh, scratch);
+        } else {
+            if (d_out == 4) linout_bwd_kernel<T, 4, false><<<grid, 256, 0, s>>>(H3, w, dlog, M, nullptr, 0, scratch);
+            else linout_bwd_kernel<T, 2, false><<<grid, 256, 0, s>>>(H3, w, dlog, M, nullptr, 0, scratch);
+        }
         SRF_LAUNCH_CHECK("linout_bwd_kernel");
     }
     const int n = d_out * SCENERF_D_HIDDEN + d_out;
@@ -430,19 +440,34 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     auto fork = [&]() -> int { return sc_ ? order_after(sc_, s, s2) : 0; };
     auto dNb = [&](int b) { return (void*)((char*)dN + (size_t)b * M * SCENERF_D_HIDDEN * es); };  // dN: [3][M][512]
 
+    // bf16, enough rows: the whole dgrad chain (6 GEMMs) runs as ONE kernel (fused.hip / wide.hip); the weight-gradient GEMMs below then
+    // only consume dH / dN
+    const bool fused_chain = prec && w->w_stream && a->sign_bits && srf_use_fused(cfg, M) && !(cfg->flags & SCENERF_FLAG_NO_FUSED_BWD);
+    const bool wide_chain = fused_chain && (cfg->flags & SCENERF_FLAG_WIDE_BWD) && (cdiv(M, 128) >= SRF_WIDE_MIN_BLOCKS || (cfg->flags & SCENERF_FLAG_WIDE_ANY_M));
+    // the 128-row chain makes lin_out's input gradient dH3 = (d_logits W_out) * [H3 > 0] in its own prologue, from d_logits and H3's
+    // sign bits (r03: as linout_bwd's output it was a 314 MB round trip, 97 us on the critical path of a KITTI step); lin_out's
+    // weight / bias gradients are then all linout_bwd is asked for -- off the critical path, beside the chain, when the caller provides
+    // scenerf_mlp_acts.lin_out_scratch for its partial sums (the dN scratch it otherwise borrows is being written by the chain)
+    const bool dh3_in_chain = wide_chain && !(cfg->flags & SCENERF_FLAG_WIDE_BWD_STAGED);
+    const int allow_tr = (cfg->flags & SCENERF_FLAG_NO_WGRAD_TR) ? 0 : 1;
     // lin_out backward -> dH3, dw_out, db_out
-    if (prec) {
+    if (dh3_in_chain) {
+        if (a->lin_out_scratch) {
+            if (int e = fork()) return e;
+            if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, nullptr, 0, g_->w_out, g_->b_out, a->lin_out_scratch, s2)) return e;
+        } else {
+            if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, nullptr, 0, g_->w_out, g_->b_out, (float*)dN, s)) return e;
+        }
+    } else if (prec) {
         if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, (float*)dN, s)) return e;
     } else {
         if (int e = launch_linout_bwd<float>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, (float*)dN, s)) return e;
     }
-    if (int e = fork()) return e;
-    // bf16, enough rows: the whole dgrad chain (6 GEMMs) runs as ONE kernel (fused.hip); the weight-gradient GEMMs below then
-    // only consume dH / dN
-    const bool fused_chain = prec && w->w_stream && a->sign_bits && srf_use_fused(cfg, M) && !(cfg->flags & SCENERF_FLAG_NO_FUSED_BWD);
-    const int allow_tr = (cfg->flags & SCENERF_FLAG_NO_WGRAD_TR) ? 0 : 1;
+    if (!dh3_in_chain) {
+        if (int e = fork()) return e;
+    }
     if (fused_chain) {
-        if (int e = ((cfg->flags & SCENERF_FLAG_WIDE_BWD) && (cdiv(M, 128) >= SRF_WIDE_MIN_BLOCKS || (cfg->flags & SCENERF_FLAG_WIDE_ANY_M))) ? launch_mlp_bwd_wide(cfg, w, M, a, dH, dN, s) : launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
+        if (int e = wide_chain ? launch_mlp_bwd_wide(cfg, w, M, a, dH, dN, dh3_in_chain ? d_logits : nullptr, s) : launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
         if (int e = fork()) return e;
     }
     GemmTN wg[8];   // the six fc weight gradients (+ lin_z, below): batched into one launch when the chain kernel already produced every dH / dN

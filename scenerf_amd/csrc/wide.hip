@@ -1,6 +1,7 @@
 // Fused ResnetFC kernels for gfx950 on 128-row blocks, ONE wave per SIMD (bf16 operands).  MODE 0: the whole 7-GEMM forward trunk
 // (lin_in + lin_z.0, three residual blocks fc_0 / fc_1 + lin_z.b) and lin_out; MODE 1: the 6-GEMM dgrad chain of the blocks in the
-// backward pass (for b = 2, 1, 0: dN_b = (dH_{b+1} W1_b) * [N_b > 0], dH_b = dH_{b+1} + (dN_b W0_b) * [H_b > 0]).
+// backward pass (for b = 2, 1, 0: dN_b = (dH_{b+1} W1_b) * [N_b > 0], dH_b = dH_{b+1} + (dN_b W0_b) * [H_b > 0]), with lin_out's input
+// gradient dH3 = (d_logits W_out) * [H3 > 0] made in its prologue (MODE 2: the same chain on a dH3 tile read from memory).
 // reference scenerf/models/resnetfc.py:41-57,133-164.
 //
 // Why this shape (measured history: DESIGN.md section 5).  A 64-row block needs all 16 KiB of a K chunk's weights per 256 MFMA cycles:
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
             }
         }
         char* const wr0 = Abuf + (ln & 31) * F_AROW + 8 * hi;
-#define H_GATE(I, J) (MODE == 1 ? ((J) == 0 ? gt[I].x : (J) == 1 ? gt[I].y : (J) == 2 ? gt[I].z : gt[I].w) >> (4 * hi) : 0u)
+#define H_GATE(I, J) (MODE != 0 ? ((J) == 0 ? gt[I].x : (J) == 1 ? gt[I].y : (J) == 2 ? gt[I].z : gt[I].w) >> (4 * hi) : 0u)
 #ifdef H_VAR_NOBIAS
 #define H_BIAS_ON false
 #else
@@ -770,8 +771,57 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
             epilogue(std::true_type(), 2 + 2 * b);
         }
     } else {
-        // the incoming gradient tile dH3 -> resident A buffer: one row (1 KiB) per piece, 32 rows per wave; lane = physical slot,
-        // fetching the logical slot physical ^ (row & 15)
+      if constexpr (MODE == 1) {
+        // ---- lin_out's input gradient, made here instead of read: dH3 = (d_logits W_out) * [H3 > 0] (resnetfc.py:160-163 backwards).
+        // A K = 4 product per output: as its own kernel it was an HBM round trip of the whole [M][512] tile (linout_bwd: 97 us per
+        // step, r03_i_step_trace), as fp32 FMAs here 1,100 vector instructions per lane (r02: net zero).  On the matrix cores it is three
+        // chunks: both fp32 operands are split into three bf16 terms (x = hi + mid + lo to 24 bits: every term product is exact in the
+        // fp32 accumulator) and chunk t multiplies term t of d_logits with all three terms of W_out -- K slots 0..3 = w_hi, 4..7 = w_mid,
+        // 8..11 = w_lo, 12..15 = 0 -- i.e. the fp32 product to fp32 accumulation accuracy.  The tile then takes the dH layers' epilogue
+        // (gate by H3's sign bits, round to bf16, A buffer + running gradient) and leaves for HBM under the first layer's K loop like any
+        // other layer's output (the weight gradients of fc_1.2 read it there).
+        H_LANE();
+        xb_dma(6);      // H3's gate bits -> H_XB
+        {
+            const int hi = ln >> 5;
+            hfrag wf[4], a3[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = wvu * 128 + 32 * j + (ln & 31);
+                float r0 = p.w_out[col], r1 = p.d_out > 1 ? p.w_out[SCENERF_D_HIDDEN + col] : 0.f;
+                float r2 = p.d_out > 2 ? p.w_out[2 * SCENERF_D_HIDDEN + col] : 0.f, r3 = p.d_out > 3 ? p.w_out[3 * SCENERF_D_HIDDEN + col] : 0.f;
+                uint32_t t[3][2];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    t[sp][0] = pack_bf16x2(r0, r1);
+                    t[sp][1] = pack_bf16x2(r2, r3);
+                    r0 -= bf16lo(t[sp][0]); r1 -= bf16hi(t[sp][0]);
+                    r2 -= bf16lo(t[sp][1]); r3 -= bf16hi(t[sp][1]);
+                }
+                wf[j] = hi ? hfrag{t[2][0], t[2][1], 0u, 0u} : hfrag{t[0][0], t[0][1], t[1][0], t[1][1]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* const dr = p.dlog + (size_t)min(m0 + 32 * i + (ln & 31), p.M - 1) * p.d_out;   // (rows past M: clamped, computed, dropped)
+                float r0 = dr[0], r1 = p.d_out > 1 ? dr[1] : 0.f, r2 = p.d_out > 2 ? dr[2] : 0.f, r3 = p.d_out > 3 ? dr[3] : 0.f;
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    const uint32_t ta = pack_bf16x2(r0, r1), tb = pack_bf16x2(r2, r3);
+                    r0 -= bf16lo(ta); r1 -= bf16hi(ta);
+                    r2 -= bf16lo(tb); r3 -= bf16hi(tb);
+                    a3[sp][i] = hfrag{ta, tb, ta, tb};
+                }
+            }
+            h_row<true, 0>(wf, a3[0][0]); h_row<true, 1>(wf, a3[0][1]); h_row<true, 2>(wf, a3[0][2]); h_row<true, 3>(wf, a3[0][3]);
+            h_row<false, 0>(wf, a3[1][0]); h_row<false, 1>(wf, a3[1][1]); h_row<false, 2>(wf, a3[1][2]); h_row<false, 3>(wf, a3[1][3]);
+            h_row<false, 0>(wf, a3[2][0]); h_row<false, 1>(wf, a3[2][1]); h_row<false, 2>(wf, a3[2][2]); h_row<false, 3>(wf, a3[2][3]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gate bits (no K loop in front of this epilogue to retire the DMA)
+        epilogue(std::true_type(), 6);                     // running gradient = 0 + gated tile
+        H_STAMP()   // incoming gradient tile made
+      } else {
+        // MODE 2 (tests, A/B runs): the incoming gradient tile dH3 as linout_bwd_kernel wrote it -> resident A buffer: one row (1 KiB) per
+        // piece, 32 rows per wave; lane = physical slot, fetching the logical slot physical ^ (row & 15)
         H_LANE();
         for (int r = 0; r < 32; ++r) {
             const int row = 32 * wvu + r;
@@ -796,6 +846,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
                     }
         }
         H_STAMP()   // incoming gradient tile staged
+      }
 #pragma unroll 1
         for (int l = 0; l < 6; l += 2) {
             xb_dma(l);
@@ -970,7 +1021,8 @@ static SrfDescCache g_wide_table;
 static int wide_attrs() {
     SRF_ONCE_PER_DEVICE(
         SRF_HIP(hipFuncSetAttribute((const void*)mlp_wide_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS));
-        SRF_HIP(hipFuncSetAttribute((const void*)mlp_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS)));
+        SRF_HIP(hipFuncSetAttribute((const void*)mlp_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS));
+        SRF_HIP(hipFuncSetAttribute((const void*)mlp_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS)));
     return 0;
 }
 
@@ -990,7 +1042,7 @@ int launch_mlp_fwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, co
     p.layer[0] = {w->b_h[0], a->H[0], sign(0), 0, H};
     for (int b = 0; b < 3; ++b) {
         p.layer[1 + 2 * b] = {w->b_fc0[b], a->Nn[b], sign(1 + 2 * b), 1, H};
-        p.layer[2 + 2 * b] = {w->b_h[b + 1], a->H[b + 1], b < 2 ? sign(2 + 2 * b) : nullptr, 2, H};
+        p.layer[2 + 2 * b] = {w->b_h[b + 1], a->H[b + 1], sign(2 + 2 * b), 2, H};   // (H3's bits gate lin_out's input gradient: MODE 1's prologue)
     }
     p.Wst = w->w_stream;
     p.X3 = a->h0pre;
@@ -1021,9 +1073,11 @@ int launch_mlp_fwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, co
     return 0;
 }
 
-// Backward dgrad chain on the same kernel shape (arguments and results as launch_mlp_bwd_fused, fused.hip)
+// Backward dgrad chain on the same kernel shape (results as launch_mlp_bwd_fused, fused.hip).  d_logits != NULL: lin_out's input gradient
+// is made in the kernel's prologue from d_logits, w_out and H3's sign bits and written to dH's column block 3 by the kernel itself (the
+// caller then only needs lin_out's WEIGHT gradients from linout_bwd); NULL: column block 3 of dH is read as the caller left it.
 int launch_mlp_bwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, int M, const scenerf_mlp_acts* a, void* dH, void* dN,
-                        hipStream_t s) {
+                        const float* d_logits, hipStream_t s) {
     if (int e = wide_attrs()) return e;
     FusedArgs p = {};
     const int H = SCENERF_D_HIDDEN;
@@ -1035,15 +1089,20 @@ int launch_mlp_bwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, in
         p.layer[l] = {nullptr, (char*)dN + (size_t)b * M * H * 2, a->sign_bits + (size_t)(2 * b + 1) * sign_layer, 1, H};   // dN_b = (dH_{b+1} W1_b) * [N_b > 0]
         p.layer[l + 1] = {nullptr, (char*)dH + (size_t)b * H * 2, a->sign_bits + (size_t)(2 * b) * sign_layer, 2, 4 * H};   // dH_b = dH_{b+1} + (dN_b W0_b) * [H_b > 0]
     }
+    p.layer[6] = {nullptr, (char*)dH + (size_t)3 * H * 2, a->sign_bits + (size_t)6 * sign_layer, 2, 4 * H};                 // dH3 = (d_logits W_out) * [H3 > 0]
     p.Wst = w->w_stream;
     p.dH3 = (const char*)dH + (size_t)3 * H * 2;
     p.dH_ld = 4 * H;
+    p.dlog = d_logits;
+    p.w_out = w->w_out;
+    p.d_out = w->d_out;
     const int* desc = nullptr;
     if (int e = srf_desc_cache_get(g_wide_table, cfg, s, wide_table_build, &desc)) return e;
     p.desc = desc + 32 * F_MAXCH;
     p.M = M;
-    SrfLaunchScope ps(s, w->d_out == 2 ? "mlp_bwd_fused/g" : "mlp_bwd_fused", 2.0 * M * 512.0 * 6.0 * 512.0, 0);
-    mlp_wide_kernel<1><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);
-    SRF_LAUNCH_CHECK("mlp_wide_kernel<1>");
+    SrfLaunchScope ps(s, w->d_out == 2 ? "mlp_bwd_fused/g" : "mlp_bwd_fused", 2.0 * M * 512.0 * (6.0 * 512.0 + (d_logits ? 48.0 : 0.0)), 0);
+    if (d_logits) mlp_wide_kernel<1><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);
+    else mlp_wide_kernel<2><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);
+    SRF_LAUNCH_CHECK("mlp_wide_kernel<bwd>");
     return 0;
 }

@@ -15,12 +15,49 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """(rank, world_size, local_rank) from torchrun's environment; initialises the process group if world > 1."""
+# True: the gradient hooks below issue their collectives also in a process group of ONE rank (where they are arithmetically no-ops).
+# For tests and ``bench.py --force-dist``: the RCCL code path -- communicator bound to the device, stream / event handling of
+# asynchronous work, graph capture of a collective -- then runs on a single leased GPU.
+FORCE_COLLECTIVES = False
+
+
+def _active() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
+def numa_pin(local_rank: int) -> Optional[str]:
+    """Restrict this process to the CPUs of its GPU's NUMA node (one process per GPU: its launch calls, pinned buffers and the RCCL
+    proxy thread then stay on the socket the GPU hangs off).  Best effort: returns a description of what was done, or None when the
+    topology is not readable (no sysfs entry, one node only, affinity already narrower)."""
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bus) as fh:
+            node = int(fh.read().strip())
+        if node < 0:
+            return None
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as fh:
+            cpus = set()
+            for part in fh.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        have = os.sched_getaffinity(0)
+        want = cpus & have
+        if not want or want == have:
+            return None
+        os.sched_setaffinity(0, want)
+        return "NUMA node %d (%d CPUs) for GPU %s" % (node, len(want), bus)
+    except Exception:
+        return None
+
+
+def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from torchrun's environment; initialises the process group if world > 1 (``force``: also for
+    a single rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -65,7 +102,7 @@ def verify_step_collectives() -> int:
     ``GradBucket(model.parameters()).allreduce_mean()`` after backward."""
     global _ISSUED
     n, _ISSUED = _ISSUED, 0
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
         t = torch.tensor([n, -n], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -86,7 +123,7 @@ def allreduce_mean_(flat: torch.Tensor) -> None:
     """In-place mean over ranks of a flat gradient buffer (no-op for a single process).  Installed as
     ``model.grad_sync``: the renderer calls it once per MLP on the packed fp32 gradient sink (21.7 MB)."""
     global _ISSUED
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         _ISSUED += 1
         t0 = _mark() if (TIMING is not None and flat.is_cuda) else None
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -99,7 +136,7 @@ def allreduce_mean_async(flat: torch.Tensor):
     """Start the same reduction without blocking the calling stream; returns ``finish()`` -- call it (on the stream that will read
     ``flat``) before the gradients are used -- or None for a single process.  Installed as ``model.grad_sync_async``."""
     global _ISSUED
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not _active():
         return None
     _ISSUED += 1
     work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
@@ -144,7 +181,7 @@ class GradBucket:
 
     def allreduce_mean(self, async_op: bool = False):
         """Sum-all-reduce the bucket and divide by world size (no-op for a single process)."""
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not _active():
             return None
         self.pack()
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
@@ -167,7 +204,8 @@ class StepGradSync:
     This object is the safe default for such trainers when DistributedDataParallel is not used: the gradients of all sessions
     accumulate locally in ``.grad`` as usual; the first parameter gradient of a backward arms ONE end-of-backward callback (the
     mechanism DDP itself uses), which averages both MLPs' gradients in a single flat all-reduce (43.3 MB over RCCL).  Every rank
-    that runs a backward issues exactly one collective, whatever its session count.
+    whose backward reaches at least one of the parameters issues exactly one collective, whatever its session count; a rank whose
+    step produced no gradient for any of them must call ``sync()`` itself (the others are waiting in the all-reduce).
 
         sync = StepGradSync(list(model.mlp.parameters()) + list(model.mlp_gaussian.parameters()))
         ... loss.backward()      # reduced when backward returns
@@ -176,17 +214,37 @@ class StepGradSync:
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.bucket = GradBucket(params)
-        self._armed = False
+        self._armed_task = None      # id of the backward pass (autograd graph task) whose end-of-backward callback is queued
         self.reductions = 0
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.bucket.params]
 
+    @staticmethod
+    def _task_id() -> int:
+        f = getattr(torch._C, "_current_graph_task_id", None)
+        return int(f()) if f is not None else -1
+
     def _on_grad(self, _p) -> None:
-        if not self._armed:
-            self._armed = True
+        # armed PER BACKWARD PASS: a backward that raised never ran its callback -- a flag that only the callback resets would then
+        # stay set and every later backward of this rank would skip its all-reduce silently (the other ranks hang or the replicas
+        # drift apart).  The graph task's id names the pass; without that API (old torch) the flag is cleared by ``begin_step``.
+        tid = self._task_id()
+        if self._armed_task is None or (tid >= 0 and tid != self._armed_task):
+            self._armed_task = tid
             torch.autograd.Variable._execution_engine.queue_callback(self._finish)
 
+    def begin_step(self) -> None:
+        """Forget a callback that never ran (a backward that raised).  Needed only where ``torch._C._current_graph_task_id`` is
+        missing; harmless otherwise."""
+        self._armed_task = None
+
     def _finish(self) -> None:
-        self._armed = False
+        self._armed_task = None
+        self.reductions += 1
+        self.bucket.allreduce_mean()
+
+    def sync(self) -> None:
+        """The collective of a step whose backward reached NO parameter of the bucket on this rank (no hook fired, so no callback was
+        queued): every rank must take part in every step's all-reduce, so such a rank calls this once instead."""
         self.reductions += 1
         self.bucket.allreduce_mean()
 

@@ -483,6 +483,8 @@ class _MlpRun:
         # fp32 lin_in output (fp32 mode) or the split-bf16 encoding [M][144] (bf16 mode)
         # (bf16: one row of slack -- lin_in's weight gradient reads the split encoding in 256-column tiles of its 144-column rows)
         self.h0pre = torch.empty((M, D_H) if prec == 0 else (M + 1, 3 * D_X // 2), dtype=torch.float32, device=dev)
+        if prec == 1 and not lean:
+            self.h0pre[M:].zero_()    # (scenerf_hip.h: the slack row is read -- into scratch columns of the gradient sink -- and must be finite)
         self.logits = torch.empty((M, d_out), dtype=torch.float32, device=dev)
         a = _capi.MlpActs()
         for i in range(4):
@@ -495,6 +497,9 @@ class _MlpRun:
         self.sign_bits = torch.empty((7, self.Mpad, 64), dtype=torch.uint8, device=dev) if (prec and not lean) else None
         a.sign_bits = self.sign_bits.data_ptr() if self.sign_bits is not None else None
         a.x3_ready = 1 if x3_direct else 0
+        # partial sums of lin_out's weight gradient: with a buffer of their own that reduction runs beside the dgrad chain
+        self.lin_out_scratch = torch.empty(_capi.LINOUT_SCRATCH_FLOATS, dtype=torch.float32, device=dev) if (prec and not lean) else None
+        a.lin_out_scratch = _capi.ptr(self.lin_out_scratch)
         self.c = a
 
 

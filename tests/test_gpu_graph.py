@@ -130,3 +130,22 @@ def test_graphed_step_refuses_what_cannot_be_captured():
     m.render_cfg.device_rng = False
     with pytest.raises(RuntimeError, match="device"):
         GraphedStep(m, opt, _loss, K, T, maps, pix)
+
+
+def test_graphed_step_with_nccl_world1():
+    """The gradient collectives on the real backend: a one-rank "nccl" (RCCL) process group on the test GPU, the renderer's hooks
+    forced to issue their all-reduces (scenerf_amd.dist.FORCE_COLLECTIVES), eagerly and inside a captured GraphedStep
+    (tests/nccl_worker.py).  A one-rank mean is the identity: every variant gives the hook-free step's gradients up to the run-to-run
+    noise of fp32 atomics, and a replayed graph keeps stepping the optimizer."""
+    import os, re, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(here, "nccl_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    err = re.search(r"NCCL_ERROR.*", r.stdout, re.S)
+    assert r.returncode == 0, (err.group(0)[-3000:] if err else r.stdout[-1500:] + r.stderr[-1500:])
+    mm = re.search(r"NCCL_RESULT spread=([\d.e+-]+) session=([\d.e+-]+) step=([\d.e+-]+) graph_steps=(\d+) moved=([\d.e+-]+) finite=(\w+)", r.stdout)
+    assert mm, r.stdout[-2000:] + r.stderr[-2000:]
+    spread, sess, step = float(mm.group(1)), float(mm.group(2)), float(mm.group(3))
+    assert sess <= 3 * spread + 1e-6 and step <= 3 * spread + 1e-6, (spread, sess, step)
+    assert int(mm.group(4)) == 5 and float(mm.group(5)) > 0 and mm.group(6) == "True"      # 2 warm-up steps + 3 replays

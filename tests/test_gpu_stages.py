@@ -748,9 +748,10 @@ def test_mlp_backward_fused_matches_layer_path(case, M):
     tex = torch.full((M, 5, 4), -1, dtype=torch.int32, device=DEV)
     tw = torch.zeros((M, 5, 4), device=DEV)
     res = {}
-    for name in ("layers", "fused", "wide"):
-        # scenerf_cfg.flags: SCENERF_FLAG_NO_FUSED_BWD (per-layer dgrad GEMMs) / SCENERF_FLAG_WIDE_BWD (wide.hip's 128-row chain)
-        cc = dataclasses.replace(rcfg, fused_backward=(name != "layers"), bwd_kernel="wide" if name == "wide" else "ring", wide_any_m=True).to_c()
+    for name in ("layers", "fused", "wide_staged", "wide"):
+        # scenerf_cfg.flags: SCENERF_FLAG_NO_FUSED_BWD (per-layer dgrad GEMMs) / SCENERF_FLAG_WIDE_BWD (wide.hip's 128-row chain, which makes
+        # lin_out's input gradient itself) / SCENERF_FLAG_WIDE_BWD_STAGED (... on linout_bwd's dH3, like the ring kernel)
+        cc = dataclasses.replace(rcfg, fused_backward=(name != "layers"), bwd_kernel=name if name.startswith("wide") else "ring", wide_any_m=True).to_c()
         gs = pk.grad_sink()
         pk.gflat.zero_()
         dH = torch.zeros((M, 2048), dtype=torch.bfloat16, device=DEV)
@@ -761,7 +762,7 @@ def test_mlp_backward_fused_matches_layer_path(case, M):
         torch.cuda.synchronize()
         res[name] = (dH.float().cpu(), dN.float().cpu(), [g.clone().cpu() for g in pk.unpack_grads()])
     dHa, dNa, ga = res["layers"]
-    for other in ("fused", "wide"):
+    for other in ("fused", "wide_staged"):
         dHb, dNb, gb = res[other]
         assert torch.equal(dHa[:, 1536:], dHb[:, 1536:])          # lin_out's backward is shared
         bad = []
@@ -777,6 +778,36 @@ def test_mlp_backward_fused_matches_layer_path(case, M):
         print("%s vs layers parameter gradients, rel L2:" % other, {k: "%.1e" % v for k, v in rels.items()})
         for n, rel in rels.items():
             assert rel <= 1e-4, "%s %s: relative L2 difference %.3e" % (other, n, rel)
+    # the default 128-row chain makes dH3 = (d_logits W_out) * [H3 > 0] in its prologue, on the matrix cores (three-term bf16 splits of
+    # both fp32 operands: every term product exact, fp32 accumulation), where linout_bwd runs an fp32 FMA chain: the two agree to fp32
+    # rounding, i.e. the bf16 results are EQUAL except where a value sits on a bf16 rounding boundary to within ~1e-7 relative
+    # (expected ~1e-5 of the elements; a differing element is one bf16 ulp off).  Against the exact product (float64 on the same
+    # operands) neither is further away than half a bf16 ulp plus fp32 rounding.  The rest of the chain is the same instruction
+    # stream as wide_staged: its outputs follow dH3 (a flipped element moves them like any bf16 rounding does).
+    dHw, dNw, gw = res["wide"]
+    x, y = dHa[:, 1536:], dHw[:, 1536:]
+    diff = x != y
+    frac = float(diff.float().mean())
+    print("prologue dH3 vs linout_bwd dH3: %.2e of the elements differ" % frac)
+    assert frac <= 2e-4, frac
+    if bool(diff.any()):
+        ulp = torch.maximum(x.abs(), y.abs())[diff] * 2.0 ** -7      # >= one bf16 ulp of the larger one
+        assert bool(((x - y).abs()[diff] <= ulp).all())
+    gate = (run.H[3].float().cpu() > 0)
+    exact = (dl.double().cpu() @ state["lin_out.weight"].double()) * gate
+    terms = (dl.double().cpu().abs() @ state["lin_out.weight"].double().abs()) * gate
+    for nm, got in (("linout_bwd", x), ("prologue", y)):
+        err = (got.double() - exact).abs()
+        bound = exact.abs() * 2.0 ** -8 + terms * 4e-7 + 1e-30    # half a bf16 ulp (8 significant bits) + fp32 rounding of the four-term sum
+        assert bool((err <= bound).all()), (nm, float((err / bound.clamp(min=1e-30)).max()))
+    for b in (2, 1, 0):
+        for nm, x, y in (("dN%d" % b, dNa[b], dNw[b]), ("dH%d" % b, dHa[:, 512 * b:512 * (b + 1)], dHw[:, 512 * b:512 * (b + 1)])):
+            rel = float((x - y).norm() / max(float(x.norm()), 1e-20))
+            assert rel <= 2e-3 and float((x == y).float().mean()) >= 0.99, (nm, rel, float((x == y).float().mean()))
+    rels = {n: float((x - y).norm() / max(float(x.norm()), 1e-20)) for n, x, y in zip(MLP_PARAM_NAMES, ga, gw)}
+    print("wide (prologue) vs layers parameter gradients, rel L2:", {k: "%.1e" % v for k, v in rels.items()})
+    for n, rel in rels.items():
+        assert rel <= 1e-3, "wide %s: relative L2 difference %.3e" % (n, rel)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

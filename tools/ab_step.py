@@ -1,6 +1,7 @@
 """A/B of a module-level knob on ONE GPU box inside ONE process: the bench's training step (channels-last maps, device RNG) timed in
 alternating blocks A B A B ... so that clock / thermal drift and box-to-box spread (+-4 %) cancel.
 usage: ab_step.py <module.attr>=<v0>,<v1>[,...] [rounds] [steps]      e.g.  ab_step.py renderer.DEFER_HEAD_PACK=0,1 4 40
+                                                                            ab_step.py "cfg.bwd_kernel='wide','wide_staged'" 4 40
 A value is parsed with ast.literal_eval; `module` is relative to scenerf_amd."""
 import argparse, ast, importlib, os, sys, time
 import torch
@@ -13,7 +14,7 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 path, vals = spec.split("=")
 modname, attr = path.rsplit(".", 1)
-mod = importlib.import_module("scenerf_amd." + modname)
+mod = None if modname == "cfg" else importlib.import_module("scenerf_amd." + modname)     # cfg.<field>: the model's RenderConfig
 vals = [ast.literal_eval(v) for v in vals.split(",")]
 
 dev = torch.device("cuda:0")
@@ -42,7 +43,7 @@ def step():
 res = {repr(v): [] for v in vals}
 for r in range(rounds):
     for v in vals:
-        setattr(mod, attr, v)
+        setattr(mod if mod is not None else model.render_cfg, attr, v)
         for _ in range(5):
             step()
         torch.cuda.synchronize()

@@ -49,8 +49,8 @@ def timed(rows, name):
 
 
 res = {}
-for name in ("ring", "wide"):
-    cfg = dataclasses.replace(rcfg, fused_min_rows=1, fwd_kernel=name, bwd_kernel=name, wide_any_m=True)
+for name in ("ring", "wide_staged", "wide"):
+    cfg = dataclasses.replace(rcfg, fused_min_rows=1, fwd_kernel=name.split("_")[0], bwd_kernel=name, wide_any_m=True, wgrad_overlap=True)
     cc = cfg.to_c()
     run = _MlpRun(M, 4, 1, dev)
     run.Z.copy_(Z); run.xenc.copy_(X); run.tile_mask[:ntile] = masks.to(dev)
@@ -73,7 +73,8 @@ for name in ("ring", "wide"):
     lib.scenerf_hip_profile_enable(0)
     print("%-5s M=%d masks=%s: forward %.1f us = %.0f TFLOP/s issued (%.1f %% of 2.5 PF) | dgrad chain %.1f us = %.0f TFLOP/s (%.1f %%)" % (
         name, M, pat, tf, fl_f / tf / 1e6, fl_f / tf / 1e6 / 25, tb, fl_b / tb / 1e6, fl_b / tb / 1e6 / 25), flush=True)
-    print("      batched weight gradients %.1f us" % timed(rows, "gemm_wgrad_fc"), flush=True)
+    print("      batched weight gradients %.1f us; linout_bwd %.1f us, linout_wgrad %.1f us" % (
+        timed(rows, "gemm_wgrad_fc"), timed(rows, "linout_bwd"), timed(rows, "linout_wgrad")), flush=True)
     if name == "wide" and hasattr(lib, "scenerf_hip_test_wgrad_cyc"):
         buf = (C.c_ulonglong * (64 * 16))()
         lib.scenerf_hip_test_wgrad_cyc(buf, 64 * 16)
@@ -96,10 +97,20 @@ msg.append("sign bits equal %.6f" % (a.sign_bits[:6, :M] == b.sign_bits[:6, :M])
 print("forward  wide vs ring: " + "; ".join(msg))
 # the chains ran on different forward states (last-ulp differences): rerun the wide chain on the ring's state for a bit-exact check
 run = a
-cc = dataclasses.replace(rcfg, fused_min_rows=1, bwd_kernel="wide", wide_any_m=True).to_c()
+cc = dataclasses.replace(rcfg, fused_min_rows=1, bwd_kernel="wide_staged", wide_any_m=True).to_c()
 gs = pk.grad_sink()
 dH2 = torch.zeros_like(dHa); dN2 = torch.zeros_like(dNa)
 _capi.check(lib.scenerf_hip_mlp_backward(C.byref(cc), C.byref(pk.c), C.byref(gs), run.Z.data_ptr(), run.xenc.data_ptr(), run.tile_mask.data_ptr(),
                                          tex.data_ptr(), tw.data_ptr(), M, C.byref(run.c), dl.data_ptr(), dH2.data_ptr(), dN2.data_ptr(), None, st), "bwd")
 torch.cuda.synchronize()
 print("backward wide vs ring on the same forward state: dH equal %s, dN equal %s" % (torch.equal(dHa, dH2), torch.equal(dNa, dN2)))
+# ... and the default chain (lin_out's input gradient made in the prologue) against it
+cc = dataclasses.replace(rcfg, fused_min_rows=1, bwd_kernel="wide", wide_any_m=True).to_c()
+dH3 = torch.zeros_like(dHa); dN3 = torch.zeros_like(dNa)
+_capi.check(lib.scenerf_hip_mlp_backward(C.byref(cc), C.byref(pk.c), C.byref(gs), run.Z.data_ptr(), run.xenc.data_ptr(), run.tile_mask.data_ptr(),
+                                         tex.data_ptr(), tw.data_ptr(), M, C.byref(run.c), dl.data_ptr(), dH3.data_ptr(), dN3.data_ptr(), None, st), "bwd")
+torch.cuda.synchronize()
+x, y = dHa[:, 1536:].float(), dH3[:, 1536:].float()
+print("prologue dH3 vs linout_bwd dH3: %.3e of the elements differ, max |diff| / max |x| %.2e; dH0 rel L2 %.2e, equal %.5f" % (
+    (x != y).float().mean().item(), ((x - y).abs().max() / x.abs().max()).item(),
+    ((dHa[:, :512].float() - dH3[:, :512].float()).norm() / dHa[:, :512].float().norm()).item(), (dHa[:, :512] == dH3[:, :512]).float().mean().item()))
