@@ -202,6 +202,7 @@ static int launch_linout_bwd(int d_out, const void* H3, const float* w, const fl
 #include <map>
 struct SideCtx {
     hipStream_t side = nullptr;
+    hipStream_t low = nullptr;     // lowest priority: work that should only take the CUs the other two streams leave idle
     hipEvent_t ev[16];
     int next = 0;
 };
@@ -213,6 +214,11 @@ static SideCtx* side_ctx(hipStream_t main) {
     if (it != g_map.end()) return it->second;
     SideCtx* c = new SideCtx();
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&c->low, hipStreamNonBlocking, least) != hipSuccess) { delete c; return nullptr; }
+    }
     for (int i = 0; i < 16; ++i) {
         if (hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
     }
@@ -451,12 +457,18 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     const bool dh3_in_chain = wide_chain && !(cfg->flags & SCENERF_FLAG_WIDE_BWD_STAGED);
     const int allow_tr = (cfg->flags & SCENERF_FLAG_NO_WGRAD_TR) ? 0 : 1;
     // lin_out backward -> dH3, dw_out, db_out
+    bool low_used = false;
     if (dh3_in_chain) {
-        if (a->lin_out_scratch) {
-            if (int e = fork()) return e;
-            if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, nullptr, 0, g_->w_out, g_->b_out, a->lin_out_scratch, s2)) return e;
+        if (a->lin_out_scratch && sc_) {
+            // queued BEHIND the chain (below), on the lowest-priority stream: 157 MB of H3 to read and next to no arithmetic.  Nothing can share
+            // a CU with a block of the chain (all of its LDS and registers), so launched first or at equal priority its workgroups take
+            // CUs the chain's 4.69 rounds of blocks then wait for (r04_a: chain 528 -> 577 us); behind it they get the CUs the chain's
+            // last, partly filled round leaves idle
+            if (int e = order_after(sc_, s, sc_->low)) return e;
+            low_used = true;
         } else {
-            if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, nullptr, 0, g_->w_out, g_->b_out, (float*)dN, s)) return e;
+            if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, nullptr, 0, g_->w_out, g_->b_out,
+                                                  a->lin_out_scratch ? a->lin_out_scratch : (float*)dN, s)) return e;
         }
     } else if (prec) {
         if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, (float*)dN, s)) return e;
@@ -468,6 +480,9 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     }
     if (fused_chain) {
         if (int e = wide_chain ? launch_mlp_bwd_wide(cfg, w, M, a, dH, dN, dh3_in_chain ? d_logits : nullptr, s) : launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
+        if (low_used) {
+            if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, nullptr, 0, g_->w_out, g_->b_out, a->lin_out_scratch, sc_->low)) return e;
+        }
         if (int e = fork()) return e;
     }
     GemmTN wg[8];   // the six fc weight gradients (+ lin_z, below): batched into one launch when the chain kernel already produced every dH / dN
@@ -592,6 +607,9 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     }
     if (sc_) {  // join: the caller's stream continues only after the weight-gradient stream has drained
         if (int e = order_after(sc_, s2, s)) return e;
+        if (low_used) {
+            if (int e = order_after(sc_, sc_->low, s)) return e;
+        }
     }
     return 0;
 }

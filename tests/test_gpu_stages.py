@@ -780,22 +780,23 @@ def test_mlp_backward_fused_matches_layer_path(case, M):
             assert rel <= 1e-4, "%s %s: relative L2 difference %.3e" % (other, n, rel)
     # the default 128-row chain makes dH3 = (d_logits W_out) * [H3 > 0] in its prologue, on the matrix cores (three-term bf16 splits of
     # both fp32 operands: every term product exact, fp32 accumulation), where linout_bwd runs an fp32 FMA chain: the two agree to fp32
-    # rounding, i.e. the bf16 results are EQUAL except where a value sits on a bf16 rounding boundary to within ~1e-7 relative
-    # (expected ~1e-5 of the elements; a differing element is one bf16 ulp off).  Against the exact product (float64 on the same
-    # operands) neither is further away than half a bf16 ulp plus fp32 rounding.  The rest of the chain is the same instruction
-    # stream as wide_staged: its outputs follow dH3 (a flipped element moves them like any bf16 rounding does).
+    # rounding of the four-term sum, i.e. the bf16 results are EQUAL except where the exact value sits within that rounding of a bf16
+    # rounding boundary (measured 1.6-1.8e-5 of the elements; such an element is one bf16 ulp off, more only where the four products
+    # cancel and fp32 rounding of the TERMS exceeds an ulp of the small sum).  Against the exact product (float64 on the same operands)
+    # neither is further away than half a bf16 ulp plus that fp32 rounding.  The rest of the chain is the same instruction stream as
+    # wide_staged: its outputs follow dH3 (a flipped element moves them like any bf16 rounding does).
     dHw, dNw, gw = res["wide"]
     x, y = dHa[:, 1536:], dHw[:, 1536:]
     diff = x != y
     frac = float(diff.float().mean())
     print("prologue dH3 vs linout_bwd dH3: %.2e of the elements differ" % frac)
     assert frac <= 2e-4, frac
-    if bool(diff.any()):
-        ulp = torch.maximum(x.abs(), y.abs())[diff] * 2.0 ** -7      # >= one bf16 ulp of the larger one
-        assert bool(((x - y).abs()[diff] <= ulp).all())
     gate = (run.H[3].float().cpu() > 0)
     exact = (dl.double().cpu() @ state["lin_out.weight"].double()) * gate
     terms = (dl.double().cpu().abs() @ state["lin_out.weight"].double().abs()) * gate
+    if bool(diff.any()):
+        ulp = torch.maximum(x.abs(), y.abs())[diff] * 2.0 ** -7 + terms[diff].float() * 1e-6     # one bf16 ulp of the larger one + fp32 rounding of the terms
+        assert bool(((x - y).abs()[diff] <= ulp).all())
     for nm, got in (("linout_bwd", x), ("prologue", y)):
         err = (got.double() - exact).abs()
         bound = exact.abs() * 2.0 ** -8 + terms * 4e-7 + 1e-30    # half a bf16 ulp (8 significant bits) + fp32 rounding of the four-term sum
