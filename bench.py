@@ -54,6 +54,14 @@ def pmc_traffic(logical_name, rows=None):
         d = json.load(open(files[-1]))
     except Exception:
         return None
+    meta = d.pop("_meta", {}) if isinstance(d, dict) else {}
+    try:
+        from scenerf_amd import build as _b
+        fresh = bool(meta.get("src_digest")) and meta.get("src_digest") == _b._digest()
+    except Exception:
+        fresh = False
+    pmc_traffic.meta = {"source": os.path.basename(files[-1]), "fresh": fresh,
+                        "collected_at": meta.get("commit") or "unknown (collected before the digest was recorded)"}
     # (the fused passes run as wide.hip's 128-row kernels where the launch is big enough, else as fused.hip's 64-row ones)
     if logical_name.startswith("mlp_fwd_fused"):
         fn = "mlp_wide_kernel<0>" if any(k.startswith("mlp_wide_kernel<0>") for k in d) and not logical_name.endswith("/g") else "mlp_fused_kernel<0>"
@@ -112,6 +120,14 @@ def parse():
                     help="train, one GPU: issue the step as ONE hipGraph replay (scenerf_amd.graph.GraphedStep: forward, loss, backward, fused "
                          "AdamW captured once); 'auto' = on when it can be captured (bf16, device noise, the fused optimizer, one rank), the "
                          "eagerly issued step is then reported next to it as `eager_step`; 'off' = the eager step is the headline")
+    ap.add_argument("--loss", default="source", choices=["source", "proxy"],
+                    help="what stands between the renderer's forward and backward in a step: 'source' = the reference's loss of one source frame "
+                         "(scenerf.py:203-238 around process_single_source: colour L1 + photometric reprojection against synthetic source / target "
+                         "images, KL, closest-gaussian term, KITTI weights) through scenerf_amd.loss_side.source_loss, one launch each way; 'proxy' = "
+                         "depth.mean() + color.mean() + loss_kl.mean() + gaussian_means.mean() in eager torch (rounds 1-3: ~12 launches, ~90 us)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="one rank: still create the process group (nccl = RCCL) and issue the gradient collectives (scenerf_amd.dist."
+                         "FORCE_COLLECTIVES): the N > 1 code path on a single GPU; reported as `allreduce`")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short BASELINE configs[3] (BundleFusion) and configs[4] (inference) legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -143,6 +159,25 @@ def make_optimizer(args, params):
         return torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, fused=True)
     from scenerf_amd.optim import FusedAdamW
     return FusedAdamW(params, lr=1e-5, weight_decay=0.0, capturable=bool(getattr(args, "capturable", False)))
+
+
+def make_loss(args, dev, img_size, K, pix, rank=0, weights=(1.0, 1.0, 0.01)):
+    """The step's loss as a function of render_rays_batch's output dict (see --loss)."""
+    if getattr(args, "loss", "source") == "proxy":
+        return lambda out: out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
+    from scenerf_amd.loss_side import source_loss
+    g = torch.Generator().manual_seed(900 + rank)
+    W, H = img_size
+    img_s, img_t = torch.rand(3, H, W, generator=g).to(dev), torch.rand(3, H, W, generator=g).to(dev)
+    T_s2t = synth.rel_pose(-1.0, 3.0).to(dev)
+    iK = torch.inverse(K)
+    R = pix.shape[0]
+
+    def loss_fn(out):
+        noise = torch.randn(R, device=dev)      # scenerf.py:378: randn * 1e-5 on the identity term (the kernel applies the scale)
+        return source_loss(out, pix, img_s, img_t, K, iK, T_s2t, noise=noise, noise_scale=1e-5, reproj_weight=weights[0],
+                           color_weight=weights[1], dist2closest_weight=weights[2])[0]
+    return loss_fn
 
 
 def make_model(args, dev, precision=None):
@@ -192,8 +227,11 @@ def cpu_baseline(args):
         times.append(time.perf_counter() - t0)
     best = min(times)
     return {"value": round(R / best, 2), "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": "%d rays x %d samples fwd+bwd on %d of %d host threads, full KITTI maps, best of %d (%s s)" % (
-                R, args.samples, threads, cores, len(times), ", ".join("%.1f" % t for t in times))}
+            "what": "oracle/scenerf_oracle.py, the CPU restatement of the reference's eager path pinned on reference-minted goldens (the "
+                    "reference itself is not on this box), render + proxy loss fwd+bwd",
+            "threads_used": threads, "threads_available": cores,
+            "sample": "%d rays x %d samples fwd+bwd on %d of %d host threads (torch's CPU kernels regress beyond a few dozen), full KITTI maps, "
+                      "best of %d (%s s)" % (R, args.samples, threads, cores, len(times), ", ".join("%.1f" % t for t in times))}
 
 
 def eager_gpu_baseline(args, dev):
@@ -360,8 +398,16 @@ def _rooflines(kernels, args, nprof, value_per_gpu, world):
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
         tot_f = sum(k["flops"] for k in mfma)
         tot_t = sum(k["total_ms"] for k in mfma)
+        tr = pmc_traffic(dom["name"], getattr(args, "rows_per_launch", None))
+        tmeta = getattr(pmc_traffic, "meta", {})
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom["name"], getattr(args, "rows_per_launch", None)),
+                "frac": round(ach / peak, 4),
+                # HBM bytes per launch of the dominant kernel from the last committed PMC pass of the bench command (counters cannot be read
+                # in-process); traffic_fresh says whether that pass was taken on THIS tree's kernel sources (content digest)
+                "traffic": tr["bytes_per_launch"] if tr else None, "traffic_kernel": tr["kernel_fn"] if tr else None,
+                "traffic_source": tmeta.get("source"), "traffic_fresh": tmeta.get("fresh"), "traffic_collected_at": tmeta.get("collected_at"),
+                "timing": "HIP events around every launch, on its launch stream, inside the library (scenerf_hip_profile_enable); the "
+                          "rocprofv3 --kernel-trace average of the same kernel in profiles/ runs 5-10 % longer (tracer overhead)",
                 "avg_launch_us": round(dom["avg_us"], 2), "flops_per_launch": dom["flops"] / dom["launches"],
                 "all_mfma_kernels_achieved": round(tot_f / (tot_t * 1e-3) / 1e12, 2),
                 "all_mfma_kernels_frac": round(tot_f / (tot_t * 1e-3) / 1e12 / peak, 4),
@@ -369,6 +415,13 @@ def _rooflines(kernels, args, nprof, value_per_gpu, world):
                 "per_kernel": {k["name"]: {"achieved": round(k["flops"] / (k["total_ms"] * 1e-3) / 1e12, 1),
                                            "frac": round(k["flops"] / (k["total_ms"] * 1e-3) / 1e12 / peak, 4), "avg_launch_us": round(k["avg_us"], 1)}
                                for k in sorted(mfma, key=lambda k: -k["total_ms"])[:6]}}
+        # the same per-kernel numbers as flat scalars (nested objects do not survive the driver's `parsed` copy of this line)
+        short = {"mlp_fwd_fused": "fwd", "mlp_bwd_fused": "dgrad_chain", "gemm_wgrad_fc": "wgrad_batch", "mlp_fwd_fused/g": "head_fwd",
+                 "mlp_bwd_fused/g": "head_dgrad", "gemm_dfeat_scatter": "dfeat", "gemm_wgrad_fc/g": "head_wgrad"}
+        for k in mfma:
+            if k["name"] in short:
+                roof["frac_" + short[k["name"]]] = round(k["flops"] / (k["total_ms"] * 1e-3) / 1e12 / peak, 4)
+                roof["us_" + short[k["name"]]] = round(k["avg_us"], 1)
         if value_per_gpu is not None:
             # with zero-K-block skipping, utilisation is reported on the FLOPs issued (above) and the rays/s are
             # quoted separately against the dense algorithmic count of the reference: fwd 2(N*5,405,696 + G*5,404,672), x3 fwd+bwd
@@ -391,7 +444,10 @@ def _rooflines(kernels, args, nprof, value_per_gpu, world):
         # the same two kernels at an inference-sized chunk (65,536 rays): at the training chunk (1,200 rays = 1,200 waves) the pass is
         # launch latency, not bandwidth; this is the number the HBM roofline applies to (tools/composite_probe.py, profiles/*composite*)
         try:
-            roof_c["at_inference_chunk"] = _composite_probe(65536, args.samples)
+            pr = _composite_probe(65536, args.samples)
+            roof_c["at_inference_chunk"] = pr
+            for nm in ("fwd", "bwd", "tail_fwd", "tail_bwd"):
+                roof_c["frac_65536_rays_" + nm] = pr[nm]["frac"]
         except Exception as e:   # never let the extra leg break the bench line
             roof_c["at_inference_chunk"] = {"error": str(e)}
     return roof, roof_c
@@ -542,12 +598,13 @@ def bundlefusion_leg(args, dev, steps=10, warmup=3):
             maps[k] = v.to(dev).requires_grad_(True)
     K, T = synth.bundlefusion_cam_K().to(dev), synth.rel_pose(0.3, 8.0).to(dev)
     pix = synth.stride2_pixels((640, 480), R, 14).to(dev)
+    loss_fn = make_loss(args, dev, (640, 480), K, pix, 0, weights=(5.0, 1.0, 0.1))      # scenerf_bf.py:215,238
 
     def step():
         for v in maps.values():
             v.grad = None
         out = m.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=R)
-        loss = out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
+        loss = loss_fn(out)
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
@@ -570,6 +627,48 @@ def bundlefusion_leg(args, dev, steps=10, warmup=3):
             "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup,
             "config": {"workload": "BundleFusion 640x480, sphere 960x720, 96 samples/ray (U=64,G=4,P=8), 1080 rays/step, D=12 m, same step as the headline",
                        "rays_per_gpu": R, "samples_per_ray": U + 4 * P, "precision": args.precision, "maps": args.maps},
+            "roofline": roof, "roofline_composite": roof_c}
+
+
+def default_n64_leg(args, dev, steps=10, warmup=3):
+    """The reference's own CLI default (train_kitti.py:33-35: n_pts_uni = 32, n_pts_per_gaussian = 8 -> 64 samples per ray), R = 1200 rays per
+    step on the KITTI geometry: the same training step as the headline at half the samples (76,800 rows: 600 row blocks)."""
+    import copy
+    a2 = copy.copy(args)
+    a2.samples = 64
+    R = args.rays
+    m = make_model(a2, dev)
+    opt = make_optimizer(args, list(m.mlp.parameters()) + list(m.mlp_gaussian.parameters()))
+    maps = _make_maps(args.maps, dev, 0)
+    K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
+    pix = synth.stride2_pixels((1220, 370), R, 100).to(dev)
+    loss_fn = make_loss(args, dev, (1220, 370), K, pix, 0)
+
+    def step():
+        for v in maps.values():
+            v.grad = None
+        loss = loss_fn(m.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=R))
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(last).item()
+    roof, roof_c = _leg_roofline(step, 2, args, 64, R / dt, R * 64)
+    if roof:
+        roof.pop("dense_equivalent", None)
+    return {"metric": "rays/sec (training fwd+bwd), KITTI, 64 samples/ray (the reference's CLI default)", "value": round(R / dt, 1), "unit": "rays/s",
+            "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "issued": "eager",
+            "config": {"workload": "KITTI 370x1220, sphere 1500x452, 64 samples/ray (U=32,G=4,P=8), %d rays/step, same step as the headline" % R,
+                       "rays_per_gpu": R, "samples_per_ray": 64, "precision": args.precision, "maps": args.maps},
             "roofline": roof, "roofline_composite": roof_c}
 
 
@@ -628,11 +727,17 @@ def main():
         if torch.cuda.device_count() < env_world:
             raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible: one process per GPU is the contract" % (
                 env_world, torch.cuda.device_count()))
-    rank, world, local = sdist.init_from_env()
+    rank, world, local = sdist.init_from_env(force=args.force_dist and not dry)
     assert world == args.gpus
+    forced = bool(args.force_dist and world == 1 and not dry)
+    if forced:
+        sdist.FORCE_COLLECTIVES = True
+    pinned = None
     if not dry:
         dev = torch.device("cuda", local)
         torch.cuda.set_device(dev)
+        if world > 1:
+            pinned = sdist.numa_pin(local)      # launch calls, pinned buffers and the RCCL proxy thread on the GPU's own socket
         _capi.load()
         sync = torch.cuda.synchronize
     else:
@@ -654,11 +759,13 @@ def main():
         pix = synth.stride2_pixels((1220, 370), R, 100 + rank).to(dev)
     # N > 1: each MLP's packed gradient sink is all-reduced (RCCL) right before it is handed to autograd: 2 x 21.7 MB
     step_sync = None
-    if world > 1 and args.sync == "step" and not dry:
+    collectives = world > 1 or forced
+    if collectives and args.sync == "step" and not dry:
         step_sync = sdist.StepGradSync(params)
     else:
-        model.grad_sync = sdist.allreduce_mean_ if world > 1 else None
-        model.grad_sync_async = sdist.allreduce_mean_async if world > 1 else None   # radiance MLP: started before the feature scatter
+        model.grad_sync = sdist.allreduce_mean_ if collectives else None
+        model.grad_sync_async = sdist.allreduce_mean_async if collectives else None   # radiance MLP: started before the feature scatter
+    loss_fn = make_loss(args, dev, (1220, 370), K, pix, rank) if not dry else None
 
     def make_step(model, opt):
         if dry:
@@ -667,7 +774,7 @@ def main():
             for v in maps.values():
                 v.grad = None
             out = model.render_rays_batch(K, T, maps, T_cam2velo=None, sampled_pixels=pix, ray_batch_size=R)
-            loss = out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
+            loss = loss_fn(out)
             loss.backward()
             opt.step()
             opt.zero_grad(set_to_none=True)
@@ -676,13 +783,16 @@ def main():
 
     step = make_step(model, opt)
     # one GPU: the step as ONE hipGraph replay (the product's GraphedStep); the eagerly issued step is measured right after it and
-    # reported as `eager_step`.  N > 1 stays eager: a captured RCCL collective has never run here.
+    # reported as `eager_step`.  N > 1: eager unless --graph on.  A step WITH its collectives does capture and replay on RCCL
+    # (tests/test_gpu_graph.py::test_graphed_step_with_nccl_world1, one rank), but a multi-rank captured all-reduce has never run on this
+    # code, and a capture that goes wrong on some ranks only is a hang, not a fallback: the scaling run is not where to find out.
     graphed = eager_leg = None
     graph_note = "eager (one launch call per kernel)"
     want_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
     if want_graph and not dry:
         why = None
-        if world > 1: why = "more than one rank"
+        if world > 1 and args.graph != "on": why = "more than one rank"
+        elif args.sync == "step" and collectives: why = "--sync step (its end-of-backward callback is host code)"
         elif args.precision != "bf16" and args.graph == "auto": why = "fp32 mode"
         elif getattr(args, "host_rng", False): why = "--host-rng (the host-side draw cannot be captured)"
         elif args.optimizer != "fused": why = "--optimizer torch"
@@ -692,7 +802,6 @@ def main():
                 args.capturable = True
                 opt_g = make_optimizer(args, params)
                 args.capturable = False
-                loss_fn = lambda out: out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
                 graphed = GraphedStep(model, opt_g, loss_fn, K, T, maps, pix, ray_batch_size=R, warmup=max(1, args.warmup))
                 graph_note = "one hipGraph replay per step (scenerf_amd.graph.GraphedStep: forward + loss + backward + fused AdamW captured once)"
             except Exception as e:      # (a capture that fails must not cost the line: the eager step is the fallback, and the line says so)
@@ -752,8 +861,26 @@ def main():
                      "issued": "eager (compare with eager_step)"}
         model.render_cfg.device_rng = not model.render_cfg.device_rng
 
+    drop_in = None
+    if world == 1 and not dry and not args.no_roofline:
+        # the configuration an UNMODIFIED reference caller presents: contiguous (C,H,W) maps (converted per call) AND the sampler's normal
+        # noise drawn on the host generator and uploaded (utils.py:208-211) -- eager (that draw cannot be captured).  (A second
+        # GraphedStep over the same parameters in this process is not attempted: their AccumulateGrad nodes stay bound to the first
+        # capture's stream, the cross-stream hand-off autograd then inserts is illegal inside a capture, and the failure mode is a
+        # segfault in hipStreamEndCapture, not an exception -- r04_c.)
+        main_maps = maps
+        maps = _make_maps("chw", dev, rank)
+        rng0 = model.render_cfg.device_rng
+        model.render_cfg.device_rng = False
+        dt4, _ = _timed(step, args, world, dev, sync)
+        model.render_cfg.device_rng = rng0
+        drop_in = {"maps": "chw", "sampling_noise": "host generator + upload", "issued": "eager", "value": round(R * args.steps / dt4, 1),
+                   "unit": "rays/s", "ms_per_step": round(dt4 / args.steps * 1e3, 3)}
+        maps = main_maps
+        torch.cuda.empty_cache()
+
     allreduce = None
-    if world > 1:   # three more steps with the collectives bracketed by events; every rank takes part, then the group is done
+    if collectives:   # three more steps with the collectives bracketed by events; every rank takes part, then the group is done
         sdist.TIMING = []
         for _ in range(3):
             step()
@@ -821,20 +948,16 @@ def main():
         except Exception as e:  # never let the side measurement break the bench line
             eager = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
-    bf_leg = inf_leg = None
+    bf_leg = inf_leg = n64_leg = None
     if rank == 0 and world == 1 and not dry and not args.no_extra_legs:
-        for name in ("bf", "infer"):
+        legs = {}
+        for name, fn in (("bf", bundlefusion_leg), ("infer", inference_leg), ("n64", default_n64_leg)):
             try:
-                if name == "bf":
-                    bf_leg = bundlefusion_leg(args, dev)
-                else:
-                    inf_leg = inference_leg(args, dev)
+                legs[name] = fn(args, dev)
             except Exception as e:  # never let a side leg break the bench line
-                if name == "bf":
-                    bf_leg = {"error": repr(e)[:300]}
-                else:
-                    inf_leg = {"error": repr(e)[:300]}
+                legs[name] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()
+        bf_leg, inf_leg, n64_leg = legs["bf"], legs["infer"], legs["n64"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
@@ -853,16 +976,44 @@ def main():
                                        "feature maps handed over channels-last ((C,H,W) tensors with (H,W,C) memory, read in place; the "
                                        "contiguous-(C,H,W) entry with its per-call layout conversion is timed as other_entry)"
                                        if args.maps == "hwc" else "incl. map layout conversion (contiguous (C,H,W) maps)"),
-                       "rays_per_gpu": R, "samples_per_ray": args.samples, "parallelism": "dp%d" % world, "grad_sync": (args.sync if world > 1 else None),
+                       "rays_per_gpu": R, "samples_per_ray": args.samples, "parallelism": "dp%d" % world, "grad_sync": (args.sync if collectives else None),
                        "optimizer": "scenerf_amd.optim.FusedAdamW" if args.optimizer == "fused" else "torch.optim.AdamW(fused=True)",
                        "precision": args.precision, "maps": args.maps, "step_issue": graph_note,
                        "sampling_noise": "host generator + upload, like the reference" if args.host_rng else
-                                         "device generator (RenderConfig.device_rng=True; --host-rng gives the reference's host-side draw: +0.1-0.25 ms per step)"},
-            "eager_step": eager_leg, "other_entry": other, "other_rng": rng_other, "steady_state": steady,
+                                         "device generator (RenderConfig.device_rng=True; --host-rng gives the reference's host-side draw: +0.1-0.25 ms per step)",
+                       "loss": "reference per-source loss (colour L1 + reprojection on synthetic images, KL, closest gaussian; scenerf_amd.loss_side."
+                               "source_loss, one launch each way)" if args.loss == "source" else "proxy: four means in eager torch",
+                       "numa_pin": pinned},
+            "eager_step": eager_leg, "other_entry": other, "other_rng": rng_other, "drop_in": drop_in, "steady_state": steady,
             "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager, "fp32_mode": fp32,
-            "bundlefusion_c4": bf_leg, "infer_c5": inf_leg,
+            "bundlefusion_c4": bf_leg, "infer_c5": inf_leg, "kitti_default_n64": n64_leg,
             "allreduce": allreduce, "ranks": census,
         }
+        # flat copies of the side measurements (scalars inside `config` / `roofline` survive the driver's `parsed` copy of this line; nested
+        # objects and extra top-level keys do not).  drop_in_* = the configuration an unmodified reference caller presents.
+        cfgd = line["config"]
+        if drop_in:
+            cfgd["drop_in_rays_per_s"], cfgd["drop_in_ms_per_step"] = drop_in["value"], drop_in["ms_per_step"]
+            cfgd["drop_in_is"] = "contiguous (C,H,W) maps converted per call + host-generator noise uploaded per chunk, eager issue"
+        if eager_leg:
+            cfgd["eager_issue_rays_per_s"], cfgd["eager_host_issue_ms_per_step"] = eager_leg["value"], eager_leg["host_issue_ms_per_step"]
+        if steady:
+            cfgd["steady_state_rays_per_s"] = steady["value"]
+        for nm, leg in (("bundlefusion_c4", bf_leg), ("infer_c5", inf_leg), ("kitti_default_n64", n64_leg)):
+            if leg and "value" in leg:
+                cfgd[nm + "_rays_per_s"] = leg["value"]
+        if roof is not None:
+            if roof_c:
+                roof["frac_tail_hbm_at_this_chunk"] = roof_c["frac"]
+                for k, v in roof_c.items():
+                    if k.startswith("frac_65536_rays_"):
+                        roof[k.replace("frac_65536_rays_", "frac_hbm_65536_rays_")] = v
+            if inf_leg and inf_leg.get("roofline"):
+                roof["frac_fwd_inference_c5"] = inf_leg["roofline"]["frac"]
+            if eager and "value" in eager:
+                roof["speedup_vs_eager_fp32_port_on_this_gpu"] = eager.get("speedup_bf16_vs_eager_fp32")
+        if allreduce:
+            cfgd["allreduce_max_exposed_wait_ms"] = allreduce["max_exposed_wait_ms_per_step"]
         if dry:
             line.update(metric="dry-run (control flow only, stub step over gloo)", dtype="none", data="none")
         print(json.dumps(line), flush=True)

@@ -166,12 +166,7 @@ typedef struct scenerf_mlp_acts {
                                      * the fused backward. */
     int32_t x3_ready;               /* bf16 mode: h0pre already holds the split encoding (scenerf_hip_encode_points wrote it): the forward
                                      * then neither reads xenc nor launches the split */
-    float* lin_out_scratch;         /* optional, fp32 [SCENERF_LINOUT_SCRATCH_FLOATS]: partial sums of lin_out's weight gradient.  With it (and
-                                     * SCENERF_FLAG_WGRAD_OVERLAP) that reduction runs beside the 128-row dgrad chain instead of in front of it;
-                                     * NULL: it borrows the dN scratch, in stream order */
 } scenerf_mlp_acts;
-#define SCENERF_LINOUT_SCRATCH_BLOCKS 512
-#define SCENERF_LINOUT_SCRATCH_FLOATS (SCENERF_LINOUT_SCRATCH_BLOCKS * (4 * SCENERF_D_HIDDEN + 8))
 
 int scenerf_hip_abi_version(void);
 const char* scenerf_hip_last_error(void);
@@ -319,6 +314,27 @@ int scenerf_hip_loss_side_forward(const float* pix, const float* color, const fl
 int scenerf_hip_loss_side_backward(const float* color, const float* col_src, const float* valid, const float* dterm_ddepth,
                                    const float* acc2, const float* g_loss_color, const float* g_loss_reprojection, int R,
                                    float* g_color, float* g_depth, scenerf_stream_t stream);
+
+/* The whole loss of ONE source frame in one launch each way (reference scenerf.py:203-238, the weights of forward(), around
+ * process_single_source :243-320; BundleFusion weights scenerf_bf.py:215,238):
+ *   total = w_rep * loss_reprojection + w_col * mean(loss_color) + mean(loss_kl) + w_d2c * mean_r min_k |gaussian_means[r][k] - depth[r]|
+ * with loss_color / loss_reprojection as in scenerf_hip_loss_side_forward and the rendered depth detached in the last term (:287-290).
+ * loss_kl [R], gmeans / gstds / som_vars [R][G] are the renderer's outputs (gstds, som_vars nullable: they only feed the two logged means).
+ * noise [R] nullable: noise[r] * noise_scale is added to the identity term (the reference draws randn * 1e-5).  out8 (device, fp32 [8]) =
+ * {total, loss_reprojection, mean loss_color, mean loss_kl, mean dist-to-closest-gaussian, mean som_vars of the closest gaussian, mean
+ * gaussian_stds of the closest gaussian, number of valid rays}.  Kept for the backward: valid, dterm_ddepth [R], col_src [R][3],
+ * closest [R] (int32); partial: scratch, fp32 [8 * ceil(R / 1024)].  Sums are taken in a fixed order (no atomics). */
+int scenerf_hip_source_loss_forward(const float* pix, const float* color, const float* depth, const float* loss_kl, const float* gmeans,
+                                    const float* gstds, const float* som_vars, int G, const float* img_source, const float* img_target,
+                                    const float* noise, float noise_scale, const float* cam_K, const float* inv_K,
+                                    const float* T_source2target, int R, int H, int W, float w_rep, float w_col, float w_d2c, float* valid,
+                                    float* dterm_ddepth, float* col_src, int32_t* closest, float* partial, float* out8,
+                                    float* total /* [1]: out8[0] once more, in a buffer of its own */, scenerf_stream_t stream);
+/* its autograd w.r.t. colour [R][3], depth [R], loss_kl [R] and gaussian_means [R][G]; g_total: device scalar, NULL = 1. */
+int scenerf_hip_source_loss_backward(const float* color, const float* col_src, const float* valid, const float* dterm_ddepth,
+                                     const float* gmeans, const float* depth, const int32_t* closest, const float* out8, const float* g_total,
+                                     int R, int G, float w_rep, float w_col, float w_d2c, float* g_color, float* g_depth, float* g_loss_kl,
+                                     float* g_gmeans, scenerf_stream_t stream);
 
 /* ---- generic building blocks exported for unit tests ------------------------------------------------------- */
 /* C[M][N] = relu?(A[M][K]) @ W[N][K]^T (+bias); act operands per `precision`, fp32 output.

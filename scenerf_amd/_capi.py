@@ -73,8 +73,7 @@ class MlpGrads(C.Structure):
 
 
 class MlpActs(C.Structure):
-    _fields_ = [("H", vp * 4), ("Nn", vp * 3), ("h0pre", vp), ("logits", vp), ("sign_bits", vp), ("x3_ready", C.c_int32),
-                ("lin_out_scratch", vp)]
+    _fields_ = [("H", vp * 4), ("Nn", vp * 3), ("h0pre", vp), ("logits", vp), ("sign_bits", vp), ("x3_ready", C.c_int32)]
 
 
 class AdamWTensor(C.Structure):
@@ -115,6 +114,8 @@ _PROTOS = {
     "scenerf_hip_sphere_resample_backward_nhwc": (C.c_int, [vp, C.c_int64, i32, i32, i32, vp, vp, i32, i32, vp, vp]),
     "scenerf_hip_loss_side_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_loss_side_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
+    "scenerf_hip_source_loss_forward": (C.c_int, [vp] * 7 + [i32] + [vp] * 3 + [C.c_float] + [vp] * 3 + [i32] * 3 + [C.c_float] * 3 + [vp] * 7 + [vp]),
+    "scenerf_hip_source_loss_backward": (C.c_int, [vp] * 9 + [i32, i32] + [C.c_float] * 3 + [vp] * 4 + [vp]),
     "scenerf_hip_mlp_feature_grads": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpWeights), vp, vp, vp, i32, vp,
                                                 C.POINTER(vp * N_SCALES), vp]),
     "scenerf_hip_gaussian_sample_sort": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
@@ -158,7 +159,6 @@ FUSED_MIN_ROWS_DEFAULT = 4096    # SCENERF_FUSED_MIN_ROWS_DEFAULT
 FLAG_NO_FUSED_BWD, FLAG_NO_WGRAD_TR, FLAG_DFEAT_PER_SCALE, FLAG_WGRAD_OVERLAP, FLAG_WIDE_BWD, FLAG_WIDE_ANY_M, FLAG_DFEAT_GEMM = 1, 2, 4, 8, 16, 32, 64   # SCENERF_FLAG_*
 FLAG_UNIFORM_ONLY = 128
 FLAG_WIDE_BWD_STAGED = 256
-LINOUT_SCRATCH_FLOATS = 512 * (4 * 512 + 8)   # SCENERF_LINOUT_SCRATCH_FLOATS
 WIN_LD = 256            # SCENERF_WIN_LD: row stride of scenerf_mlp_grads.w_in
 
 

@@ -14,7 +14,8 @@ struct LossArgs {
     const float* depth;      // [R] rendered depth
     const float* img_s;      // [3][H][W]
     const float* img_t;      // [3][H][W]
-    const float* noise;      // [R] or NULL: added to the identity term (the reference draws randn * 1e-5 there)
+    const float* noise;      // [R] or NULL: noise[r] * noise_scale is added to the identity term (the reference draws randn * 1e-5 there)
+    float noise_scale;
     const float *K, *invK, *T;    // device: row-major 3x3, 3x3, and the 4x4 source->target transform (top three rows are read)
     int R, H, W;
     float* loss_color;       // [R][3]
@@ -49,51 +50,57 @@ __device__ static inline void bilin3(const float* img, int H, int W, float px, f
     }
 }
 
+// one ray of the colour + reprojection terms: writes the per-ray records and returns (term, valid, sum_c |colour - source colour|)
+__device__ static inline void loss_ray(const LossArgs& p, int r, float& term, float& val, float& col_l1) {
+    const float px = p.pix[2 * r], py = p.pix[2 * r + 1], depth = p.depth[r];
+    float cs[3], ci[3], ct[3], d0[3], d1[3], tx[3], ty[3];
+    bilin3(p.img_s, p.H, p.W, px, py, cs, d0, d1);
+    bilin3(p.img_t, p.H, p.W, px, py, ci, d0, d1);
+    // back-project, transform, project (scenerf.py:355-368)
+    const float vx = p.invK[0] * px + p.invK[1] * py + p.invK[2], vy = p.invK[3] * px + p.invK[4] * py + p.invK[5],
+                vz = p.invK[6] * px + p.invK[7] * py + p.invK[8];
+    const float sxp = depth * vx, syp = depth * vy, szp = depth * vz;
+    const float cx = p.T[0] * sxp + p.T[1] * syp + p.T[2] * szp + p.T[3], cy = p.T[4] * sxp + p.T[5] * syp + p.T[6] * szp + p.T[7],
+                cz = p.T[8] * sxp + p.T[9] * syp + p.T[10] * szp + p.T[11];
+    // d(cam_tgt) / d(depth) = R v
+    const float rx = p.T[0] * vx + p.T[1] * vy + p.T[2] * vz, ry = p.T[4] * vx + p.T[5] * vy + p.T[6] * vz,
+                rz = p.T[8] * vx + p.T[9] * vy + p.T[10] * vz;
+    const float hx = p.K[0] * cx + p.K[1] * cy + p.K[2] * cz, hy = p.K[3] * cx + p.K[4] * cy + p.K[5] * cz,
+                hz = p.K[6] * cx + p.K[7] * cy + p.K[8] * cz;
+    const float gx = p.K[0] * rx + p.K[1] * ry + p.K[2] * rz, gy = p.K[3] * rx + p.K[4] * ry + p.K[5] * rz,
+                gz = p.K[6] * rx + p.K[7] * ry + p.K[8] * rz;
+    val = cz > 0.f ? 1.f : 0.f;
+    const bool front = hz > 0.f;
+    const float qx = front ? hx / hz : -1.f, qy = front ? hy / hz : -1.f;
+    const float dqx = front ? (gx * hz - hx * gz) / (hz * hz) : 0.f, dqy = front ? (gy * hz - hy * gz) / (hz * hz) : 0.f;
+    bilin3(p.img_t, p.H, p.W, qx, qy, ct, tx, ty);
+    float l_rep = 0.f, l_id = 0.f, dl = 0.f;
+    col_l1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float e = ct[c] - cs[c];
+        l_rep += fabsf(e);
+        dl += (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * (tx[c] * dqx + ty[c] * dqy);
+        l_id += fabsf(ci[c] - cs[c]);
+        const float col = p.color[3 * r + c];
+        const float lc = fabsf(col - cs[c]);
+        col_l1 += lc;
+        if (p.loss_color) p.loss_color[3 * r + c] = lc;
+        p.col_src[3 * r + c] = cs[c];
+    }
+    l_rep *= (1.f / 3.f);
+    l_id = l_id * (1.f / 3.f) + (p.noise ? p.noise[r] * p.noise_scale : 0.f);
+    const bool rep = l_rep <= l_id;   // torch.minimum: the gradient goes to the reprojection term where it is the smaller (or equal)
+    term = rep ? l_rep : l_id;
+    if (p.ray_term) p.ray_term[r] = term;
+    p.valid[r] = val;
+    p.dterm_ddepth[r] = rep ? dl * (1.f / 3.f) : 0.f;
+}
+
 __global__ __launch_bounds__(256) void loss_side_fwd_kernel(LossArgs p) {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    float term = 0.f, val = 0.f;
-    if (r < p.R) {
-        const float px = p.pix[2 * r], py = p.pix[2 * r + 1], depth = p.depth[r];
-        float cs[3], ci[3], ct[3], d0[3], d1[3], tx[3], ty[3];
-        bilin3(p.img_s, p.H, p.W, px, py, cs, d0, d1);
-        bilin3(p.img_t, p.H, p.W, px, py, ci, d0, d1);
-        // back-project, transform, project (scenerf.py:355-368)
-        const float vx = p.invK[0] * px + p.invK[1] * py + p.invK[2], vy = p.invK[3] * px + p.invK[4] * py + p.invK[5],
-                    vz = p.invK[6] * px + p.invK[7] * py + p.invK[8];
-        const float sxp = depth * vx, syp = depth * vy, szp = depth * vz;
-        const float cx = p.T[0] * sxp + p.T[1] * syp + p.T[2] * szp + p.T[3], cy = p.T[4] * sxp + p.T[5] * syp + p.T[6] * szp + p.T[7],
-                    cz = p.T[8] * sxp + p.T[9] * syp + p.T[10] * szp + p.T[11];
-        // d(cam_tgt) / d(depth) = R v
-        const float rx = p.T[0] * vx + p.T[1] * vy + p.T[2] * vz, ry = p.T[4] * vx + p.T[5] * vy + p.T[6] * vz,
-                    rz = p.T[8] * vx + p.T[9] * vy + p.T[10] * vz;
-        const float hx = p.K[0] * cx + p.K[1] * cy + p.K[2] * cz, hy = p.K[3] * cx + p.K[4] * cy + p.K[5] * cz,
-                    hz = p.K[6] * cx + p.K[7] * cy + p.K[8] * cz;
-        const float gx = p.K[0] * rx + p.K[1] * ry + p.K[2] * rz, gy = p.K[3] * rx + p.K[4] * ry + p.K[5] * rz,
-                    gz = p.K[6] * rx + p.K[7] * ry + p.K[8] * rz;
-        val = cz > 0.f ? 1.f : 0.f;
-        const bool front = hz > 0.f;
-        const float qx = front ? hx / hz : -1.f, qy = front ? hy / hz : -1.f;
-        const float dqx = front ? (gx * hz - hx * gz) / (hz * hz) : 0.f, dqy = front ? (gy * hz - hy * gz) / (hz * hz) : 0.f;
-        bilin3(p.img_t, p.H, p.W, qx, qy, ct, tx, ty);
-        float l_rep = 0.f, l_id = 0.f, dl = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float e = ct[c] - cs[c];
-            l_rep += fabsf(e);
-            dl += (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * (tx[c] * dqx + ty[c] * dqy);
-            l_id += fabsf(ci[c] - cs[c]);
-            const float col = p.color[3 * r + c];
-            p.loss_color[3 * r + c] = fabsf(col - cs[c]);
-            p.col_src[3 * r + c] = cs[c];
-        }
-        l_rep *= (1.f / 3.f);
-        l_id = l_id * (1.f / 3.f) + (p.noise ? p.noise[r] : 0.f);
-        const bool rep = l_rep <= l_id;   // torch.minimum: the gradient goes to the reprojection term where it is the smaller (or equal)
-        term = rep ? l_rep : l_id;
-        p.ray_term[r] = term;
-        p.valid[r] = val;
-        p.dterm_ddepth[r] = rep ? dl * (1.f / 3.f) : 0.f;
-    }
+    float term = 0.f, val = 0.f, cl = 0.f;
+    if (r < p.R) loss_ray(p, r, term, val, cl);
     // masked mean: numerator / denominator per wave, then two atomics per wave; the last block to arrive divides
     float num = wave_sum(term * val), den = wave_sum(val);
     if ((threadIdx.x & 63) == 0) {
@@ -118,6 +125,115 @@ __global__ __launch_bounds__(256) void loss_side_bwd_kernel(const float* color, 
     g_depth[r] = gl * valid[r] * dterm[r];
 }
 
+
+// ---- the whole loss of one source frame (reference scenerf.py:203-238 around process_single_source :243-320) -------------------------
+//   total = w_rep * loss_reprojection + w_col * mean(loss_color) + mean(loss_kl) + w_d2c * mean_r min_k |gaussian_means[r][k] - depth[r]|
+// (depth detached in the last term, scenerf.py:287-290), plus the two means the trainer only logs (som_vars / gaussian_stds of the closest
+// gaussian).  ~12 eager kernels forward and as many backward between the renderer's forward and backward -- on the critical path of a
+// step, 6-7 us each -- become one launch each way (a second, one-wave launch sums the per-block partials when R > 1024).  Sums are
+// taken per block in a fixed order (no atomics): the value is reproducible run to run.
+#define SL_TERMS 8      // rep numerator, rep denominator, colour sum, kl sum, d2c sum, som_vars sum, stds sum, (unused)
+#define SL_THREADS 1024
+struct SrcLossArgs {
+    LossArgs L;
+    const float* loss_kl;    // [R]
+    const float* gmeans;     // [R][G]
+    const float* gstds;      // [R][G] or NULL
+    const float* som_vars;   // [R][G] or NULL
+    int G;
+    float w_rep, w_col, w_d2c;
+    int* closest;            // [R] index of the gaussian closest to the rendered depth (kept for the backward)
+    float* partial;          // [blocks][SL_TERMS]
+    float* out;              // [8]: total, loss_reprojection, mean loss_color, mean loss_kl, mean dist2closest, mean min_som_vars, mean min_stds, n_valid
+    float* total;            // [1]: the total once more, in a buffer of its own (the differentiable output)
+};
+
+__device__ static inline void sl_finish(const SrcLossArgs& p, const float (&t)[SL_TERMS]) {
+    const float invR = 1.f / (float)p.L.R;
+    const float rep = t[0] / fmaxf(t[1], 1.f), col = t[2] * invR * (1.f / 3.f), kl = t[3] * invR, d2c = t[4] * invR;
+    p.out[0] = p.w_rep * rep + p.w_col * col + kl + p.w_d2c * d2c;
+    p.total[0] = p.out[0];
+    p.out[1] = rep; p.out[2] = col; p.out[3] = kl; p.out[4] = d2c;
+    p.out[5] = t[5] * invR; p.out[6] = t[6] * invR; p.out[7] = t[1];
+}
+
+__global__ __launch_bounds__(SL_THREADS) void source_loss_fwd_kernel(SrcLossArgs p) {
+    __shared__ float s_part[SL_THREADS / 64][SL_TERMS];
+    const int r = blockIdx.x * SL_THREADS + threadIdx.x;
+    float t[SL_TERMS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < p.L.R) {
+        float term, val, cl;
+        loss_ray(p.L, r, term, val, cl);
+        t[0] = term * val; t[1] = val; t[2] = cl; t[3] = p.loss_kl[r];
+        const float d = p.L.depth[r];
+        float best = fabsf(p.gmeans[(size_t)r * p.G] - d);
+        int bi = 0;
+        for (int k = 1; k < p.G; ++k) {     // torch.min(dim=1): the first minimum
+            const float v = fabsf(p.gmeans[(size_t)r * p.G + k] - d);
+            if (v < best) { best = v; bi = k; }
+        }
+        p.closest[r] = bi;
+        t[4] = best;
+        t[5] = p.som_vars ? p.som_vars[(size_t)r * p.G + bi] : 0.f;
+        t[6] = p.gstds ? p.gstds[(size_t)r * p.G + bi] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < SL_TERMS; ++i) t[i] = wave_sum(t[i]);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < SL_TERMS; ++i) s_part[wv][i] = t[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < SL_TERMS) {
+        float a = 0.f;
+        for (int w = 0; w < SL_THREADS / 64; ++w) a += s_part[w][threadIdx.x];
+        if (gridDim.x > 1) p.partial[blockIdx.x * SL_TERMS + threadIdx.x] = a;
+        s_part[0][threadIdx.x] = a;
+    }
+    if (gridDim.x == 1) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tt[SL_TERMS];
+#pragma unroll
+            for (int i = 0; i < SL_TERMS; ++i) tt[i] = s_part[0][i];
+            sl_finish(p, tt);
+        }
+    }
+}
+__global__ void source_loss_finish_kernel(SrcLossArgs p, int blocks) {
+    float tt[SL_TERMS];
+#pragma unroll
+    for (int i = 0; i < SL_TERMS; ++i) {
+        float a = 0.f;
+        for (int b = (int)threadIdx.x; b < blocks; b += 64) a += p.partial[b * SL_TERMS + i];
+        tt[i] = wave_sum(a);
+    }
+    if (threadIdx.x == 0) sl_finish(p, tt);
+}
+
+// backward of the total w.r.t. colour, depth, loss_kl and the gaussian means; g = upstream gradient of the total (device scalar or NULL = 1)
+__global__ __launch_bounds__(256) void source_loss_bwd_kernel(const float* color, const float* col_src, const float* valid, const float* dterm,
+                                                              const float* gmeans, const float* depth, const int* closest, const float* out,
+                                                              const float* g, int R, int G, float w_rep, float w_col, float w_d2c,
+                                                              float* g_color, float* g_depth, float* g_kl, float* g_gmeans) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float gt = g ? g[0] : 1.f, invR = 1.f / (float)R;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float e = color[3 * r + c] - col_src[3 * r + c];
+        g_color[3 * r + c] = gt * w_col * invR * (1.f / 3.f) * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+    }
+    g_depth[r] = gt * w_rep / fmaxf(out[7], 1.f) * valid[r] * dterm[r];
+    g_kl[r] = gt * invR;
+    const int bi = closest[r];
+    for (int k = 0; k < G; ++k) {
+        const float e = gmeans[(size_t)r * G + k] - depth[r];
+        g_gmeans[(size_t)r * G + k] = k == bi ? gt * w_d2c * invR * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) : 0.f;
+    }
+}
+
 extern "C" {
 
 int scenerf_hip_loss_side_forward(const float* pix, const float* color, const float* depth, const float* img_source,
@@ -128,7 +244,7 @@ int scenerf_hip_loss_side_forward(const float* pix, const float* color, const fl
                   dterm_ddepth && col_src && acc2 && loss_reprojection && R > 0 && H > 1 && W > 1,
               "loss_side_forward: NULL / empty argument");
     LossArgs p = {};
-    p.pix = pix; p.color = color; p.depth = depth; p.img_s = img_source; p.img_t = img_target; p.noise = noise;
+    p.pix = pix; p.color = color; p.depth = depth; p.img_s = img_source; p.img_t = img_target; p.noise = noise; p.noise_scale = 1.f;
     p.K = cam_K; p.invK = inv_K; p.T = T_source2target;   // device memory (wave-uniform scalar loads): no host round trip per call
     p.R = R; p.H = H; p.W = W;
     p.loss_color = loss_color; p.ray_term = ray_term; p.valid = valid; p.dterm_ddepth = dterm_ddepth; p.col_src = col_src;
@@ -151,6 +267,47 @@ int scenerf_hip_loss_side_backward(const float* color, const float* col_src, con
     loss_side_bwd_kernel<<<cdiv(R, 256), 256, 0, s>>>(color, col_src, valid, dterm_ddepth, acc2, g_loss_color, g_loss_reprojection, R, g_color,
                                                        g_depth);
     SRF_LAUNCH_CHECK("loss_side_bwd_kernel");
+    return 0;
+}
+
+
+int scenerf_hip_source_loss_forward(const float* pix, const float* color, const float* depth, const float* loss_kl, const float* gmeans,
+                                    const float* gstds, const float* som_vars, int G, const float* img_source, const float* img_target,
+                                    const float* noise, float noise_scale, const float* cam_K, const float* inv_K,
+                                    const float* T_source2target, int R, int H, int W, float w_rep, float w_col, float w_d2c, float* valid,
+                                    float* dterm_ddepth, float* col_src, int32_t* closest, float* partial, float* out8,
+                                    float* total, scenerf_stream_t stream) {
+    SRF_CHECK(pix && color && depth && loss_kl && gmeans && img_source && img_target && cam_K && inv_K && T_source2target && valid &&
+                  dterm_ddepth && col_src && closest && partial && out8 && total && R > 0 && H > 1 && W > 1 && G >= 1 && G <= SCENERF_MAX_GAUSSIANS,
+              "source_loss_forward: NULL / empty argument");
+    SrcLossArgs p = {};
+    p.L.pix = pix; p.L.color = color; p.L.depth = depth; p.L.img_s = img_source; p.L.img_t = img_target; p.L.noise = noise; p.L.noise_scale = noise_scale;
+    p.L.K = cam_K; p.L.invK = inv_K; p.L.T = T_source2target;
+    p.L.R = R; p.L.H = H; p.L.W = W;
+    p.L.valid = valid; p.L.dterm_ddepth = dterm_ddepth; p.L.col_src = col_src;    // (loss_color / ray_term: not materialised)
+    p.loss_kl = loss_kl; p.gmeans = gmeans; p.gstds = gstds; p.som_vars = som_vars; p.G = G;
+    p.w_rep = w_rep; p.w_col = w_col; p.w_d2c = w_d2c;
+    p.closest = closest; p.partial = partial; p.out = out8; p.total = total;
+    hipStream_t s = as_stream(stream);
+    const int blocks = cdiv(R, SL_THREADS);
+    SrfLaunchScope ps(s, "source_loss_fwd", 0, 0);
+    source_loss_fwd_kernel<<<blocks, SL_THREADS, 0, s>>>(p);
+    if (blocks > 1) source_loss_finish_kernel<<<1, 64, 0, s>>>(p, blocks);
+    SRF_LAUNCH_CHECK("source_loss_fwd_kernel");
+    return 0;
+}
+
+int scenerf_hip_source_loss_backward(const float* color, const float* col_src, const float* valid, const float* dterm_ddepth,
+                                     const float* gmeans, const float* depth, const int32_t* closest, const float* out8, const float* g_total,
+                                     int R, int G, float w_rep, float w_col, float w_d2c, float* g_color, float* g_depth, float* g_loss_kl,
+                                     float* g_gmeans, scenerf_stream_t stream) {
+    SRF_CHECK(color && col_src && valid && dterm_ddepth && gmeans && depth && closest && out8 && g_color && g_depth && g_loss_kl && g_gmeans &&
+                  R > 0 && G >= 1, "source_loss_backward: NULL / empty argument");
+    hipStream_t s = as_stream(stream);
+    SrfLaunchScope ps(s, "source_loss_bwd", 0, 0);
+    source_loss_bwd_kernel<<<cdiv(R, 256), 256, 0, s>>>(color, col_src, valid, dterm_ddepth, gmeans, depth, closest, out8, g_total, R, G, w_rep,
+                                                         w_col, w_d2c, g_color, g_depth, g_loss_kl, g_gmeans);
+    SRF_LAUNCH_CHECK("source_loss_bwd_kernel");
     return 0;
 }
 

@@ -167,14 +167,12 @@ static int launch_linout_fwd(int d_out, const void* H3, const float* w, const fl
     SRF_LAUNCH_CHECK("linout_fwd_kernel");
     return 0;
 }
-// dH3 == NULL: weight / bias gradients only, at most SCENERF_LINOUT_SCRATCH_BLOCKS blocks (the partial sums then fit
-// scenerf_mlp_acts.lin_out_scratch)
+// dH3 == NULL: weight / bias gradients only
 template <typename T>
 static int launch_linout_bwd(int d_out, const void* H3, const float* w, const float* dlog, int M, void* dH3, int lddh, float* dw,
                              float* db, float* scratch, hipStream_t s) {
     int grid = cdiv(M, 128);   // 32 rows per wave
-    const int cap = dH3 ? 2048 : SCENERF_LINOUT_SCRATCH_BLOCKS;
-    if (grid > cap) grid = cap;
+    if (grid > 2048) grid = 2048;
     {
         SrfLaunchScope ps(s, dH3 ? "linout_bwd" : "linout_wgrad", 0, (double)M * ((dH3 ? 1024.0 : 512.0) * sizeof(T) + 4.0 * d_out));
         if (dH3) {
@@ -202,7 +200,6 @@ static int launch_linout_bwd(int d_out, const void* H3, const float* w, const fl
 #include <map>
 struct SideCtx {
     hipStream_t side = nullptr;
-    hipStream_t low = nullptr;     // lowest priority: work that should only take the CUs the other two streams leave idle
     hipEvent_t ev[16];
     int next = 0;
 };
@@ -214,11 +211,6 @@ static SideCtx* side_ctx(hipStream_t main) {
     if (it != g_map.end()) return it->second;
     SideCtx* c = new SideCtx();
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
-    {
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&c->low, hipStreamNonBlocking, least) != hipSuccess) { delete c; return nullptr; }
-    }
     for (int i = 0; i < 16; ++i) {
         if (hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
     }
@@ -452,24 +444,15 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     const bool wide_chain = fused_chain && (cfg->flags & SCENERF_FLAG_WIDE_BWD) && (cdiv(M, 128) >= SRF_WIDE_MIN_BLOCKS || (cfg->flags & SCENERF_FLAG_WIDE_ANY_M));
     // the 128-row chain makes lin_out's input gradient dH3 = (d_logits W_out) * [H3 > 0] in its own prologue, from d_logits and H3's
     // sign bits (r03: as linout_bwd's output it was a 314 MB round trip, 97 us on the critical path of a KITTI step); lin_out's
-    // weight / bias gradients are then all linout_bwd is asked for -- off the critical path, beside the chain, when the caller provides
-    // scenerf_mlp_acts.lin_out_scratch for its partial sums (the dN scratch it otherwise borrows is being written by the chain)
+    // weight / bias gradients are then all linout_bwd is asked for: 157 MB of H3 to read instead of a 314 MB round trip
     const bool dh3_in_chain = wide_chain && !(cfg->flags & SCENERF_FLAG_WIDE_BWD_STAGED);
     const int allow_tr = (cfg->flags & SCENERF_FLAG_NO_WGRAD_TR) ? 0 : 1;
     // lin_out backward -> dH3, dw_out, db_out
-    bool low_used = false;
     if (dh3_in_chain) {
-        if (a->lin_out_scratch && sc_) {
-            // queued BEHIND the chain (below), on the lowest-priority stream: 157 MB of H3 to read and next to no arithmetic.  Nothing can share
-            // a CU with a block of the chain (all of its LDS and registers), so launched first or at equal priority its workgroups take
-            // CUs the chain's 4.69 rounds of blocks then wait for (r04_a: chain 528 -> 577 us); behind it they get the CUs the chain's
-            // last, partly filled round leaves idle
-            if (int e = order_after(sc_, s, sc_->low)) return e;
-            low_used = true;
-        } else {
-            if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, nullptr, 0, g_->w_out, g_->b_out,
-                                                  a->lin_out_scratch ? a->lin_out_scratch : (float*)dN, s)) return e;
-        }
+        // (measured, r04_b: the same reduction queued beside or behind the chain, on a side stream of equal or of lowest priority, with a
+        // scratch buffer of its own -- nothing can share a CU with a block of the chain (all of its LDS and registers), so its workgroups
+        // displace chain blocks by what they save in front of it: chain 537 -> 577 / 611 us, step time unchanged.  In stream order.)
+        if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, nullptr, 0, g_->w_out, g_->b_out, (float*)dN, s)) return e;
     } else if (prec) {
         if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, (float*)dN, s)) return e;
     } else {
@@ -480,9 +463,6 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     }
     if (fused_chain) {
         if (int e = wide_chain ? launch_mlp_bwd_wide(cfg, w, M, a, dH, dN, dh3_in_chain ? d_logits : nullptr, s) : launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
-        if (low_used) {
-            if (int e = launch_linout_bwd<bf16_t>(w->d_out, a->H[3], w->w_out, d_logits, M, nullptr, 0, g_->w_out, g_->b_out, a->lin_out_scratch, sc_->low)) return e;
-        }
         if (int e = fork()) return e;
     }
     GemmTN wg[8];   // the six fc weight gradients (+ lin_z, below): batched into one launch when the chain kernel already produced every dH / dN
@@ -607,9 +587,6 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     }
     if (sc_) {  // join: the caller's stream continues only after the weight-gradient stream has drained
         if (int e = order_after(sc_, s2, s)) return e;
-        if (low_used) {
-            if (int e = order_after(sc_, sc_->low, s)) return e;
-        }
     }
     return 0;
 }

@@ -9,6 +9,17 @@ maps are the caller's tensors, captured by address (write new features into the 
 ``map_grads`` (the ``.grad`` of the captured leaves, zeroed by the graph itself at the top of each replay).  The gaussian sampler's
 noise must be drawn on the device (``RenderConfig.device_rng``: the generator state advances inside the graph); the optimizer must be
 capturable (``scenerf_amd.optim.FusedAdamW(capturable=True)`` or torch's ``capturable=True`` optimizers).
+
+One GraphedStep per set of parameters and process at a time: autograd binds a leaf's AccumulateGrad node to the stream of its first use,
+so a SECOND capture over the same parameters meets nodes that belong to the first capture's stream; the cross-stream hand-off autograd
+inserts is not capturable and hipStreamEndCapture fails hard (observed: a segfault, r04).  Drop the first object (and anything that keeps
+its autograd graph alive) before building another.
+
+Construction has side effects: it runs ``warmup`` real optimizer steps on whatever the static inputs hold at that moment (allocator
+pools, one-time setup and the optimizer state must exist before the capture) and then one more while capturing, whose kernels do
+not execute.  Parameters, AdamW moments, the step count and the device RNG have therefore advanced by ``warmup`` steps when the
+constructor returns (``steps_warmup``); pass ``restore=True`` to have parameters, optimizer state and RNG state put back afterwards,
+so that the first replay is step 1 on the data the caller copies into the static tensors.
 """
 from __future__ import annotations
 
@@ -20,9 +31,10 @@ import torch
 class GraphedStep:
     def __init__(self, model, optimizer: Optional[torch.optim.Optimizer], loss_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
                  cam_K: torch.Tensor, T_source2infer: torch.Tensor, x_rgb: Dict[str, torch.Tensor], pixels: torch.Tensor,
-                 ray_batch_size: Optional[int] = None, warmup: int = 3, noise=None):
+                 ray_batch_size: Optional[int] = None, warmup: int = 3, noise=None, restore: bool = False):
         """``noise``: optional static ``(noise_u, noise_g)`` tensors handed to ``render_rays_batch`` (the caller refills them between
-        replays); without it the sampler draws on the device inside the graph."""
+        replays); without it the sampler draws on the device inside the graph.  ``restore``: undo the warm-up steps' effect on
+        parameters, optimizer state and the device RNG (module docstring)."""
         if noise is None and not getattr(model.render_cfg, "device_rng", False):
             raise RuntimeError("GraphedStep: the sampler noise must be drawn on the device (render_cfg.device_rng = True); the "
                                "reference's host-side draw cannot be captured")
@@ -37,6 +49,9 @@ class GraphedStep:
         self._params = [p for g in optimizer.param_groups for p in g["params"]] if optimizer is not None else \
             [p for p in model.parameters() if p.requires_grad]
         self._map_leaves = [v for v in x_rgb.values() if v.requires_grad]
+        snap = None
+        if restore:
+            snap = ([p.detach().clone() for p in self._params], torch.cuda.get_rng_state(dev))
         # warm-up on a side stream (allocator pools, one-time setup, optimizer state), as torch's capture recipe asks
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -50,6 +65,18 @@ class GraphedStep:
             self.loss = self._eager()
         self.map_grads = {k: v.grad for k, v in x_rgb.items() if v.requires_grad}
         self.steps_warmup = max(1, warmup)
+        if snap is not None:
+            # parameters and moments back IN PLACE (the graph holds their addresses), step counts to zero, the RNG where it was
+            with torch.no_grad():
+                for p, v in zip(self._params, snap[0]):
+                    p.copy_(v)
+                if optimizer is not None:
+                    for st in optimizer.state.values():
+                        for k, v in st.items():
+                            if torch.is_tensor(v):
+                                v.zero_()
+            torch.cuda.set_rng_state(snap[1], dev)
+            self.steps_warmup = 0
 
     def _eager(self) -> torch.Tensor:
         for p in self._params:

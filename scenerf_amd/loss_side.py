@@ -74,3 +74,74 @@ def loss_side(color: torch.Tensor, depth: torch.Tensor, pix_source: torch.Tensor
     """(loss_color [R,3], loss_reprojection scalar) of scenerf.py:302-307 / 349-386 in one kernel.  ``noise`` [R]: the values the
     reference adds to the identity term (``torch.randn(R) * 1e-5``); None = no noise."""
     return LossSide.apply(color, depth.reshape(-1), pix_source, img_source, img_target, cam_K, inv_K, T_source2target, noise)
+
+
+class SourceLoss(torch.autograd.Function):
+    """(total [], terms [8]) = the whole loss of one source frame (scenerf.py:203-238 around process_single_source :243-320) from the
+    renderer's outputs, one HIP launch each way (``scenerf_hip_source_loss_forward / _backward``); differentiable w.r.t. ``color``,
+    ``depth``, ``loss_kl`` and ``gaussian_means``.  ``terms`` (detached) = {total, loss_reprojection, mean loss_color, mean loss_kl, mean
+    dist2closest, mean min_som_vars, mean min_stds, n_valid}: what the trainer logs."""
+
+    @staticmethod
+    def forward(ctx, color, depth, loss_kl, gmeans, gstds, som_vars, pix_source, img_source, img_target, cam_K, inv_K, T_source2target, noise,
+                noise_scale, w_rep, w_col, w_d2c):
+        for name, t in (("color", color), ("depth", depth), ("loss_kl", loss_kl), ("gaussian_means", gmeans), ("pix_source", pix_source),
+                        ("img_source", img_source), ("img_target", img_target)):
+            if not t.is_cuda:
+                raise RuntimeError("%s must live on the GPU: the fused source-loss kernel has no CPU path" % name)
+        lib = _capi.load()
+        dev = color.device
+        R = int(depth.numel())
+        _, H, W = img_source.shape
+        if tuple(img_target.shape) != tuple(img_source.shape) or img_source.shape[0] != 3:
+            raise RuntimeError("img_source / img_target must both be (3, H, W)")
+        col, dep, pix, kl, gm = _f32(color), _f32(depth).reshape(-1), _f32(pix_source), _f32(loss_kl).reshape(-1), _f32(gmeans)
+        G = int(gm.shape[1])
+        gs = _f32(gstds) if gstds is not None else None
+        sv = _f32(som_vars) if som_vars is not None else None
+        ims, imt = _f32(img_source), _f32(img_target)
+        K, iK, T = _f32(cam_K), _f32(inv_K), _f32(T_source2target)
+        nz = _f32(noise).reshape(-1) if noise is not None else None
+        f = dict(dtype=torch.float32, device=dev)
+        valid, dterm, col_src = torch.empty(R, **f), torch.empty(R, **f), torch.empty((R, 3), **f)
+        closest = torch.empty(R, dtype=torch.int32, device=dev)
+        partial, out8, total = torch.empty(8 * ((R + 1023) // 1024), **f), torch.empty(8, **f), torch.empty((), **f)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _capi.check(lib.scenerf_hip_source_loss_forward(pix.data_ptr(), col.data_ptr(), dep.data_ptr(), kl.data_ptr(), gm.data_ptr(),
+                                                            _capi.ptr(gs), _capi.ptr(sv), G, ims.data_ptr(), imt.data_ptr(), _capi.ptr(nz),
+                                                            float(noise_scale), K.data_ptr(), iK.data_ptr(), T.data_ptr(), R, H, W,
+                                                            float(w_rep), float(w_col), float(w_d2c), valid.data_ptr(), dterm.data_ptr(),
+                                                            col_src.data_ptr(), closest.data_ptr(), partial.data_ptr(), out8.data_ptr(),
+                                                            total.data_ptr(), st), "source_loss_forward")
+        ctx.save_for_backward(col, col_src, valid, dterm, gm, dep, closest, out8)
+        ctx.w = (float(w_rep), float(w_col), float(w_d2c))
+        ctx.mark_non_differentiable(out8)
+        return total, out8
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        col, col_src, valid, dterm, gm, dep, closest, out8 = ctx.saved_tensors
+        lib = _capi.load()
+        R, G = int(valid.numel()), int(gm.shape[1])
+        g_color, g_depth, g_kl, g_gm = torch.empty_like(col), torch.empty_like(valid), torch.empty_like(valid), torch.empty_like(gm)
+        gt = _f32(g_total).reshape(1) if g_total is not None else None
+        with torch.cuda.device(col.device):
+            st = torch.cuda.current_stream(col.device).cuda_stream
+            _capi.check(lib.scenerf_hip_source_loss_backward(col.data_ptr(), col_src.data_ptr(), valid.data_ptr(), dterm.data_ptr(), gm.data_ptr(),
+                                                             dep.data_ptr(), closest.data_ptr(), out8.data_ptr(), _capi.ptr(gt), R, G, ctx.w[0],
+                                                             ctx.w[1], ctx.w[2], g_color.data_ptr(), g_depth.data_ptr(), g_kl.data_ptr(),
+                                                             g_gm.data_ptr(), st), "source_loss_backward")
+        return (g_color, g_depth, g_kl, g_gm) + (None,) * 13
+
+
+def source_loss(out, pix_source: torch.Tensor, img_source: torch.Tensor, img_target: torch.Tensor, cam_K: torch.Tensor, inv_K: torch.Tensor,
+                T_source2target: torch.Tensor, noise: Optional[torch.Tensor] = None, noise_scale: float = 1e-5, reproj_weight: float = 1.0,
+                color_weight: float = 1.0, dist2closest_weight: float = 0.01) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The loss of one source frame from ``out`` = the dict of ``render_rays_batch`` (keys depth, color, loss_kl, gaussian_means,
+    gaussian_stds, som_vars): (total, terms[8]).  ``noise`` [R] ~ N(0, 1) (scaled by ``noise_scale`` in the kernel: the reference adds
+    ``randn * 1e-5`` to the identity term); the weights are those of the reference's ``forward`` (KITTI: 1, 1, 0.01; BundleFusion: 5, 1,
+    0.1; a term switched off by ``use_reprojection`` / ``use_color`` = weight 0)."""
+    return SourceLoss.apply(out["color"], out["depth"].reshape(-1), out["loss_kl"], out["gaussian_means"], out.get("gaussian_stds"),
+                            out.get("som_vars"), pix_source, img_source, img_target, cam_K, inv_K, T_source2target, noise, noise_scale,
+                            reproj_weight, color_weight, dist2closest_weight)

@@ -33,8 +33,29 @@ try:  # the reference derives from pl.LightningModule; Lightning is optional her
     _Base = pl.LightningModule
 except Exception:  # pragma: no cover - Lightning is not installed in the build image
     class _Base(nn.Module):
-        def save_hyperparameters(self, *a, **k):
-            pass
+        """What the evaluation / reconstruction scripts and a plain training loop use of ``pl.LightningModule`` when Lightning is not
+        installed: ``hparams`` / ``save_hyperparameters``, ``log`` (a no-op), ``device`` and ``load_from_checkpoint`` for
+        Lightning-format checkpoints (``{"state_dict": ..., "hyper_parameters": ...}``)."""
+
+        def save_hyperparameters(self, *a, ignore=(), **k):
+            # Lightning's behaviour for a bare call: the arguments of every __init__ frame of this object, innermost last
+            import inspect
+            hp = {}
+            fr = inspect.currentframe().f_back
+            frames = []
+            while fr is not None and fr.f_code.co_name == "__init__" and fr.f_locals.get("self") is self:
+                frames.append(fr)
+                fr = fr.f_back
+            for fr in reversed(frames):     # outermost (the subclass) first, so that what it forwards does not shadow its own arguments
+                info = inspect.getargvalues(fr)
+                for name in info.args[1:]:
+                    hp.setdefault(name, info.locals[name])
+                if info.keywords:
+                    for name, v in info.locals[info.keywords].items():
+                        hp.setdefault(name, v)
+            for name in ([ignore] if isinstance(ignore, str) else list(ignore)):
+                hp.pop(name, None)
+            self.hparams = hp
 
         def log(self, *a, **k):
             pass
@@ -42,6 +63,58 @@ except Exception:  # pragma: no cover - Lightning is not installed in the build 
         @property
         def device(self):
             return next(self.parameters()).device
+
+        @classmethod
+        def load_from_checkpoint(cls, checkpoint_path, map_location=None, hparams_file=None, strict=True, **kwargs):
+            """``pl.LightningModule.load_from_checkpoint`` for the callers of the reference (render_colors.py:38-40,
+            save_depth_metrics.py:57, generate_novel_depths.py:48): constructor arguments from the checkpoint's ``hyper_parameters``
+            (overridden by ``kwargs``; arguments this constructor does not have are dropped), then ``load_state_dict``."""
+            import inspect
+            if hparams_file is not None:
+                raise NotImplementedError("hparams_file is not supported without pytorch_lightning")
+            try:
+                ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
+            except TypeError:
+                ckpt = torch.load(checkpoint_path, map_location=map_location)
+            if not isinstance(ckpt, dict) or "state_dict" not in ckpt:
+                raise ValueError("%s is not a Lightning checkpoint (no 'state_dict')" % (checkpoint_path,))
+            hp = dict(ckpt.get("hyper_parameters") or {})
+            hp.update(kwargs)
+            accepted = set()
+            takes_kw = False
+            for klass in cls.__mro__:
+                init = klass.__dict__.get("__init__")
+                if init is None or klass in (nn.Module, object):
+                    continue
+                sig = inspect.signature(init)
+                accepted.update(n for n, prm in sig.parameters.items() if prm.kind in (prm.POSITIONAL_OR_KEYWORD, prm.KEYWORD_ONLY))
+                takes_kw = any(prm.kind == prm.VAR_KEYWORD for prm in sig.parameters.values())
+                if not takes_kw:
+                    break
+            model = cls(**{k: v for k, v in hp.items() if k in accepted and k != "self"})
+            return _load_reference_state(model, ckpt["state_dict"], strict)
+
+
+def _load_reference_state(model, state_dict, strict=True):
+    """load_state_dict for a checkpoint written by the reference's module tree.  The image encoder lives under ``net_rgb.`` there; a
+    model built without one (``net_rgb`` is injected by the caller here) takes everything else and says what it left out; with an
+    encoder in place those keys load like any others."""
+    sd = dict(state_dict)
+    has_encoder = any(True for _ in model.net_rgb.parameters()) or any(True for _ in model.net_rgb.buffers())
+    skipped = []
+    if not has_encoder:
+        skipped = [k for k in sd if k.startswith("net_rgb.")]
+        for k in skipped:
+            del sd[k]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    if strict and (missing or unexpected):
+        raise RuntimeError("load_from_checkpoint: missing keys %s, unexpected keys %s" % (list(missing)[:8], list(unexpected)[:8]))
+    if skipped:
+        import warnings
+        warnings.warn("load_from_checkpoint: %d encoder tensors under 'net_rgb.' were not loaded (no encoder was injected: pass "
+                      "net_rgb=<module> to load them)" % len(skipped))
+    object.__setattr__(model, "_skipped_checkpoint_keys", skipped)
+    return model
 
 
 class ResnetBlockFC(nn.Module):

@@ -29,26 +29,48 @@ class FusedAdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, capturable=bool(capturable)))
-        self._hyper = {}      # id(group) -> (device tensor [lr, t], the lr it holds)
+        self._hyper = {}      # index of the group in param_groups -> [device tensor [lr, t], the lr it holds]
+
+    def _group_index(self, group) -> int:
+        for i, g in enumerate(self.param_groups):
+            if g is group:
+                return i
+        raise KeyError("not a parameter group of this optimizer")
 
     def _group_hyper(self, group, dev):
-        h = self._hyper.get(id(group))
+        gi = self._group_index(group)
+        h = self._hyper.get(gi)
         if h is None:
-            steps = [int(self.state[p]["step"]) for p in group["params"] if self.state.get(p)]
+            steps = [float(self.state[p]["step"]) for p in group["params"] if self.state.get(p)]
             t0 = float(max(steps)) if steps else 0.0
             h = [torch.tensor([float(group["lr"]), t0], dtype=torch.float32, device=dev), float(group["lr"])]
-            self._hyper[id(group)] = h
+            self._hyper[gi] = h
         return h
 
     def load_state_dict(self, state_dict) -> None:
+        """The device-side [lr, t] tensors SURVIVE a load: a hipGraph captured earlier (GraphedStep) holds their addresses, so they are
+        refreshed in place -- lr from the loaded group, t = the largest loaded step count -- and the per-parameter ``step`` entries are
+        pointed at them again.  (torch's load_state_dict builds new group dicts and new state entries: keyed by the group's INDEX, a
+        tensor that was dropped here would leave every later replay counting on freed memory.)"""
         super().load_state_dict(state_dict)
-        self._hyper = {}      # (the step counts just loaded seed the device-side counters at the next step)
+        for gi, group in enumerate(self.param_groups):
+            h = self._hyper.get(gi)
+            if h is None:
+                continue
+            steps = [float(self.state[p]["step"]) for p in group["params"] if self.state.get(p) and "step" in self.state[p]]
+            h[0][0:1].fill_(float(group["lr"]))
+            h[0][1:2].fill_(float(max(steps)) if steps else 0.0)
+            h[1] = float(group["lr"])
+            if group.get("capturable"):
+                for p in group["params"]:
+                    if self.state.get(p):
+                        self.state[p]["step"] = h[0][1]
 
     def sync_hyper(self) -> None:
         """Write the groups' current learning rates into their device-side copies (capturable mode; call it after a scheduler step
         and before the next graph replay -- an eager ``step()`` does it by itself)."""
-        for group in self.param_groups:
-            h = self._hyper.get(id(group))
+        for gi, group in enumerate(self.param_groups):
+            h = self._hyper.get(gi)
             if h is not None and h[1] != float(group["lr"]):
                 h[0][0:1].fill_(float(group["lr"]))
                 h[1] = float(group["lr"])

@@ -57,10 +57,7 @@ PREFILL_AT = 2               # where a training session zeroes the map-gradient 
                              #  beside the radiance MLP's forward instead of behind it: +16 us, not offered)
 MAIN_WGRAD_OVERLAP = True    # radiance MLP's weight gradients on the library's side stream, beside its feature-map gradients (-35 us/step)
 DEFER_HEAD_PACK = True     # (tools/ab_step.py toggles this)
-LINOUT_SCRATCH = False     # True: lin_out's weight-gradient reduction (157 MB of H3 to read) gets a scratch buffer of its own and is queued behind the
-                           # dgrad chain on a low-priority stream; False: in front of the chain, in stream order.  Same step time either way
-                           # (r04_b: 2.691 / 2.683 ms): no workgroup can share a CU with a block of the chain, so beside it the reduction
-                           # displaces chain blocks (chain 537 -> 611 us) by what it saves in front of it
+
 
 
 def _side_stream(dev) -> "torch.cuda.Stream":
@@ -501,9 +498,6 @@ class _MlpRun:
         self.sign_bits = torch.empty((7, self.Mpad, 64), dtype=torch.uint8, device=dev) if (prec and not lean) else None
         a.sign_bits = self.sign_bits.data_ptr() if self.sign_bits is not None else None
         a.x3_ready = 1 if x3_direct else 0
-        # partial sums of lin_out's weight gradient: with a buffer of their own that reduction runs beside the dgrad chain
-        self.lin_out_scratch = torch.empty(_capi.LINOUT_SCRATCH_FLOATS, dtype=torch.float32, device=dev) if (prec and not lean and LINOUT_SCRATCH) else None
-        a.lin_out_scratch = _capi.ptr(self.lin_out_scratch)
         self.c = a
 
 

@@ -94,6 +94,20 @@ class TrainingMixin:
         depth, color = out["depth"], out["color"]
         self.log(step_type + "depth/closest_pts_to_depth", out["closest_pts_to_depths"].mean().detach(), on_epoch=True, sync_dist=True)
         self.log(step_type + "depth/weights_at_depth", out["weights_at_depth"].mean().detach(), on_epoch=True, sync_dist=True)
+        if color.is_cuda and getattr(self, "fused_loss_side", True) and getattr(self, "fused_source_loss", True):
+            # the WHOLE loss of this source frame in one kernel per direction (scenerf_amd.loss_side.source_loss -> csrc/loss.hip):
+            # the three image gathers, the reprojection, both L1 terms, the closest-gaussian term, the means and the weights forward()
+            # applies -- ~25 eager launches between the renderer's forward and its backward otherwise, each of them on the step's
+            # critical path.  The noise is drawn like the reference's (randn on the device; the kernel scales it by 1e-5)
+            from .loss_side import source_loss
+            noise = torch.randn(depth.shape[0], device=dev)
+            fused = source_loss(out, pix_source, img_source, img_target, cam_K, inv_K, T_source2target, noise=noise, noise_scale=0.00001,
+                                reproj_weight=self.reproj_weight if self.use_reprojection else 0.0,
+                                color_weight=1.0 if self.use_color else 0.0, dist2closest_weight=self.dist2closest_weight)
+            terms = fused[1]
+            self.log(step_type + "_som/dist_2_closest_gaussian", terms[4], on_epoch=True, sync_dist=True)
+            self.log(step_type + "_som/closest_std", terms[6], on_epoch=True, sync_dist=True)
+            return dict(fused=fused, depth_source_rendered=depth, pix_source=pix_source)
         diff = torch.abs(out["gaussian_means"] - depth.unsqueeze(-1).detach())
         min_diff, gi = torch.min(diff, dim=1)
         min_stds = torch.gather(out["gaussian_stds"], 1, gi.unsqueeze(-1))
@@ -112,6 +126,43 @@ class TrainingMixin:
             loss_rep = self.compute_reprojection_loss(pix_source, col_src, depth, img_target, inv_K, cam_K, T_source2target)
         return dict(loss_kl=out["loss_kl"], loss_dist2closest_gauss=min_diff, loss_reprojection=loss_rep, loss_color=loss_color,
                     min_som_vars=min_som_vars, min_stds=min_stds, depth_source_rendered=depth, pix_source=pix_source)
+
+    @staticmethod
+    def _accumulate(tot, ret):
+        """One source frame's terms into the running sums of forward() (scenerf.py:183-188).  With the fused source loss the frame's
+        weighted total is already one differentiable scalar (``fused_total``) and the individual terms are only logged."""
+        if ret.get("fused") is not None:
+            total_src, terms = ret["fused"]
+            tot["fused_total"] = tot.get("fused_total", 0.0) + total_src
+            for key, i in (("rep", 1), ("col", 2), ("kl", 3), ("d2c", 4), ("somv", 5), ("stds", 6)):
+                tot[key] = tot[key] + terms[i]
+            return
+        tot["somv"] = tot["somv"] + ret["min_som_vars"].mean()
+        tot["kl"] = tot["kl"] + ret["loss_kl"].mean()
+        tot["d2c"] = tot["d2c"] + ret["loss_dist2closest_gauss"].mean()
+        tot["stds"] = tot["stds"] + ret["min_stds"].mean()
+        tot["rep"] = tot["rep"] + ret["loss_reprojection"].mean()
+        tot["col"] = tot["col"] + ret["loss_color"].mean()
+
+    def _combine(self, tot, bs, step_type):
+        """scenerf.py:203-238: the weighted total and the logged terms."""
+        det = lambda t: t.detach() if torch.is_tensor(t) else t
+        total = 0.0
+        if self.use_reprojection:
+            total = total + tot["rep"] / bs * self.reproj_weight
+            self.log(step_type + "/loss_reprojection", det(tot["rep"] / bs), on_epoch=True, sync_dist=True)
+        if self.use_color:
+            total = total + tot["col"] / bs
+            self.log(step_type + "/loss_color", det(tot["col"] / bs), on_epoch=True, sync_dist=True)
+        total = total + tot["kl"] / bs
+        self.log(step_type + "/loss_som_kl", det(tot["kl"] / bs), on_epoch=True, sync_dist=True)
+        self.log(step_type + "/min_som_vars", det(tot["somv"] / bs), on_epoch=True, sync_dist=True)
+        total = total + tot["d2c"] / bs * self.dist2closest_weight
+        self.log(step_type + "/loss_dist2closest_gauss", det(tot["d2c"] / bs), on_epoch=True, sync_dist=True)
+        if "fused_total" in tot:   # the same sum, assembled per source frame by the kernel (differentiable); the terms above were logged
+            total = tot["fused_total"] / bs
+        self.log(step_type + "/total_loss", det(total), on_epoch=True, sync_dist=True)
+        return {"total_loss": total}
 
     # True: never synchronise for the depth metrics -- a source frame without a single valid depth then logs all-zero metrics (biasing
     # the on_epoch means towards 0); False (default): one scalar device->host read per masked evaluation decides whether to log at all,
@@ -148,31 +199,13 @@ class TrainingMixin:
                                                  img_source=batch["img_sources"][i][sid], img_target=batch["img_targets"][i][sid],
                                                  T_source2target=batch["T_source2targets"][i][sid], T_source2infer=T_s2i,
                                                  T_cam2velo=T_cam2velo, step_type=step_type)
-                tot["somv"] = tot["somv"] + ret["min_som_vars"].mean()
-                tot["kl"] = tot["kl"] + ret["loss_kl"].mean()
-                tot["d2c"] = tot["d2c"] + ret["loss_dist2closest_gauss"].mean()
-                tot["stds"] = tot["stds"] + ret["min_stds"].mean()
-                tot["rep"] = tot["rep"] + ret["loss_reprojection"].mean()
-                tot["col"] = tot["col"] + ret["loss_color"].mean()
+                self._accumulate(tot, ret)
                 if "loc2d_with_depths" in batch:   # depth metrics on the lidar pixels, scenerf.py:190-201
                     gt_pix = batch["loc2d_with_depths"][i][sid].float()
                     with torch.no_grad():
                         r = self.render_rays_batch(cam_K, T_s2i, x_rgb, ray_batch_size=gt_pix.shape[0], sampled_pixels=gt_pix)
                     self.evaluate_depth(step_type, batch["lidar_depths"][i][sid], r["depth"])
-        total = 0.0
-        if self.use_reprojection:
-            total = total + tot["rep"] / bs * self.reproj_weight
-            self.log(step_type + "/loss_reprojection", (tot["rep"] / bs).detach(), on_epoch=True, sync_dist=True)
-        if self.use_color:
-            total = total + tot["col"] / bs
-            self.log(step_type + "/loss_color", (tot["col"] / bs).detach(), on_epoch=True, sync_dist=True)
-        total = total + tot["kl"] / bs
-        self.log(step_type + "/loss_som_kl", (tot["kl"] / bs).detach(), on_epoch=True, sync_dist=True)
-        self.log(step_type + "/min_som_vars", (tot["somv"] / bs).detach(), on_epoch=True, sync_dist=True)
-        total = total + tot["d2c"] / bs * self.dist2closest_weight
-        self.log(step_type + "/loss_dist2closest_gauss", (tot["d2c"] / bs).detach(), on_epoch=True, sync_dist=True)
-        self.log(step_type + "/total_loss", total.detach(), on_epoch=True, sync_dist=True)
-        return {"total_loss": total}
+        return self._combine(tot, bs, step_type)
 
     def step(self, batch, step_type):
         return self.forward(batch, step_type)["total_loss"]
@@ -214,26 +247,8 @@ class BundleFusionTrainingMixin(TrainingMixin):
                                                  img_source=batch["img_sources"][i][sid], img_target=batch["img_targets"][i][sid],
                                                  T_source2target=batch["T_source2targets"][i][sid],
                                                  T_source2infer=batch["T_source2infers"][i][sid], T_cam2velo=None, step_type=step_type)
-                tot["somv"] = tot["somv"] + ret["min_som_vars"].mean()
-                tot["kl"] = tot["kl"] + ret["loss_kl"].mean()
-                tot["d2c"] = tot["d2c"] + ret["loss_dist2closest_gauss"].mean()
-                tot["stds"] = tot["stds"] + ret["min_stds"].mean()
-                tot["rep"] = tot["rep"] + ret["loss_reprojection"].mean()
-                tot["col"] = tot["col"] + ret["loss_color"].mean()
+                self._accumulate(tot, ret)
                 ps = ret["pix_source"].detach().long()
                 depth_gt = torch.as_tensor(batch["source_depths"][i][sid]).to(ps.device)[ps[:, 1], ps[:, 0]]      # scenerf_bf.py:201-205
                 self.evaluate_depth(step_type, depth_gt, ret["depth_source_rendered"], mask=depth_gt > 0)
-        total = 0.0
-        if self.use_reprojection:
-            total = total + tot["rep"] / bs * self.reproj_weight
-            self.log(step_type + "/loss_reprojection", (tot["rep"] / bs).detach(), on_epoch=True, sync_dist=True)
-        if self.use_color:
-            total = total + tot["col"] / bs
-            self.log(step_type + "/loss_color", (tot["col"] / bs).detach(), on_epoch=True, sync_dist=True)
-        total = total + tot["kl"] / bs
-        self.log(step_type + "/loss_som_kl", (tot["kl"] / bs).detach(), on_epoch=True, sync_dist=True)
-        self.log(step_type + "/min_som_vars", (tot["somv"] / bs).detach(), on_epoch=True, sync_dist=True)
-        total = total + tot["d2c"] / bs * self.dist2closest_weight
-        self.log(step_type + "/loss_dist2closest_gauss", (tot["d2c"] / bs).detach(), on_epoch=True, sync_dist=True)
-        self.log(step_type + "/total_loss", total.detach(), on_epoch=True, sync_dist=True)
-        return {"total_loss": total}
+        return self._combine(tot, bs, step_type)

@@ -51,7 +51,7 @@ def test_struct_layouts_match_header_constants():
     assert consts["SCENERF_TILE_ROWS"] == _capi.TILE_ROWS
     # scenerf_cfg: 6 int32 + 10 float + 5*5 int32 + precision + map_chw[5] + fused_min_rows + fwd_kernel + flags
     assert ctypes.sizeof(_capi.Cfg) == 4 * (6 + 10 + 25 + 1 + 5 + 3)
-    assert ctypes.sizeof(_capi.MlpActs) == 8 * 12   # H[4], Nn[3], h0pre, logits, sign_bits, x3_ready (+ padding), lin_out_scratch
+    assert ctypes.sizeof(_capi.MlpActs) == 8 * 11   # H[4], Nn[3], h0pre, logits, sign_bits, x3_ready (+ padding)
     assert ctypes.sizeof(_capi.ProfRec) == 48 + 4 + 4 + 8 + 8
 
 

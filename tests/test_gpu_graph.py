@@ -47,6 +47,46 @@ def test_capturable_adamw_follows_the_host_counted_one():
         assert torch.equal(b.detach(), c.detach())
 
 
+def test_load_state_dict_after_capture_keeps_the_captured_hyper_tensor():
+    """A hipGraph that holds FusedAdamW(capturable=True).step() reads [lr, t] from a device tensor by ADDRESS: load_state_dict must refresh
+    that tensor in place (loaded learning rate, loaded step count), not drop it -- later replays would count on freed memory."""
+    from scenerf_amd.optim import FusedAdamW
+    g = torch.Generator().manual_seed(4)
+    p = torch.nn.Parameter(torch.randn(1000, generator=g).to(DEV))
+    q = torch.nn.Parameter(p.detach().clone())
+    opt, ref = FusedAdamW([p], lr=1e-2, weight_decay=0.0, capturable=True), FusedAdamW([q], lr=1e-2, weight_decay=0.0)
+    grad = torch.randn(1000, generator=g).to(DEV)
+    p.grad, q.grad = grad.clone(), grad.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        opt.step()
+    torch.cuda.current_stream().wait_stream(side)
+    ref.step()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        opt.step()
+    graph.replay(); ref.step()
+    torch.cuda.synchronize()
+    ptr = opt._hyper[0][0].data_ptr()
+    sd = copy.deepcopy(opt.state_dict())
+    sd["param_groups"][0]["lr"] = 5e-3
+    for st in sd["state"].values():
+        st["step"] = torch.tensor(10.0, device=DEV)
+    opt.load_state_dict(sd)
+    assert opt._hyper[0][0].data_ptr() == ptr                      # same memory, new contents
+    assert opt._hyper[0][0].tolist() == [pytest.approx(5e-3), 10.0]
+    sr = copy.deepcopy(ref.state_dict())
+    sr["param_groups"][0]["lr"] = 5e-3
+    for st in sr["state"].values():
+        st["step"] = 10
+    ref.load_state_dict(sr)
+    graph.replay(); ref.step()
+    torch.cuda.synchronize()
+    assert float(opt.state[p]["step"]) == 11.0 and int(ref.state[q]["step"]) == 11
+    torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-5, atol=2e-6)
+
+
 def _setup(seed):
     torch.manual_seed(seed)
     m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, n_pts_uni=32, n_pts_per_gaussian=8, precision="bf16",

@@ -76,3 +76,53 @@ def test_fused_loss_side_refuses_cpu_tensors():
     d = {k: torch.from_numpy(v) for k, v in inputs(11, behind=False).items()}
     with pytest.raises(RuntimeError, match="GPU"):
         loss_side(torch.rand(300, 3), d["depth"], d["pix"], d["img_s"], d["img_t"], d["K"], torch.inverse(d["K"]), d["T"], None)
+
+
+@pytest.mark.parametrize("behind,seed,R_rep", [(False, 21, 1), (True, 22, 1), (True, 23, 5)])
+def test_source_loss_matches_the_torch_assembly(behind, seed, R_rep):
+    """scenerf_amd.loss_side.source_loss (the whole loss of one source frame, one launch each way) against the reference's assembly
+    written with the stock-PyTorch pieces of scenerf_amd/training.py (pinned on the reference's own functions by tests/test_loss_side.py):
+    total, every logged term, and the gradients w.r.t. colour, depth, loss_kl and the gaussian means.  R_rep > 1: more than 1,024 rays
+    (the per-block partial sums and the finishing launch)."""
+    from scenerf_amd.loss_side import source_loss
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in inputs(seed, behind=behind).items()}
+    if R_rep > 1:
+        d["pix"], d["depth"] = d["pix"].repeat(R_rep, 1), d["depth"].repeat(R_rep) * (1 + 0.01 * torch.arange(d["depth"].shape[0] * R_rep, device=DEV) / 100)
+    R, Gn = d["pix"].shape[0], 4
+    gen = torch.Generator().manual_seed(seed)
+    color0 = torch.rand(R, 3, generator=gen).to(DEV)
+    kl0 = torch.rand(R, generator=gen).to(DEV)
+    gm0 = (torch.rand(R, Gn, generator=gen).to(DEV) * 2 - 1) * 3 + d["depth"][:, None]
+    gs0, sv0 = torch.rand(R, Gn, generator=gen).to(DEV) + 1.5, torch.rand(R, Gn, generator=gen).to(DEV)
+    noise = torch.randn(R, generator=gen).to(DEV)
+    w = dict(reproj_weight=5.0, color_weight=1.0, dist2closest_weight=0.1)
+    outs = {}
+    for kind in ("fused", "torch"):
+        color, depth = color0.clone().requires_grad_(True), d["depth"].clone().requires_grad_(True)
+        kl, gm = kl0.clone().requires_grad_(True), gm0.clone().requires_grad_(True)
+        out = {"color": color, "depth": depth, "loss_kl": kl, "gaussian_means": gm, "gaussian_stds": gs0, "som_vars": sv0}
+        if kind == "fused":
+            total, terms = source_loss(out, d["pix"], d["img_s"], d["img_t"], d["K"], torch.inverse(d["K"]), d["T"], noise=noise, noise_scale=1e-5, **w)
+            terms = terms.detach()
+        else:
+            lc, lr, _ = _torch_reference(dict(d, depth=depth), color, noise * 0.00001)
+            diff = torch.abs(gm - depth.unsqueeze(-1).detach())
+            min_diff, gi = torch.min(diff, dim=1)
+            total = lr * w["reproj_weight"] + lc.mean() * w["color_weight"] + kl.mean() + min_diff.mean() * w["dist2closest_weight"]
+            terms = torch.stack([total.detach(), lr.detach(), lc.mean().detach(), kl.mean().detach(), min_diff.mean().detach(),
+                                 torch.gather(sv0, 1, gi[:, None]).mean(), torch.gather(gs0, 1, gi[:, None]).mean()])
+        (total * 1.7).backward()
+        outs[kind] = (float(total), terms[:7].cpu(), color.grad.clone(), depth.grad.clone(), kl.grad.clone(), gm.grad.clone())
+    a, b = outs["fused"], outs["torch"]
+    assert abs(a[0] - b[0]) <= 2e-5 * (1 + abs(b[0])), (a[0], b[0])
+    torch.testing.assert_close(a[1], b[1], rtol=2e-5, atol=8e-6)
+    torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-9)       # colour: sign / (3 R)
+    scale = float(b[3].abs().max())
+    assert scale > 0 and float((a[3] - b[3]).abs().max()) <= 2e-4 * scale
+    torch.testing.assert_close(a[4], b[4], rtol=1e-6, atol=0)
+    torch.testing.assert_close(a[5], b[5], rtol=1e-6, atol=0)
+    # reproducible run to run (fixed summation order, no atomics)
+    out = {"color": color0, "depth": d["depth"], "loss_kl": kl0, "gaussian_means": gm0, "gaussian_stds": gs0, "som_vars": sv0}
+    t1 = source_loss(out, d["pix"], d["img_s"], d["img_t"], d["K"], torch.inverse(d["K"]), d["T"], noise=noise, **w)[1].clone()
+    t2 = source_loss(out, d["pix"], d["img_s"], d["img_t"], d["K"], torch.inverse(d["K"]), d["T"], noise=noise, **w)[1].clone()
+    assert torch.equal(t1, t2)

@@ -321,6 +321,45 @@ def test_training_step_through_the_boundary():
         m.validation_step(batch, 0)
 
 
+def test_training_forward_with_the_fused_source_loss_equals_the_stock_assembly():
+    """forward(batch) with the per-source loss assembled by one kernel (scenerf_amd.loss_side.source_loss) against the same forward
+    with the loss-side kernel + the stock torch assembly (fused_source_loss = False): same RNG streams, same renderer outputs -> the
+    same total, the same logged terms and the same gradient at the encoder."""
+    from scenerf_amd import synth
+    maps = synth.feature_maps(376, 114, 31, smooth=True)
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(0)
+        m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, sphere_W=376, sphere_H=114, n_rays=96,
+                    net_rgb=_StubEncoder(maps), precision="fp32").to(DEV)
+        m.fused_source_loss = fused
+        logged = {}
+        m.log = lambda k, v, **kw: logged.__setitem__(k, float(v))
+        m.mlp.load_state_dict(synth.mlp_state(32, 4))
+        m.mlp_gaussian.load_state_dict(synth.mlp_state(33, 2, out_scale=4.0))
+        g = torch.Generator().manual_seed(1)
+        img = lambda: torch.rand(3, 370, 1220, generator=g).to(DEV)
+        batch = {
+            "img_inputs": torch.rand(1, 3, 370, 1220, generator=g).to(DEV),
+            "cam_K": synth.kitti_cam_K().unsqueeze(0).to(DEV),
+            "T_velo_2_cam": torch.eye(4).unsqueeze(0).to(DEV),
+            "T_source2infers": [[synth.rel_pose(2.0, 0.0).to(DEV), synth.rel_pose(3.0, 2.0).to(DEV)]],
+            "T_source2targets": [[synth.rel_pose(1.0, 5.0).to(DEV), synth.rel_pose(-1.0, 3.0).to(DEV)]],
+            "img_sources": [[img(), img()]], "img_targets": [[img(), img()]],
+        }
+        torch.manual_seed(5)
+        loss = m.training_step(batch, 0)
+        loss.backward()
+        res[fused] = (float(loss), dict(logged), float(m.net_rgb.gain.grad), m.mlp_gaussian.lin_out.weight.grad.clone())
+    (la, ga, ea, wa), (lb, gb, eb, wb) = res[True], res[False]
+    assert abs(la - lb) <= 2e-5 * (1 + abs(lb)), (la, lb)
+    assert set(ga) == set(gb)
+    for k in gb:
+        assert abs(ga[k] - gb[k]) <= 2e-5 * (1 + abs(gb[k])), (k, ga[k], gb[k])
+    assert abs(ea - eb) <= 1e-3 * abs(eb) + 1e-9, (ea, eb)
+    assert float((wa - wb).norm()) <= 1e-3 * float(wb.norm())
+
+
 def test_optional_output_gradients_match_oracle():
     """weights / alphas / densities / depth_volumes are differentiable outputs like in the reference."""
     from scenerf_amd import synth

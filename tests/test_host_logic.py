@@ -86,6 +86,53 @@ def test_reference_state_dict_loads():
     assert [tuple(p.shape) for p in m.mlp.ordered_params()][:4] == [(512, 42), (512,), (4, 512), (4,)]
 
 
+def test_load_from_checkpoint_reads_a_lightning_format_file(tmp_path):
+    """SceneRF.load_from_checkpoint as the reference's evaluation / reconstruction scripts call it (render_colors.py:38-40,
+    save_depth_metrics.py:57, generate_novel_depths.py:48, *_bf.py:58-59), on a Lightning-format file written with the reference's key
+    names: {"state_dict": <REF_KEYS + the encoder under net_rgb.>, "hyper_parameters": <the reference ctor's arguments>}.  Works with or
+    without pytorch_lightning installed (the fallback base class implements it)."""
+    import warnings
+    src = SceneRF(som_sigma=1.25, n_pts_uni=64, n_pts_per_gaussian=16, std=2.0, add_fov_hor=20, add_fov_ver=8)
+    src.mlp.load_state_dict(synth.mlp_state(5, 4))
+    src.mlp_gaussian.load_state_dict(synth.mlp_state(6, 2))
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    assert sorted(sd) == sorted(REF_KEYS)
+    sd["net_rgb.encoder.conv_stem.weight"] = torch.randn(8, 3, 3, 3)        # the reference's encoder travels in the same file
+    sd["net_rgb.decoder.conv2.bias"] = torch.randn(8)
+    hp = dict(som_sigma=1.25, lr=1e-5, weight_decay=0, img_size=(1220, 370), n_rays=1200, max_infer_depth=120, max_sample_depth=100,
+              eval_depth=80, std=2.0, n_gaussians=4, n_pts_uni=64, n_pts_per_gaussian=16, sampling_method="uniform", batch_size=1,
+              add_fov_hor=20, add_fov_ver=8, sphere_H=452, sphere_W=1500, use_color=True, use_reprojection=True)   # scenerf.py:23-43
+    path = str(tmp_path / "last.ckpt")
+    torch.save({"state_dict": sd, "hyper_parameters": hp, "epoch": 3, "pytorch-lightning_version": "1.4.9"}, path)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m = SceneRF.load_from_checkpoint(path)
+    assert isinstance(m, SceneRF)
+    assert (m.n_pts_uni, m.n_pts_per_gaussian, m.std, float(m.ray_som.som_sigma)) == (64, 16, 2.0, 1.25)
+    assert m.render_cfg.n_samples == 128 and m.render_cfg.add_fov_hor == 20
+    for k, v in src.state_dict().items():
+        assert torch.equal(m.state_dict()[k], v), k
+    if hasattr(m, "_skipped_checkpoint_keys"):      # (the no-Lightning base class: says which encoder tensors it left out)
+        assert m._skipped_checkpoint_keys == ["net_rgb.encoder.conv_stem.weight", "net_rgb.decoder.conv2.bias"]
+        assert any("net_rgb" in str(x.message) for x in w)
+        # keyword overrides like Lightning's, and an injected encoder takes its tensors
+        enc = torch.nn.Module()
+        enc.encoder = torch.nn.Module(); enc.encoder.conv_stem = torch.nn.Conv2d(3, 8, 3, bias=False)
+        enc.decoder = torch.nn.Module(); enc.decoder.conv2 = torch.nn.Conv2d(8, 8, 1)
+        sd["net_rgb.decoder.conv2.weight"] = torch.randn(8, 8, 1, 1)
+        torch.save({"state_dict": sd, "hyper_parameters": hp}, path)
+        m2 = SceneRF.load_from_checkpoint(path, net_rgb=enc, precision="bf16")
+        assert m2.render_cfg.precision == "bf16" and torch.equal(m2.net_rgb.encoder.conv_stem.weight, sd["net_rgb.encoder.conv_stem.weight"])
+        with pytest.raises(RuntimeError, match="missing keys"):
+            bad = {k: v for k, v in sd.items() if k != "mlp.lin_in.weight"}
+            torch.save({"state_dict": bad, "hyper_parameters": hp}, path)
+            SceneRF.load_from_checkpoint(path)
+    b = SceneRFBundleFusion(som_sigma=0.02, sample_grid_size=3)
+    torch.save({"state_dict": b.state_dict(), "hyper_parameters": dict(b.hparams)}, path)
+    b2 = SceneRFBundleFusion.load_from_checkpoint(path)
+    assert b2.sample_grid_size == 3 and b2.render_cfg.gauss_floor == 0.5
+
+
 def test_hot_path_refuses_cpu_tensors():
     """No CPU / eager fallback: CPU inputs raise instead of silently running something else."""
     m = SceneRF(som_sigma=2.0, sphere_W=376, sphere_H=114)

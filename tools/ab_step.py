@@ -18,7 +18,8 @@ mod = None if modname == "cfg" else importlib.import_module("scenerf_amd." + mod
 vals = [ast.literal_eval(v) for v in vals.split(",")]
 
 dev = torch.device("cuda:0")
-args = argparse.Namespace(samples=128, precision="bf16", host_rng=False, optimizer=os.environ.get("AB_OPT", "fused"))
+args = argparse.Namespace(samples=128, precision="bf16", host_rng=False, optimizer=os.environ.get("AB_OPT", "fused"),
+                          loss=os.environ.get("AB_LOSS", "source"))
 R = 1200
 torch.manual_seed(1)
 model = bench.make_model(args, dev)
@@ -27,13 +28,14 @@ opt = bench.make_optimizer(args, params)
 maps = bench._make_maps("hwc", dev, 0)
 K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
 pix = synth.stride2_pixels((1220, 370), R, 100).to(dev)
+loss_fn = bench.make_loss(args, dev, (1220, 370), K, pix)
 
 
 def step():
     for v in maps.values():
         v.grad = None
     out = model.render_rays_batch(K, T, maps, T_cam2velo=None, sampled_pixels=pix, ray_batch_size=R)
-    loss = out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
+    loss = loss_fn(out)
     loss.backward()
     opt.step()
     opt.zero_grad(set_to_none=True)

@@ -27,6 +27,20 @@ for k in sorted(set(ft) | set(wt)):
     write = wt.get(k, 0.0) * 1024 / max(wc.get(k, 1), 1)
     out[k] = {"launches": n, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
               "hbm_bytes_per_launch": fetch + write}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
+# which kernel sources these counters were taken on: bench.py compares the digest with the tree it runs on (roofline.traffic_fresh)
+import os, subprocess
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+meta = {}
+try:
+    from scenerf_amd import build as _b
+    meta["src_digest"] = _b._digest()
+except Exception as e:
+    meta["src_digest_error"] = repr(e)
+try:
+    meta["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(os.path.abspath(__file__)), text=True,
+                                             stderr=subprocess.DEVNULL).strip()
+except Exception:
+    meta["commit"] = os.environ.get("SRF_COMMIT", "")       # (the GPU box has no .git: tools/profile_round.sh passes the commit in)
+json.dump(dict(out, _meta=meta), open(sys.argv[3], "w"), indent=1)
 for k, v in sorted(((k, v) for k, v in out.items() if "@grid" not in k), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
     print("%-60s n=%4d fetch %8.1f MB  write %8.1f MB" % (k[:60], v["launches"], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6))
