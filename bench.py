@@ -128,6 +128,10 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="one rank: still create the process group (nccl = RCCL) and issue the gradient collectives (scenerf_amd.dist."
                          "FORCE_COLLECTIVES): the N > 1 code path on a single GPU; reported as `allreduce`")
+    ap.add_argument("--device-warm-steps", type=int, default=150,
+                    help="untimed steps issued as part of the setup, before the W warm-up steps: the GPU idles through model construction and "
+                         "capture and its clocks take a few hundred ms of load to settle (20 timed steps right after 5 warm-ups measure "
+                         "2-4 %% slower than the 300-step steady_state of the same process); 0 = rounds 1-3 behaviour")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short BASELINE configs[3] (BundleFusion) and configs[4] (inference) legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -727,7 +731,9 @@ def main():
         if torch.cuda.device_count() < env_world:
             raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible: one process per GPU is the contract" % (
                 env_world, torch.cuda.device_count()))
-    rank, world, local = sdist.init_from_env(force=args.force_dist and not dry)
+    # (a captured step with collectives needs the NCCL watchdog's event polling off: scenerf_amd.dist.init_from_env)
+    cap = (args.graph == "on" or (args.graph == "auto" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.force_dist)) and not dry
+    rank, world, local = sdist.init_from_env(force=args.force_dist and not dry, graph_capture=cap)
     assert world == args.gpus
     forced = bool(args.force_dist and world == 1 and not dry)
     if forced:
@@ -810,6 +816,9 @@ def main():
                 torch.cuda.synchronize()
         else:
             graph_note = "eager (%s)" % why
+    if not dry:
+        for _ in range(max(0, args.device_warm_steps)):     # setup: the device at its sustained clocks before W + K (see --device-warm-steps)
+            (graphed or step)()
     if graphed is not None:
         dt, last = _timed(graphed, args, world, dev, sync)
         host_ms = _timed.host_s / args.steps * 1e3
@@ -983,7 +992,7 @@ def main():
                                          "device generator (RenderConfig.device_rng=True; --host-rng gives the reference's host-side draw: +0.1-0.25 ms per step)",
                        "loss": "reference per-source loss (colour L1 + reprojection on synthetic images, KL, closest gaussian; scenerf_amd.loss_side."
                                "source_loss, one launch each way)" if args.loss == "source" else "proxy: four means in eager torch",
-                       "numa_pin": pinned},
+                       "numa_pin": pinned, "device_warm_steps": args.device_warm_steps},
             "eager_step": eager_leg, "other_entry": other, "other_rng": rng_other, "drop_in": drop_in, "steady_state": steady,
             "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager, "fp32_mode": fp32,
             "bundlefusion_c4": bf_leg, "infer_c5": inf_leg, "kitti_default_n64": n64_leg,

@@ -20,6 +20,17 @@
 //     atomic per (run, channel) -- see the epilogue.  (Measured dead ends, same results: a hash table texel -> slot with a counting
 //     sort and a segmented sum -- exact de-duplication, but three dependent LDS reads per entry: 31k cycles per round; LDS float
 //     atomics into a per-texel table -- rows that share a texel serialise on one address: 278k cycles per round.)
+//   * measured in round 4, not kept (tools/dfeat_probe.py, finest level alone: 153-159 us per launch, 472 MB = 3.0 TB/s; per tile and
+//     workgroup 91-98k cycles of K loop + 25k of epilogue, two workgroups per CU):
+//       - producer waves (4 + 4 waves, wgrad.hip's protocol, the multiplying waves never issue a vector-memory instruction; two 8-wave
+//         workgroups per CU at 128 registers; eight waves in the scatter): same results, 171 us -- the "46k cycles stalled issuing DMA"
+//         of r03 are back-pressure of a saturated memory path (a full round of K loops already moves 4.5-5 TB/s), not an issue limit
+//         that other waves could lift;
+//       - the second resident workgroup of each CU started half a tile late, so that one streams while the other scatters:
+//         152-154 us at 4-5 x 8k cycles of delay, 162 at 8 -- one workgroup alone does not pull the CU's share of the stream;
+//       - the scatter without its atomics: 136 us (the epilogue 22k instead of 27k cycles): the walk over (row, tap) pairs, not the
+//         atomics, is what the epilogue costs.
+//     Kept: the first level's taps requested before the K loop (epilogue 31k -> 25k cycles; step time within noise).
 #include "gemm.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_d;
@@ -27,6 +38,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_d;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_d;
 
 #define DF_BM 128
+#ifdef DF_VAR_NOATOM      // (development: the scatter without its atomics -- results are garbage)
+#define DF_ATOM(p_, v_) asm volatile("" ::"v"(p_), "v"(v_))
+#else
+#define DF_ATOM(p_, v_) unsafeAtomicAdd(p_, v_)
+#endif
 #define DF_THREADS 256
 #define DF_K (3 * SCENERF_D_HIDDEN)        // 1536
 #define DF_NCH (DF_K / 16)                 // 96 chunks
@@ -241,6 +257,19 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
         for (int t = 0; t < NTP; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        // the taps of the pass's first level, requested NOW: two (texel, weight) pairs per thread stay in registers through the K loop and go
+        // to LDS behind it (r04: requested after the loop they cost the epilogue 6-7k of its 32k cycles, every wave waiting for the round trip)
+        int s_first, c_first;
+        tile_level(t0, s_first, c_first);
+        int pf_tx[2];
+        float pf_tw[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * DF_THREADS, m = m0 + (i >> 2);
+            const size_t o = ((size_t)min(m, p.M - 1) * SCENERF_N_SCALES + s_first) * 4 + (i & 3);
+            pf_tx[u] = m < p.M ? p.tap_texel[o] : -1;
+            pf_tw[u] = m < p.M ? p.tap_weight[o] : 0.f;
+        }
         // DMA sources of this wave's pieces: lane -> (row of the piece, physical slot), fetching logical slot physical ^ swz(row)
         const char* srcA[NPA_];
         const char* srcW[NPW_];
@@ -383,7 +412,14 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
             const long gst = p.st[s], gsc = p.sc[s];
             for (int tr = tb; tr < te; tr += DF_RT) {
                 __syncthreads();   // (the K loop / the previous round is done with this LDS)
-                if (taps_level != s) {
+                if (taps_level < 0 && s == s_first) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        s_tx[tid + u * DF_THREADS] = pf_tx[u];
+                        s_tw[tid + u * DF_THREADS] = pf_tw[u];
+                    }
+                    taps_level = s;
+                } else if (taps_level != s) {
                     for (int i = tid; i < 512; i += DF_THREADS) {
                         const int m = m0 + (i >> 2);
                         const size_t o = ((size_t)min(m, p.M - 1) * SCENERF_N_SCALES + s) * 4 + (i & 3);
@@ -392,6 +428,7 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
                     }
                     taps_level = s;
                 }
+                DF_STAMP()   // taps requested
                 // stage: lane = row (lane & 31) of the wave's 32, quads of 4 consecutive channels 8 q + 4 hi
                 const int row = 32 * wv + (lane & 31), hi = lane >> 5;
 #pragma unroll
@@ -405,6 +442,7 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
                     }
                 }
                 __syncthreads();
+                DF_STAMP()   // tile staged
                 // scatter.  A ray's samples are sorted along the ray and their texels advance slowly, so for each of the four taps the
                 // texel is constant over runs of consecutive rows: a wave walks its 32 rows in order (eight rows of independent LDS
                 // reads in flight: staged values, tap texels, tap weights -- no indirection), keeps one running sum per tap (lanes =
@@ -442,8 +480,8 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
                             if (t_ != cur[k]) {   // wave-uniform
                                 if (cur[k] >= 0) {
                                     float* const gp = gl + (size_t)cur[k] * gst;
-                                    if (ok0) unsafeAtomicAdd(gp, v0[k]);
-                                    if (ok1) unsafeAtomicAdd(gp + g64, v1[k]);
+                                    if (ok0) DF_ATOM(gp, v0[k]);
+                                    if (ok1) DF_ATOM(gp + g64, v1[k]);
                                 }
                                 cur[k] = t_; v0[k] = 0.f; v1[k] = 0.f;
                             }
@@ -456,8 +494,8 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
                 for (int k = 0; k < 4; ++k) {
                     if (cur[k] >= 0) {
                         float* const gp = gl + (size_t)cur[k] * gst;
-                        if (ok0) unsafeAtomicAdd(gp, v0[k]);
-                        if (ok1) unsafeAtomicAdd(gp + g64, v1[k]);
+                        if (ok0) DF_ATOM(gp, v0[k]);
+                        if (ok1) DF_ATOM(gp + g64, v1[k]);
                     }
                 }
                 DF_STAMP()   // round scattered
@@ -468,6 +506,7 @@ __global__ __launch_bounds__(DF_THREADS, DF_WGS) void dfeat_kernel(DfeatArgs p) 
     }   // items
 }
 
+// NTP = column tiles (32 channels each) whose accumulators a pass keeps in registers
 int launch_dfeat_scatter(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const uint8_t* tile_mask, const int32_t* tap_texel,
                          const float* tap_weight, int M, const void* dH, float* const gmaps[SCENERF_N_SCALES], hipStream_t s) {
     SRF_ONCE_PER_DEVICE(

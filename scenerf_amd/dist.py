@@ -51,9 +51,16 @@ def numa_pin(local_rank: int) -> Optional[str]:
         return None
 
 
-def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:
+def init_from_env(backend: Optional[str] = None, force: bool = False, graph_capture: bool = False) -> Tuple[int, int, int]:
     """(rank, world_size, local_rank) from torchrun's environment; initialises the process group if world > 1 (``force``: also for
-    a single rank)."""
+    a single rank).  ``graph_capture``: the collectives of this group will be captured into a hipGraph (GraphedStep with the gradient
+    hooks installed).  ProcessGroupNCCL's watchdog thread polls the completion events of outstanding work; an event recorded inside a
+    capture must not be queried (hipErrorCapturedEvent: the watchdog then terminates the process -- observed on RCCL, r04), so its
+    asynchronous error handling is switched off for this process, as PyTorch's whole-network-capture recipe for DDP prescribes
+    (TORCH_NCCL_ASYNC_ERROR_HANDLING=0; must be set before the group exists)."""
+    if graph_capture:
+        os.environ["TORCH_NCCL_ASYNC_ERROR_HANDLING"] = "0"
+        os.environ["NCCL_ASYNC_ERROR_HANDLING"] = "0"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

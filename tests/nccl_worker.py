@@ -16,7 +16,7 @@ from scenerf_amd.model import SceneRF          # noqa: E402
 
 def main():
     os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
-    rank, world, local = sdist.init_from_env("nccl", force=True)
+    rank, world, local = sdist.init_from_env("nccl", force=True, graph_capture=True)
     assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
     sdist.FORCE_COLLECTIVES = True
     dev = torch.device("cuda", 0)
