@@ -132,6 +132,8 @@ def parse():
                     help="untimed steps issued as part of the setup, before the W warm-up steps: the GPU idles through model construction and "
                          "capture and its clocks take a few hundred ms of load to settle (20 timed steps right after 5 warm-ups measure "
                          "2-4 %% slower than the 300-step steady_state of the same process); 0 = rounds 1-3 behaviour")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed region (no eager / other-entry / drop-in / steady-state / roofline legs): what a profiler should see")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short BASELINE configs[3] (BundleFusion) and configs[4] (inference) legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -141,6 +143,8 @@ def parse():
     ap.add_argument("--no-eager-baseline", action="store_true")
     ap.add_argument("--kernels-json", default="", help="write the per-kernel table here")
     a = ap.parse_args()
+    if a.headline_only:
+        a.no_roofline = a.no_extra_legs = a.no_cpu_baseline = a.no_eager_baseline = a.no_fp32_mode = True
     if a.steps is None:
         a.steps = 5 if a.mode == "infer" else 20
     if a.warmup is None:
@@ -169,18 +173,18 @@ def make_loss(args, dev, img_size, K, pix, rank=0, weights=(1.0, 1.0, 0.01)):
     """The step's loss as a function of render_rays_batch's output dict (see --loss)."""
     if getattr(args, "loss", "source") == "proxy":
         return lambda out: out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
-    from scenerf_amd.loss_side import source_loss
+    from scenerf_amd.loss_side import make_rng_state, source_loss
+    rng = make_rng_state(dev, seed=4242 + rank)
     g = torch.Generator().manual_seed(900 + rank)
     W, H = img_size
     img_s, img_t = torch.rand(3, H, W, generator=g).to(dev), torch.rand(3, H, W, generator=g).to(dev)
     T_s2t = synth.rel_pose(-1.0, 3.0).to(dev)
-    iK = torch.inverse(K)
+    iK = torch.inverse(K).contiguous()
     R = pix.shape[0]
 
-    def loss_fn(out):
-        noise = torch.randn(R, device=dev)      # scenerf.py:378: randn * 1e-5 on the identity term (the kernel applies the scale)
-        return source_loss(out, pix, img_s, img_t, K, iK, T_s2t, noise=noise, noise_scale=1e-5, reproj_weight=weights[0],
-                           color_weight=weights[1], dist2closest_weight=weights[2])[0]
+    def loss_fn(out):      # (scenerf.py:378's randn * 1e-5 on the identity term: made inside the kernel, like scenerf_amd.training does)
+        return source_loss(out, pix, img_s, img_t, K, iK, T_s2t, noise=None, noise_scale=1e-5, reproj_weight=weights[0],
+                           color_weight=weights[1], dist2closest_weight=weights[2], rng_state=rng)[0]
     return loss_fn
 
 
@@ -822,11 +826,12 @@ def main():
     if graphed is not None:
         dt, last = _timed(graphed, args, world, dev, sync)
         host_ms = _timed.host_s / args.steps * 1e3
-        dt_e, last_e = _timed(step, args, world, dev, sync)
-        assert torch.isfinite(last_e).item(), "loss is not finite (eager step)"
-        eager_leg = {"value": round(R * args.steps / dt_e, 1), "unit": "rays/s", "ms_per_step": round(dt_e / args.steps * 1e3, 3),
-                     "host_issue_ms_per_step": round(_timed.host_s / args.steps * 1e3, 3),
-                     "note": "the same step issued eagerly (~57 launch calls per step from Python), same process, right after the timed region"}
+        if not args.headline_only:
+            dt_e, last_e = _timed(step, args, world, dev, sync)
+            assert torch.isfinite(last_e).item(), "loss is not finite (eager step)"
+            eager_leg = {"value": round(R * args.steps / dt_e, 1), "unit": "rays/s", "ms_per_step": round(dt_e / args.steps * 1e3, 3),
+                         "host_issue_ms_per_step": round(_timed.host_s / args.steps * 1e3, 3),
+                         "note": "the same step issued eagerly (~50 launch calls per step from Python), same process, right after the timed region"}
         step_main = graphed
     else:
         dt, last = _timed(step, args, world, dev, sync)

@@ -116,6 +116,10 @@ typedef struct scenerf_mlp_weights {
      * contiguous 16 KiB block [512 rows][32 B] holding the exact LDS image (16-byte halves of row r swapped when
      * (r >> 3) & 1).  SCENERF_W_STREAM_BLOCKS blocks in all. */
     const void* w_stream;
+    /* optional (scenerf_hip_mlp_pack only): fp32 buffer of clear_floats elements that the pack launch zero-fills on its way -- the
+     * gradient sink (scenerf_mlp_grads) of the backward that will follow: no fill launch of its own */
+    float* clear;
+    int64_t clear_floats;
 } scenerf_mlp_weights;
 #define SCENERF_W_STREAM_BLOCKS ((3 * SCENERF_D_XENC + SCENERF_D_LATENT) / 16 + 2 * ((SCENERF_D_HIDDEN + SCENERF_D_LATENT) / 16) + 10 * (SCENERF_D_HIDDEN / 16))
 
@@ -148,6 +152,8 @@ typedef struct scenerf_mlp_grads {
     float* b_z;                     /* [1536] */
     float* w_out;                   /* [d_out][512] */
     float* b_out;                   /* [d_out] */
+    float* w_in_dense;              /* optional [512][42]: written (not accumulated) at the end of every scenerf_hip_mlp_backward with columns 0..41 of
+                                     * w_in as they stand -- lin_in.weight's gradient as a dense tensor (no zeroing needed) */
 } scenerf_mlp_grads;
 
 /* Saved activations of one ResnetFC evaluation over M rows (caller-allocated).
@@ -201,8 +207,8 @@ int scenerf_hip_encode_points(const scenerf_cfg* cfg, const float* dist, int dis
                               const float* inv_K /*[9]*/, const float* T_s2i /*[16]*/, int M,
                               float* pts /*[M][3] or NULL*/, int32_t* sphere_idx /*[M][2]*/,
                               float* xenc /*[M][48]; may be NULL when x3 is given*/,
-                              void* x3 /*bf16 [M][144] or NULL: the split encoding [hi | lo | hi] of scenerf_mlp_acts.h0pre, written directly
-                                         (set scenerf_mlp_acts.x3_ready)*/,
+                              void* x3 /*bf16 [M + 1][144] or NULL: the split encoding [hi | lo | hi] of scenerf_mlp_acts.h0pre, written directly
+                                         (set scenerf_mlp_acts.x3_ready); the slack row M is zero-filled*/,
                               scenerf_stream_t stream);
 
 /* utils.py:232-247 x5 (scenerf.py:522-527): bilinear 2x2 gather of the 5 maps at idx/div*2-1 with zeros
@@ -320,14 +326,16 @@ int scenerf_hip_loss_side_backward(const float* color, const float* col_src, con
  *   total = w_rep * loss_reprojection + w_col * mean(loss_color) + mean(loss_kl) + w_d2c * mean_r min_k |gaussian_means[r][k] - depth[r]|
  * with loss_color / loss_reprojection as in scenerf_hip_loss_side_forward and the rendered depth detached in the last term (:287-290).
  * loss_kl [R], gmeans / gstds / som_vars [R][G] are the renderer's outputs (gstds, som_vars nullable: they only feed the two logged means).
- * noise [R] nullable: noise[r] * noise_scale is added to the identity term (the reference draws randn * 1e-5).  out8 (device, fp32 [8]) =
+ * noise [R] nullable: noise[r] * noise_scale is added to the identity term (the reference draws randn * 1e-5); with noise == NULL and
+ * rng_state = device uint64 {seed, calls so far} the N(0,1) values are made in the kernel (Philox4x32-10 on (ray, call), Box-Muller) and the
+ * call counter is advanced by the launch itself (capturable: a replayed hipGraph draws fresh noise).  out8 (device, fp32 [8]) =
  * {total, loss_reprojection, mean loss_color, mean loss_kl, mean dist-to-closest-gaussian, mean som_vars of the closest gaussian, mean
  * gaussian_stds of the closest gaussian, number of valid rays}.  Kept for the backward: valid, dterm_ddepth [R], col_src [R][3],
- * closest [R] (int32); partial: scratch, fp32 [8 * ceil(R / 1024)].  Sums are taken in a fixed order (no atomics). */
+ * closest [R] (int32); partial: scratch, fp32 [8 * ceil(R / 64)].  Sums are taken in a fixed order (no atomics). */
 int scenerf_hip_source_loss_forward(const float* pix, const float* color, const float* depth, const float* loss_kl, const float* gmeans,
                                     const float* gstds, const float* som_vars, int G, const float* img_source, const float* img_target,
-                                    const float* noise, float noise_scale, const float* cam_K, const float* inv_K,
-                                    const float* T_source2target, int R, int H, int W, float w_rep, float w_col, float w_d2c, float* valid,
+                                    const float* noise, uint64_t* rng_state /* device [2] or NULL */, float noise_scale, const float* cam_K,
+                                    const float* inv_K, const float* T_source2target, int R, int H, int W, float w_rep, float w_col, float w_d2c, float* valid,
                                     float* dterm_ddepth, float* col_src, int32_t* closest, float* partial, float* out8,
                                     float* total /* [1]: out8[0] once more, in a buffer of its own */, scenerf_stream_t stream);
 /* its autograd w.r.t. colour [R][3], depth [R], loss_kl [R] and gaussian_means [R][G]; g_total: device scalar, NULL = 1. */

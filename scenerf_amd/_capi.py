@@ -52,6 +52,7 @@ class MlpWeights(C.Structure):
         ("w_out", vp), ("b_out", vp),
         ("w_fc0_t", vp * 3), ("w_fc1_t", vp * 3), ("w_z_t", vp * N_SCALES),
         ("w_stream", vp),
+        ("clear", vp), ("clear_floats", C.c_int64),
     ]
 
 
@@ -68,7 +69,7 @@ class MlpGrads(C.Structure):
         ("w_in", vp), ("b_in", vp),
         ("w_fc0", vp * 3), ("b_fc0", vp * 3),
         ("w_fc1", vp * 3), ("b_fc1", vp * 3),
-        ("w_z", vp), ("b_z", vp), ("w_out", vp), ("b_out", vp),
+        ("w_z", vp), ("b_z", vp), ("w_out", vp), ("b_out", vp), ("w_in_dense", vp),
     ]
 
 
@@ -114,7 +115,7 @@ _PROTOS = {
     "scenerf_hip_sphere_resample_backward_nhwc": (C.c_int, [vp, C.c_int64, i32, i32, i32, vp, vp, i32, i32, vp, vp]),
     "scenerf_hip_loss_side_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_loss_side_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
-    "scenerf_hip_source_loss_forward": (C.c_int, [vp] * 7 + [i32] + [vp] * 3 + [C.c_float] + [vp] * 3 + [i32] * 3 + [C.c_float] * 3 + [vp] * 7 + [vp]),
+    "scenerf_hip_source_loss_forward": (C.c_int, [vp] * 7 + [i32] + [vp] * 4 + [C.c_float] + [vp] * 3 + [i32] * 3 + [C.c_float] * 3 + [vp] * 7 + [vp]),
     "scenerf_hip_source_loss_backward": (C.c_int, [vp] * 9 + [i32, i32] + [C.c_float] * 3 + [vp] * 4 + [vp]),
     "scenerf_hip_mlp_feature_grads": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpWeights), vp, vp, vp, i32, vp,
                                                 C.POINTER(vp * N_SCALES), vp]),

@@ -16,6 +16,7 @@ struct LossArgs {
     const float* img_t;      // [3][H][W]
     const float* noise;      // [R] or NULL: noise[r] * noise_scale is added to the identity term (the reference draws randn * 1e-5 there)
     float noise_scale;
+    const unsigned long long* rng;   // or NULL; noise == NULL: {seed, calls so far}: the noise is made in the kernel (source_loss only)
     const float *K, *invK, *T;    // device: row-major 3x3, 3x3, and the 4x4 source->target transform (top three rows are read)
     int R, H, W;
     float* loss_color;       // [R][3]
@@ -39,15 +40,46 @@ __device__ static inline void bilin3(const float* img, int H, int W, float px, f
     const float fx = x - x0f, fy = y - y0f;
     const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W, oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
     const size_t plane = (size_t)H * W;
+    // branch-free taps: an out-of-range tap reads a clamped (valid) texel and is replaced by zero afterwards, so that the twelve loads of
+    // a sample -- 36 per ray -- are all in flight together.  Guarded loads compile to one basic block and one s_waitcnt each: 36
+    // dependent memory latencies per thread, 83 us for 1,200 rays (r04_e; the images are 5 MB each, every tap a miss)
+    const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1), ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
+    float tv[3][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float* p = img + c * plane;
-        const float a = (okx0 && oky0) ? p[(size_t)y0 * W + x0] : 0.f, b = (okx1 && oky0) ? p[(size_t)y0 * W + x0 + 1] : 0.f;
-        const float d = (okx0 && oky1) ? p[(size_t)(y0 + 1) * W + x0] : 0.f, e = (okx1 && oky1) ? p[(size_t)(y0 + 1) * W + x0 + 1] : 0.f;
+        tv[c][0] = p[(size_t)ya * W + xa]; tv[c][1] = p[(size_t)ya * W + xb];
+        tv[c][2] = p[(size_t)yb * W + xa]; tv[c][3] = p[(size_t)yb * W + xb];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a = (okx0 && oky0) ? tv[c][0] : 0.f, b = (okx1 && oky0) ? tv[c][1] : 0.f;
+        const float d = (okx0 && oky1) ? tv[c][2] : 0.f, e = (okx1 && oky1) ? tv[c][3] : 0.f;
         v[c] = a * (1.f - fx) * (1.f - fy) + b * fx * (1.f - fy) + d * (1.f - fx) * fy + e * fx * fy;
         dx[c] = ((b - a) * (1.f - fy) + (e - d) * fy) * sx;
         dy[c] = ((d - a) * (1.f - fx) + (e - b) * fx) * sy;
     }
+}
+
+// ---- N(0, 1) noise made in the kernel (Philox4x32-10 keyed by a seed and a per-call counter held in device memory, Box-Muller): the
+// reference draws torch.randn(R) * 1e-5 per source frame to break ties between the two reprojection terms (scenerf.py:378) -- as a torch
+// call that is two more launches (29 us in a step's trace, r04_f) in front of this kernel
+__device__ static inline void sl_philox(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+    uint32_t c[4] = {c0, c1, 0u, 0u};
+#pragma unroll 1
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+__device__ static inline float sl_normal(const unsigned long long* state, int r) {
+    uint32_t o[4];
+    sl_philox((uint32_t)r, (uint32_t)state[1], (uint32_t)state[0], (uint32_t)(state[0] >> 32), o);
+    const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.f / 16777216.f), u2 = ((float)(o[1] >> 8) + 0.5f) * (1.f / 16777216.f);
+    return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 
 // one ray of the colour + reprojection terms: writes the per-ray records and returns (term, valid, sum_c |colour - source colour|)
@@ -89,7 +121,7 @@ __device__ static inline void loss_ray(const LossArgs& p, int r, float& term, fl
         p.col_src[3 * r + c] = cs[c];
     }
     l_rep *= (1.f / 3.f);
-    l_id = l_id * (1.f / 3.f) + (p.noise ? p.noise[r] * p.noise_scale : 0.f);
+    l_id = l_id * (1.f / 3.f) + (p.noise ? p.noise[r] * p.noise_scale : (p.rng ? sl_normal(p.rng, r) * p.noise_scale : 0.f));
     const bool rep = l_rep <= l_id;   // torch.minimum: the gradient goes to the reprojection term where it is the smaller (or equal)
     term = rep ? l_rep : l_id;
     if (p.ray_term) p.ray_term[r] = term;
@@ -133,7 +165,10 @@ __global__ __launch_bounds__(256) void loss_side_bwd_kernel(const float* color, 
 // step, 6-7 us each -- become one launch each way (a second, one-wave launch sums the per-block partials when R > 1024).  Sums are
 // taken per block in a fixed order (no atomics): the value is reproducible run to run.
 #define SL_TERMS 8      // rep numerator, rep denominator, colour sum, kl sum, d2c sum, som_vars sum, stds sum, (unused)
-#define SL_THREADS 1024
+#define SL_THREADS 64   // one wave per block: a ray's 36 image taps are 36 cache misses (two 5 MB images, random pixels), and what bounds the
+                        // kernel is how many misses a CU keeps in flight -- 1,200 rays in two 1,024-thread blocks (two CUs) took 71 us, in
+                        // nineteen one-wave blocks they spread over nineteen CUs (r04_f)
+
 struct SrcLossArgs {
     LossArgs L;
     const float* loss_kl;    // [R]
@@ -155,6 +190,7 @@ __device__ static inline void sl_finish(const SrcLossArgs& p, const float (&t)[S
     p.total[0] = p.out[0];
     p.out[1] = rep; p.out[2] = col; p.out[3] = kl; p.out[4] = d2c;
     p.out[5] = t[5] * invR; p.out[6] = t[6] * invR; p.out[7] = t[1];
+    if (p.L.rng && !p.L.noise) ((unsigned long long*)p.L.rng)[1] += 1ull;     // the next call draws fresh noise (every block has read the counter)
 }
 
 __global__ __launch_bounds__(SL_THREADS) void source_loss_fwd_kernel(SrcLossArgs p) {
@@ -273,7 +309,7 @@ int scenerf_hip_loss_side_backward(const float* color, const float* col_src, con
 
 int scenerf_hip_source_loss_forward(const float* pix, const float* color, const float* depth, const float* loss_kl, const float* gmeans,
                                     const float* gstds, const float* som_vars, int G, const float* img_source, const float* img_target,
-                                    const float* noise, float noise_scale, const float* cam_K, const float* inv_K,
+                                    const float* noise, uint64_t* rng_state, float noise_scale, const float* cam_K, const float* inv_K,
                                     const float* T_source2target, int R, int H, int W, float w_rep, float w_col, float w_d2c, float* valid,
                                     float* dterm_ddepth, float* col_src, int32_t* closest, float* partial, float* out8,
                                     float* total, scenerf_stream_t stream) {
@@ -282,6 +318,7 @@ int scenerf_hip_source_loss_forward(const float* pix, const float* color, const 
               "source_loss_forward: NULL / empty argument");
     SrcLossArgs p = {};
     p.L.pix = pix; p.L.color = color; p.L.depth = depth; p.L.img_s = img_source; p.L.img_t = img_target; p.L.noise = noise; p.L.noise_scale = noise_scale;
+    p.L.rng = (const unsigned long long*)rng_state;
     p.L.K = cam_K; p.L.invK = inv_K; p.L.T = T_source2target;
     p.L.R = R; p.L.H = H; p.L.W = W;
     p.L.valid = valid; p.L.dterm_ddepth = dterm_ddepth; p.L.col_src = col_src;    // (loss_color / ray_term: not materialised)

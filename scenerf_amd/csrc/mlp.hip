@@ -291,8 +291,16 @@ static int feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
     return 0;
 }
 
-// dst[0:512] = a, dst[512:1024] = b, dst[1024:1536] = c
-__global__ void copy3_kernel(float* __restrict__ dst, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c) {
+// blocks 0..5: dst[0:512] = a, dst[512:1024] = b, dst[1024:1536] = c ; blocks 6..: w_dense[512][42] = w_in[512][SCENERF_WIN_LD][:, 0:42]
+// (lin_in.weight's gradient as the dense tensor autograd wants: handed over as a column slice of the 256-wide sink, AccumulateGrad
+// cloned it -- one more launch per MLP on the step's critical path, in front of the optimizer)
+__global__ void copy3_kernel(float* __restrict__ dst, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                             float* __restrict__ w_dense, const float* __restrict__ w_in) {
+    if (blockIdx.x >= 3 * SCENERF_D_HIDDEN / 256) {
+        const int i = (blockIdx.x - 3 * SCENERF_D_HIDDEN / 256) * 256 + threadIdx.x;
+        if (w_dense && i < SCENERF_D_HIDDEN * 42) w_dense[i] = w_in[(i / 42) * SCENERF_WIN_LD + i % 42];
+        return;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x, j = i & (SCENERF_D_HIDDEN - 1);
     dst[i] = i < SCENERF_D_HIDDEN ? a[j] : (i < 2 * SCENERF_D_HIDDEN ? b[j] : c[j]);
 }
@@ -580,7 +588,8 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     }
     // lin_z.b.bias is added at the same place as lin_in.bias (b=0) / fc_1.(b-1).bias: same column sums of dH_b
     // (one 6-block kernel: three asynchronous device-to-device copies were three ~10 us blit launches per pass)
-    copy3_kernel<<<3 * SCENERF_D_HIDDEN / 256, 256, 0, s2>>>(g_->b_z, g_->b_in, g_->b_fc1[0], g_->b_fc1[1]);
+    copy3_kernel<<<3 * SCENERF_D_HIDDEN / 256 + (g_->w_in_dense ? cdiv(SCENERF_D_HIDDEN * 42, 256) : 0), 256, 0, s2>>>(
+        g_->b_z, g_->b_in, g_->b_fc1[0], g_->b_fc1[1], g_->w_in_dense, g_->w_in);
     SRF_LAUNCH_CHECK("copy3_kernel");
     if (gmaps_hwc) {
         if (int e = feature_grads(cfg, w, tile_mask, tap_texel, tap_weight, M, dH, gmaps_hwc, s)) return e;
@@ -754,6 +763,12 @@ extern "C" int scenerf_hip_mlp_pack(const scenerf_cfg* cfg, const scenerf_mlp_pa
         for (int b = 0; b < 3; ++b)
             add(P->linz_w[b] + off, at(W->w_z_t[sc], (size_t)b * H), cfg->map_C[sc], H, L, 3 * H, 1, 0, H, 0);
         off += cfg->map_C[sc];
+    }
+    if (W->clear && W->clear_floats > 0) {   // zero jobs: no source (valid_cols = 0 -> every element is padding)
+        const int64_t cols = 4096, full = W->clear_floats / cols, rem = W->clear_floats - full * cols;
+        SRF_CHECK(full < (1 << 30), "mlp_pack: clear buffer too large");
+        if (full > 0) add(nullptr, W->clear, (int)full, (int)cols, 0, (int)cols, 0, 0, 0, 1);
+        if (rem > 0) add(nullptr, W->clear + full * cols, 1, (int)rem, 0, (int)rem, 0, 0, 0, 1);
     }
     SRF_CHECK(tab.njobs <= PACK_MAX_JOBS, "mlp_pack: job table overflow");
     {

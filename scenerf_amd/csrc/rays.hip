@@ -134,6 +134,8 @@ __global__ __launch_bounds__(256) void encode_points_kernel(const float* __restr
         for (int c = 0; c < SCENERF_D_XENC; c += 4) *(float4*)(o + c) = make_float4(e[c], e[c + 1], e[c + 2], e[c + 3]);
     }
     if (x3) {
+        // one row of slack behind [M][144]: lin_in's weight gradient reads the rows in 256-column tiles (scenerf_hip.h: h0pre) -- zeroed here
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x < ENC_X3_ROW / 4) ((uint32_t*)((char*)x3 + (size_t)M * ENC_X3_ROW))[threadIdx.x] = 0u;
         const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
         char* const row = s_x3[wv] + lane * ENC_X3_LD;
 #pragma unroll
@@ -649,32 +651,35 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------------ RaySOM
 #define MAXG SCENERF_MAX_GAUSSIANS
-// one wave per ray; lanes stride over the N samples.  ray_som_kl.py:10-87.
+// one wave per ray; lanes stride over the N samples.  ray_som_kl.py:10-87.  GM = compile-time bound of the gaussian count (4 for every
+// configuration the reference ships, 8 = SCENERF_MAX_GAUSSIANS otherwise): with the bound at 8 a ray of 4 gaussians paid 8 expf and 8
+// divisions per sample and pass -- the per-ray tail is latency (one wave walks a ray: 38 us at R = 1,200 whatever the chip could do)
+template <int GM>
 __global__ __launch_bounds__(256) void raysom_fwd_kernel(const float* __restrict__ gmeans, const float* __restrict__ gstds,
                                                          const float* __restrict__ dist, const float* __restrict__ alphas,
                                                          int R, int N, int G, float som_sigma, float kl_floor,
                                                          float* __restrict__ loss_kl, float* __restrict__ som_means,
                                                          float* __restrict__ som_vars, float* __restrict__ kl_saved,
                                                          uint8_t* __restrict__ bmu_out) {
-    __shared__ float s_nb[4][MAXG][MAXG], s_p12[4][MAXG][MAXG];
+    __shared__ float s_nb[4][GM][GM], s_p12[4][GM][GM];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + wv;
     const bool active = r < R;
-    float m[MAXG], s[MAXG], var[MAXG];
+    float m[GM], s[GM], var[GM];
 #pragma unroll
-    for (int g = 0; g < MAXG; ++g) {
+    for (int g = 0; g < GM; ++g) {
         bool ok = active && g < G;
         m[g] = ok ? gmeans[(size_t)r * G + g] : 0.f;
         s[g] = ok ? gstds[(size_t)r * G + g] : 1.f;
         var[g] = s[g] * s[g];
     }
     const float two_sig2 = (float)(2.0 * (double)som_sigma * (double)som_sigma);
-    if (lane < MAXG * MAXG) {
-        int c2 = lane / MAXG, c1 = lane % MAXG;
+    if (lane < GM * GM) {
+        int c2 = lane / GM, c1 = lane % GM;
         float dm = m[0];  // select m[c2]-m[c1] without dynamic register indexing
         float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int g = 0; g < MAXG; ++g) {
+        for (int g = 0; g < GM; ++g) {
             if (g == c2) a = m[g];
             if (g == c1) b = m[g];
         }
@@ -682,8 +687,8 @@ __global__ __launch_bounds__(256) void raysom_fwd_kernel(const float* __restrict
         s_nb[wv][c2][c1] = (c2 < G && c1 < G) ? expf(-(dm * dm) / two_sig2) : 0.f;  // ray_som_kl.py:89-91
     }
     __syncthreads();
-    if (lane < MAXG * MAXG) {
-        int c2 = lane / MAXG, c1 = lane % MAXG;
+    if (lane < GM * GM) {
+        int c2 = lane / GM, c1 = lane % GM;
         float sum = 0.f;
         for (int g = 0; g < G; ++g) sum += s_nb[wv][c2][g];
         s_p12[wv][c2][c1] = (c2 < G && c1 < G) ? s_nb[wv][c2][c1] / sum : 0.f;
@@ -691,16 +696,16 @@ __global__ __launch_bounds__(256) void raysom_fwd_kernel(const float* __restrict
     __syncthreads();
     if (!active) return;
     const float sqrt2pi = 2.5066282746310002f;
-    float sw[MAXG], swd[MAXG];
+    float sw[GM], swd[GM];
 #pragma unroll
-    for (int g = 0; g < MAXG; ++g) { sw[g] = 0.f; swd[g] = 0.f; }
+    for (int g = 0; g < GM; ++g) { sw[g] = 0.f; swd[g] = 0.f; }
     // pass 1: weighted means
     for (int i = lane; i < N; i += 64) {
         float d = dist[(size_t)r * N + i];
         float dens = alphas[(size_t)r * N + i] + 1e-8f;
-        float pz1[MAXG];
+        float pz1[GM];
 #pragma unroll
-        for (int c = 0; c < MAXG; ++c) {
+        for (int c = 0; c < GM; ++c) {
             float gap = fabsf(m[c] - d);
             float p = expf(-(gap * gap) / (2.f * var[c])) / (sqrt2pi * s[c]) + 1e-5f;
             pz1[c] = (c < G) ? p * dens + 1e-8f : 0.f;
@@ -710,12 +715,12 @@ __global__ __launch_bounds__(256) void raysom_fwd_kernel(const float* __restrict
         for (int c2 = 0; c2 < G; ++c2) {
             float acc = 0.f;
 #pragma unroll
-            for (int c1 = 0; c1 < MAXG; ++c1)
+            for (int c1 = 0; c1 < GM; ++c1)
                 if (c1 < G) acc += pz1[c1] * s_p12[wv][c2][c1] + 1e-8f;
             if (acc > pbest) { pbest = acc; bmu = c2; }
         }
 #pragma unroll
-        for (int g = 0; g < MAXG; ++g) {
+        for (int g = 0; g < GM; ++g) {
             if (g < G) {
                 float wgt = s_nb[wv][g][bmu] * pz1[g] / pbest + 1e-5f;
                 sw[g] += wgt;
@@ -723,23 +728,23 @@ __global__ __launch_bounds__(256) void raysom_fwd_kernel(const float* __restrict
             }
         }
     }
-    float nm[MAXG];
+    float nm[GM];
 #pragma unroll
-    for (int g = 0; g < MAXG; ++g) {
+    for (int g = 0; g < GM; ++g) {
         sw[g] = wave_sum(sw[g]);
         swd[g] = wave_sum(swd[g]);
         nm[g] = swd[g] / sw[g];
     }
     // pass 2: weighted variances around the new means (weights recomputed, not stored)
-    float sv[MAXG];
+    float sv[GM];
 #pragma unroll
-    for (int g = 0; g < MAXG; ++g) sv[g] = 0.f;
+    for (int g = 0; g < GM; ++g) sv[g] = 0.f;
     for (int i = lane; i < N; i += 64) {
         float d = dist[(size_t)r * N + i];
         float dens = alphas[(size_t)r * N + i] + 1e-8f;
-        float pz1[MAXG];
+        float pz1[GM];
 #pragma unroll
-        for (int c = 0; c < MAXG; ++c) {
+        for (int c = 0; c < GM; ++c) {
             float gap = fabsf(m[c] - d);
             float p = expf(-(gap * gap) / (2.f * var[c])) / (sqrt2pi * s[c]) + 1e-5f;
             pz1[c] = (c < G) ? p * dens + 1e-8f : 0.f;
@@ -749,13 +754,13 @@ __global__ __launch_bounds__(256) void raysom_fwd_kernel(const float* __restrict
         for (int c2 = 0; c2 < G; ++c2) {
             float acc = 0.f;
 #pragma unroll
-            for (int c1 = 0; c1 < MAXG; ++c1)
+            for (int c1 = 0; c1 < GM; ++c1)
                 if (c1 < G) acc += pz1[c1] * s_p12[wv][c2][c1] + 1e-8f;
             if (acc > pbest) { pbest = acc; bmu = c2; }
         }
         if (bmu_out) bmu_out[(size_t)r * N + i] = (uint8_t)bmu;   // parity tests: the discrete choice of ray_som_kl.py:52
 #pragma unroll
-        for (int g = 0; g < MAXG; ++g) {
+        for (int g = 0; g < GM; ++g) {
             if (g < G) {
                 float wgt = s_nb[wv][g][bmu] * pz1[g] / pbest + 1e-5f;
                 float e = d - nm[g];
@@ -765,7 +770,7 @@ __global__ __launch_bounds__(256) void raysom_fwd_kernel(const float* __restrict
     }
     float klsum = 0.f;
 #pragma unroll
-    for (int g = 0; g < MAXG; ++g) {
+    for (int g = 0; g < GM; ++g) {
         sv[g] = wave_sum(sv[g]);
         if (g < G) {
             float nv = sv[g] / sw[g];
@@ -795,12 +800,13 @@ __global__ __launch_bounds__(256) void raysom_fwd_kernel(const float* __restrict
 // the alphas the compositing just produced stay in the wave's registers for the SOM update -- one launch and one pass over
 // (logits, dist, z) per ray instead of two launches and a re-read of dist / alphas.  Same arithmetic, statement for statement, as
 // the two stage kernels (tests hold the outputs bit-identical to theirs).
-__device__ __forceinline__ void raysom_sample(const float d, const float dens, const float (&m)[MAXG], const float (&s)[MAXG],
-                                              const float (&var)[MAXG], const int G, const float (*p12)[MAXG], float (&pz1)[MAXG],
+template <int GM>
+__device__ __forceinline__ void raysom_sample(const float d, const float dens, const float (&m)[GM], const float (&s)[GM],
+                                              const float (&var)[GM], const int G, const float (*p12)[GM], float (&pz1)[GM],
                                               float& pbest, int& bmu) {
     const float sqrt2pi = 2.5066282746310002f;
 #pragma unroll
-    for (int c = 0; c < MAXG; ++c) {
+    for (int c = 0; c < GM; ++c) {
         float gap = fabsf(m[c] - d);
         float p = expf(-(gap * gap) / (2.f * var[c])) / (sqrt2pi * s[c]) + 1e-5f;
         pz1[c] = (c < G) ? p * dens + 1e-8f : 0.f;
@@ -810,13 +816,13 @@ __device__ __forceinline__ void raysom_sample(const float d, const float dens, c
     for (int c2 = 0; c2 < G; ++c2) {
         float acc = 0.f;
 #pragma unroll
-        for (int c1 = 0; c1 < MAXG; ++c1)
+        for (int c1 = 0; c1 < GM; ++c1)
             if (c1 < G) acc += pz1[c1] * p12[c2][c1] + 1e-8f;
         if (acc > pbest) { pbest = acc; bmu = c2; }
     }
 }
 
-template <int C>
+template <int C, int GM>
 __global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ dist,
                                                            const float* __restrict__ zv, const float* __restrict__ gmeans,
                                                            const float* __restrict__ gstds, int R, int N, int G, float som_sigma,
@@ -827,25 +833,25 @@ __global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restri
                                                            float* __restrict__ loss_kl, float* __restrict__ som_means,
                                                            float* __restrict__ som_vars, float* __restrict__ kl_saved,
                                                            uint8_t* __restrict__ bmu_out) {
-    __shared__ float s_nb[4][MAXG][MAXG], s_p12[4][MAXG][MAXG];
+    __shared__ float s_nb[4][GM][GM], s_p12[4][GM][GM];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + wv;
     const bool active = r < R;
     // ---- RaySOM tables of this ray (ray_som_kl.py:30-38), before anything else: the barriers are block-wide
-    float m[MAXG], s[MAXG], var[MAXG];
+    float m[GM], s[GM], var[GM];
 #pragma unroll
-    for (int g = 0; g < MAXG; ++g) {
+    for (int g = 0; g < GM; ++g) {
         bool ok = active && g < G;
         m[g] = ok ? gmeans[(size_t)r * G + g] : 0.f;
         s[g] = ok ? gstds[(size_t)r * G + g] : 1.f;
         var[g] = s[g] * s[g];
     }
     const float two_sig2 = (float)(2.0 * (double)som_sigma * (double)som_sigma);
-    if (lane < MAXG * MAXG) {
-        int c2 = lane / MAXG, c1 = lane % MAXG;
+    if (lane < GM * GM) {
+        int c2 = lane / GM, c1 = lane % GM;
         float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int g = 0; g < MAXG; ++g) {
+        for (int g = 0; g < GM; ++g) {
             if (g == c2) a = m[g];
             if (g == c1) b = m[g];
         }
@@ -853,8 +859,8 @@ __global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restri
         s_nb[wv][c2][c1] = (c2 < G && c1 < G) ? expf(-(dm * dm) / two_sig2) : 0.f;
     }
     __syncthreads();
-    if (lane < MAXG * MAXG) {
-        int c2 = lane / MAXG, c1 = lane % MAXG;
+    if (lane < GM * GM) {
+        int c2 = lane / GM, c1 = lane % GM;
         float sum = 0.f;
         for (int g = 0; g < G; ++g) sum += s_nb[wv][c2][g];
         s_p12[wv][c2][c1] = (c2 < G && c1 < G) ? s_nb[wv][c2][c1] / sum : 0.f;
@@ -937,21 +943,21 @@ __global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restri
     // ---- RaySOM update + KL (raysom_fwd_kernel) on the registers' (distance, alpha)
     // (the per-sample update weights of pass 1 are kept for pass 2 -- C x G registers -- instead of being recomputed: the stage kernel
     // evaluates the same expressions twice, the values are identical)
-    float sw[MAXG], swd[MAXG], wk[C][MAXG];
+    float sw[GM], swd[GM], wk[C][GM];
 #pragma unroll
-    for (int g = 0; g < MAXG; ++g) { sw[g] = 0.f; swd[g] = 0.f; }
+    for (int g = 0; g < GM; ++g) { sw[g] = 0.f; swd[g] = 0.f; }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const int i = c * 64 + lane;
 #pragma unroll
-        for (int g = 0; g < MAXG; ++g) wk[c][g] = 0.f;
+        for (int g = 0; g < GM; ++g) wk[c][g] = 0.f;
         if (i < N) {
-            float pz1[MAXG], pbest;
+            float pz1[GM], pbest;
             int bmu;
-            raysom_sample(d[c], al[c] + 1e-8f, m, s, var, G, s_p12[wv], pz1, pbest, bmu);
+            raysom_sample<GM>(d[c], al[c] + 1e-8f, m, s, var, G, s_p12[wv], pz1, pbest, bmu);
             if (bmu_out) bmu_out[base + i] = (uint8_t)bmu;
 #pragma unroll
-            for (int g = 0; g < MAXG; ++g) {
+            for (int g = 0; g < GM; ++g) {
                 if (g < G) {
                     float wgt = s_nb[wv][g][bmu] * pz1[g] / pbest + 1e-5f;
                     wk[c][g] = wgt;
@@ -961,22 +967,22 @@ __global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restri
             }
         }
     }
-    float nm[MAXG];
+    float nm[GM];
 #pragma unroll
-    for (int g = 0; g < MAXG; ++g) {
+    for (int g = 0; g < GM; ++g) {
         sw[g] = wave_sum(sw[g]);
         swd[g] = wave_sum(swd[g]);
         nm[g] = swd[g] / sw[g];
     }
-    float sv[MAXG];
+    float sv[GM];
 #pragma unroll
-    for (int g = 0; g < MAXG; ++g) sv[g] = 0.f;
+    for (int g = 0; g < GM; ++g) sv[g] = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const int i = c * 64 + lane;
         if (i < N) {
 #pragma unroll
-            for (int g = 0; g < MAXG; ++g) {
+            for (int g = 0; g < GM; ++g) {
                 if (g < G) {
                     float e = d[c] - nm[g];
                     sv[g] += wk[c][g] * (e * e);
@@ -986,7 +992,7 @@ __global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restri
     }
     float klsum = 0.f;
 #pragma unroll
-    for (int g = 0; g < MAXG; ++g) {
+    for (int g = 0; g < GM; ++g) {
         sv[g] = wave_sum(sv[g]);
         if (g < G) {
             float nv = sv[g] / sw[g];
@@ -1477,8 +1483,12 @@ int scenerf_hip_raysom_forward(const scenerf_cfg* cfg, const float* gmeans, cons
               "raysom_forward: NULL argument");
     hipStream_t s = as_stream(stream);
     SrfLaunchScope ps(s, "raysom_fwd", 0, (double)R * cfg->n_samples * 16);
-    raysom_fwd_kernel<<<cdiv(R, 4), 256, 0, s>>>(gmeans, gstds, dist_sorted, alphas, R, cfg->n_samples, cfg->n_gaussians,
-                                                 cfg->som_sigma, cfg->kl_std_floor, loss_kl, som_means, som_vars, kl_saved, bmu_out);
+    if (cfg->n_gaussians <= 4)
+        raysom_fwd_kernel<4><<<cdiv(R, 4), 256, 0, s>>>(gmeans, gstds, dist_sorted, alphas, R, cfg->n_samples, cfg->n_gaussians, cfg->som_sigma,
+                                                        cfg->kl_std_floor, loss_kl, som_means, som_vars, kl_saved, bmu_out);
+    else
+        raysom_fwd_kernel<MAXG><<<cdiv(R, 4), 256, 0, s>>>(gmeans, gstds, dist_sorted, alphas, R, cfg->n_samples, cfg->n_gaussians, cfg->som_sigma,
+                                                           cfg->kl_std_floor, loss_kl, som_means, som_vars, kl_saved, bmu_out);
     SRF_LAUNCH_CHECK("raysom_fwd_kernel");
     return 0;
 }
@@ -1511,12 +1521,14 @@ int scenerf_hip_ray_tail_forward(const scenerf_cfg* cfg, const float* logits, co
     hipStream_t s = as_stream(stream);
     dim3 grid(cdiv(R, 4));
     SrfLaunchScope ps(s, "ray_tail_fwd", 0, (double)R * (32.0 * N + 24.0));
-#define TF(C) ray_tail_fwd_kernel<C><<<grid, 256, 0, s>>>(logits, dist_sorted, z_sorted, gmeans, gstds, R, N, cfg->n_gaussians, cfg->som_sigma, cfg->kl_std_floor, densities, alphas, weights, depth, color, closest, weights_at_depth, closest_idx, loss_kl, som_means, som_vars, kl_saved, bmu_out)
-    if (N <= 64) TF(1);
-    else if (N <= 128) TF(2);
-    else if (N <= 256) TF(4);
-    else TF(8);
+#define TF2(C, GB) ray_tail_fwd_kernel<C, GB><<<grid, 256, 0, s>>>(logits, dist_sorted, z_sorted, gmeans, gstds, R, N, cfg->n_gaussians, cfg->som_sigma, cfg->kl_std_floor, densities, alphas, weights, depth, color, closest, weights_at_depth, closest_idx, loss_kl, som_means, som_vars, kl_saved, bmu_out)
+#define TF(C) { if (cfg->n_gaussians <= 4) TF2(C, 4); else TF2(C, MAXG); }
+    if (N <= 64) TF(1)
+    else if (N <= 128) TF(2)
+    else if (N <= 256) TF(4)
+    else TF(8)
 #undef TF
+#undef TF2
     SRF_LAUNCH_CHECK("ray_tail_fwd_kernel");
     return 0;
 }

@@ -46,6 +46,7 @@ class GraphedStep:
         self.cam_K, self.T_source2infer, self.pixels, self.x_rgb = cam_K, T_source2infer, pixels, x_rgb
         self.ray_batch_size = int(ray_batch_size or pixels.shape[0])
         self.noise = noise
+        self._one = None
         self._params = [p for g in optimizer.param_groups for p in g["params"]] if optimizer is not None else \
             [p for p in model.parameters() if p.requires_grad]
         self._map_leaves = [v for v in x_rgb.values() if v.requires_grad]
@@ -60,6 +61,12 @@ class GraphedStep:
                 self._eager()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl":
+            # the warm-up steps' collectives are still on ProcessGroupNCCL's watchdog list until its next sweep; a completion query that
+            # thread makes while this one is capturing is an error inside the watchdog (observed on RCCL, ~1 run in 10: the process
+            # aborts).  All of that work has finished (synchronize above): give the sweep time to retire it before the capture starts
+            import time
+            time.sleep(0.6)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._eager()
@@ -83,10 +90,14 @@ class GraphedStep:
             p.grad = None
         for v in self._map_leaves:
             v.grad = None
+        if self.optimizer is not None and hasattr(self.optimizer, "advance"):
+            self.optimizer.advance()    # the step count, bumped beside the forward instead of in front of the update kernel
         out = self.model.render_rays_batch(self.cam_K, self.T_source2infer, self.x_rgb, T_cam2velo=None, sampled_pixels=self.pixels,
                                            ray_batch_size=self.ray_batch_size, **({"noise": self.noise} if self.noise is not None else {}))
         loss = self.loss_fn(out)
-        loss.backward()
+        if self._one is None or self._one.shape != loss.shape or self._one.dtype != loss.dtype:
+            self._one = torch.ones_like(loss)
+        loss.backward(self._one)        # (a cached root gradient: autograd's own ones_like is one more fill launch per step)
         if self.optimizer is not None:
             self.optimizer.step()
         return loss.detach()

@@ -84,7 +84,7 @@ class SourceLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, color, depth, loss_kl, gmeans, gstds, som_vars, pix_source, img_source, img_target, cam_K, inv_K, T_source2target, noise,
-                noise_scale, w_rep, w_col, w_d2c):
+                noise_scale, w_rep, w_col, w_d2c, rng_state=None):
         for name, t in (("color", color), ("depth", depth), ("loss_kl", loss_kl), ("gaussian_means", gmeans), ("pix_source", pix_source),
                         ("img_source", img_source), ("img_target", img_target)):
             if not t.is_cuda:
@@ -105,16 +105,19 @@ class SourceLoss(torch.autograd.Function):
         f = dict(dtype=torch.float32, device=dev)
         valid, dterm, col_src = torch.empty(R, **f), torch.empty(R, **f), torch.empty((R, 3), **f)
         closest = torch.empty(R, dtype=torch.int32, device=dev)
-        partial, out8, total = torch.empty(8 * ((R + 1023) // 1024), **f), torch.empty(8, **f), torch.empty((), **f)
+        partial, out8, total = torch.empty(8 * ((R + 63) // 64), **f), torch.empty(8, **f), torch.empty((), **f)
+        if rng_state is not None and (rng_state.dtype != torch.int64 or rng_state.numel() != 2 or not rng_state.is_cuda):
+            raise RuntimeError("rng_state must be a CUDA int64 tensor of two elements {seed, calls so far}")
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             _capi.check(lib.scenerf_hip_source_loss_forward(pix.data_ptr(), col.data_ptr(), dep.data_ptr(), kl.data_ptr(), gm.data_ptr(),
                                                             _capi.ptr(gs), _capi.ptr(sv), G, ims.data_ptr(), imt.data_ptr(), _capi.ptr(nz),
-                                                            float(noise_scale), K.data_ptr(), iK.data_ptr(), T.data_ptr(), R, H, W,
+                                                            _capi.ptr(rng_state), float(noise_scale), K.data_ptr(), iK.data_ptr(), T.data_ptr(), R, H, W,
                                                             float(w_rep), float(w_col), float(w_d2c), valid.data_ptr(), dterm.data_ptr(),
                                                             col_src.data_ptr(), closest.data_ptr(), partial.data_ptr(), out8.data_ptr(),
                                                             total.data_ptr(), st), "source_loss_forward")
         ctx.save_for_backward(col, col_src, valid, dterm, gm, dep, closest, out8)
+        ctx.set_materialize_grads(False)     # (no zero tensor -- a fill launch -- for the logged terms nobody differentiates)
         ctx.w = (float(w_rep), float(w_col), float(w_d2c))
         ctx.mark_non_differentiable(out8)
         return total, out8
@@ -125,23 +128,36 @@ class SourceLoss(torch.autograd.Function):
         lib = _capi.load()
         R, G = int(valid.numel()), int(gm.shape[1])
         g_color, g_depth, g_kl, g_gm = torch.empty_like(col), torch.empty_like(valid), torch.empty_like(valid), torch.empty_like(gm)
-        gt = _f32(g_total).reshape(1) if g_total is not None else None
+        if g_total is None:     # only the (non-differentiable) terms received a gradient: nothing flows
+            return (None,) * 18
+        gt = _f32(g_total).reshape(1)
         with torch.cuda.device(col.device):
             st = torch.cuda.current_stream(col.device).cuda_stream
             _capi.check(lib.scenerf_hip_source_loss_backward(col.data_ptr(), col_src.data_ptr(), valid.data_ptr(), dterm.data_ptr(), gm.data_ptr(),
                                                              dep.data_ptr(), closest.data_ptr(), out8.data_ptr(), _capi.ptr(gt), R, G, ctx.w[0],
                                                              ctx.w[1], ctx.w[2], g_color.data_ptr(), g_depth.data_ptr(), g_kl.data_ptr(),
                                                              g_gm.data_ptr(), st), "source_loss_backward")
-        return (g_color, g_depth, g_kl, g_gm) + (None,) * 13
+        return (g_color, g_depth, g_kl, g_gm) + (None,) * 14
 
 
 def source_loss(out, pix_source: torch.Tensor, img_source: torch.Tensor, img_target: torch.Tensor, cam_K: torch.Tensor, inv_K: torch.Tensor,
                 T_source2target: torch.Tensor, noise: Optional[torch.Tensor] = None, noise_scale: float = 1e-5, reproj_weight: float = 1.0,
-                color_weight: float = 1.0, dist2closest_weight: float = 0.01) -> Tuple[torch.Tensor, torch.Tensor]:
+                color_weight: float = 1.0, dist2closest_weight: float = 0.01,
+                rng_state: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """The loss of one source frame from ``out`` = the dict of ``render_rays_batch`` (keys depth, color, loss_kl, gaussian_means,
     gaussian_stds, som_vars): (total, terms[8]).  ``noise`` [R] ~ N(0, 1) (scaled by ``noise_scale`` in the kernel: the reference adds
     ``randn * 1e-5`` to the identity term); the weights are those of the reference's ``forward`` (KITTI: 1, 1, 0.01; BundleFusion: 5, 1,
-    0.1; a term switched off by ``use_reprojection`` / ``use_color`` = weight 0)."""
+    0.1; a term switched off by ``use_reprojection`` / ``use_color`` = weight 0).  ``rng_state`` (with ``noise=None``): a CUDA int64 tensor
+    ``[seed, calls so far]`` -- the noise is then made inside the kernel (Philox + Box-Muller) and the counter advanced by the launch:
+    no ``randn`` launches in front of the kernel (``make_rng_state``)."""
     return SourceLoss.apply(out["color"], out["depth"].reshape(-1), out["loss_kl"], out["gaussian_means"], out.get("gaussian_stds"),
                             out.get("som_vars"), pix_source, img_source, img_target, cam_K, inv_K, T_source2target, noise, noise_scale,
-                            reproj_weight, color_weight, dist2closest_weight)
+                            reproj_weight, color_weight, dist2closest_weight, rng_state)
+
+
+def make_rng_state(device, seed: Optional[int] = None) -> torch.Tensor:
+    """``[seed, 0]`` for ``source_loss(rng_state=...)``; the seed is taken from torch's CPU generator (so ``torch.manual_seed`` makes runs
+    repeatable) unless given."""
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return torch.tensor([int(seed), 0], dtype=torch.int64, device=device)

@@ -286,7 +286,8 @@ class SceneRF(TrainingMixin, _Base):
         a new tensor may reuse it), so a loop that passes the same K tensor pays once and anything else recomputes."""
         hit = getattr(self, "_inv_K_cache", None)
         if hit is None or hit[0] is not cam_K or hit[1] != cam_K._version:
-            hit = (cam_K, cam_K._version, torch.inverse(cam_K))
+            hit = (cam_K, cam_K._version, torch.inverse(cam_K).contiguous())    # (torch.inverse hands back a column-major view: every
+                                                                                 #  consumer's .contiguous() would be a copy launch per chunk)
             object.__setattr__(self, "_inv_K_cache", hit)
         return hit[2]
 

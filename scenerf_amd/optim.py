@@ -76,6 +76,19 @@ class FusedAdamW(torch.optim.Optimizer):
                 h[1] = float(group["lr"])
 
     @torch.no_grad()
+    def advance(self) -> None:
+        """Capturable mode: count the coming step NOW (t += 1 on the device) instead of inside ``step()``.  The increment is a launch of
+        its own that ``step()`` otherwise issues right in front of the update kernel -- at the very end of a training step's critical
+        chain; called at the top of the step (scenerf_amd.graph.GraphedStep does) it runs beside the forward.  The next ``step()`` of each
+        group then skips its own increment.  No-op for groups that have not stepped yet (their counter does not exist) and outside
+        capturable mode."""
+        for gi, group in enumerate(self.param_groups):
+            h = self._hyper.get(gi)
+            if group.get("capturable") and h is not None:
+                h[0][1:2].add_(1.0)
+                group["_advanced"] = True
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
@@ -128,7 +141,10 @@ class FusedAdamW(torch.optim.Optimizer):
                     hyper, lr_held = self._group_hyper(group, dev)
                     if not torch.cuda.is_current_stream_capturing() and lr_held != float(group["lr"]):
                         self.sync_hyper()
-                    hyper[1:2].add_(1.0)                        # t, on the device: a replayed graph counts on
+                    if group.pop("_advanced", False):
+                        pass                                    # (advance() has counted this step already)
+                    else:
+                        hyper[1:2].add_(1.0)                    # t, on the device: a replayed graph counts on
                     for p in group["params"]:
                         self.state[p]["step"] = hyper[1]        # (like torch's capturable optimizers: a device scalar)
                     _capi.check(lib.scenerf_hip_adamw_step_dev(len(entries), arr, hyper.data_ptr(), float(b1), float(b2), float(group["eps"]),

@@ -83,6 +83,19 @@ def _sampler_constants(dev, U: int, G: int, max_depth: float):
     return hit
 
 
+_ZERO1 = {}
+
+
+def _zero_token(dev) -> torch.Tensor:
+    """The gradient RenderChunk.backward returns for its three autograd tokens: a zero nobody reads (PackMLP / PrepareMaps ignore the
+    value), created once per device instead of by a fill launch per backward."""
+    key = torch.device(dev).index
+    z = _ZERO1.get(key)
+    if z is None:
+        z = _ZERO1[key] = torch.zeros(1, dtype=torch.float32, device=dev)
+    return z
+
+
 def _require_cuda(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise RuntimeError("%s must live on the GPU (got %s): the SceneRF hot path has no CPU fallback" % (name, t.device))
@@ -319,6 +332,14 @@ class PackedMLP:
         for i in range(5):
             s.w_z_t[i] = av["w_z_t.%d" % i].data_ptr()
         s.w_stream = av["w_stream"].data_ptr() if prec else None
+        # a training session's pack launch also zeroes the gradient sink of the backward to come (no fill launch of its own: on a
+        # replayed step every extra node is a queue the executor may serialise the critical chain behind -- r04_h)
+        self.gflat: Optional[torch.Tensor] = None
+        if pack_stream is not None:
+            self.gflat = torch.empty(self._sink_numel(), dtype=torch.float32, device=dev)
+            s.clear, s.clear_floats = self.gflat.data_ptr(), self.gflat.numel()
+        else:
+            s.clear, s.clear_floats = None, 0
         self.c = s
         raw = _capi.MlpParams()
         raw.d_out = d_out
@@ -336,13 +357,14 @@ class PackedMLP:
         if pack_stream is not None:
             pack_stream.wait_stream(torch.cuda.current_stream(dev))   # the parameters were last written on the current stream
             _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(raw), C.byref(s), pack_stream.cuda_stream), "mlp_pack")
+            self.gflat.record_stream(pack_stream)
             self._ready = pack_stream.record_event()
             self.act_buf.record_stream(pack_stream)   # (same hazard as the map accumulators if the consumer never waits)
             self.f32_buf.record_stream(pack_stream)
         else:
             _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(raw), C.byref(s), _stream(dev)), "mlp_pack")
-        # gradient sink (flat fp32 buffer carved into the scenerf_mlp_grads fields), allocated on first backward
-        self.gflat: Optional[torch.Tensor] = None
+        # gradient sink (flat fp32 buffer carved into the scenerf_mlp_grads fields): allocated and zeroed on first backward, or zeroed by
+        # the pack launch above
         self.gviews: Dict[str, torch.Tensor] = {}
         self.gc: Optional[_capi.MlpGrads] = None
 
@@ -357,6 +379,7 @@ class PackedMLP:
         changed in place since construction, whatever way they were written (optimizer step, ``p.data.copy_``, ``load_state_dict``),
         while every device address a captured hipGraph holds stays valid.  Requires ``same_storage``."""
         self.wait_ready()
+        self.c.clear, self.c.clear_floats = None, 0     # (a sink zeroed by the first pack may hold gradients by now)
         _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(cfg.to_c()), C.byref(self._raw), C.byref(self.c), _stream(self.device)), "mlp_pack")
 
     def wait_ready(self) -> None:
@@ -365,17 +388,30 @@ class PackedMLP:
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
 
-    def grad_sink(self) -> "_capi.MlpGrads":
-        if self.gc is not None:
-            return self.gc
+    def _sink_fields(self):
         d = self.d_out
         fields = [("w_in", (D_H, _capi.WIN_LD)), ("b_in", (D_H,))]   # (columns >= 48 of w_in: scratch of the batched wgrad kernel)
         for b in range(3):
             fields += [("w_fc0.%d" % b, (D_H, D_H)), ("b_fc0.%d" % b, (D_H,)),
                        ("w_fc1.%d" % b, (D_H, D_H)), ("b_fc1.%d" % b, (D_H,))]
-        fields += [("w_z", (3 * D_H, D_L)), ("b_z", (3 * D_H,)), ("w_out", (d, D_H)), ("b_out", (d,))]
-        total = sum(int(torch.tensor(s).prod()) for _, s in fields)
-        self.gflat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        fields += [("w_z", (3 * D_H, D_L)), ("b_z", (3 * D_H,)), ("w_out", (d, D_H)), ("b_out", (d,)), ("w_in_dense", (D_H, 42))]
+        return fields
+
+    def _sink_numel(self) -> int:
+        n = 0
+        for _, shp in self._sink_fields():
+            k = 1
+            for x in shp:
+                k *= x
+            n += k
+        return n
+
+    def grad_sink(self) -> "_capi.MlpGrads":
+        if self.gc is not None:
+            return self.gc
+        fields = self._sink_fields()
+        if self.gflat is None:
+            self.gflat = torch.zeros(self._sink_numel(), dtype=torch.float32, device=self.device)
         off = 0
         for name, shp in fields:
             n = 1
@@ -390,15 +426,18 @@ class PackedMLP:
             g.w_fc1[b], g.b_fc1[b] = self.gviews["w_fc1.%d" % b].data_ptr(), self.gviews["b_fc1.%d" % b].data_ptr()
         g.w_z, g.b_z = self.gviews["w_z"].data_ptr(), self.gviews["b_z"].data_ptr()
         g.w_out, g.b_out = self.gviews["w_out"].data_ptr(), self.gviews["b_out"].data_ptr()
+        g.w_in_dense = self.gviews["w_in_dense"].data_ptr()
         self.gc = g
         return g
 
     def unpack_grads(self) -> List[Optional[torch.Tensor]]:
         """Gradients in MLP_PARAM_NAMES order (None if no chunk ran a backward)."""
-        if self.gflat is None:
+        if self.gflat is None or not self.gviews:
             return [None] * len(MLP_PARAM_NAMES)
         v = self.gviews
-        out = {"lin_in.weight": v["w_in"][:, :42].contiguous(), "lin_in.bias": v["b_in"],
+        # (lin_in.weight: the dense copy scenerf_hip_mlp_backward leaves next to the 256-wide sink -- a column slice handed to autograd
+        # was cloned by AccumulateGrad, one launch per MLP in front of the optimizer)
+        out = {"lin_in.weight": v["w_in_dense"], "lin_in.bias": v["b_in"],
                "lin_out.weight": v["w_out"], "lin_out.bias": v["b_out"]}
         for b in range(3):
             out["blocks.%d.fc_0.weight" % b] = v["w_fc0.%d" % b]
@@ -484,8 +523,9 @@ class _MlpRun:
         # fp32 lin_in output (fp32 mode) or the split-bf16 encoding [M][144] (bf16 mode)
         # (bf16: one row of slack -- lin_in's weight gradient reads the split encoding in 256-column tiles of its 144-column rows)
         self.h0pre = torch.empty((M, D_H) if prec == 0 else (M + 1, 3 * D_X // 2), dtype=torch.float32, device=dev)
-        if prec == 1 and not lean:
-            self.h0pre[M:].zero_()    # (scenerf_hip.h: the slack row is read -- into scratch columns of the gradient sink -- and must be finite)
+        if prec == 1 and not lean and not x3_direct:
+            self.h0pre[M:].zero_()    # (scenerf_hip.h: the slack row is read -- into scratch columns of the gradient sink -- and must be finite;
+                                      #  scenerf_hip_encode_points zeroes it itself when it writes the split encoding: x3_direct)
         self.logits = torch.empty((M, d_out), dtype=torch.float32, device=dev)
         a = _capi.MlpActs()
         for i in range(4):
@@ -571,6 +611,12 @@ class RenderChunk(torch.autograd.Function):
         # constants the reference builds with torch.linspace (utils.py:79-81, scenerf.py:556-560)
         lin_u, anchors = _sampler_constants(dev, U, G, float(cfg.max_sample_depth))
 
+        # device-drawn sampler noise (RenderConfig.device_rng): requested NOW, in stream order behind the caller's uniform draw -- two small
+        # launches back to back at the top of the chunk.  (Between the head's forward and the sampler it was a launch on the critical chain;
+        # on the side stream it was worse: in a replayed hipGraph every edge between two queues costs 12-15 us of idle time
+        # (profiles/r04_g_step_trace.md), more than the 5 us the draw takes.)
+        if noise_g is None and cfg.device_rng:
+            noise_g = draw_noise_g(cfg, R, dev)
         unit_dir = torch.empty((R, 3), **f32)
         viewdir = torch.empty((R, 3), **f32)
         dist_u = torch.empty((R, U), **f32) if U > 0 else None
@@ -716,7 +762,7 @@ class RenderChunk(torch.autograd.Function):
                 if t is not None:
                     t.record_stream(side)
         ctx.keep = None
-        z1 = torch.zeros(1, **f32)
+        z1 = _zero_token(dev)
         return (None, None, None, None, None, None, None, None, None, None,
                 z1 if ctx.needs_input_grad[10] else None, z1 if ctx.needs_input_grad[11] else None,
                 z1 if ctx.needs_input_grad[12] else None)

@@ -98,12 +98,20 @@ class TrainingMixin:
             # the WHOLE loss of this source frame in one kernel per direction (scenerf_amd.loss_side.source_loss -> csrc/loss.hip):
             # the three image gathers, the reprojection, both L1 terms, the closest-gaussian term, the means and the weights forward()
             # applies -- ~25 eager launches between the renderer's forward and its backward otherwise, each of them on the step's
-            # critical path.  The noise is drawn like the reference's (randn on the device; the kernel scales it by 1e-5)
-            from .loss_side import source_loss
-            noise = torch.randn(depth.shape[0], device=dev)
+            # critical path.  The tie-breaking noise (randn * 1e-5, scenerf.py:378) is made inside the kernel (Philox + Box-Muller on a
+            # per-module seed and call counter); ``fused_loss_noise = "torch"`` draws it with the reference's torch.randn call instead
+            from .loss_side import make_rng_state, source_loss
+            noise = rng = None
+            if getattr(self, "fused_loss_noise", "kernel") == "torch":
+                noise = torch.randn(depth.shape[0], device=dev)     # the reference's call on the device generator (two more launches)
+            else:   # made inside the kernel from a per-module (seed, call counter) pair in device memory
+                rng = self.__dict__.get("_loss_rng")
+                if rng is None or rng.device != dev:
+                    rng = make_rng_state(dev)
+                    object.__setattr__(self, "_loss_rng", rng)
             fused = source_loss(out, pix_source, img_source, img_target, cam_K, inv_K, T_source2target, noise=noise, noise_scale=0.00001,
                                 reproj_weight=self.reproj_weight if self.use_reprojection else 0.0,
-                                color_weight=1.0 if self.use_color else 0.0, dist2closest_weight=self.dist2closest_weight)
+                                color_weight=1.0 if self.use_color else 0.0, dist2closest_weight=self.dist2closest_weight, rng_state=rng)
             terms = fused[1]
             self.log(step_type + "_som/dist_2_closest_gaussian", terms[4], on_epoch=True, sync_dist=True)
             self.log(step_type + "_som/closest_std", terms[6], on_epoch=True, sync_dist=True)
@@ -192,7 +200,7 @@ class TrainingMixin:
         for i in range(bs):
             x_rgb = {k: x_rgbs[k][i] for k in x_rgbs}
             cam_K = batch["cam_K"][i]
-            inv_K = torch.inverse(cam_K)
+            inv_K = torch.inverse(cam_K).contiguous()
             for sid in range(len(batch["img_sources"][i])):
                 T_s2i = batch["T_source2infers"][i][sid]
                 ret = self.process_single_source(self.n_rays, x_rgb=x_rgb, cam_K=cam_K, inv_K=inv_K,
@@ -235,7 +243,7 @@ class BundleFusionTrainingMixin(TrainingMixin):
         img_input = batch["img_inputs"]
         bs = img_input.shape[0]
         cam_K = batch["cam_K_depth"][0]
-        inv_K = torch.inverse(cam_K)
+        inv_K = torch.inverse(cam_K).contiguous()
         pix, pix_sphere, _ = self.spherical_mapping.from_pixels(inv_K=inv_K)
         x_rgbs = self.net_rgb(img_input, pix=pix, pix_sphere=pix_sphere)
         n_grids = self.n_rays // (self.sample_grid_size ** 2)

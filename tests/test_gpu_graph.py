@@ -179,11 +179,17 @@ def test_graphed_step_with_nccl_world1():
     noise of fp32 atomics, and a replayed graph keeps stepping the optimizer."""
     import os, re, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, os.path.join(here, "nccl_worker.py")], env=env, capture_output=True, text=True, timeout=600)
     err = re.search(r"NCCL_ERROR.*", r.stdout, re.S)
-    assert r.returncode == 0, (err.group(0)[-3000:] if err else r.stdout[-1500:] + r.stderr[-1500:])
+    what = re.findall(r"what\(\):.*", r.stderr)
+    assert r.returncode == 0, (err.group(0)[-3000:] if err else (what[:2], r.stdout[-800:], r.stderr[-1500:]))
     mm = re.search(r"NCCL_RESULT spread=([\d.e+-]+) session=([\d.e+-]+) step=([\d.e+-]+) graph_steps=(\d+) moved=([\d.e+-]+) finite=(\w+)", r.stdout)
     assert mm, r.stdout[-2000:] + r.stderr[-2000:]
     spread, sess, step = float(mm.group(1)), float(mm.group(2)), float(mm.group(3))

@@ -126,3 +126,34 @@ def test_source_loss_matches_the_torch_assembly(behind, seed, R_rep):
     t1 = source_loss(out, d["pix"], d["img_s"], d["img_t"], d["K"], torch.inverse(d["K"]), d["T"], noise=noise, **w)[1].clone()
     t2 = source_loss(out, d["pix"], d["img_s"], d["img_t"], d["K"], torch.inverse(d["K"]), d["T"], noise=noise, **w)[1].clone()
     assert torch.equal(t1, t2)
+
+
+def test_source_loss_in_kernel_noise_is_standard_normal_and_advances():
+    """rng_state = [seed, calls]: the tie-breaking noise of scenerf.py:378 made inside the kernel.  With a huge noise scale s the ray term
+    is min(l_rep, l_id + s n) ~ s min(0, n), whose mean over rays is -s / sqrt(2 pi) for n ~ N(0, 1): a moment check of the generator
+    through the only place its values go.  The launch advances the call counter (a replayed graph draws fresh noise); the same state gives
+    the same numbers."""
+    import math
+    from scenerf_amd.loss_side import make_rng_state, source_loss
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in inputs(31, n=4000, behind=False).items()}
+    R = d["pix"].shape[0]
+    gen = torch.Generator().manual_seed(31)
+    out = {"color": torch.rand(R, 3, generator=gen).to(DEV), "depth": d["depth"], "loss_kl": torch.rand(R, generator=gen).to(DEV),
+           "gaussian_means": torch.rand(R, 4, generator=gen).to(DEV) * 20, "gaussian_stds": None, "som_vars": None}
+    args = (d["pix"], d["img_s"], d["img_t"], d["K"], torch.inverse(d["K"]), d["T"])
+    st = make_rng_state(DEV, seed=1234)
+    assert st.tolist() == [1234, 0]
+    s_big = 1e4
+    t1 = source_loss(out, *args, noise=None, noise_scale=s_big, rng_state=st)[1].clone()
+    assert st.tolist() == [1234, 1]
+    t2 = source_loss(out, *args, noise=None, noise_scale=s_big, rng_state=st)[1].clone()
+    assert st.tolist() == [1234, 2] and float(t1[1]) != float(t2[1])            # fresh noise per call
+    for t in (t1, t2):
+        assert abs(float(t[1]) / s_big + 1 / math.sqrt(2 * math.pi)) < 0.04, float(t[1]) / s_big      # E[min(0, n)] = -0.3989 (4,000 rays: SE 0.009)
+    st.copy_(torch.tensor([1234, 0]))
+    t1b = source_loss(out, *args, noise=None, noise_scale=s_big, rng_state=st)[1]
+    assert torch.equal(t1, t1b)                                                 # same state, same values
+    # scale 0 == no noise at all
+    a = source_loss(out, *args, noise=None, noise_scale=0.0, rng_state=st)[1]
+    b = source_loss(out, *args, noise=None)[1]
+    assert torch.equal(a, b)

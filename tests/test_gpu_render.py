@@ -333,6 +333,7 @@ def test_training_forward_with_the_fused_source_loss_equals_the_stock_assembly()
         m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, sphere_W=376, sphere_H=114, n_rays=96,
                     net_rgb=_StubEncoder(maps), precision="fp32").to(DEV)
         m.fused_source_loss = fused
+        m.fused_loss_noise = "torch"      # (the reference's randn call in both runs: the device generator then advances identically)
         logged = {}
         m.log = lambda k, v, **kw: logged.__setitem__(k, float(v))
         m.mlp.load_state_dict(synth.mlp_state(32, 4))

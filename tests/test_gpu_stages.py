@@ -136,7 +136,7 @@ def _encode(case, rcfg, dist, stride, ppr, M):
     pts = torch.empty((M, 3), device=DEV)
     idx = torch.empty((M, 2), dtype=torch.int32, device=DEV)
     xenc = torch.empty((M, 48), device=DEV)
-    x3 = torch.zeros((M, 144), dtype=torch.bfloat16, device=DEV)
+    x3 = torch.full((M + 1, 144), float("nan"), dtype=torch.bfloat16, device=DEV)     # (one row of slack: scenerf_hip.h, encode_points zero-fills it)
     _capi.check(lib.scenerf_hip_encode_points(C.byref(cc), dist.data_ptr(), stride, ppr, dv(o["_unit"]).data_ptr(),
                                               dv(o["_viewdir"]).data_ptr(), dv(g.cam_K).data_ptr(), dv(iK).data_ptr(),
                                               dv(g.T).data_ptr(), M, pts.data_ptr(), idx.data_ptr(), xenc.data_ptr(), x3.data_ptr(), _st()),
@@ -144,9 +144,10 @@ def _encode(case, rcfg, dist, stride, ppr, M):
     # the split-bf16 form written by the same launch: [hi | lo | hi] with hi = bf16(x), lo = bf16(x - hi), exactly
     hi = xenc.to(torch.bfloat16)
     lo = (xenc - hi.float()).to(torch.bfloat16)
-    assert torch.equal(x3, torch.cat([hi, lo, hi], dim=1)), "split encoding differs from bf16 hi / lo of the fp32 encoding"
+    assert torch.equal(x3[:M], torch.cat([hi, lo, hi], dim=1)), "split encoding differs from bf16 hi / lo of the fp32 encoding"
+    assert float(x3[M:].float().abs().max()) == 0.0, "the slack row behind the split encoding must be zero-filled"
     # ... and alone (xenc = NULL: the product's bf16 path)
-    x3b = torch.zeros_like(x3)
+    x3b = torch.full_like(x3, float("nan"))
     idx2 = torch.empty_like(idx)
     _capi.check(lib.scenerf_hip_encode_points(C.byref(cc), dist.data_ptr(), stride, ppr, dv(o["_unit"]).data_ptr(),
                                               dv(o["_viewdir"]).data_ptr(), dv(g.cam_K).data_ptr(), dv(iK).data_ptr(),
