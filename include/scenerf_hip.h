@@ -192,11 +192,15 @@ int scenerf_hip_grads_hwc_to_chw(const float* hwc, float* chw, int C, int H, int
 
 /* ---- ray / sample geometry ----------------------------------------------------------------------------- */
 /* utils.py:177-182 (unit dirs), utils.py:112-173 + 75-90 (uniform distances, un-normalised viewdir in the
- * infer frame).  lin_u = torch.linspace(0.2, D, U); noise_u in [0,1) is the reference's rand_like. */
+ * infer frame).  lin_u = torch.linspace(0.2, D, U); noise_u in [0,1) is the reference's rand_like.
+ * Sampler noise made on the device WITHOUT a generator launch: noise_u == NULL with rng_state = device uint64 [3] {seed, calls so far,
+ * scratch}: ray_setup makes the uniform noise itself (Philox4x32-10 on (element, call), 24-bit uniforms like torch.rand) and
+ * scenerf_hip_gaussian_sample_sort, handed the same rng_state, makes the normal noise (Box-Muller), writes it to noise_g for the backward
+ * and advances the call counter: one ray_setup + one gaussian_sample_sort per chunk, in this order, on one stream.  Capturable. */
 int scenerf_hip_ray_setup(const scenerf_cfg* cfg, const float* pixels /*[R][2]*/, const float* inv_K /*[9]*/,
-                          const float* T_s2i /*[16]*/, const float* lin_u /*[U]*/, const float* noise_u /*[R][U]*/,
-                          int R, float* unit_dir /*[R][3]*/, float* viewdir /*[R][3]*/, float* dist_u /*[R][U]*/,
-                          scenerf_stream_t stream);
+                          const float* T_s2i /*[16]*/, const float* lin_u /*[U]*/, const float* noise_u /*[R][U] or NULL*/,
+                          uint64_t* rng_state /*[3] or NULL*/, int R, float* unit_dir /*[R][3]*/, float* viewdir /*[R][3]*/,
+                          float* dist_u /*[R][U]*/, scenerf_stream_t stream);
 
 /* scenerf.py:505-520 up to the gather: points = T @ (dist * unit_dir) (utils.py:158-166), cam_pts_2_pix
  * (utils.py:298-315), SphericalMapping.from_pixels (spherical_mapping.py:80-115, round-half-even),
@@ -253,7 +257,8 @@ int scenerf_hip_mlp_feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weig
  * stable ascending order (ties by original index).  z = dist * unit_dir.z (depth in the source frame). */
 int scenerf_hip_gaussian_sample_sort(const scenerf_cfg* cfg, const float* offsets /*[R][G][2]*/,
                                      const float* anchors /*[G]*/, const float* dist_u /*[R][U]*/,
-                                     const float* noise_g /*[R][G*P]*/, const float* unit_dir, int R,
+                                     float* noise_g /*[R][G*P]: read; WRITTEN when rng_state is given*/, uint64_t* rng_state /*[3] or NULL*/,
+                                     const float* unit_dir, int R,
                                      float* gmeans /*[R][G]*/, float* gstds /*[R][G]*/, float* dist_sorted /*[R][N]*/,
                                      float* z_sorted /*[R][N]*/, int32_t* perm /*[R][N]*/, scenerf_stream_t stream);
 

@@ -94,7 +94,7 @@ _PROTOS = {
     "scenerf_hip_prepare": (C.c_int, [C.POINTER(Cfg), vp]),
     "scenerf_hip_maps_chw_to_hwc": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "scenerf_hip_grads_hwc_to_chw": (C.c_int, [vp, vp, i32, i32, i32, vp]),
-    "scenerf_hip_ray_setup": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "scenerf_hip_ray_setup": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "scenerf_hip_encode_points": (C.c_int, [C.POINTER(Cfg), vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "scenerf_hip_gather_features": (C.c_int, [C.POINTER(Cfg), C.POINTER(vp * N_SCALES), vp, i32, vp, vp, vp, vp, vp]),
     "scenerf_hip_mlp_pack": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpParams), C.POINTER(MlpWeights), vp]),
@@ -119,7 +119,7 @@ _PROTOS = {
     "scenerf_hip_source_loss_backward": (C.c_int, [vp] * 9 + [i32, i32] + [C.c_float] * 3 + [vp] * 4 + [vp]),
     "scenerf_hip_mlp_feature_grads": (C.c_int, [C.POINTER(Cfg), C.POINTER(MlpWeights), vp, vp, vp, i32, vp,
                                                 C.POINTER(vp * N_SCALES), vp]),
-    "scenerf_hip_gaussian_sample_sort": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+    "scenerf_hip_gaussian_sample_sort": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_composite_forward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_composite_backward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_raysom_forward": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),

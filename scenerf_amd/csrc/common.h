@@ -146,6 +146,27 @@ template <> __device__ inline void store8<float>(void* base, size_t idx, const f
 }
 
 // wave-level helpers (64 lanes)
+// ---- counter-based random numbers made inside kernels (Philox4x32-10, the generator behind torch's device RNG): keyed by a 64-bit seed,
+// counted by (element, call).  Used where a torch.rand / torch.randn call in front of a kernel would only feed that kernel: a launch of
+// its own on a step's critical chain, plus two generator-state fills at the top of every hipGraph replay.
+__device__ static inline void srf_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint64_t seed, uint32_t (&out)[4]) {
+    uint32_t c[4] = {c0, c1, c2, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll 1
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+__device__ static inline float srf_u01(uint32_t x) { return (float)(x >> 8) * (1.f / 16777216.f); }                  // [0, 1), 24 bits (torch.rand)
+__device__ static inline float srf_normal(uint32_t a, uint32_t b) {                                                  // Box-Muller on (0, 1] x [0, 1)
+    const float u1 = ((float)(a >> 8) + 1.f) * (1.f / 16777216.f), u2 = srf_u01(b);
+    return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
 __device__ static inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);

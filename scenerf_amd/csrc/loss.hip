@@ -61,25 +61,13 @@ __device__ static inline void bilin3(const float* img, int H, int W, float px, f
     }
 }
 
-// ---- N(0, 1) noise made in the kernel (Philox4x32-10 keyed by a seed and a per-call counter held in device memory, Box-Muller): the
-// reference draws torch.randn(R) * 1e-5 per source frame to break ties between the two reprojection terms (scenerf.py:378) -- as a torch
-// call that is two more launches (29 us in a step's trace, r04_f) in front of this kernel
-__device__ static inline void sl_philox(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
-    uint32_t c[4] = {c0, c1, 0u, 0u};
-#pragma unroll 1
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
-}
+// ---- N(0, 1) noise made in the kernel (common.h: Philox4x32-10 keyed by a seed, counted by (ray, call), Box-Muller): the reference draws
+// torch.randn(R) * 1e-5 per source frame to break ties between the two reprojection terms (scenerf.py:378) -- as a torch call that is two
+// more launches (29 us in a step's trace, r04_f) in front of this kernel
 __device__ static inline float sl_normal(const unsigned long long* state, int r) {
     uint32_t o[4];
-    sl_philox((uint32_t)r, (uint32_t)state[1], (uint32_t)state[0], (uint32_t)(state[0] >> 32), o);
-    const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.f / 16777216.f), u2 = ((float)(o[1] >> 8) + 0.5f) * (1.f / 16777216.f);
-    return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+    srf_philox((uint32_t)r, (uint32_t)state[1], 0x10551u, state[0], o);
+    return srf_normal(o[0], o[1]);
 }
 
 // one ray of the colour + reprojection terms: writes the per-ray records and returns (term, valid, sum_c |colour - source colour|)

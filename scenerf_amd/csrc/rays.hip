@@ -19,15 +19,30 @@ __device__ static inline float dot4(float a0, float a1, float a2, float a3, floa
 
 // ------------------------------------------------------------------------------------------------ ray setup
 // one thread per (ray, j): j < U writes dist_u; j == 0 also writes unit_dir / viewdir.
+// rng (device uint64 {seed, calls, calls'} or NULL): with noise_u == NULL the uniform noise of utils.py:84 is made here (common.h: Philox
+// on (element, call)).  The call counter is passed on in ping-pong fashion so that no launch reads a word another thread of the same
+// launch writes: this kernel reads rng[1] and leaves rng[1] + 1 in rng[2]; gaussian_sample_sort_kernel reads rng[2] and copies it to
+// rng[1] -- a replayed hipGraph therefore draws fresh noise on every replay.
 __global__ void ray_setup_kernel(const float* __restrict__ pixels, const float* __restrict__ iK,
                                  const float* __restrict__ T, const float* __restrict__ lin_u,
-                                 const float* __restrict__ noise_u, int R, int U, float step,
+                                 const float* __restrict__ noise_u, unsigned long long* __restrict__ rng, int R, int U, float step,
                                  float* __restrict__ unit_dir, float* __restrict__ viewdir, float* __restrict__ dist_u) {
     int W = U > 0 ? U : 1;
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long call = rng ? rng[1] : 0ull;
+    if (rng && gid == 0) rng[2] = call + 1ull;
     if (gid >= R * W) return;
     int r = gid / W, j = gid - r * W;
-    if (j < U) dist_u[(size_t)r * U + j] = lin_u[j] + noise_u[(size_t)r * U + j] * step;  // utils.py:84-85
+    if (j < U) {
+        float nu;
+        if (noise_u) nu = noise_u[(size_t)r * U + j];
+        else {
+            uint32_t o[4];
+            srf_philox((uint32_t)gid, (uint32_t)call, (uint32_t)(call >> 32) ^ 0x0u, rng[0], o);
+            nu = srf_u01(o[0]);
+        }
+        dist_u[(size_t)r * U + j] = lin_u[j] + nu * step;  // utils.py:84-85
+    }
     if (j == 0) {
         float u = pixels[2 * r], v = pixels[2 * r + 1];
         float dx = dot3(iK[0], iK[1], iK[2], u, v, 1.f);
@@ -379,15 +394,18 @@ __global__ __launch_bounds__(256) void gather_kernel(MapPtrs maps, GatherConsts 
 
 // ------------------------------------------------------------------------------------------------ sampler + sort
 // one wave per ray; N <= 512 keys sorted with a bitonic network in LDS (stable via (key, index) compare).
+// rng != NULL: the normal noise of utils.py:208-211 is made here and WRITTEN to noise_g (the sampler's backward reads it back)
 __global__ __launch_bounds__(64) void gaussian_sample_sort_kernel(
     const float* __restrict__ offsets, const float* __restrict__ anchors, const float* __restrict__ dist_u,
-    const float* __restrict__ noise_g, const float* __restrict__ unit_dir, int R, int U, int G, int P, int N, int NP,
+    float* __restrict__ noise_g, unsigned long long* __restrict__ rng, const float* __restrict__ unit_dir, int R, int U, int G, int P, int N, int NP,
     float base_std, float floor_, float* __restrict__ gmeans, float* __restrict__ gstds,
     float* __restrict__ dist_sorted, float* __restrict__ z_sorted, int32_t* __restrict__ perm) {
     __shared__ float s_key[SCENERF_MAX_SAMPLES];
     __shared__ int s_idx[SCENERF_MAX_SAMPLES];
     __shared__ float s_mean[SCENERF_MAX_GAUSSIANS], s_std[SCENERF_MAX_GAUSSIANS];
     const int r = blockIdx.x, lane = threadIdx.x;
+    const unsigned long long call = rng ? rng[2] - 1ull : 0ull;      // (ray_setup_kernel left calls + 1 there)
+    if (rng && r == 0 && lane == 0) rng[1] = call + 1ull;
     if (lane < G) {
         float o0 = offsets[((size_t)r * G + lane) * 2], o1 = offsets[((size_t)r * G + lane) * 2 + 1];
         float mean = fmaxf(anchors[lane] + o0, 0.f) + floor_;  // scenerf.py:588-592
@@ -405,7 +423,16 @@ __global__ __launch_bounds__(64) void gaussian_sample_sort_kernel(
                 key = dist_u[(size_t)r * U + j];
             } else {
                 int jj = j - U, g = jj / P;
-                float d = s_mean[g] + noise_g[(size_t)r * G * P + jj] * s_std[g];  // utils.py:213
+                float nz;
+                if (rng) {
+                    uint32_t o[4];
+                    srf_philox((uint32_t)(r * G * P + jj), (uint32_t)call, (uint32_t)(call >> 32) ^ 0x80000000u, rng[0], o);
+                    nz = srf_normal(o[0], o[1]);
+                    noise_g[(size_t)r * G * P + jj] = nz;
+                } else {
+                    nz = noise_g[(size_t)r * G * P + jj];
+                }
+                float d = s_mean[g] + nz * s_std[g];  // utils.py:213
                 key = d < 0.1f ? 0.1f : d;                                           // utils.py:214
             }
         }
@@ -1363,17 +1390,17 @@ int scenerf_hip_grads_hwc_to_chw(const float* hwc, float* chw, int C, int H, int
 }
 
 int scenerf_hip_ray_setup(const scenerf_cfg* cfg, const float* pixels, const float* inv_K, const float* T_s2i,
-                          const float* lin_u, const float* noise_u, int R, float* unit_dir, float* viewdir, float* dist_u,
+                          const float* lin_u, const float* noise_u, uint64_t* rng_state, int R, float* unit_dir, float* viewdir, float* dist_u,
                           scenerf_stream_t stream) {
     if (check_cfg(cfg)) return 1;
     SRF_CHECK(pixels && inv_K && T_s2i && unit_dir && viewdir && R > 0, "ray_setup: bad args");
     int U = cfg->n_pts_uni;
-    SRF_CHECK(U == 0 || (lin_u && noise_u && dist_u), "ray_setup: uniform buffers missing");
+    SRF_CHECK(U == 0 || (lin_u && (noise_u || rng_state) && dist_u), "ray_setup: uniform buffers missing");
     hipStream_t s = as_stream(stream);
     int total = R * (U > 0 ? U : 1);
     SrfLaunchScope ps(s, "ray_setup", 0, (double)R * (8 + 24 + 8.0 * U));
-    ray_setup_kernel<<<cdiv(total, 256), 256, 0, s>>>(pixels, inv_K, T_s2i, lin_u, noise_u, R, U, cfg->uni_step, unit_dir,
-                                                      viewdir, dist_u);
+    ray_setup_kernel<<<cdiv(total, 256), 256, 0, s>>>(pixels, inv_K, T_s2i, lin_u, noise_u, (unsigned long long*)rng_state, R, U,
+                                                      cfg->uni_step, unit_dir, viewdir, dist_u);
     SRF_LAUNCH_CHECK("ray_setup_kernel");
     return 0;
 }
@@ -1419,7 +1446,7 @@ int scenerf_hip_gather_features(const scenerf_cfg* cfg, const void* const maps_h
 }
 
 int scenerf_hip_gaussian_sample_sort(const scenerf_cfg* cfg, const float* offsets, const float* anchors, const float* dist_u,
-                                     const float* noise_g, const float* unit_dir, int R, float* gmeans, float* gstds,
+                                     float* noise_g, uint64_t* rng_state, const float* unit_dir, int R, float* gmeans, float* gstds,
                                      float* dist_sorted, float* z_sorted, int32_t* perm, scenerf_stream_t stream) {
     if (check_cfg(cfg)) return 1;
     SRF_CHECK(offsets && anchors && noise_g && unit_dir && gmeans && gstds && dist_sorted && z_sorted && perm && R > 0,
@@ -1429,7 +1456,7 @@ int scenerf_hip_gaussian_sample_sort(const scenerf_cfg* cfg, const float* offset
     while (NP < N) NP <<= 1;
     hipStream_t s = as_stream(stream);
     SrfLaunchScope ps(s, "gaussian_sample_sort", 0, (double)R * N * 20);
-    gaussian_sample_sort_kernel<<<R, 64, 0, s>>>(offsets, anchors, dist_u, noise_g, unit_dir, R, cfg->n_pts_uni,
+    gaussian_sample_sort_kernel<<<R, 64, 0, s>>>(offsets, anchors, dist_u, noise_g, (unsigned long long*)rng_state, unit_dir, R, cfg->n_pts_uni,
                                                  cfg->n_gaussians, cfg->n_pts_per_gaussian, N, NP, cfg->base_std,
                                                  cfg->gauss_floor, gmeans, gstds, dist_sorted, z_sorted, perm);
     SRF_LAUNCH_CHECK("gaussian_sample_sort_kernel");

@@ -291,6 +291,20 @@ class SceneRF(TrainingMixin, _Base):
             object.__setattr__(self, "_inv_K_cache", hit)
         return hit[2]
 
+    def _device_rng_state(self, dev) -> torch.Tensor:
+        """{seed, calls so far, scratch} of the in-kernel sampler noise (``device_rng=True``): one per model and device, kept across calls
+        -- a captured hipGraph holds its address and every replay advances the call counter on the device.  The seed comes from torch's
+        CPU generator when the state is first needed (``torch.manual_seed`` makes a run repeatable); ``reseed_device_rng`` resets it."""
+        st = self.__dict__.setdefault("_rng_states", {})
+        key = torch.device(dev).index
+        if key not in st:
+            st[key] = torch.tensor([int(torch.randint(0, 2 ** 62, (1,)).item()), 0, 0], dtype=torch.int64, device=dev)
+        return st[key]
+
+    def reseed_device_rng(self, seed: int) -> None:
+        for t in self.__dict__.get("_rng_states", {}).values():
+            t.copy_(torch.tensor([int(seed), 0, 0], dtype=torch.int64))
+
     def render_rays_batch(self, cam_K, T_source2infer, x_rgb: Dict[str, torch.Tensor], depth_window=100,
                           T_cam2velo=None, sampled_pixels=None, ray_batch_size=128, noise=None):
         """scenerf.py:392-471.  ``depth_window`` / ``T_cam2velo`` are accepted and unused, as in the reference.
@@ -311,7 +325,8 @@ class SceneRF(TrainingMixin, _Base):
         cfg.som_sigma = float(self.ray_som.som_sigma)
         inv_K = self._inv_K(cam_K)
         sess = RenderSession(cfg, x_rgb, self.mlp.ordered_params(), self.mlp_gaussian.ordered_params(),
-                             grad_sync=self.grad_sync, grad_sync_async=self.grad_sync_async, debug_aux=self.debug_aux)
+                             grad_sync=self.grad_sync, grad_sync_async=self.grad_sync_async, debug_aux=self.debug_aux,
+                             rng=self._device_rng_state(sampled_pixels.device) if (cfg.device_rng and noise is None) else None)
         outs, auxs = [], []
         n = sampled_pixels.shape[0]
         sess.mlpg.single_chunk = n <= ray_batch_size   # training (scenerf.py:262-275): lets the head's gradient all-reduce start early

@@ -154,6 +154,7 @@ class MapHolder:
         self.gmaps: Optional[List[torch.Tensor]] = None
         self._gflat: Optional[torch.Tensor] = None      # the one allocation the five accumulators are views of
         self.debug_aux: Optional[Dict[str, torch.Tensor]] = None   # dict when the session was opened with debug_aux=True
+        self.rng: Optional[torch.Tensor] = None     # device int64 [3] {seed, calls, scratch}: in-kernel sampler noise (device_rng sessions)
 
     def convert(self, chw: Sequence[torch.Tensor]) -> None:
         """Also serves as the refresh of a long-lived session (inference.ImageRenderer): a second call writes into the SAME converted
@@ -607,21 +608,25 @@ class RenderChunk(torch.autograd.Function):
         U, G, P, N = cfg.n_uni_used, cfg.n_gaussians, cfg.n_pts_per_gaussian, cfg.n_samples
         f32 = dict(dtype=torch.float32, device=dev)
         pixels, K, iK, T = _f32c(pixels), _f32c(cam_K), _f32c(inv_K), _f32c(T_s2i)
-        noise_u = _f32c(noise_u).reshape(R, max(U, 0)) if U > 0 else None
+        # device_rng sessions (RenderSession.rng): neither noise tensor is drawn by torch -- ray_setup and gaussian_sample_sort make the
+        # uniform / normal noise themselves from a {seed, call counter} pair in device memory (scenerf_hip.h)
+        rng = maps.rng if (noise_u is None and noise_g is None and cfg.device_rng) else None
+        if rng is None and noise_u is None and U > 0:
+            raise RuntimeError("RenderChunk: noise_u is missing (only a device_rng session with an rng state may omit it)")
+        noise_u = _f32c(noise_u).reshape(R, max(U, 0)) if (U > 0 and noise_u is not None) else None
         # constants the reference builds with torch.linspace (utils.py:79-81, scenerf.py:556-560)
         lin_u, anchors = _sampler_constants(dev, U, G, float(cfg.max_sample_depth))
 
-        # device-drawn sampler noise (RenderConfig.device_rng): requested NOW, in stream order behind the caller's uniform draw -- two small
-        # launches back to back at the top of the chunk.  (Between the head's forward and the sampler it was a launch on the critical chain;
-        # on the side stream it was worse: in a replayed hipGraph every edge between two queues costs 12-15 us of idle time
-        # (profiles/r04_g_step_trace.md), more than the 5 us the draw takes.)
-        if noise_g is None and cfg.device_rng:
+        # device-drawn sampler noise without an rng state (a caller that injected only noise_u): requested NOW, in stream order -- between the
+        # head's forward and the sampler it was a launch on the critical chain; on the side stream it was worse: in a replayed hipGraph
+        # every edge between two queues costs 12-15 us of idle time (profiles/r04_g_step_trace.md), more than the 5 us the draw takes
+        if noise_g is None and cfg.device_rng and rng is None:
             noise_g = draw_noise_g(cfg, R, dev)
         unit_dir = torch.empty((R, 3), **f32)
         viewdir = torch.empty((R, 3), **f32)
         dist_u = torch.empty((R, U), **f32) if U > 0 else None
         _capi.check(lib.scenerf_hip_ray_setup(C.byref(ccfg), pixels.data_ptr(), iK.data_ptr(), T.data_ptr(), _capi.ptr(lin_u),
-                                              _capi.ptr(noise_u), R, unit_dir.data_ptr(), viewdir.data_ptr(),
+                                              _capi.ptr(noise_u), _capi.ptr(rng), R, unit_dir.data_ptr(), viewdir.data_ptr(),
                                               _capi.ptr(dist_u), st), "ray_setup")
         # gaussian head on the G anchors per ray (scenerf.py:549-596)
         # (grad mode is off inside Function.forward: whether a backward can follow is what needs_input_grad says)
@@ -633,7 +638,9 @@ class RenderChunk(torch.autograd.Function):
         # the gaussian sampler's normal noise, if the caller did not inject it: drawn HERE, with the gaussian head's chain already queued
         # -- the reference's host-side draw (utils.py:208-211) takes ~0.25 ms of host time per 1,200 rays, which at the top of the
         # chunk left the GPU without work (3.29 -> 3.04 ms per KITTI step, tools/ab_host.py devrng); same generator, same call order
-        if noise_g is None:
+        if rng is not None:
+            noise_g = torch.empty((R, G * P), **f32)     # written by the sampler (its backward reads it)
+        elif noise_g is None:
             noise_g = draw_noise_g(cfg, R, dev)
         noise_g = _f32c(noise_g).reshape(R, G * P)
         gmeans = torch.empty((R, G), **f32)
@@ -642,7 +649,7 @@ class RenderChunk(torch.autograd.Function):
         z_s = torch.empty((R, N), **f32)
         perm = torch.empty((R, N), dtype=torch.int32, device=dev)
         _capi.check(lib.scenerf_hip_gaussian_sample_sort(C.byref(ccfg), run_g.logits.data_ptr(), anchors.data_ptr(),
-                                                         _capi.ptr(dist_u), noise_g.data_ptr(), unit_dir.data_ptr(), R,
+                                                         _capi.ptr(dist_u), noise_g.data_ptr(), _capi.ptr(rng), unit_dir.data_ptr(), R,
                                                          gmeans.data_ptr(), gstds.data_ptr(), dist_s.data_ptr(), z_s.data_ptr(),
                                                          perm.data_ptr(), st), "gaussian_sample_sort")
         # radiance MLP on the sorted samples (scenerf.py:661-665)
@@ -773,7 +780,8 @@ class RenderSession:
     """Per-call state of ``render_rays_batch``: converted maps + packed MLPs, shared by all chunks."""
 
     def __init__(self, cfg: RenderConfig, x_rgb: Dict[str, torch.Tensor], mlp_params: Sequence[torch.Tensor],
-                 mlpg_params: Sequence[torch.Tensor], grad_sync=None, grad_sync_async=None, debug_aux: bool = False):
+                 mlpg_params: Sequence[torch.Tensor], grad_sync=None, grad_sync_async=None, debug_aux: bool = False,
+                 rng: Optional[torch.Tensor] = None):
         hwc, chw = self.classify_maps(x_rgb)
         if hwc or cfg.hwc_scales:   # per-call layout state (scenerf_cfg.map_chw): a copy, the model's config is not touched
             cfg = dataclasses.replace(cfg, hwc_scales=hwc, direct_scales=tuple(i for i in cfg.direct_scales if i not in hwc))
@@ -781,6 +789,10 @@ class RenderSession:
         self.device = chw[0].device
         with _on(self.device):
             self._open(cfg, chw, mlp_params, mlpg_params, grad_sync, grad_sync_async, debug_aux)
+        if rng is not None:
+            if not (rng.is_cuda and rng.dtype == torch.int64 and rng.numel() == 3 and rng.device == self.device):
+                raise RuntimeError("rng must be a CUDA int64 tensor {seed, calls, scratch} on the maps' device")
+            self.maps.rng = rng if cfg.device_rng else None
 
     @staticmethod
     def classify_maps(x_rgb):
@@ -845,7 +857,9 @@ class RenderSession:
 
     def render_chunk(self, pixels, cam_K, inv_K, T_s2i, noise_u=None, noise_g=None) -> Dict[str, torch.Tensor]:
         _require_cuda(pixels, "sampled_pixels")
-        if noise_u is None:   # (the gaussian noise, if not injected, is drawn inside the chunk: RenderChunk._forward)
+        if noise_u is None and not (self.maps.rng is not None and noise_g is None):
+            # (the gaussian noise, if not injected, is drawn inside the chunk: RenderChunk._forward; a device_rng session with an rng
+            #  state draws neither: the kernels make their noise)
             noise_u = self._draw_noise_u(pixels.shape[0], pixels.device)
         outs = RenderChunk.apply(self.cfg, self.maps, self.mlp, self.mlpg, pixels, cam_K, inv_K, T_s2i, noise_u, noise_g,
                                  self.tok_maps, self.tok_mlp, self.tok_mlpg)

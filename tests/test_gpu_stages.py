@@ -114,9 +114,66 @@ def _ray_setup(case, rcfg):
     vd = torch.empty((R, 3), device=DEV)
     du = torch.empty((R, U), device=DEV)
     _capi.check(lib.scenerf_hip_ray_setup(C.byref(cc), dv(g.pixels).data_ptr(), dv(iK).data_ptr(), dv(g.T).data_ptr(),
-                                          dv(lin).data_ptr(), dv(g.noise_u.reshape(R, U)).data_ptr(), R, unit.data_ptr(),
+                                          dv(lin).data_ptr(), dv(g.noise_u.reshape(R, U)).data_ptr(), None, R, unit.data_ptr(),
                                           vd.data_ptr(), du.data_ptr(), _st()), "ray_setup")
     return unit, vd, du
+
+
+def test_in_kernel_sampler_noise_statistics_and_call_counter():
+    """RenderConfig.device_rng sessions: ray_setup makes the uniform noise of utils.py:84 and gaussian_sample_sort the normal noise of
+    utils.py:208-211 themselves (Philox on (element, call); scenerf_hip.h).  Recovered through the outputs they feed: moments of both,
+    the call counter advancing once per (ray_setup, gaussian_sample_sort) pair, fresh values per call, the same values from the same
+    state."""
+    lib = _capi.load()
+    rcfg = RenderConfig.kitti(precision="bf16", n_pts_uni=64, n_pts_per_gaussian=16)
+    cc = rcfg.to_c()
+    R, U, G, P, N = 2048, 64, 4, 16, 128
+    gen = torch.Generator().manual_seed(9)
+    pix = dv(torch.rand(R, 2, generator=gen) * torch.tensor([1219.0, 369.0]))
+    K = synth.kitti_cam_K()
+    iK, T = dv(torch.inverse(K).contiguous()), dv(synth.rel_pose(1.0, 0.0))
+    lin = dv(torch.linspace(0.2, rcfg.max_sample_depth, steps=U))
+    anchors = dv(orc.gaussian_anchor_distances(orc.OracleConfig.kitti(n_pts_uni=U, n_pts_per_gaussian=P)))
+    offs = torch.zeros((R, G, 2), device=DEV)
+    rng = torch.tensor([777, 0, 0], dtype=torch.int64, device=DEV)
+
+    def chunk():
+        unit, vd, du = torch.empty((R, 3), device=DEV), torch.empty((R, 3), device=DEV), torch.empty((R, U), device=DEV)
+        _capi.check(lib.scenerf_hip_ray_setup(C.byref(cc), pix.data_ptr(), iK.data_ptr(), T.data_ptr(), lin.data_ptr(), None, rng.data_ptr(), R,
+                                              unit.data_ptr(), vd.data_ptr(), du.data_ptr(), _st()), "ray_setup")
+        ng = torch.full((R, G * P), float("nan"), device=DEV)
+        gm, gs = torch.empty((R, G), device=DEV), torch.empty((R, G), device=DEV)
+        ds, zs = torch.empty((R, N), device=DEV), torch.empty((R, N), device=DEV)
+        perm = torch.empty((R, N), dtype=torch.int32, device=DEV)
+        _capi.check(lib.scenerf_hip_gaussian_sample_sort(C.byref(cc), offs.data_ptr(), anchors.data_ptr(), du.data_ptr(), ng.data_ptr(),
+                                                         rng.data_ptr(), unit.data_ptr(), R, gm.data_ptr(), gs.data_ptr(), ds.data_ptr(),
+                                                         zs.data_ptr(), perm.data_ptr(), _st()), "gaussian_sample_sort")
+        torch.cuda.synchronize()
+        nu = ((du - lin[None, :]) / rcfg.to_c().uni_step).double().cpu()
+        return nu, ng.double().cpu(), ds.cpu(), gm.cpu(), gs.cpu(), perm.cpu()
+
+    nu1, ng1, ds1, gm1, gs1, perm1 = chunk()
+    assert rng.tolist()[:2] == [777, 1]
+    nu2, ng2, _, _, _, _ = chunk()
+    assert rng.tolist()[:2] == [777, 2]
+    for nu in (nu1, nu2):           # U[0, 1): n = 131,072 -> SE of the mean 8e-4
+        assert float(nu.min()) >= -1e-4 and float(nu.max()) < 1.0 + 1e-4
+        assert abs(float(nu.mean()) - 0.5) < 5e-3 and abs(float(nu.var()) - 1.0 / 12.0) < 2e-3
+    for ng in (ng1, ng2):           # N(0, 1): n = 131,072
+        assert bool(torch.isfinite(ng).all())
+        assert abs(float(ng.mean())) < 1.5e-2 and abs(float(ng.std()) - 1.0) < 1.5e-2
+        assert abs(float((ng ** 4).mean()) - 3.0) < 0.15 and abs(float((ng ** 3).mean())) < 0.06
+    assert float((nu1 - nu2).abs().mean()) > 0.2 and float((ng1 - ng2).abs().mean()) > 0.5       # fresh per call
+    assert abs(float((nu1[:, :-1] * nu1[:, 1:]).mean()) - 0.25) < 5e-3                            # neighbours uncorrelated
+    # the sampler used the noise it wrote: samples = clamp(mean + noise * std, 0.1), merged with the uniform ones and sorted
+    d_g = torch.clamp(gm1.double().repeat_interleave(P, 1) + ng1 * gs1.double().repeat_interleave(P, 1), min=0.1)
+    got = torch.sort(ds1.double(), dim=1).values
+    want = torch.sort(torch.cat([(nu1 * rcfg.to_c().uni_step + lin.double().cpu()[None, :]), d_g], dim=1), dim=1).values
+    assert float((got - want).abs().max()) < 1e-4
+    assert bool((torch.sort(perm1, dim=1).values == torch.arange(N)[None, :]).all())
+    rng.copy_(torch.tensor([777, 0, 0]))
+    nu1b, ng1b, _, _, _, _ = chunk()
+    assert torch.equal(nu1, nu1b) and torch.equal(ng1, ng1b)                                      # same state, same values
 
 
 def test_ray_setup(case):
@@ -272,7 +329,7 @@ def test_gaussian_sample_sort(case):
     zs = torch.empty((R, N), device=DEV)
     perm = torch.empty((R, N), dtype=torch.int32, device=DEV)
     _capi.check(lib.scenerf_hip_gaussian_sample_sort(C.byref(cc), dv(o["_offsets"]).data_ptr(), dv(anchors).data_ptr(),
-                                                     dv(o["_dist_u"]).data_ptr(), dv(g.noise_g).data_ptr(), dv(o["_unit"]).data_ptr(),
+                                                     dv(o["_dist_u"]).data_ptr(), dv(g.noise_g).data_ptr(), None, dv(o["_unit"]).data_ptr(),
                                                      R, gm.data_ptr(), gs.data_ptr(), ds.data_ptr(), zs.data_ptr(), perm.data_ptr(),
                                                      _st()), "gaussian_sample_sort")
     assert torch.equal(gm.cpu(), o["gaussian_means"].detach())
