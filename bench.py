@@ -132,6 +132,8 @@ def parse():
                     help="untimed steps issued as part of the setup, before the W warm-up steps: the GPU idles through model construction and "
                          "capture and its clocks take a few hundred ms of load to settle (20 timed steps right after 5 warm-ups measure "
                          "2-4 %% slower than the 300-step steady_state of the same process); 0 = rounds 1-3 behaviour")
+    ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE",
+                    help="development: set a module-level knob of scenerf_amd before the run, e.g. --set renderer.PREFILL_AT=3")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed region (no eager / other-entry / drop-in / steady-state / roofline legs): what a profiler should see")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short BASELINE configs[3] (BundleFusion) and configs[4] (inference) legs")
@@ -143,6 +145,11 @@ def parse():
     ap.add_argument("--no-eager-baseline", action="store_true")
     ap.add_argument("--kernels-json", default="", help="write the per-kernel table here")
     a = ap.parse_args()
+    for kv in a.set:
+        import ast, importlib
+        path, val = kv.split("=", 1)
+        modname, attr = path.rsplit(".", 1)
+        setattr(importlib.import_module("scenerf_amd." + modname), attr, ast.literal_eval(val))
     if a.headline_only:
         a.no_roofline = a.no_extra_legs = a.no_cpu_baseline = a.no_eager_baseline = a.no_fp32_mode = True
     if a.steps is None:

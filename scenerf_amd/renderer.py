@@ -51,10 +51,12 @@ def _on(dev):
 
 
 _SIDE = {}
-PREFILL_AT = 2               # where a training session zeroes the map-gradient accumulators on the side stream: 0 = at the session's
-                             # start (beside the gaussian head's chain), 1 = behind the head's forward, 2 = behind the radiance MLP's
-                             # (2.635 / -- / 2.622 ms per step: the fill no longer runs beside the head's latency-bound chain;
-                             #  beside the radiance MLP's forward instead of behind it: +16 us, not offered)
+PREFILL_AT = 1               # where a training session zeroes the map-gradient accumulators (217 MB at KITTI) on the side stream: 0 = at the
+                             # session's start (beside the gaussian head's chain), 1 = behind the head's forward (beside the sampler, the radiance
+                             # MLP's encode / gather and the start of its forward), 2 = behind the radiance MLP's forward (beside the per-ray tail
+                             # and the loss: latency-bound kernels that a 58-us fill over all CUs slows 2-3x: ray_tail_fwd 17 -> 45 us), 3 = behind
+                             # the tail's backward (beside lin_out's reduction and the chain).  As replayed hipGraphs, 400 steps, three runs each
+                             # on one box (r04): 1: 2.569-2.583 ms, 2: 2.587-2.623, 3: 2.627-2.632.  (r03, eager issue: 0: 2.635, 2: 2.622.)
 MAIN_WGRAD_OVERLAP = True    # radiance MLP's weight gradients on the library's side stream, beside its feature-map gradients (-35 us/step)
 DEFER_HEAD_PACK = True     # (tools/ab_step.py toggles this)
 
@@ -734,6 +736,9 @@ class RenderChunk(torch.autograd.Function):
                                                       k["kl_saved"].data_ptr(), _capi.ptr(g_kl), _capi.ptr(g_gmeans), _capi.ptr(g_gstds),
                                                       d_logits.data_ptr(), d_off.data_ptr(), None, None, st), "ray_tail_backward")
         want_maps = bool(ctx.needs_input_grad[10])
+        if PREFILL_AT == 3 and want_maps and getattr(ctx.maps, "_want_prefill", False):
+            ctx.maps._want_prefill = False
+            ctx.maps.prefill_grad_accumulators()      # (side stream, behind the per-ray tail's backward: beside lin_out's reduction and the chain)
         # The gaussian head's backward (R*G rows: small grids) is independent of the radiance MLP's backward: run it
         # on a side stream so its workgroups fill the gaps of the big GEMMs.  Both scatter into the same map-gradient
         # accumulators with atomics; the main stream waits for the side stream before anything reads them.
