@@ -545,7 +545,7 @@ class _MlpRun:
 
 
 def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dist_ray_stride, ppr, unit_dir, viewdir,
-              K, inv_K, T, M, keep_acts: bool = True) -> _MlpRun:
+              K, inv_K, T, M, keep_acts: bool = True, before_forward=None) -> _MlpRun:
     lib = _capi.load()
     st = _stream(dist.device)
     run = _MlpRun(M, pk.d_out, cfg.precision_code, dist.device, lean=(not keep_acts) and cfg.uses_fused(M),
@@ -558,6 +558,8 @@ def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dis
                                                 run.Z.data_ptr(), run.tile_mask.data_ptr(), run.tap_texel.data_ptr(),
                                                 run.tap_weight.data_ptr(), st), "gather_features")
     pk.wait_ready()   # (the operands may have been packed on the side stream: first needed here, behind the encode and the gather)
+    if before_forward is not None:
+        before_forward()
     _capi.check(lib.scenerf_hip_mlp_forward(C.byref(ccfg), C.byref(pk.c), run.Z.data_ptr(), _capi.ptr(run.xenc),
                                             run.tile_mask.data_ptr(), M, C.byref(run.c), st), "mlp_forward")
     return run
@@ -633,7 +635,11 @@ class RenderChunk(torch.autograd.Function):
         # gaussian head on the G anchors per ray (scenerf.py:549-596)
         # (grad mode is off inside Function.forward: whether a backward can follow is what needs_input_grad says)
         keep = any(ctx.needs_input_grad)
-        run_g = _mlp_eval(ccfg, cfg, maps, mlpg.packed, anchors, 0, G, unit_dir, viewdir, K, iK, T, R * G, keep)
+        def _prefill4():
+            if PREFILL_AT == 4 and getattr(maps, "_want_prefill", False):
+                maps._want_prefill = False
+                maps.prefill_grad_accumulators()
+        run_g = _mlp_eval(ccfg, cfg, maps, mlpg.packed, anchors, 0, G, unit_dir, viewdir, K, iK, T, R * G, keep, before_forward=_prefill4)
         if PREFILL_AT == 1 and getattr(maps, "_want_prefill", False):
             maps._want_prefill = False
             maps.prefill_grad_accumulators()
