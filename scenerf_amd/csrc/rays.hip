@@ -67,20 +67,28 @@ struct SphereConsts {
 
 // x3 (bf16 mode, may be NULL): the split-bf16 encoding [M][144] = [hi(48) | lo(48) | hi(48)] the first hidden GEMM consumes (mlp.hip:
 // split_xenc_kernel -- same values, bit for bit), written from here so that the fp32 encoding never makes the round trip through HBM.
-// A thread's row is 288 bytes: staged per wave in LDS and written back as 18 fully coalesced 1-KiB stores (the wave's 64 rows are
-// one contiguous 18-KiB range) instead of 64 row-strided pieces per store instruction.
+// FOUR threads per row (round 4): the 36 precise sines of a row's positional encoding are ~3,600 instructions -- with one thread per
+// row the kernel was one long serial chain per thread (18-28 us for the gaussian head's 4,800 rows on 19 CUs, 22 us for a training
+// chunk's 153,600: latency, not throughput) and 34 KB of straight-line code; thread (row, part) now evaluates the (frequency, phase)
+// pairs 3 part .. 3 part + 2, i.e. nine sines.  Every thread of a row recomputes the row's point (30 instructions); part 0 writes the
+// per-row outputs.  A block's 64 rows are staged in LDS (the fp32 encoding, then its split form) and leave as fully coalesced 16-byte
+// stores (a row is 192 / 288 bytes: the block's rows are one contiguous range).
 #define ENC_X3_ROW (3 * SCENERF_D_XENC * 2)          // 288 bytes
 #define ENC_X3_LD (ENC_X3_ROW + 16)                   // LDS row stride (16-byte aligned, off the 32-bank period)
+#define ENC_ROWS 64                                   // rows per 256-thread block
+#define ENC_F32_LD (SCENERF_D_XENC + 4)               // fp32 staging row stride in floats (16-byte aligned rows)
 __global__ __launch_bounds__(256) void encode_points_kernel(const float* __restrict__ dist, int dist_ray_stride, int ppr,
                                      const float* __restrict__ unit_dir, const float* __restrict__ viewdir,
                                      const float* __restrict__ K, const float* __restrict__ iK,
                                      const float* __restrict__ T, SphereConsts sc, int M,
                                      float* __restrict__ pts_out, int32_t* __restrict__ sphere_idx,
                                      float* __restrict__ xenc, bf16_t* __restrict__ x3) {
-    __shared__ __attribute__((aligned(16))) char s_x3[4][64 * ENC_X3_LD];
-    const int m_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float s_f32[ENC_ROWS * ENC_F32_LD];
+    __shared__ __attribute__((aligned(16))) char s_x3[ENC_ROWS * ENC_X3_LD];
+    const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int m0 = blockIdx.x * ENC_ROWS;
+    const int m_raw = m0 + row;
     const bool live = m_raw < M;
-    if (!x3 && !live) return;
     const int m = live ? m_raw : M - 1;   // (rows past M: computed on the last row, never stored)
     int r = m / ppr, j = m - r * ppr;
     float d = dist[(size_t)r * dist_ray_stride + j];
@@ -89,90 +97,96 @@ __global__ __launch_bounds__(256) void encode_points_kernel(const float* __restr
     float qx = dot4(T[0], T[1], T[2], T[3], px, py, pz, 1.f);
     float qy = dot4(T[4], T[5], T[6], T[7], px, py, pz, 1.f);
     float qz = dot4(T[8], T[9], T[10], T[11], px, py, pz, 1.f);
-    if (pts_out && live) {
-        pts_out[3 * (size_t)m] = qx;
-        pts_out[3 * (size_t)m + 1] = qy;
-        pts_out[3 * (size_t)m + 2] = qz;
+    if (part == 0) {
+        if (pts_out && live) {
+            pts_out[3 * (size_t)m] = qx;
+            pts_out[3 * (size_t)m + 1] = qy;
+            pts_out[3 * (size_t)m + 2] = qz;
+        }
+        // cam_pts_2_pix, utils.py:298-315
+        float h0 = dot3(K[0], K[1], K[2], qx, qy, qz);
+        float h1 = dot3(K[3], K[4], K[5], qx, qy, qz);
+        float h2 = dot3(K[6], K[7], K[8], qx, qy, qz);
+        float u = -1.f, v = -1.f;
+        if (h2 > 0.f) {
+            u = h0 / h2;
+            v = h1 / h2;
+        }
+        // SphericalMapping.from_pixels at depth 1, spherical_mapping.py:80-115
+        float cx = dot3(iK[0], iK[1], iK[2], u, v, 1.f);
+        float cy = dot3(iK[3], iK[4], iK[5], u, v, 1.f);
+        float cz = dot3(iK[6], iK[7], iK[8], u, v, 1.f);
+        float cd = sqrtf(cx * cx + cy * cy + cz * cz);
+        float v_angle = acosf(-cy / cd) / PI_F * 180.f;
+        float h_angle = 180.f - atan2f(cz, cx) / PI_F * 180.f;
+        float ox = (h_angle - sc.h_min) / sc.h_fov * (float)(sc.W - 1);
+        float oy = (v_angle - sc.v_min) / sc.v_fov * (float)(sc.H - 1);
+        // torch.round = half-to-even = rintf; clamp so the int conversion is defined for far-out points
+        ox = fminf(fmaxf(rintf(ox), -1.0e9f), 1.0e9f);
+        oy = fminf(fmaxf(rintf(oy), -1.0e9f), 1.0e9f);
+        if (!(ox == ox)) ox = -1.0e9f;
+        if (!(oy == oy)) oy = -1.0e9f;
+        if (live) {
+            sphere_idx[2 * (size_t)m] = (int32_t)ox;
+            sphere_idx[2 * (size_t)m + 1] = (int32_t)oy;
+        }
     }
-    // cam_pts_2_pix, utils.py:298-315
-    float h0 = dot3(K[0], K[1], K[2], qx, qy, qz);
-    float h1 = dot3(K[3], K[4], K[5], qx, qy, qz);
-    float h2 = dot3(K[6], K[7], K[8], qx, qy, qz);
-    float u = -1.f, v = -1.f;
-    if (h2 > 0.f) {
-        u = h0 / h2;
-        v = h1 / h2;
-    }
-    // SphericalMapping.from_pixels at depth 1, spherical_mapping.py:80-115
-    float cx = dot3(iK[0], iK[1], iK[2], u, v, 1.f);
-    float cy = dot3(iK[3], iK[4], iK[5], u, v, 1.f);
-    float cz = dot3(iK[6], iK[7], iK[8], u, v, 1.f);
-    float cd = sqrtf(cx * cx + cy * cy + cz * cz);
-    float v_angle = acosf(-cy / cd) / PI_F * 180.f;
-    float h_angle = 180.f - atan2f(cz, cx) / PI_F * 180.f;
-    float ox = (h_angle - sc.h_min) / sc.h_fov * (float)(sc.W - 1);
-    float oy = (v_angle - sc.v_min) / sc.v_fov * (float)(sc.H - 1);
-    // torch.round = half-to-even = rintf; clamp so the int conversion is defined for far-out points
-    ox = fminf(fmaxf(rintf(ox), -1.0e9f), 1.0e9f);
-    oy = fminf(fmaxf(rintf(oy), -1.0e9f), 1.0e9f);
-    if (!(ox == ox)) ox = -1.0e9f;
-    if (!(oy == oy)) oy = -1.0e9f;
-    if (live) {
-        sphere_idx[2 * (size_t)m] = (int32_t)ox;
-        sphere_idx[2 * (size_t)m + 1] = (int32_t)oy;
-    }
-    // PositionalEncoding pe.py:32-43: [x, sin(f0 x), sin(f0 x + pi/2), ...] then viewdir, zero pad to 48
-    float e[SCENERF_D_XENC];
-    float q[3] = {qx, qy, qz};
-    e[0] = qx;
-    e[1] = qy;
-    e[2] = qz;
-    float f = PI_F;
+    // PositionalEncoding pe.py:32-43: [x, sin(f0 x), sin(f0 x + pi/2), ...] then viewdir, zero pad to 48.  Columns of this thread:
+    // 3 + 3 i + c for the (frequency, phase) pairs i = 3 part .. 3 part + 2 (pair i = frequency i / 2, phase i & 1); part 0 adds columns
+    // 0..2 (the point), part 3 columns 39..47 (viewdir, padding)
+    const float q[3] = {qx, qy, qz};
+    float e[9];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int t = 0; t < 3; ++t) {
+        const int i = 3 * part + t;
+        float f = PI_F;
+        for (int k = 0; k < (i >> 1); ++k) f *= 2.f;      // (pi 2^k: the reference's freq_factor * 2 ** k, exact doublings)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float a = q[c] * f;  // addcmul: phase + x*f, product rounded first
-            e[3 + (2 * k) * 3 + c] = sinf(a);
-            e[3 + (2 * k + 1) * 3 + c] = sinf(HALF_PI_F + a);
+            const float a = q[c] * f;  // addcmul: phase + x*f, product rounded first
+            e[3 * t + c] = sinf((i & 1) ? HALF_PI_F + a : a);
         }
-        f *= 2.f;
     }
-    e[39] = viewdir[3 * r];
-    e[40] = viewdir[3 * r + 1];
-    e[41] = viewdir[3 * r + 2];
+    // the row's fp32 encoding into LDS, column by column ...
+    float* const rowf = s_f32 + row * ENC_F32_LD;
 #pragma unroll
-    for (int c = 42; c < SCENERF_D_XENC; ++c) e[c] = 0.f;
-    if (xenc && live) {
-        float* o = xenc + (size_t)m * SCENERF_D_XENC;
+    for (int t = 0; t < 9; ++t) rowf[3 + 9 * part + t] = e[t];
+    if (part == 0) { rowf[0] = qx; rowf[1] = qy; rowf[2] = qz; }
+    if (part == 3) {
+        rowf[39] = viewdir[3 * r]; rowf[40] = viewdir[3 * r + 1]; rowf[41] = viewdir[3 * r + 2];
 #pragma unroll
-        for (int c = 0; c < SCENERF_D_XENC; c += 4) *(float4*)(o + c) = make_float4(e[c], e[c + 1], e[c + 2], e[c + 3]);
+        for (int c = 42; c < SCENERF_D_XENC; ++c) rowf[c] = 0.f;
+    }
+    __syncthreads();
+    const int nrows = min(M - m0, ENC_ROWS);
+    if (xenc) {   // ... out as the block's contiguous [nrows][48] fp32 range, 16 bytes per thread and pass
+        float* const g = xenc + (size_t)m0 * SCENERF_D_XENC;
+        for (int v = threadIdx.x; v < nrows * (SCENERF_D_XENC / 4); v += 256) {
+            const int rr = v / (SCENERF_D_XENC / 4), cc = v - rr * (SCENERF_D_XENC / 4);
+            *(float4*)(g + (size_t)rr * SCENERF_D_XENC + 4 * cc) = *(const float4*)(s_f32 + rr * ENC_F32_LD + 4 * cc);
+        }
     }
     if (x3) {
         // one row of slack behind [M][144]: lin_in's weight gradient reads the rows in 256-column tiles (scenerf_hip.h: h0pre) -- zeroed here
         if (blockIdx.x == gridDim.x - 1 && threadIdx.x < ENC_X3_ROW / 4) ((uint32_t*)((char*)x3 + (size_t)M * ENC_X3_ROW))[threadIdx.x] = 0u;
-        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        char* const row = s_x3[wv] + lane * ENC_X3_LD;
+        // ... and split: thread (row, part) takes columns 12 part .. 12 part + 11.  x = hi + lo, hi = bf16(x), lo = bf16(x - hi): mlp.hip
+        // split_xenc_kernel
+        char* const rowp = s_x3 + row * ENC_X3_LD;
 #pragma unroll
-        for (int c = 0; c < SCENERF_D_XENC; c += 2) {
-            // x = hi + lo, hi = bf16(x), lo = bf16(x - hi): mlp.hip split_xenc_kernel
-            const uint32_t hi = pack_bf16x2(e[c], e[c + 1]);
-            const uint32_t lo = pack_bf16x2(e[c] - bf16lo(hi), e[c + 1] - bf16hi(hi));
-            *(uint32_t*)(row + c * 2) = hi;
-            *(uint32_t*)(row + SCENERF_D_XENC * 2 + c * 2) = lo;
-            *(uint32_t*)(row + SCENERF_D_XENC * 4 + c * 2) = hi;
+        for (int t = 0; t < 6; ++t) {
+            const int c = 12 * part + 2 * t;
+            const float v0 = rowf[c], v1 = rowf[c + 1];
+            const uint32_t hi = pack_bf16x2(v0, v1);
+            const uint32_t lo = pack_bf16x2(v0 - bf16lo(hi), v1 - bf16hi(hi));
+            *(uint32_t*)(rowp + c * 2) = hi;
+            *(uint32_t*)(rowp + SCENERF_D_XENC * 2 + c * 2) = lo;
+            *(uint32_t*)(rowp + SCENERF_D_XENC * 4 + c * 2) = hi;
         }
         __syncthreads();
-        const int m0 = blockIdx.x * blockDim.x + wv * 64;      // first row of this wave
         char* const g = (char*)x3 + (size_t)m0 * ENC_X3_ROW;
-        const int nbytes = (min(M - m0, 64)) * ENC_X3_ROW;     // (<= 0 for a wave past M)
-#pragma unroll
-        for (int it = 0; it < ENC_X3_ROW * 64 / 1024; ++it) {
-            const int off = (it * 64 + lane) * 16;
-            if (off < nbytes) {
-                const int rr = off / ENC_X3_ROW, cc = off - rr * ENC_X3_ROW;
-                *(uint4*)(g + off) = *(const uint4*)(s_x3[wv] + rr * ENC_X3_LD + cc);
-            }
+        for (int v = threadIdx.x; v < nrows * (ENC_X3_ROW / 16); v += 256) {
+            const int rr = v / (ENC_X3_ROW / 16), cc = v - rr * (ENC_X3_ROW / 16);
+            *(uint4*)(g + (size_t)rr * ENC_X3_ROW + 16 * cc) = *(const uint4*)(s_x3 + rr * ENC_X3_LD + 16 * cc);
         }
     }
 }
@@ -1415,7 +1429,7 @@ int scenerf_hip_encode_points(const scenerf_cfg* cfg, const float* dist, int dis
     hipStream_t s = as_stream(stream);
     SphereConsts sc{cfg->v_min, cfg->v_fov, cfg->h_min, cfg->h_fov, cfg->sphere_W, cfg->sphere_H};
     SrfLaunchScope ps(s, "encode_points", 0, (double)M * (4 + 8 + (xenc ? 4.0 * SCENERF_D_XENC : 0.0) + (x3 ? 6.0 * SCENERF_D_XENC : 0.0)));
-    encode_points_kernel<<<cdiv(M, 256), 256, 0, s>>>(dist, dist_ray_stride, pts_per_ray, unit_dir, viewdir, K, inv_K, T_s2i,
+    encode_points_kernel<<<cdiv(M, ENC_ROWS), 256, 0, s>>>(dist, dist_ray_stride, pts_per_ray, unit_dir, viewdir, K, inv_K, T_s2i,
                                                       sc, M, pts, sphere_idx, xenc, (bf16_t*)x3);
     SRF_LAUNCH_CHECK("encode_points_kernel");
     return 0;

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.." || exit 1
 rounds=${1:-3}; shift
 for i in $(seq 1 $rounds); do
   for t in .base_tree .; do
-    python $t/bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-eager-baseline --no-fp32-mode --no-roofline --no-extra-legs "$@" 2>/dev/null | python -c "
+    python $t/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-eager-baseline --no-fp32-mode --no-roofline --no-extra-legs "$@" 2>/dev/null | python -c "
 import json,sys
 b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-12s %.3f ms/step  %.0f rays/s  host %.3f' % ('$t', b['ms_per_step'], b['value'], b.get('host_issue_ms_per_step', float('nan'))))"
   done
