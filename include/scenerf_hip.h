@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SCENERF_HIP_ABI_VERSION 6
+#define SCENERF_HIP_ABI_VERSION 7
 #define SCENERF_N_SCALES 5          /* feature maps "1_1","1_2","1_4","1_8","1_16" */
 #define SCENERF_D_LATENT 2480       /* 80+160+320+640+1280 (resnetfc d_latent, scenerf.py:100-114) */
 #define SCENERF_D_HIDDEN 512
@@ -92,6 +92,10 @@ typedef struct scenerf_cfg {
                                            * the chain then also makes lin_out's input gradient (dH column block 3) from d_logits and H3's sign bits */
 #define SCENERF_FLAG_WIDE_BWD_STAGED 256u /* ... but reads dH column block 3 as linout_bwd wrote it, like fused.hip's chain (tests, A/B runs: bit-identical
                                            * to the per-layer dgrad GEMMs) */
+#define SCENERF_FLAG_PACK_FORWARD   512u  /* scenerf_hip_mlp_pack in two calls (bf16 with w_stream; otherwise ignored): this one packs what a forward
+                                            * pass reads (untransposed operands, their w_stream blocks, biases) ... */
+#define SCENERF_FLAG_PACK_REST     1024u  /* ... this one the rest (transposed operands, their w_stream blocks, w_z_t, the `clear` zeroes): a forward
+                                            * can be ordered behind the first call alone */
 
 /* Packed ResnetFC operands (built by the host from the nn.Linear parameters).
  * T = float (precision 0) or bf16 (precision 1).  reference scenerf/models/resnetfc.py:88-118,133-164 */
@@ -404,10 +408,13 @@ typedef struct scenerf_adamw_tensor {
 } scenerf_adamw_tensor;
 int scenerf_hip_adamw_step(int count, const scenerf_adamw_tensor* tensors, float lr, float beta1, float beta2, float eps,
                            float weight_decay, scenerf_stream_t stream);
-/* The capturable form (torch.optim.AdamW(capturable=True)): the learning rate and the step count -- INCLUDING this step, the same for
- * every tensor -- are read from device memory, hyper = [lr, t] (fp32), so a hipGraph that holds this launch advances when the caller's
- * graph (or a copy in front of the replay) updates them; bias corrections are formed on the device in fp32.  tensors[i].step is ignored. */
-int scenerf_hip_adamw_step_dev(int count, const scenerf_adamw_tensor* tensors, const float* hyper, float beta1, float beta2, float eps,
+/* The capturable form (torch.optim.AdamW(capturable=True)): the learning rate and the step count are read from device memory,
+ * hyper = [lr, t, scratch[SCENERF_ADAMW_SCRATCH]] (fp32; scratch zero-initialised by the caller, owned by the kernel): t = the steps completed BEFORE this
+ * call, the same for every tensor; the update uses t + 1 and the launch stores t + 1 back when its last workgroup retires, so a
+ * hipGraph that holds this launch counts on with every replay and no separate increment is launched.  Bias corrections are formed on
+ * the device in fp32.  tensors[i].step is ignored. */
+#define SCENERF_ADAMW_SCRATCH 65
+int scenerf_hip_adamw_step_dev(int count, const scenerf_adamw_tensor* tensors, float* hyper, float beta1, float beta2, float eps,
                                float weight_decay, scenerf_stream_t stream);
 
 /* ---- image -> sphere resampling of the encoder levels --------------------------------------------------------

@@ -23,7 +23,7 @@ D_HIDDEN = 512
 D_XENC = 48
 TILE_ROWS = 128
 W_STREAM_BLOCKS = (3 * D_XENC + D_LATENT) // 16 + 2 * ((512 + D_LATENT) // 16) + 10 * (512 // 16)   # scenerf_hip.h
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 vp = C.c_void_p
 
@@ -160,6 +160,8 @@ FUSED_MIN_ROWS_DEFAULT = 4096    # SCENERF_FUSED_MIN_ROWS_DEFAULT
 FLAG_NO_FUSED_BWD, FLAG_NO_WGRAD_TR, FLAG_DFEAT_PER_SCALE, FLAG_WGRAD_OVERLAP, FLAG_WIDE_BWD, FLAG_WIDE_ANY_M, FLAG_DFEAT_GEMM = 1, 2, 4, 8, 16, 32, 64   # SCENERF_FLAG_*
 FLAG_UNIFORM_ONLY = 128
 FLAG_WIDE_BWD_STAGED = 256
+FLAG_PACK_FORWARD, FLAG_PACK_REST = 512, 1024
+ADAMW_SCRATCH = 65        # SCENERF_ADAMW_SCRATCH: words behind [lr, t] in scenerf_hip_adamw_step_dev's hyper
 WIN_LD = 256            # SCENERF_WIN_LD: row stride of scenerf_mlp_grads.w_in
 
 

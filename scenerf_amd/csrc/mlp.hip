@@ -469,6 +469,9 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     if (!dh3_in_chain) {
         if (int e = fork()) return e;
     }
+    // (r04: the feature-map gradients launched in FRONT of the side stream's weight gradients -- so that, as the first-captured successor
+    // of the chain kernel, they keep its queue in a replayed graph -- cost 36 us: the batched weight-gradient launch is one round of 240
+    // long-lived workgroups, and behind dfeat's 1,200 it gets its CUs late and staggered: 742 against 593 us.  Weight gradients first.)
     if (fused_chain) {
         if (int e = wide_chain ? launch_mlp_bwd_wide(cfg, w, M, a, dH, dN, dh3_in_chain ? d_logits : nullptr, s) : launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
         if (int e = fork()) return e;
@@ -650,11 +653,27 @@ struct PackJob {
 struct PackTable {
     PackJob job[PACK_MAX_JOBS];
     int njobs;
+    // the four hidden-layer bias vectors ride in the same launch as two more blocks behind the tiles (a launch of their own was the third
+    // dependent launch in front of a training step's first GEMM): b_h[0] = lin_z.0.bias (+ lin_in.bias when lin_in is fused),
+    // b_h[1] = fc_1.0.bias + lin_z.1.bias, b_h[2] = fc_1.1.bias + lin_z.2.bias, b_h[3] = fc_1.2.bias
+    int bias_block0;              // first of the two bias blocks, or -1
+    const float *a0, *c0, *a1, *z1, *a2, *z2, *a3;
+    float *o0, *o1, *o2, *o3;
 };
 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_kernel(PackTable tab) {
     __shared__ float tile[64][65];
+    if (tab.bias_block0 >= 0 && (int)blockIdx.x >= tab.bias_block0) {
+        const int i = ((int)blockIdx.x - tab.bias_block0) * 256 + threadIdx.x;
+        if (i < SCENERF_D_HIDDEN) {
+            tab.o0[i] = tab.a0[i] + (tab.c0 ? tab.c0[i] : 0.f);
+            tab.o1[i] = tab.a1[i] + tab.z1[i];
+            tab.o2[i] = tab.a2[i] + tab.z2[i];
+            tab.o3[i] = tab.a3[i];
+        }
+        return;
+    }
     int j = 0;
     while (j + 1 < tab.njobs && (int)blockIdx.x >= tab.job[j + 1].tile0) ++j;
     const PackJob J = tab.job[j];
@@ -685,17 +704,6 @@ __global__ __launch_bounds__(256) void pack_kernel(PackTable tab) {
     }
 }
 
-// b_h[0] = lin_z.0.bias (+ lin_in.bias when lin_in is fused), b_h[1] = fc_1.0.bias + lin_z.1.bias, ...
-__global__ void pack_bias_kernel(const float* a0, const float* c0, const float* a1, const float* z1, const float* a2, const float* z2,
-                                 const float* a3, float* o0, float* o1, float* o2, float* o3) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= SCENERF_D_HIDDEN) return;
-    o0[i] = a0[i] + (c0 ? c0[i] : 0.f);
-    o1[i] = a1[i] + z1[i];
-    o2[i] = a2[i] + z2[i];
-    o3[i] = a3[i];
-}
-
 // w_stream (scenerf_hip.h): the seven forward operands re-tiled into 16 KiB blocks [512 rows][32 B] per 16 columns of K, the
 // two 16-byte halves of row r swapped when (r >> 3) & 1 -- the LDS image fused.hip's fragment reads expect, so a streaming
 // piece (1 KiB per wave) is contiguous in memory.  One thread per 16-byte half row.
@@ -704,11 +712,12 @@ struct StreamSrc {
     const bf16_t* W[STREAM_OPS];
     int ld[STREAM_OPS];
     int block0[STREAM_OPS + 1];   // first block of each operand; the last entry = total
+    int first, last;              // this launch writes blocks [first, last)
 };
 __global__ __launch_bounds__(256) void pack_stream_kernel(StreamSrc t, uint4* __restrict__ dst) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = (blockIdx.x + 4 * t.first) * 256 + threadIdx.x;
     const int blk = idx >> 10;
-    if (blk >= t.block0[STREAM_OPS]) return;
+    if (blk >= t.last) return;
     int l = 0;
     while (blk >= t.block0[l + 1]) ++l;
     const int r = (idx & 1023) >> 1, ps = idx & 1;
@@ -727,8 +736,17 @@ extern "C" int scenerf_hip_mlp_pack(const scenerf_cfg* cfg, const scenerf_mlp_pa
     PackTable tab;
     tab.njobs = 0;
     int tiles = 0;
+    // Two-call form (bf16 with the streaming layout; SCENERF_FLAG_PACK_FORWARD, then SCENERF_FLAG_PACK_REST): the first call packs what a
+    // FORWARD pass reads (the untransposed operands, their streaming blocks, the biases), the second the rest (transposed operands
+    // and their streaming blocks, the per-level W_z^T, the gradient sink's zeroes) -- the gaussian head's forward is the first MFMA
+    // kernel of a training step and waited ~30 us for a pack of which it needs a third (r04 trace)
+    const bool split_ok = prec && W->w_stream;
+    const bool only_fwd = split_ok && (cfg->flags & SCENERF_FLAG_PACK_FORWARD), only_rest = split_ok && (cfg->flags & SCENERF_FLAG_PACK_REST);
+    SRF_CHECK(!(only_fwd && only_rest), "mlp_pack: SCENERF_FLAG_PACK_FORWARD and _REST are two calls");
+    bool fwd_job = true;   // class of the jobs being added
     auto add = [&](const float* src, void* dst, int rows, int cols, int src_ld, int dst_ld, int transpose, int mode, int valid_cols,
                    int dst_f32) {
+        if ((only_fwd && !fwd_job) || (only_rest && fwd_job)) return;
         if (tab.njobs >= PACK_MAX_JOBS) { ++tab.njobs; return; }
         PackJob& J = tab.job[tab.njobs++];
         J.src = src; J.dst = dst; J.rows = rows; J.cols = cols; J.src_ld = src_ld; J.dst_ld = dst_ld;
@@ -755,9 +773,12 @@ extern "C" int scenerf_hip_mlp_pack(const scenerf_cfg* cfg, const scenerf_mlp_pa
         add(P->fc1_w[b], (void*)W->w_h[b + 1], H, H, H, ld, 0, 0, H, 0);
         if (b < 2) add(P->linz_w[b + 1], at(W->w_h[b + 1], H), H, L, L, ld, 0, 0, L, 0);
         add(P->fc0_w[b], (void*)W->w_fc0[b], H, H, H, H, 0, 0, H, 0);
+        fwd_job = false;
         add(P->fc0_w[b], (void*)W->w_fc0_t[b], H, H, H, H, 1, 0, H, 0);
         add(P->fc1_w[b], (void*)W->w_fc1_t[b], H, H, H, H, 1, 0, H, 0);
+        fwd_job = true;
     }
+    fwd_job = false;
     int off = 0;
     for (int sc = 0; sc < 5; ++sc) {   // w_z_t[s][c][b*512 + n] = lin_z.b.weight[n][off_s + c]
         for (int b = 0; b < 3; ++b)
@@ -771,10 +792,15 @@ extern "C" int scenerf_hip_mlp_pack(const scenerf_cfg* cfg, const scenerf_mlp_pa
         if (rem > 0) add(nullptr, W->clear + full * cols, 1, (int)rem, 0, (int)rem, 0, 0, 0, 1);
     }
     SRF_CHECK(tab.njobs <= PACK_MAX_JOBS, "mlp_pack: job table overflow");
-    {
+    tab.bias_block0 = only_rest ? -1 : tiles;
+    tab.a0 = P->linz_b[0]; tab.c0 = prec ? P->lin_in_b : nullptr; tab.a1 = P->fc1_b[0]; tab.z1 = P->linz_b[1]; tab.a2 = P->fc1_b[1];
+    tab.z2 = P->linz_b[2]; tab.a3 = P->fc1_b[2];
+    tab.o0 = (float*)W->b_h[0]; tab.o1 = (float*)W->b_h[1]; tab.o2 = (float*)W->b_h[2]; tab.o3 = (float*)W->b_h[3];
+    const int blocks = tiles + (only_rest ? 0 : 2);
+    if (blocks > 0) {
         SrfLaunchScope ps(s, "mlp_pack", 0, 0);
-        if (prec) pack_kernel<bf16_t><<<tiles, 256, 0, s>>>(tab);
-        else pack_kernel<float><<<tiles, 256, 0, s>>>(tab);
+        if (prec) pack_kernel<bf16_t><<<blocks, 256, 0, s>>>(tab);
+        else pack_kernel<float><<<blocks, 256, 0, s>>>(tab);
         SRF_LAUNCH_CHECK("pack_kernel");
     }
     if (prec && W->w_stream) {
@@ -791,12 +817,11 @@ extern "C" int scenerf_hip_mlp_pack(const scenerf_cfg* cfg, const scenerf_mlp_pa
         }
         t.block0[STREAM_OPS] = nb;
         SRF_CHECK(nb == SCENERF_W_STREAM_BLOCKS, "mlp_pack: stream block count");
-        SrfLaunchScope ps(s, "mlp_pack_stream", 0, (double)nb * 32768);
-        pack_stream_kernel<<<nb * 4, 256, 0, s>>>(t, (uint4*)W->w_stream);
+        t.first = only_rest ? t.block0[7] : 0;      // operands 0..6: the forward's, 7..12: the dgrad chain's
+        t.last = only_fwd ? t.block0[7] : nb;
+        SrfLaunchScope ps(s, "mlp_pack_stream", 0, (double)(t.last - t.first) * 32768);
+        pack_stream_kernel<<<(t.last - t.first) * 4, 256, 0, s>>>(t, (uint4*)W->w_stream);
         SRF_LAUNCH_CHECK("pack_stream_kernel");
     }
-    pack_bias_kernel<<<2, 256, 0, s>>>(P->linz_b[0], prec ? P->lin_in_b : nullptr, P->fc1_b[0], P->linz_b[1], P->fc1_b[1], P->linz_b[2],
-                                       P->fc1_b[2], (float*)W->b_h[0], (float*)W->b_h[1], (float*)W->b_h[2], (float*)W->b_h[3]);
-    SRF_LAUNCH_CHECK("pack_bias_kernel");
     return 0;
 }

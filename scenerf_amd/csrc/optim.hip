@@ -24,9 +24,13 @@ struct OptArgs {
     int first_chunk[OPT_MAX_TENSORS + 1];   // prefix sum of chunks per tensor
     int count;
     float decay, b1, b2, eps;     // decay = 1 - lr * weight_decay
-    // capturable form (scenerf_hip_adamw_step_dev): the learning rate and the step count live in device memory, [lr, t] -- a replayed
-    // hipGraph then advances with them; bias corrections are formed here, in fp32, the same for every tensor of the launch
-    const float* hyper;
+    // capturable form (scenerf_hip_adamw_step_dev): the learning rate and the step count live in device memory, [lr, t, scratch] -- a
+    // replayed hipGraph then advances with them; bias corrections are formed here, in fp32, the same for every tensor of the launch.
+    // t = steps completed BEFORE this one; the workgroup that finishes last (a counter in the scratch word) stores t + 1 -- every
+    // workgroup has read t by then -- so counting the step is neither a launch of its own nor an edge in a captured graph (r04: the
+    // one-element add in front of the step was the root of the replayed graph, and the fork behind it cost the chain 14 us)
+    float* hyper;
+    int bump;                     // this launch counts the step (the last launch of a call)
     float wd;
 };
 
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(OptArgs a) {
     const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2;
     float decay = a.decay, step_size = T.step_size, inv_sqrt_bc2 = T.inv_sqrt_bc2;
     if (a.hyper) {
-        const float lr = a.hyper[0], t = a.hyper[1];
+        const float lr = a.hyper[0], t = a.hyper[1] + 1.f;
         decay = 1.f - lr * a.wd;
         step_size = lr / (1.f - powf(a.b1, t));
         inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(a.b2, t));
@@ -87,9 +91,29 @@ __global__ __launch_bounds__(256) void adamw_kernel(OptArgs a) {
                 if (e + q < T.n) { T.p[e + q] = p[q]; T.m[e + q] = m[q]; T.v[e + q] = v[q]; }
         }
     }
+    if (a.hyper && a.bump) {
+        // count the step: every workgroup has read t by the time the last one gets here.  Relaxed device-scope atomics and NO fence: a
+        // __threadfence() here is an L2 write-back on this multi-die part, and 2,664 workgroups each flushing the 130 MB this kernel
+        // has just written made it 162-198 us instead of 51 (r04).  Nothing needs one: a workgroup's read of t has returned before
+        // its atomic is issued (the barrier below), and the stores become visible to the next launch at the kernel boundary.  Two levels
+        // of counters (64 groups, then one) keep the returning atomics off a single address.
+        __syncthreads();          // (all of this workgroup's reads of t have returned)
+        if (threadIdx.x == 0) {
+            unsigned* cnt = (unsigned*)(a.hyper + 2);
+            const unsigned grp = blockIdx.x & 63u, ngrp = gridDim.x < 64u ? gridDim.x : 64u;
+            const unsigned in_grp = (gridDim.x - grp + 63u) >> 6;
+            if (__hip_atomic_fetch_add(cnt + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
+                __hip_atomic_store(cnt + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1) {
+                    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.hyper + 1, a.hyper[1] + 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
 }
 
-static int adamw_launch(int count, const scenerf_adamw_tensor* tensors, const float* hyper, float lr, float beta1, float beta2, float eps,
+static int adamw_launch(int count, const scenerf_adamw_tensor* tensors, float* hyper, float lr, float beta1, float beta2, float eps,
                         float weight_decay, scenerf_stream_t stream) {
     SRF_CHECK(tensors && count > 0, "adamw_step: no tensors");
     hipStream_t s = as_stream(stream);
@@ -97,7 +121,7 @@ static int adamw_launch(int count, const scenerf_adamw_tensor* tensors, const fl
         OptArgs a;
         a.count = count - base < OPT_MAX_TENSORS ? count - base : OPT_MAX_TENSORS;
         a.decay = 1.f - lr * weight_decay; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
-        a.hyper = hyper; a.wd = weight_decay;
+        a.hyper = hyper; a.wd = weight_decay; a.bump = (hyper && base + OPT_MAX_TENSORS >= count) ? 1 : 0;
         int chunks = 0;
         double bytes = 0;
         for (int i = 0; i < a.count; ++i) {
@@ -124,7 +148,7 @@ extern "C" int scenerf_hip_adamw_step(int count, const scenerf_adamw_tensor* ten
     return adamw_launch(count, tensors, nullptr, lr, beta1, beta2, eps, weight_decay, stream);
 }
 
-extern "C" int scenerf_hip_adamw_step_dev(int count, const scenerf_adamw_tensor* tensors, const float* hyper, float beta1, float beta2,
+extern "C" int scenerf_hip_adamw_step_dev(int count, const scenerf_adamw_tensor* tensors, float* hyper, float beta1, float beta2,
                                           float eps, float weight_decay, scenerf_stream_t stream) {
     SRF_CHECK(hyper, "adamw_step_dev: hyper is NULL");
     return adamw_launch(count, tensors, hyper, 0.f, beta1, beta2, eps, weight_decay, stream);

@@ -90,8 +90,6 @@ class GraphedStep:
             p.grad = None
         for v in self._map_leaves:
             v.grad = None
-        if self.optimizer is not None and hasattr(self.optimizer, "advance"):
-            self.optimizer.advance()    # the step count, bumped beside the forward instead of in front of the update kernel
         out = self.model.render_rays_batch(self.cam_K, self.T_source2infer, self.x_rgb, T_cam2velo=None, sampled_pixels=self.pixels,
                                            ray_batch_size=self.ray_batch_size, **({"noise": self.noise} if self.noise is not None else {}))
         loss = self.loss_fn(out)

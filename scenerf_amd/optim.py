@@ -8,8 +8,9 @@ optimizer first copies into a contiguous tensor.  amsgrad / maximize are not off
 (no fallback).
 
 ``capturable=True`` (like torch's): the step count and the learning rate live in a device tensor per parameter group (``hyper`` =
-[lr, t]); ``step()`` advances t with a device-side add and the kernel forms the bias corrections itself, so the call can sit inside a
-captured hipGraph (``scenerf_amd.graph.GraphedStep``) and every replay is one more optimizer step.  A learning rate changed by a
+[lr, t, scratch]); the update kernel forms the bias corrections from t + 1 itself and stores t + 1 back when its last workgroup
+retires (no increment launch: in a replayed graph that one-element add was a node the whole step hung behind), so the call can sit
+inside a captured hipGraph (``scenerf_amd.graph.GraphedStep``) and every replay is one more optimizer step.  A learning rate changed by a
 scheduler reaches a captured graph through ``sync_hyper()`` (one small fill, outside the graph).  All parameters of a group step
 together in this mode (a parameter without a gradient raises).
 """
@@ -29,7 +30,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, capturable=bool(capturable)))
-        self._hyper = {}      # index of the group in param_groups -> [device tensor [lr, t], the lr it holds]
+        self._hyper = {}      # index of the group in param_groups -> [device tensor [lr, t, kernel scratch], the lr it holds]
 
     def _group_index(self, group) -> int:
         for i, g in enumerate(self.param_groups):
@@ -43,7 +44,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if h is None:
             steps = [float(self.state[p]["step"]) for p in group["params"] if self.state.get(p)]
             t0 = float(max(steps)) if steps else 0.0
-            h = [torch.tensor([float(group["lr"]), t0], dtype=torch.float32, device=dev), float(group["lr"])]
+            h = [torch.tensor([float(group["lr"]), t0] + [0.0] * _capi.ADAMW_SCRATCH, dtype=torch.float32, device=dev), float(group["lr"])]
             self._hyper[gi] = h
         return h
 
@@ -74,19 +75,6 @@ class FusedAdamW(torch.optim.Optimizer):
             if h is not None and h[1] != float(group["lr"]):
                 h[0][0:1].fill_(float(group["lr"]))
                 h[1] = float(group["lr"])
-
-    @torch.no_grad()
-    def advance(self) -> None:
-        """Capturable mode: count the coming step NOW (t += 1 on the device) instead of inside ``step()``.  The increment is a launch of
-        its own that ``step()`` otherwise issues right in front of the update kernel -- at the very end of a training step's critical
-        chain; called at the top of the step (scenerf_amd.graph.GraphedStep does) it runs beside the forward.  The next ``step()`` of each
-        group then skips its own increment.  No-op for groups that have not stepped yet (their counter does not exist) and outside
-        capturable mode."""
-        for gi, group in enumerate(self.param_groups):
-            h = self._hyper.get(gi)
-            if group.get("capturable") and h is not None:
-                h[0][1:2].add_(1.0)
-                group["_advanced"] = True
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -141,12 +129,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     hyper, lr_held = self._group_hyper(group, dev)
                     if not torch.cuda.is_current_stream_capturing() and lr_held != float(group["lr"]):
                         self.sync_hyper()
-                    if group.pop("_advanced", False):
-                        pass                                    # (advance() has counted this step already)
-                    else:
-                        hyper[1:2].add_(1.0)                    # t, on the device: a replayed graph counts on
                     for p in group["params"]:
-                        self.state[p]["step"] = hyper[1]        # (like torch's capturable optimizers: a device scalar)
+                        self.state[p]["step"] = hyper[1]        # (like torch's capturable optimizers: a device scalar; the kernel counts)
                     _capi.check(lib.scenerf_hip_adamw_step_dev(len(entries), arr, hyper.data_ptr(), float(b1), float(b2), float(group["eps"]),
                                                                float(group["weight_decay"]), torch.cuda.current_stream(dev).cuda_stream),
                                 "adamw_step_dev")

@@ -57,8 +57,13 @@ PREFILL_AT = 1               # where a training session zeroes the map-gradient 
                              # and the loss: latency-bound kernels that a 58-us fill over all CUs slows 2-3x: ray_tail_fwd 17 -> 45 us), 3 = behind
                              # the tail's backward (beside lin_out's reduction and the chain).  As replayed hipGraphs, 400 steps, three runs each
                              # on one box (r04): 1: 2.569-2.583 ms, 2: 2.587-2.623, 3: 2.627-2.632.  (r03, eager issue: 0: 2.635, 2: 2.622.)
+                             # Also tried (r04): forked behind the head's gather, i.e. beside the head's forward alone: that kernel 117 -> 163 us
+                             # (its weight stream shares L2 with 217 MB of fill), the radiance MLP's encode + gather 125 -> 92 us: +14 us net.
+CHAIN_FIRST = True           # capture / issue order: at every fork the critical chain's next kernel is launched BEFORE the side stream's, and
+                             # the packs are launched behind the chain's first kernels (below: "Launch order")
 MAIN_WGRAD_OVERLAP = True    # radiance MLP's weight gradients on the library's side stream, beside its feature-map gradients (-35 us/step)
 DEFER_HEAD_PACK = True     # (tools/ab_step.py toggles this)
+SPLIT_HEAD_PACK = True     # the head's pack in two calls, its forward's operands first
 
 
 
@@ -215,21 +220,46 @@ class MapHolder:
         if zero_now:
             self._gflat.zero_()
 
-    def prefill_grad_accumulators(self) -> None:
+    def prefill_grad_accumulators(self, after=None) -> None:
         """Called from the forward when a map gradient will be asked for: the accumulators (217 MB at the KITTI shapes) are zeroed on
-        the side stream, under the forward's MFMA-bound kernels, instead of on the backward's critical path (81 us of fills, r02_d)."""
-        if self.gmaps is not None:
+        the side stream, under the forward's MFMA-bound kernels, instead of on the backward's critical path (81 us of fills, r02_d).
+        ``after``: an event of the current stream the fill waits for (instead of everything the stream holds now) -- recorded where
+        the buffer was allocated (``alloc_grad_accumulators``), so that the caller can launch the chain's next kernel first."""
+        if self.gmaps is None:
+            self._alloc_gmaps(False)
+        elif after is None:
             return
+        if getattr(self, "_gmaps_filled", False):
+            return
+        self._gmaps_filled = True
         dev = self.hwc[0].device
         main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-        self._alloc_gmaps(False)
-        side.wait_stream(main)    # the blocks may have just been freed by work still queued on the main stream
+        if after is not None:
+            side.wait_event(after)
+        else:
+            side.wait_stream(main)    # the blocks may have just been freed by work still queued on the main stream
         with torch.cuda.stream(side):
             self._gflat.zero_()
             self._gmaps_ready = side.record_event()
         # if no backward ever waits on the event (graph dropped, exception): the allocator must not hand this block to a main-stream
         # tenant while the side-stream fill is still pending
         self._gflat.record_stream(side)
+
+    def alloc_grad_accumulators(self):
+        """Allocate the accumulators now (current stream) and return the event a later ``prefill_grad_accumulators(after=...)`` orders
+        its fill behind: whatever used the blocks before is in front of it."""
+        if self.gmaps is not None:
+            return None
+        self._alloc_gmaps(False)
+        self._gmaps_filled = False
+        return torch.cuda.current_stream(self.hwc[0].device).record_event()
+
+    def join_prefill(self) -> None:
+        """Order the current stream behind the side-stream fill NOW (the backward's ``grad_accumulators()`` then has nothing to wait
+        for): called where the stream joins the side stream anyway, so that the two waits are one node of a captured graph."""
+        ev, self._gmaps_ready = getattr(self, "_gmaps_ready", None), None
+        if ev is not None:
+            torch.cuda.current_stream(self.hwc[0].device).wait_event(ev)
 
     def grad_accumulators(self) -> List[torch.Tensor]:
         if self.gmaps is None:
@@ -292,7 +322,13 @@ class PrepareMaps(torch.autograd.Function):
 class PackedMLP:
     """ResnetFC parameters in the operand layout of include/scenerf_hip.h::scenerf_mlp_weights."""
 
-    def __init__(self, params: Sequence[torch.Tensor], d_out: int, cfg: RenderConfig, pack_stream=None):
+    def __init__(self, params: Sequence[torch.Tensor], d_out: int, cfg: RenderConfig, pack_stream=None, defer: bool = False,
+                 split: bool = False):
+        """``pack_stream``: launch the pack there instead of on the current stream.  ``defer`` (with a pack stream): do not launch yet --
+        ``launch_pack()`` (or the first ``wait_ready()``) does, ordered behind the point of the current stream this constructor ran at
+        (where the parameters were last written), not behind whatever the current stream has been given since.  ``split`` (with a pack
+        stream, bf16): the pack in two calls, a forward's operands first (SCENERF_FLAG_PACK_FORWARD / _REST) -- ``wait_ready()`` then
+        waits for the first, ``wait_ready(backward=True)`` for both."""
         p = dict(zip(MLP_PARAM_NAMES, [_f32c(t) for t in params]))
         for n, t in p.items():
             _require_cuda(t, n)
@@ -357,13 +393,16 @@ class PackedMLP:
         # pack_stream: launch the pack there instead of on the current stream (the radiance MLP's operands are first read ~0.3 ms into
         # a training step, after the gaussian head's chain: its pack runs beside that chain); wait_ready() orders the consumer
         self._ready = None
+        self._ready_rest = None
+        self._pack_stream = pack_stream
+        self._split = bool(split and pack_stream is not None and prec == 1)
+        self._pending = None
         if pack_stream is not None:
-            pack_stream.wait_stream(torch.cuda.current_stream(dev))   # the parameters were last written on the current stream
-            _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(raw), C.byref(s), pack_stream.cuda_stream), "mlp_pack")
-            self.gflat.record_stream(pack_stream)
-            self._ready = pack_stream.record_event()
-            self.act_buf.record_stream(pack_stream)   # (same hazard as the map accumulators if the consumer never waits)
-            self.f32_buf.record_stream(pack_stream)
+            # the parameters were last written on the current stream: an event HERE, so that a deferred launch does not also wait for
+            # the kernels the current stream is given in between
+            self._pending = (ccfg, pack_stream, torch.cuda.current_stream(dev).record_event())
+            if not defer:
+                self.launch_pack()
         else:
             _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(raw), C.byref(s), _stream(dev)), "mlp_pack")
         # gradient sink (flat fp32 buffer carved into the scenerf_mlp_grads fields): allocated and zeroed on first backward, or zeroed by
@@ -381,12 +420,46 @@ class PackedMLP:
         """Run the pack again into the same operand buffers (current stream): the packed operands follow parameter VALUES that
         changed in place since construction, whatever way they were written (optimizer step, ``p.data.copy_``, ``load_state_dict``),
         while every device address a captured hipGraph holds stays valid.  Requires ``same_storage``."""
-        self.wait_ready()
+        self.wait_ready(backward=True)
         self.c.clear, self.c.clear_floats = None, 0     # (a sink zeroed by the first pack may hold gradients by now)
         _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(cfg.to_c()), C.byref(self._raw), C.byref(self.c), _stream(self.device)), "mlp_pack")
 
-    def wait_ready(self) -> None:
-        """Order the current stream after a pack that was launched on another stream (no-op otherwise, and after the first call)."""
+    def launch_pack(self) -> None:
+        """Launch a deferred pack on its stream (no-op if there is none pending)."""
+        pend, self._pending = self._pending, None
+        if pend is None:
+            return
+        ccfg, pack_stream, params_written = pend
+        pack_stream.wait_event(params_written)
+        lib = _capi.load()
+        with torch.cuda.device(self.device):
+            if self._split:
+                cf = type(ccfg).from_buffer_copy(ccfg)
+                cf.flags |= _capi.FLAG_PACK_FORWARD
+                _capi.check(lib.scenerf_hip_mlp_pack(C.byref(cf), C.byref(self._raw), C.byref(self.c), pack_stream.cuda_stream), "mlp_pack")
+                self._ready = pack_stream.record_event()
+                cf.flags = (cf.flags & ~_capi.FLAG_PACK_FORWARD) | _capi.FLAG_PACK_REST
+                _capi.check(lib.scenerf_hip_mlp_pack(C.byref(cf), C.byref(self._raw), C.byref(self.c), pack_stream.cuda_stream), "mlp_pack")
+                self._ready_rest = pack_stream.record_event()
+            else:
+                _capi.check(lib.scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(self._raw), C.byref(self.c), pack_stream.cuda_stream), "mlp_pack")
+                self._ready = pack_stream.record_event()
+        # if no consumer ever waits on the event (exception, graph dropped): the allocator must not hand these blocks to a tenant of
+        # another stream while the pack is still pending
+        for t in (self.gflat, self.act_buf, self.f32_buf):
+            if t is not None:
+                t.record_stream(pack_stream)
+
+    def wait_ready(self, backward: bool = False) -> None:
+        """Order the current stream after a pack that was launched on another stream (no-op otherwise, and after the first call).
+        ``backward``: also after the second half of a split pack (transposed operands, W_z^T, the zeroed gradient sink)."""
+        self.launch_pack()
+        if backward and self._ready_rest is not None:     # (the second half is behind the first on the pack stream)
+            ev, self._ready_rest, self._ready = self._ready_rest, None, None
+            cur = torch.cuda.current_stream(self.device)
+            if cur != self._pack_stream:                   # (the pack stream itself is behind its own launches)
+                cur.wait_event(ev)
+            return
         ev, self._ready = self._ready, None
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
@@ -461,6 +534,7 @@ class MlpHolder:
         self.synced = False          # the sink was already reduced (early, on the side stream: RenderChunk.backward)
         self.single_chunk = False    # set by render_rays_batch when the whole call is one chunk
         self.defer_pack = False      # pack on the side stream (the radiance MLP: first used after the gaussian head's chain)
+        self.split_pack = False      # ... in two calls, a forward's operands first (the gaussian head: its forward is the step's first GEMM)
 
 
 class PackMLP(torch.autograd.Function):
@@ -468,7 +542,7 @@ class PackMLP(torch.autograd.Function):
     def forward(ctx, holder: MlpHolder, d_out: int, cfg: RenderConfig, *params):
         # training sessions (a parameter gradient will be asked for): the radiance MLP is packed on the side stream
         side = _side_stream(params[0].device) if (holder.defer_pack and any(ctx.needs_input_grad[3:])) else None
-        holder.packed = PackedMLP(params, d_out, cfg, pack_stream=side)
+        holder.packed = PackedMLP(params, d_out, cfg, pack_stream=side, defer=CHAIN_FIRST, split=CHAIN_FIRST and holder.split_pack)
         ctx.holder = holder
         return torch.empty(1, device=params[0].device)   # autograd token: its value is never read (no fill launch)
 
@@ -545,7 +619,7 @@ class _MlpRun:
 
 
 def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dist_ray_stride, ppr, unit_dir, viewdir,
-              K, inv_K, T, M, keep_acts: bool = True, before_forward=None) -> _MlpRun:
+              K, inv_K, T, M, keep_acts: bool = True, before_forward=None, before_wait=None) -> _MlpRun:
     lib = _capi.load()
     st = _stream(dist.device)
     run = _MlpRun(M, pk.d_out, cfg.precision_code, dist.device, lean=(not keep_acts) and cfg.uses_fused(M),
@@ -557,6 +631,8 @@ def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dis
     _capi.check(lib.scenerf_hip_gather_features(C.byref(ccfg), C.byref(maps.map_ptr_array()), run.sphere_idx.data_ptr(), M,
                                                 run.Z.data_ptr(), run.tile_mask.data_ptr(), run.tap_texel.data_ptr(),
                                                 run.tap_weight.data_ptr(), st), "gather_features")
+    if before_wait is not None:
+        before_wait()
     pk.wait_ready()   # (the operands may have been packed on the side stream: first needed here, behind the encode and the gather)
     if before_forward is not None:
         before_forward()
@@ -571,7 +647,7 @@ def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: 
     gradient GEMMs are queued, so their all-reduce is started there and the feature-gradient GEMM + scatter (0.5 ms) runs while
     the collective is in flight; returns the collective's finisher (or None)."""
     lib = _capi.load()
-    pk.wait_ready()
+    pk.wait_ready(backward=True)
     act = _act_dtype(cfg.precision_code)
     dev = d_logits.device
     dH = torch.empty((run.M, 4 * D_H), dtype=act, device=dev)
@@ -639,10 +715,18 @@ class RenderChunk(torch.autograd.Function):
             if PREFILL_AT == 4 and getattr(maps, "_want_prefill", False):
                 maps._want_prefill = False
                 maps.prefill_grad_accumulators()
-        run_g = _mlp_eval(ccfg, cfg, maps, mlpg.packed, anchors, 0, G, unit_dir, viewdir, K, iK, T, R * G, keep, before_forward=_prefill4)
+        def _launch_packs():   # deferred packs (CHAIN_FIRST): on the side stream, the head's first, behind the chain's first three launches
+            mlpg.packed.launch_pack()
+            mlp.packed.launch_pack()
+        run_g = _mlp_eval(ccfg, cfg, maps, mlpg.packed, anchors, 0, G, unit_dir, viewdir, K, iK, T, R * G, keep, before_forward=_prefill4,
+                          before_wait=_launch_packs)
+        fill_after = None
         if PREFILL_AT == 1 and getattr(maps, "_want_prefill", False):
             maps._want_prefill = False
-            maps.prefill_grad_accumulators()
+            if CHAIN_FIRST:
+                fill_after = maps.alloc_grad_accumulators()    # (the fill itself: behind the sampler's launch, below)
+            else:
+                maps.prefill_grad_accumulators()
         # the gaussian sampler's normal noise, if the caller did not inject it: drawn HERE, with the gaussian head's chain already queued
         # -- the reference's host-side draw (utils.py:208-211) takes ~0.25 ms of host time per 1,200 rays, which at the top of the
         # chunk left the GPU without work (3.29 -> 3.04 ms per KITTI step, tools/ab_host.py devrng); same generator, same call order
@@ -660,8 +744,12 @@ class RenderChunk(torch.autograd.Function):
                                                          _capi.ptr(dist_u), noise_g.data_ptr(), _capi.ptr(rng), unit_dir.data_ptr(), R,
                                                          gmeans.data_ptr(), gstds.data_ptr(), dist_s.data_ptr(), z_s.data_ptr(),
                                                          perm.data_ptr(), st), "gaussian_sample_sort")
+        if fill_after is not None:
+            maps.prefill_grad_accumulators(after=fill_after)
         # radiance MLP on the sorted samples (scenerf.py:661-665)
-        run_m = _mlp_eval(ccfg, cfg, maps, mlp.packed, dist_s, N, N, unit_dir, viewdir, K, iK, T, R * N, keep)
+        # (its forward joins the side stream for the packed operands: the accumulator fill queued there is waited for by the same node)
+        run_m = _mlp_eval(ccfg, cfg, maps, mlp.packed, dist_s, N, N, unit_dir, viewdir, K, iK, T, R * N, keep,
+                          before_forward=maps.join_prefill if (CHAIN_FIRST and keep) else None)
         if PREFILL_AT == 2 and getattr(maps, "_want_prefill", False):
             maps._want_prefill = False
             maps.prefill_grad_accumulators()
@@ -760,10 +848,7 @@ class RenderChunk(torch.autograd.Function):
                     ccm.flags |= _capi.FLAG_WGRAD_OVERLAP
                 ctx.mlp.pending = _mlp_backward(ccm, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps, sync_async=early)
 
-        if do_head:
-            if want_maps:
-                ctx.maps.grad_accumulators()   # allocate + zero on the main stream before the fork
-            ctx.mlpg.packed.grad_sink()
+        def head_backward():
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 _mlp_backward(ccfg, cfg, ctx.maps, ctx.mlpg.packed, run_g, d_off.view(R * G, 2), want_maps)
@@ -773,12 +858,24 @@ class RenderChunk(torch.autograd.Function):
                 if ctx.mlpg.single_chunk and ctx.mlpg.grad_sync is not None and ctx.needs_input_grad[12]:
                     ctx.mlpg.grad_sync(ctx.mlpg.packed.gflat)
                     ctx.mlpg.synced = True
-        main_backward()     # (queued before the head's instead: no difference, 2.653 / 2.659 ms per step)
+
         if do_head:
+            if want_maps:
+                ctx.maps.grad_accumulators()   # allocate + zero on the main stream before the fork
+            ctx.mlpg.packed.grad_sink()
+            # (the head's backward is launched FIRST here although it is not the chain: launched second it shares the replayed graph's
+            #  second queue with the radiance MLP's weight gradients, and that queue runs the deeper fork's kernels first -- the head's
+            #  backward then waits ~0.6 ms behind kernels that are not ready (tools/graph_queue_probe.py: order_h_then_w / order_w_then_h;
+            #  measured in the step: 2.93 against 2.67 ms).  Launched first it keeps the chain's queue and the chain moves on: 13 us
+            #  at this fork instead of 5.)
+            head_backward()
+            main_backward()
             main.wait_stream(side)
             for t in (d_off, run_g.Z, run_g.xenc, run_g.h0pre, run_g.logits):
                 if t is not None:
                     t.record_stream(side)
+        else:
+            main_backward()
         ctx.keep = None
         z1 = _zero_token(dev)
         return (None, None, None, None, None, None, None, None, None, None,
@@ -837,6 +934,7 @@ class RenderSession:
         # (first read ~0.3 ms into the step).  The side stream runs them in this order: head, then radiance MLP.
         self.mlp.defer_pack = True
         self.mlpg.defer_pack = DEFER_HEAD_PACK
+        self.mlpg.split_pack = SPLIT_HEAD_PACK
         self.tok_mlpg = PackMLP.apply(self.mlpg, 2, cfg, *mlpg_params)
         self.tok_mlp = PackMLP.apply(self.mlp, 4, cfg, *mlp_params)
         self.maps = MapHolder(cfg)

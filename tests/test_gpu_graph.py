@@ -47,6 +47,37 @@ def test_capturable_adamw_follows_the_host_counted_one():
         assert torch.equal(b.detach(), c.detach())
 
 
+def test_capturable_adamw_counts_its_steps_inside_the_update_kernel():
+    """No increment launch: the kernel reads t (steps done), updates with t + 1, and its last workgroup to retire stores t + 1.  More
+    than 48 tensors = two launches per step (only the last one counts), thousands of workgroups, replayed as a graph: after n steps the
+    parameters equal the host-counted optimizer's and the device counter reads n, the scratch word 0."""
+    from scenerf_amd.optim import FusedAdamW
+    g = torch.Generator().manual_seed(5)
+    shapes = [(512, 512)] * 20 + [(37,)] * 35
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = FusedAdamW(pa, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.01)
+    ob = FusedAdamW(pb, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.01, capturable=True)
+    grads = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    for a, b, gr in zip(pa, pb, grads):
+        a.grad, b.grad = gr.clone(), gr.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ob.step()
+    torch.cuda.current_stream().wait_stream(side)
+    oa.step()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ob.step()
+    for _ in range(6):
+        graph.replay(); oa.step()
+    torch.cuda.synchronize()
+    assert float(ob._hyper[0][0][1]) == 7.0 and not ob._hyper[0][0][2:].any()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(b.detach(), a.detach(), rtol=2e-5, atol=2e-6)
+
+
 def test_load_state_dict_after_capture_keeps_the_captured_hyper_tensor():
     """A hipGraph that holds FusedAdamW(capturable=True).step() reads [lr, t] from a device tensor by ADDRESS: load_state_dict must refresh
     that tensor in place (loaded learning rate, loaded step count), not drop it -- later replays would count on freed memory."""
@@ -75,7 +106,7 @@ def test_load_state_dict_after_capture_keeps_the_captured_hyper_tensor():
         st["step"] = torch.tensor(10.0, device=DEV)
     opt.load_state_dict(sd)
     assert opt._hyper[0][0].data_ptr() == ptr                      # same memory, new contents
-    assert opt._hyper[0][0].tolist() == [pytest.approx(5e-3), 10.0]
+    assert opt._hyper[0][0].tolist()[:3] == [pytest.approx(5e-3), 10.0, 0.0] and not opt._hyper[0][0][2:].any()    # [lr, steps done, the kernel's scratch]
     sr = copy.deepcopy(ref.state_dict())
     sr["param_groups"][0]["lr"] = 5e-3
     for st in sr["state"].values():

@@ -58,7 +58,45 @@ CASES = {
     "bf_c4_r1080_n96": dict(variant="bf", R=1080, U=64, P=8, sphere=(960, 720), img=(640, 480), pose=(0.3, 8.0), seed=910),
     # one chunk at BASELINE.json configs[4]'s sampling: N = 512 (U=256, P=64); 32 rays = 16,384 rows (fused kernels)
     "kitti_c5_r32_n512": dict(variant="kitti", R=32, U=256, P=64, sphere=(1500, 452), img=(1220, 370), pose=(2.0, 5.0), seed=920),
+    # the reference's own CLI default (train_kitti.py:33-35: n_pts_uni = 32, n_pts_per_gaussian = 8 -> N = 64) at its n_rays = 1200: 76,800
+    # rows = 600 row blocks of the 128-row kernels (two rays per block), the C = 1 instantiations of the per-ray tail
+    "kitti_default_r1200_n64": dict(variant="kitti", R=1200, U=32, P=8, sphere=(1500, 452), img=(1220, 370), pose=(1.0, 0.0), seed=930),
 }
+
+# ---- regression gate: the values MEASURED on MI355X for the committed kernels (tests/golden/parity_full_measured.json, written by
+# tools/make_parity_reference.py from a run's gpurun_out/parity_full_*.json) -- a result may not be more than REGRESSION x worse than
+# what was measured (with small floors: values at rounding noise move from run to run through the fp32 atomics' order).  The absolute
+# gates below stay as the outer bound; this one makes a 1.9 x degradation inside them visible.
+REGRESSION = 1.25
+_MEASURED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_full_measured.json")
+MEASURED = json.load(open(_MEASURED_PATH)) if os.path.exists(_MEASURED_PATH) else {}
+
+
+def _regression_fails(key, rep):
+    ref = MEASURED.get(key)
+    if not ref:
+        return []
+    fails = []
+    def chk(what, got, want, floor):
+        if got > max(REGRESSION * want, floor):
+            fails.append("[regression] %s: %.3e against %.3e measured for the committed kernels (x %.2f > %.2f)" % (what, got, want, got / max(want, 1e-300), REGRESSION))
+    for k, v in ref.get("out", {}).items():
+        m = rep["matched"]["out"].get(k)
+        if m is not None:
+            chk("output " + k, m["max_abs"] if k in ABS_KEYS else m["max_rel"], v, 2e-6)
+    groups = {}
+    for nm, v in rep["matched"]["grad"].items():
+        if "rel_l2" in v:
+            g = nm.split(".")[0] + "."
+            groups[g] = max(groups.get(g, 0.0), v["rel_l2"])
+    for g, v in ref.get("grad", {}).items():
+        if g in groups:
+            chk("gradients " + g + "* (worst tensor, rel L2)", groups[g], v, 2e-4)
+    if "loss" in ref:
+        chk("proxy loss rel", rep["matched"]["loss"]["rel"], ref["loss"], 2e-6)
+    if "head" in ref:
+        chk("gaussian head offsets rel L2", rep["head_offsets"]["rel_l2"], ref["head"], 1e-6)
+    return fails
 
 # ---- gates -------------------------------------------------------------------------------------------------------------------
 # per-ray: |got - ref| <= tol * (1 + |ref|) ("rel" keys) or <= tol (ABS_KEYS), required of EVERY ray in the matched comparison.
@@ -67,8 +105,18 @@ OUT_GATE = {
     # depth rel 1e-4, colour abs 1e-5; the (R, N) outputs at 2 x measured (alphas 3.4e-5, weights 2.9e-6 rel, densities 2.3e-5)
     "fp32": dict(depth=1e-4, color=1e-5, gaussian_means=1e-6, gaussian_stds=1e-6, depth_volumes=1e-6, alphas=1e-4, weights=2e-5, densities=1e-4),
     # measured at identical sample positions (KITTI R=1200 worst case): depth 3.9e-4, colour 1.5e-4, alphas 1.6e-3, weights 1.1e-4, densities 8e-4
-    "bf16": dict(depth=1e-3, color=3e-4, gaussian_means=1e-6, gaussian_stds=1e-6, depth_volumes=1e-6, alphas=3e-3, weights=2.5e-4, densities=2e-3),
+    # at N = 128 and 2.04e-3 on one ray of 1,200 at N = 64 (these are the OUTER bounds: each case is also held to 1.25 x its own measured
+    # values, REGRESSION above)
+    "bf16": dict(depth=1e-3, color=3e-4, gaussian_means=1e-6, gaussian_stds=1e-6, depth_volumes=1e-6, alphas=3e-3, weights=2.5e-4, densities=3e-3),
 }
+
+
+def _out_gate(precision, N):
+    """alpha = 1 - exp(-sigma delta) carries a density error through the sample spacing delta: its absolute gate, set at N = 128,
+    scales with 128 / N below that (measured at the reference's default N = 64: bf16 3.4e-3 against 1.6e-3 at N = 128)."""
+    g = dict(OUT_GATE[precision])
+    g["alphas"] *= max(1.0, 128.0 / N)
+    return g
 # relative L2 of a whole gradient tensor, by group.  fp32: SURVEY 8d's 1e-3 for the radiance MLP (measured <= 3.7e-4); the gaussian
 # head and the maps also carry the KL term's gradient, and ~2 % of the rays flip a RaySOM mask term (docstring): measured 1.3e-3 /
 # 1.5e-3 at KITTI R = 1200.  bf16 (identical positions): measured 2.4e-2 / 5.6e-2 / 6.7e-2 (worst case: the N = 512 chunk).
@@ -91,6 +139,11 @@ SOM_TIE = {"fp32": dict(bmu=1e-6, mask=1e-4, max_frac_bmu=2e-3, max_frac_mask=1e
 # depth_volumes 1.1e-5, loss_kl 5.9e-4
 FREE_FP32_GATE = dict(depth=1e-4, color=1e-5, alphas=1e-4, weights=2e-5, densities=1e-4, gaussian_means=1e-5, gaussian_stds=1e-4,
                       depth_volumes=5e-5, loss_kl=2e-3)
+# alpha = 1 - exp(-sigma delta): the same density error (gated relative, above) seen through the sample spacing.  The 1e-4 was set at
+# N = 128 (measured 3.2e-5); the reference's default N = 64 doubles the spacing (measured 8.6e-5 (1 + alpha), densities 4.3e-5 as at
+# N = 128): the absolute gate scales with 128 / N below 128
+def _free_alpha_gate(N):
+    return FREE_FP32_GATE["alphas"] * max(1.0, 128.0 / N)
 FREE_FP32_MAX_TOUCHED_RAYS = 0.10                              # rays with any differing discrete choice (index, order, BMU, mask) vs the free oracle
 FREE_BF16_GATE = dict(depth_rel_median=1e-3, depth_rel_p99=5e-3, color_abs_p99=2e-3, gaussian_means_rel_max=3e-3)   # measured 3.0e-4 / 2.3e-3 / 6.6e-4 / 1.5e-3
 MAX_FLIPPED_SAMPLE_FRACTION = 5e-4                             # samples whose sphere index differs from the oracle's (measured 1.2e-4)
@@ -196,8 +249,10 @@ def _within(got, ref, tol, absolute):
     return ((got - ref).abs() <= lim).all(dim=1)
 
 
-def _compare(tag, o, out, grads, loss, R, rep, out_gate, grad_gate, loss_gate):
-    """Fill rep[tag] with measured errors of the 12 outputs, the proxy loss and every gradient; return the gate violations."""
+def _compare(tag, o, out, grads, loss, R, rep, out_gate, grad_gate, loss_gate, cond=None):
+    """Fill rep[tag] with measured errors of the 12 outputs, the proxy loss and every gradient; return the gate violations.
+    ``cond`` {name: rel L2}: how far the ORACLE's own gradient moves when its sample positions move by one fp32 ulp (_run_case);
+    added to the gate of that tensor and recorded next to the measured error."""
     r = rep[tag] = {"out": {}, "grad": {}}
     fails = []
     for k in OUT_KEYS:
@@ -229,6 +284,9 @@ def _compare(tag, o, out, grads, loss, R, rep, out_gate, grad_gate, loss_gate):
         rel = float((gc - ref.double()).norm() / rn)
         r["grad"][nm] = dict(rel_l2=rel, cosine=float((gc * ref.double()).sum() / (gc.norm() * rn)), ref_norm=rn)
         gate = [v for k, v in grad_gate.items() if nm.startswith(k)][0]
+        if cond is not None:
+            r["grad"][nm]["one_ulp_conditioning"] = cond.get(nm, 0.0)
+            gate += cond.get(nm, 0.0)
         if rel > gate:
             fails.append("[%s] %s: gradient rel L2 %.2e > %.1e" % (tag, nm, rel, gate))
     worst = sorted(((v["rel_l2"], k) for k, v in r["grad"].items() if "rel_l2" in v), reverse=True)[:4]
@@ -354,7 +412,22 @@ def _run_case(name, precision, entry):
         fails.append("gaussian head offsets rel L2 %.2e > %.1e" % (rep["head_offsets"]["rel_l2"], HEAD_GATE[precision]))
 
     # step 2: every ray, every gradient, arithmetic only
-    fails += _compare("matched", o, out, grads, loss.item(), R, rep, OUT_GATE[precision], GRAD_GATE[precision], LOSS_GATE[precision])
+    cond = None
+    if precision == "fp32":
+        # The conditioning of the gradients themselves: the positional encoding runs to |x| f ~ 1e4 rad, so a sample position that
+        # differs in its last fp32 bit (the GPU forms origin + t * dir with fused multiply-adds, torch with separate roundings) moves
+        # cos(x f) f -- the derivative every position gradient goes through -- by up to 1e4 * 6e-8.  Measured rather than argued: the
+        # oracle again, its gaussian samples (half of the rows; the uniform ones stay, so this under-states it) nudged by ONE ulp of
+        # the head's offsets in a seeded random direction, same discrete choices.  How far the oracle's own gradient moves is added to
+        # SURVEY 8d's 1e-3 per tensor and recorded (``one_ulp_conditioning``).  At the reference's default N = 64 (oracle against
+        # itself, CPU): x_rgb.1_2 4.6e-4, the radiance MLP's lin_z weights 3.9-4.2e-4, x_rgb.1_1 3.1e-4 (the one tensor measured above
+        # 1e-3 on the GPU: 1.07e-3), every other tensor <= 1.6e-5 -- the tensors that multiply white-noise features, whose sums cancel.
+        gsign = torch.Generator().manual_seed(spec["seed"] + 77)
+        away = torch.where(torch.rand(off_gpu.shape, generator=gsign) < 0.5, torch.full_like(off_gpu, float("inf")), torch.full_like(off_gpu, float("-inf")))
+        o2 = _oracle_run(name, head_offsets=torch.nextafter(off_gpu, away), sphere_idx=(idx_main, idx_head), som_choices=(bmu_gpu, mask_gpu))
+        cond = {nm: float((o2["grads"][nm].double() - g.double()).norm() / max(float(g.double().norm()), 1e-300)) for nm, g in o["grads"].items()}
+        del o2
+    fails += _compare("matched", o, out, grads, loss.item(), R, rep, _out_gate(precision, N), GRAD_GATE[precision], LOSS_GATE[precision], cond)
     kl_got, kl_ref = out["loss_kl"].detach().cpu(), o["out"]["loss_kl"]
     klg = KL_GATE[precision]
     rep["loss_kl"] = dict(mean_rel=abs(float(kl_got.mean()) - float(kl_ref.mean())) / abs(float(kl_ref.mean())),
@@ -379,6 +452,7 @@ def _run_case(name, precision, entry):
         if int(touched_kl.sum()) > FREE_FP32_MAX_TOUCHED_RAYS * R:
             fails.append("[free fp32] %d of %d rays have a differing discrete choice" % (int(touched_kl.sum()), R))
         for k, tol in FREE_FP32_GATE.items():
+            tol = _free_alpha_gate(N) if k == "alphas" else tol
             keep = ~(touched_kl if k == "loss_kl" else touched)
             got, ref = out[k].detach().float().cpu()[keep], free["out"][k][keep]
             ok = _within(got, ref, tol, k in ABS_KEYS)
@@ -415,7 +489,9 @@ def _run_case(name, precision, entry):
         for k, v in fb.items():
             if v > FREE_BF16_GATE[k]:
                 fails.append("free-running bf16 %s = %.2e > %.1e" % (k, v, FREE_BF16_GATE[k]))
+    tag = "%s_%s%s" % (name, precision, "" if entry == "chw" else "_" + entry)
+    fails += _regression_fails(tag, rep)
     if os.path.isdir("gpurun_out"):
-        with open(os.path.join("gpurun_out", "parity_full_%s_%s%s.json" % (name, precision, "" if entry == "chw" else "_" + entry)), "w") as f:
+        with open(os.path.join("gpurun_out", "parity_full_%s.json" % tag), "w") as f:
             json.dump(rep, f, indent=1)
     assert not fails, "\n".join(fails)

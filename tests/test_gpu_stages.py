@@ -989,3 +989,27 @@ def test_feature_gradient_kernel_matches_gemm_scatter_epilogue(M):
         err = float((a - b).abs().max())
         print("level %d: max |diff| %.2e of %.2e" % (i, err, scale))
         assert err <= 4e-6 * scale, (i, err, scale)   # measured <= 6.4e-7 (fp32 summation order)
+
+
+def test_pack_in_two_calls_writes_the_same_operands():
+    """SCENERF_FLAG_PACK_FORWARD then _REST (PackedMLP(split=True): a forward's operands first, on a pack stream, launch deferred) leaves the
+    same bytes in every operand buffer as the one-call pack, and a zeroed gradient sink; wait_ready() orders a forward behind the first
+    call, wait_ready(backward=True) behind both."""
+    from scenerf_amd.renderer import MLP_PARAM_NAMES, PackedMLP
+    rcfg = RenderConfig.kitti(precision="bf16", n_pts_uni=64, n_pts_per_gaussian=16)
+    state = synth.mlp_state(41, 2, out_scale=4.0)
+    params = [state[n].to(DEV) for n in MLP_PARAM_NAMES]
+    one = PackedMLP(params, 2, rcfg)
+    side = torch.cuda.Stream()
+    two = PackedMLP(params, 2, rcfg, pack_stream=side, defer=True, split=True)
+    assert two._pending is not None and two._split
+    two.gflat.fill_(float("nan"))            # (the second call zeroes the sink)
+    torch.cuda.synchronize()
+    two.wait_ready()
+    assert two._pending is None and two._ready is None and two._ready_rest is not None
+    two.wait_ready(backward=True)
+    assert two._ready_rest is None
+    torch.cuda.synchronize()
+    assert torch.equal(one.act_buf.view(torch.int16), two.act_buf.view(torch.int16))
+    assert torch.equal(one.f32_buf, two.f32_buf)
+    assert not two.gflat.any()
