@@ -193,6 +193,9 @@ int scenerf_hip_prepare(const scenerf_cfg* cfg, scenerf_stream_t stream);
 int scenerf_hip_maps_chw_to_hwc(const float* chw, void* hwc, int C, int H, int W, int precision, scenerf_stream_t stream);
 /* (H,W,C) fp32 gradient accumulator -> (C,H,W) fp32 (grid_sampler_2d_backward's output layout). */
 int scenerf_hip_grads_hwc_to_chw(const float* hwc, float* chw, int C, int H, int W, scenerf_stream_t stream);
+/* Zero `bytes` (a multiple of 16, dst 16-byte aligned) with `workgroups` workgroups of streaming stores: the fill of the map-gradient
+ * accumulators, sized so that it can run beside the forward's latency-bound kernels. */
+int scenerf_hip_fill_zero(void* dst, int64_t bytes, int workgroups, scenerf_stream_t stream);
 
 /* ---- ray / sample geometry ----------------------------------------------------------------------------- */
 /* utils.py:177-182 (unit dirs), utils.py:112-173 + 75-90 (uniform distances, un-normalised viewdir in the

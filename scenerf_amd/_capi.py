@@ -94,6 +94,7 @@ _PROTOS = {
     "scenerf_hip_prepare": (C.c_int, [C.POINTER(Cfg), vp]),
     "scenerf_hip_maps_chw_to_hwc": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "scenerf_hip_grads_hwc_to_chw": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "scenerf_hip_fill_zero": (C.c_int, [vp, C.c_int64, i32, vp]),
     "scenerf_hip_ray_setup": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "scenerf_hip_encode_points": (C.c_int, [C.POINTER(Cfg), vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "scenerf_hip_gather_features": (C.c_int, [C.POINTER(Cfg), C.POINTER(vp * N_SCALES), vp, i32, vp, vp, vp, vp, vp]),

@@ -1393,6 +1393,22 @@ int scenerf_hip_maps_chw_to_hwc(const float* chw, void* hwc, int C, int H, int W
     return 0;
 }
 
+// Zero a buffer with a bounded number of workgroups and streaming stores: the map-gradient accumulators (420 MB at KITTI) are zeroed on a
+// side stream beside the forward's small kernels, and a full-speed fill through L2 slows every latency-bound kernel beside it 2-3 x
+typedef unsigned int srf_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void fill_zero_kernel(srf_u4* __restrict__ dst, long long n16) {
+    const srf_u4 z = {0u, 0u, 0u, 0u};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) __builtin_nontemporal_store(z, dst + i);
+}
+int scenerf_hip_fill_zero(void* dst, int64_t bytes, int workgroups, scenerf_stream_t stream) {
+    SRF_CHECK(dst && bytes > 0 && bytes % 16 == 0 && ((uintptr_t)dst & 15) == 0 && workgroups > 0, "fill_zero: dst must be 16-byte aligned, bytes a multiple of 16");
+    hipStream_t s = as_stream(stream);
+    SrfLaunchScope ps(s, "fill_zero", 0, (double)bytes);
+    fill_zero_kernel<<<workgroups, 256, 0, s>>>((srf_u4*)dst, bytes / 16);
+    SRF_LAUNCH_CHECK("fill_zero_kernel");
+    return 0;
+}
+
 int scenerf_hip_grads_hwc_to_chw(const float* hwc, float* chw, int C, int H, int W, scenerf_stream_t stream) {
     SRF_CHECK(chw && hwc && C > 0 && H > 0 && W > 0, "grads_hwc_to_chw: bad args");
     hipStream_t s = as_stream(stream);

@@ -51,14 +51,19 @@ def _on(dev):
 
 
 _SIDE = {}
-PREFILL_AT = 1               # where a training session zeroes the map-gradient accumulators (217 MB at KITTI) on the side stream: 0 = at the
-                             # session's start (beside the gaussian head's chain), 1 = behind the head's forward (beside the sampler, the radiance
-                             # MLP's encode / gather and the start of its forward), 2 = behind the radiance MLP's forward (beside the per-ray tail
-                             # and the loss: latency-bound kernels that a 58-us fill over all CUs slows 2-3x: ray_tail_fwd 17 -> 45 us), 3 = behind
-                             # the tail's backward (beside lin_out's reduction and the chain).  As replayed hipGraphs, 400 steps, three runs each
-                             # on one box (r04): 1: 2.569-2.583 ms, 2: 2.587-2.623, 3: 2.627-2.632.  (r03, eager issue: 0: 2.635, 2: 2.622.)
-                             # Also tried (r04): forked behind the head's gather, i.e. beside the head's forward alone: that kernel 117 -> 163 us
-                             # (its weight stream shares L2 with 217 MB of fill), the radiance MLP's encode + gather 125 -> 92 us: +14 us net.
+PREFILL_AT = 6               # where a training session zeroes the map-gradient accumulators (420 MB at KITTI: 217 MB for the finest level) on the
+                             # side stream: 0 = at the session's start (beside the gaussian head's encode / gather), 1 = behind the head's forward
+                             # (beside the sampler, the radiance MLP's encode / gather), 2 = behind the radiance MLP's forward (beside the
+                             # per-ray tail and the loss: latency-bound kernels that a 58-us fill over all CUs slows 2-3x: ray_tail_fwd 17 ->
+                             # 45 us), 3 = behind the tail's backward (beside lin_out's reduction and the chain), 5 = forked behind the head's
+                             # gather, 6 = in the side stream's own order behind the first half of the head's pack (beside the head's
+                             # forward: that kernel 108 -> ~150 us, but the sampler, the radiance MLP's encode and its gather run clean:
+                             # 14 + 18 + 64 us instead of 17 + 38 + 86).  As replayed hipGraphs, 300-400 steps, three runs each on one box
+                             # (r04): 1: 2.569-2.583 ms, 2: 2.587-2.623, 3: 2.627-2.632; later in the round 1: 2.499-2.513, 6 with
+                             # FILL_WORKGROUPS 64 / 128 / 256: 2.471-2.492 / 2.474-2.488 / 2.476-2.489, 6 with torch's fill 2.515-2.528,
+                             # 5 with 64 workgroups 2.518-2.524.  (r03, eager issue: 0: 2.635, 2: 2.622.)
+FILL_WORKGROUPS = 128        # > 0: that fill by the library's bounded streaming-store kernel (scenerf_hip_fill_zero) with this many workgroups
+                             # instead of torch's fill kernel
 CHAIN_FIRST = True           # capture / issue order: at every fork the critical chain's next kernel is launched BEFORE the side stream's, and
                              # the packs are launched behind the chain's first kernels (below: "Launch order")
 MAIN_WGRAD_OVERLAP = True    # radiance MLP's weight gradients on the library's side stream, beside its feature-map gradients (-35 us/step)
@@ -239,20 +244,25 @@ class MapHolder:
         else:
             side.wait_stream(main)    # the blocks may have just been freed by work still queued on the main stream
         with torch.cuda.stream(side):
-            self._gflat.zero_()
+            if FILL_WORKGROUPS > 0 and self._gflat.numel() % 4 == 0:
+                with torch.cuda.device(dev):
+                    _capi.check(_capi.load().scenerf_hip_fill_zero(self._gflat.data_ptr(), self._gflat.numel() * 4, FILL_WORKGROUPS,
+                                                                   side.cuda_stream), "fill_zero")
+            else:
+                self._gflat.zero_()
             self._gmaps_ready = side.record_event()
         # if no backward ever waits on the event (graph dropped, exception): the allocator must not hand this block to a main-stream
         # tenant while the side-stream fill is still pending
         self._gflat.record_stream(side)
 
-    def alloc_grad_accumulators(self):
+    def alloc_grad_accumulators(self, record: bool = True):
         """Allocate the accumulators now (current stream) and return the event a later ``prefill_grad_accumulators(after=...)`` orders
-        its fill behind: whatever used the blocks before is in front of it."""
+        its fill behind: whatever used the blocks before is in front of it (``record=False``: the caller has such an event)."""
         if self.gmaps is not None:
             return None
         self._alloc_gmaps(False)
         self._gmaps_filled = False
-        return torch.cuda.current_stream(self.hwc[0].device).record_event()
+        return torch.cuda.current_stream(self.hwc[0].device).record_event() if record else None
 
     def join_prefill(self) -> None:
         """Order the current stream behind the side-stream fill NOW (the backward's ``grad_accumulators()`` then has nothing to wait
@@ -394,13 +404,15 @@ class PackedMLP:
         # a training step, after the gaussian head's chain: its pack runs beside that chain); wait_ready() orders the consumer
         self._ready = None
         self._ready_rest = None
+        self.params_written = None       # event of the stream position the parameters were last written at (deferred packs)
         self._pack_stream = pack_stream
         self._split = bool(split and pack_stream is not None and prec == 1)
         self._pending = None
         if pack_stream is not None:
             # the parameters were last written on the current stream: an event HERE, so that a deferred launch does not also wait for
             # the kernels the current stream is given in between
-            self._pending = (ccfg, pack_stream, torch.cuda.current_stream(dev).record_event())
+            self.params_written = torch.cuda.current_stream(dev).record_event()
+            self._pending = (ccfg, pack_stream, self.params_written, 0)
             if not defer:
                 self.launch_pack()
         else:
@@ -424,26 +436,37 @@ class PackedMLP:
         self.c.clear, self.c.clear_floats = None, 0     # (a sink zeroed by the first pack may hold gradients by now)
         _capi.check(_capi.load().scenerf_hip_mlp_pack(C.byref(cfg.to_c()), C.byref(self._raw), C.byref(self.c), _stream(self.device)), "mlp_pack")
 
-    def launch_pack(self) -> None:
-        """Launch a deferred pack on its stream (no-op if there is none pending)."""
-        pend, self._pending = self._pending, None
+    def launch_pack(self, upto: int = 2) -> None:
+        """Launch a deferred pack on its stream (no-op if there is none pending).  ``upto`` = 1: only the first half of a split pack
+        (the caller has something to put between the halves on the pack stream)."""
+        pend = self._pending
         if pend is None:
             return
-        ccfg, pack_stream, params_written = pend
-        pack_stream.wait_event(params_written)
+        ccfg, pack_stream, params_written, done = pend
         lib = _capi.load()
+        if done == 0:
+            pack_stream.wait_event(params_written)
         with torch.cuda.device(self.device):
             if self._split:
                 cf = type(ccfg).from_buffer_copy(ccfg)
-                cf.flags |= _capi.FLAG_PACK_FORWARD
-                _capi.check(lib.scenerf_hip_mlp_pack(C.byref(cf), C.byref(self._raw), C.byref(self.c), pack_stream.cuda_stream), "mlp_pack")
-                self._ready = pack_stream.record_event()
-                cf.flags = (cf.flags & ~_capi.FLAG_PACK_FORWARD) | _capi.FLAG_PACK_REST
-                _capi.check(lib.scenerf_hip_mlp_pack(C.byref(cf), C.byref(self._raw), C.byref(self.c), pack_stream.cuda_stream), "mlp_pack")
-                self._ready_rest = pack_stream.record_event()
+                if done == 0:
+                    cf.flags |= _capi.FLAG_PACK_FORWARD
+                    _capi.check(lib.scenerf_hip_mlp_pack(C.byref(cf), C.byref(self._raw), C.byref(self.c), pack_stream.cuda_stream), "mlp_pack")
+                    self._ready = pack_stream.record_event()
+                    done = 1
+                if upto >= 2:
+                    cf.flags = (cf.flags & ~_capi.FLAG_PACK_FORWARD) | _capi.FLAG_PACK_REST
+                    _capi.check(lib.scenerf_hip_mlp_pack(C.byref(cf), C.byref(self._raw), C.byref(self.c), pack_stream.cuda_stream), "mlp_pack")
+                    self._ready_rest = pack_stream.record_event()
+                    done = 2
             else:
                 _capi.check(lib.scenerf_hip_mlp_pack(C.byref(ccfg), C.byref(self._raw), C.byref(self.c), pack_stream.cuda_stream), "mlp_pack")
                 self._ready = pack_stream.record_event()
+                done = 2
+        if done < 2:
+            self._pending = (ccfg, pack_stream, params_written, done)
+            return
+        self._pending = None
         # if no consumer ever waits on the event (exception, graph dropped): the allocator must not hand these blocks to a tenant of
         # another stream while the pack is still pending
         for t in (self.gflat, self.act_buf, self.f32_buf):
@@ -715,13 +738,28 @@ class RenderChunk(torch.autograd.Function):
             if PREFILL_AT == 4 and getattr(maps, "_want_prefill", False):
                 maps._want_prefill = False
                 maps.prefill_grad_accumulators()
+        fill5 = []
         def _launch_packs():   # deferred packs (CHAIN_FIRST): on the side stream, the head's first, behind the chain's first three launches
-            mlpg.packed.launch_pack()
+            fill6 = PREFILL_AT == 6 and getattr(maps, "_want_prefill", False) and mlpg.packed.params_written is not None
+            mlpg.packed.launch_pack(upto=1 if fill6 else 2)
+            if fill6:
+                # the fill in the side stream's own order, behind the half of the head's pack its forward waits for: it starts when the
+                # head's encode and gather are over, runs beside the head's forward and is gone before the sampler; ordered behind the
+                # point where the parameters were written (= behind everything of the previous step), not behind this step's chain
+                maps._want_prefill = False
+                maps.alloc_grad_accumulators(record=False)
+                maps.prefill_grad_accumulators(after=mlpg.packed.params_written)
             mlp.packed.launch_pack()
+            mlpg.packed.launch_pack()      # (the head's second half -- its backward's operands -- last)
+            if PREFILL_AT == 5 and getattr(maps, "_want_prefill", False):     # fill beside the head's forward: fork point = behind its gather
+                maps._want_prefill = False
+                fill5.append(maps.alloc_grad_accumulators())
         run_g = _mlp_eval(ccfg, cfg, maps, mlpg.packed, anchors, 0, G, unit_dir, viewdir, K, iK, T, R * G, keep, before_forward=_prefill4,
                           before_wait=_launch_packs)
+        if fill5 and fill5[0] is not None:
+            maps.prefill_grad_accumulators(after=fill5[0])
         fill_after = None
-        if PREFILL_AT == 1 and getattr(maps, "_want_prefill", False):
+        if PREFILL_AT in (1, 6) and getattr(maps, "_want_prefill", False):     # (6 without deferred packs: like 1)
             maps._want_prefill = False
             if CHAIN_FIRST:
                 fill_after = maps.alloc_grad_accumulators()    # (the fill itself: behind the sampler's launch, below)

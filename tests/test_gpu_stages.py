@@ -1013,3 +1013,17 @@ def test_pack_in_two_calls_writes_the_same_operands():
     assert torch.equal(one.act_buf.view(torch.int16), two.act_buf.view(torch.int16))
     assert torch.equal(one.f32_buf, two.f32_buf)
     assert not two.gflat.any()
+
+
+def test_fill_zero_streams_zeroes_over_the_whole_buffer():
+    """scenerf_hip_fill_zero (the accumulator fill a training session launches beside the head's forward): every byte zero for sizes that
+    are not a multiple of the grid's stride, with few and with many workgroups; misaligned / ragged arguments are refused."""
+    lib = _capi.load()
+    for n, wg in ((4 * 1000 + 4, 3), (1 << 20, 128), (4 * 77777, 1024)):
+        t = torch.full((n + 8,), float("nan"), device=DEV)
+        _capi.check(lib.scenerf_hip_fill_zero(t.data_ptr(), n * 4, wg, _st()), "fill_zero")
+        torch.cuda.synchronize()
+        assert not t[:n].any() and bool(torch.isnan(t[n:]).all())
+    t = torch.zeros(64, device=DEV)
+    assert lib.scenerf_hip_fill_zero(t.data_ptr() + 4, 64, 4, _st()) != 0
+    assert lib.scenerf_hip_fill_zero(t.data_ptr(), 60, 4, _st()) != 0
