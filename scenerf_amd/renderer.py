@@ -226,7 +226,7 @@ class MapHolder:
             self._gflat.zero_()
 
     def prefill_grad_accumulators(self, after=None) -> None:
-        """Called from the forward when a map gradient will be asked for: the accumulators (217 MB at the KITTI shapes) are zeroed on
+        """Called from the forward when a map gradient will be asked for: the accumulators (420 MB at the KITTI shapes) are zeroed on
         the side stream, under the forward's MFMA-bound kernels, instead of on the backward's critical path (81 us of fills, r02_d).
         ``after``: an event of the current stream the fill waits for (instead of everything the stream holds now) -- recorded where
         the buffer was allocated (``alloc_grad_accumulators``), so that the caller can launch the chain's next kernel first."""
