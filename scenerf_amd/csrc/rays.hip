@@ -1398,7 +1398,10 @@ int scenerf_hip_maps_chw_to_hwc(const float* chw, void* hwc, int C, int H, int W
 typedef unsigned int srf_u4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void fill_zero_kernel(srf_u4* __restrict__ dst, long long n16) {
     const srf_u4 z = {0u, 0u, 0u, 0u};
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) __builtin_nontemporal_store(z, dst + i);
+    // system-scope streaming stores (sc0 sc1 nt: written through, no line allocated in L2): beside the gaussian head's forward -- whose
+    // weight stream lives in L2 -- the step is 15-20 us shorter than with `nt` alone (2.455 / 2.456 / 2.475 against 2.477 / 2.473 / 2.478 ms)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(dst + i), "v"(z) : "memory");
 }
 int scenerf_hip_fill_zero(void* dst, int64_t bytes, int workgroups, scenerf_stream_t stream) {
     SRF_CHECK(dst && bytes > 0 && bytes % 16 == 0 && ((uintptr_t)dst & 15) == 0 && workgroups > 0, "fill_zero: dst must be 16-byte aligned, bytes a multiple of 16");

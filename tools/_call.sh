@@ -1,3 +1,4 @@
-export SRF_COMMIT=e34bb7d
-bash tools/profile_round.sh r04_l > gpurun_out/r04_l_profile_round.log 2>&1
-tail -3 gpurun_out/r04_l_profile_round.log
+mkdir -p gpurun_out
+R=$(pwd); O=$R/gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1
+tail -3 $O/pytest_gpu.log
