@@ -560,6 +560,8 @@ int launch_dfeat_scatter(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
     bool rest = false;
     for (int sc = 0; sc < SCENERF_N_SCALES; ++sc) rest = rest || (((p.levels >> sc) & 1u) && gmaps[sc]);
     p.live = p.levels & have;
+    // (r04: this launch in FRONT of the finest level's -- it is the step's tail, 77 us alone -- changes nothing: whichever of the two runs
+    // beside the batched weight gradients takes ~610 us there, the other ~150 us behind it: 2.496 / 2.497 against 2.485-2.496 ms)
     // the coarser levels: a quarter of the tiles at KITTI's geometry, so two workgroups per CU take the items in turn (a workgroup
     // that finds no item still pays the scan: 15 us per launch with one workgroup per tile and nothing to do)
     int cus = 256;
