@@ -257,14 +257,14 @@ class MapHolder:
         # tenant while the side-stream fill is still pending
         self._gflat.record_stream(side)
 
-    def alloc_grad_accumulators(self, record: bool = True):
+    def alloc_grad_accumulators(self):
         """Allocate the accumulators now (current stream) and return the event a later ``prefill_grad_accumulators(after=...)`` orders
-        its fill behind: whatever used the blocks before is in front of it (``record=False``: the caller has such an event)."""
+        its fill behind: whatever used the blocks before is in front of it."""
         if self.gmaps is not None:
             return None
         self._alloc_gmaps(False)
         self._gmaps_filled = False
-        return torch.cuda.current_stream(self.hwc[0].device).record_event() if record else None
+        return torch.cuda.current_stream(self.hwc[0].device).record_event()
 
     def join_prefill(self) -> None:
         """Order the current stream behind the side-stream fill NOW (the backward's ``grad_accumulators()`` then has nothing to wait
@@ -298,6 +298,10 @@ class PrepareMaps(torch.autograd.Function):
                 holder.prefill_grad_accumulators()
             else:
                 holder._want_prefill = True     # (zeroed from the first chunk's forward: RenderChunk._forward)
+                if PREFILL_AT == 6:
+                    # allocated HERE, with an event of this point of the stream: the fill is queued later, on the side stream, behind
+                    # this event only -- whatever used the block before is in front of it, and nothing freed later can be handed out
+                    holder._fill_after = holder.alloc_grad_accumulators()
         return torch.empty(1, device=chw[0].device)   # autograd token: its value is never read (no fill launch)
 
     @staticmethod
@@ -742,15 +746,15 @@ class RenderChunk(torch.autograd.Function):
                 maps.prefill_grad_accumulators()
         fill5 = []
         def _launch_packs():   # deferred packs (CHAIN_FIRST): on the side stream, the head's first, behind the chain's first three launches
-            fill6 = PREFILL_AT == 6 and getattr(maps, "_want_prefill", False) and mlpg.packed.params_written is not None
+            fill6 = PREFILL_AT == 6 and getattr(maps, "_want_prefill", False) and getattr(maps, "_fill_after", None) is not None
             mlpg.packed.launch_pack(upto=1 if fill6 else 2)
             if fill6:
                 # the fill in the side stream's own order, behind the half of the head's pack its forward waits for: it starts when the
                 # head's encode and gather are over, runs beside the head's forward and is gone before the sampler; ordered behind the
-                # point where the parameters were written (= behind everything of the previous step), not behind this step's chain
+                # point of the session's start where the accumulators were allocated (PrepareMaps.forward), not behind this step's chain
                 maps._want_prefill = False
-                maps.alloc_grad_accumulators(record=False)
-                maps.prefill_grad_accumulators(after=mlpg.packed.params_written)
+                maps.prefill_grad_accumulators(after=maps._fill_after)
+                maps._fill_after = None
             mlp.packed.launch_pack()
             mlpg.packed.launch_pack()      # (the head's second half -- its backward's operands -- last)
             if PREFILL_AT == 5 and getattr(maps, "_want_prefill", False):     # fill beside the head's forward: fork point = behind its gather
