@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-R=$(pwd); O=$R/gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1
-tail -3 $O/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_render.py tests/test_gpu_graph.py tests/test_gpu_dp.py tests/test_gpu_loss_side.py -m gpu -x -q 2>&1 | tail -2
+export SRF_COMMIT=e1da126
+bash tools/profile_round.sh r04_n > gpurun_out/r04_n_profile_round.log 2>&1
+tail -1 gpurun_out/r04_n_profile_round.log | cut -c1-260
