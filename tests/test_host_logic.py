@@ -260,3 +260,47 @@ def test_pixel_grid_follows_the_reference_scripts():
         want = torch.cat([gx.unsqueeze(-1), gy.unsqueeze(-1)], dim=2).reshape(-1, 2)
         assert torch.equal(pixel_grid((1220, 370), stride, "cpu"), want)
     assert pixel_grid((1220, 370), 1, "cpu").shape[0] == 451400 and pixel_grid((1220, 370), 3, "cpu").shape[0] == 407 * 124
+
+
+def test_parity_regression_gate_fires_between_1_2_and_1_3_times_the_measured_values():
+    """tests/test_gpu_parity_full.py holds every case to 1.25 x the errors measured for the committed kernels
+    (tests/golden/parity_full_measured.json).  The gate itself, on a made-up report: 1.2 x everything passes, 1.3 x any one of
+    an output, a gradient group, the loss or the head's offsets is reported; values at rounding noise sit under the floors; a case
+    without a stored reference is not gated."""
+    import copy
+    import json
+    import os
+    import test_gpu_parity_full as pf
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_full_measured.json")
+    measured = json.load(open(path))
+    assert {"kitti_c2_r1200_n128_bf16", "kitti_c2_r1200_n128_bf16_hwc", "kitti_default_r1200_n64_bf16", "kitti_default_r1200_n64_fp32",
+            "bf_c4_r1080_n96_bf16", "kitti_c5_r32_n512_bf16"} <= set(measured)
+    key = "kitti_c2_r1200_n128_bf16"
+    ref = measured[key]
+
+    def report(scale, bump=None):
+        out = {k: {"max_abs": v * scale, "max_rel": v * scale} for k, v in ref["out"].items()}
+        grad = {g + "w": {"rel_l2": v * scale} for g, v in ref["grad"].items()}
+        rep = {"matched": {"out": out, "grad": grad, "loss": {"rel": ref["loss"] * scale}}, "head_offsets": {"rel_l2": ref["head"] * scale}}
+        if bump == "out":
+            rep["matched"]["out"]["depth"] = {"max_abs": 1.0, "max_rel": ref["out"]["depth"] * 1.3}
+        elif bump == "grad":
+            rep["matched"]["grad"]["mlp.w"]["rel_l2"] = ref["grad"]["mlp."] * 1.3
+        elif bump == "loss":
+            rep["matched"]["loss"]["rel"] = ref["loss"] * 1.3
+        elif bump == "head":
+            rep["head_offsets"]["rel_l2"] = ref["head"] * 1.3
+        return rep
+
+    assert pf._regression_fails(key, report(1.2)) == []
+    assert len(pf._regression_fails(key, report(1.3))) >= 4
+    for what in ("out", "grad", "loss", "head"):
+        fails = pf._regression_fails(key, report(1.0, bump=what))
+        assert len(fails) == 1 and "[regression]" in fails[0], (what, fails)
+    assert pf._regression_fails("no_such_case_bf16", report(100.0)) == []
+    # fp32 values at rounding noise: the floors, not 1.25 x 3e-8
+    k32 = "kitti_c2_r1200_n128_fp32"
+    r32 = copy.deepcopy(measured[k32])
+    rep = {"matched": {"out": {k: {"max_abs": 1.5e-6, "max_rel": 1.5e-6} for k in r32["out"]}, "grad": {}, "loss": {"rel": 1.5e-6}},
+           "head_offsets": {"rel_l2": 9e-7}}
+    assert [f for f in pf._regression_fails(k32, rep) if "output" in f and "depth_volumes" in f] == []
