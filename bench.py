@@ -500,7 +500,7 @@ def _composite_probe(R, N, reps=20):
     bwd = lambda: lib.scenerf_hip_ray_tail_backward(C.byref(cc), logits.data_ptr(), dist.data_ptr(), z.data_ptr(), R, gd.data_ptr(), gc.data_ptr(),
                                                     None, None, None, None, offs.data_ptr(), anchors.data_ptr(), noise.data_ptr(), unit.data_ptr(),
                                                     gm.data_ptr(), gs.data_ptr(), perm.data_ptr(), ks.data_ptr(), None, None, None, dl.data_ptr(),
-                                                    do.data_ptr(), None, None, st)
+                                                    do.data_ptr(), None, None, None, None, None, st)
     dd, dz = f(R, N), f(R, N)
     cfwd = lambda: lib.scenerf_hip_composite_forward(logits.data_ptr(), dist.data_ptr(), z.data_ptr(), R, N, dens.data_ptr(), al.data_ptr(),
                                                      w.data_ptr(), dep.data_ptr(), col.data_ptr(), clo.data_ptr(), wat.data_ptr(), ci.data_ptr(), st)

@@ -308,7 +308,10 @@ int scenerf_hip_ray_tail_backward(const scenerf_cfg* cfg, const float* logits, c
                                   const float* noise_g, const float* unit_dir, const float* gmeans, const float* gstds,
                                   const int32_t* perm, const float* kl_saved, const float* g_loss_kl, const float* g_gmeans,
                                   const float* g_gstds, float* d_logits /*[R*N][4]*/, float* d_offsets /*[R][G][2]*/,
-                                  float* d_dist /*[R][N] or NULL*/, float* d_z /*[R][N] or NULL*/, scenerf_stream_t stream);
+                                  float* d_dist /*[R][N] or NULL*/, float* d_z /*[R][N] or NULL*/,
+                                  const float* g_weights_at_depth /*[R] or NULL*/, const float* g_closest /*[R] or NULL*/,
+                                  const int32_t* closest_idx /*[R]: the forward's argmin, needed with either of the two*/,
+                                  scenerf_stream_t stream);
 
 /* autograd of the sampler + KL w.r.t. the gaussian-head outputs: reparameterisation (utils.py:213, not
  * through the 0.1 clamp), z = dist*unit.z, relu of scenerf.py:591-594, kl_gauss(m1,s1).  Upstream NULL = 0. */

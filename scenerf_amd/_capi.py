@@ -106,7 +106,7 @@ _PROTOS = {
                                              C.POINTER(C.c_float * 9), C.POINTER(C.c_float * 16), C.POINTER(C.c_double * 16), vp, vp,
                                              i32, i32, C.c_float, C.c_float, i32, vp]),
     "scenerf_hip_ray_tail_forward": (C.c_int, [C.POINTER(Cfg)] + [vp] * 5 + [i32] + [vp] * 13 + [vp]),
-    "scenerf_hip_ray_tail_backward": (C.c_int, [C.POINTER(Cfg)] + [vp] * 3 + [i32] + [vp] * 21 + [vp]),
+    "scenerf_hip_ray_tail_backward": (C.c_int, [C.POINTER(Cfg)] + [vp] * 3 + [i32] + [vp] * 24 + [vp]),
     "scenerf_hip_adamw_step": (C.c_int, [i32, C.POINTER(AdamWTensor), C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     "scenerf_hip_adamw_step_dev": (C.c_int, [i32, C.POINTER(AdamWTensor), vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     "scenerf_hip_sphere_map_build": (C.c_int, [vp, vp, C.c_int64, i32, i32, i32, vp, vp, vp]),

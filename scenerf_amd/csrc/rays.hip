@@ -1136,7 +1136,8 @@ __global__ __launch_bounds__(256) void ray_tail_bwd_kernel(const float* __restri
                                                            const int32_t* __restrict__ perm, const float* __restrict__ kl_saved,
                                                            const float* __restrict__ g_loss_kl, const float* __restrict__ g_gmeans,
                                                            const float* __restrict__ g_gstds, int U, int G, int P, float base_std,
-                                                           float* __restrict__ d_offsets) {
+                                                           float* __restrict__ d_offsets, const float* __restrict__ g_wat,
+                                                           const float* __restrict__ g_clo, const int32_t* __restrict__ closest_idx) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -1156,7 +1157,7 @@ __global__ __launch_bounds__(256) void ray_tail_bwd_kernel(const float* __restri
         cg[c] = sigmoidf(lg.y);
         cb[c] = sigmoidf(lg.z);
     }
-    const float gd = g_depth[r];
+    float gd = g_depth[r];
     const float gcr = g_color[3 * r], gcg = g_color[3 * r + 1], gcb = g_color[3 * r + 2];
     float carryT = 1.f, carry_d = 0.f;
     float gw[C];
@@ -1174,8 +1175,35 @@ __global__ __launch_bounds__(256) void ray_tail_bwd_kernel(const float* __restri
         w[c] = al[c] * Ti[c];
         carryT *= wave_total_prod_from_excl(excl, sfac);
         carry_d = __shfl(d[c], 63, WAVE);
+    }
+    // weights_at_depth = weights[k] and closest_pts_to_depth = |depth - z_k| at k = argmin |depth - z| (scenerf.py:729-736; the index itself
+    // carries no gradient): their gradients join the weights' at k, the rendered depth's, and z_k's
+    int kci = -1;
+    float s_clo = 0.f, gwat = 0.f;
+    if (g_wat || g_clo) {
+        kci = closest_idx[r];
+        if (g_wat) gwat = g_wat[r];
+        if (g_clo) {
+            float sdz = 0.f, zk = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                sdz += w[c] * z[c];                                  // the rendered depth, summed as the forward sums it
+                const float t = __shfl(z[c], kci & 63, WAVE);
+                if ((kci >> 6) == c) zk = t;
+            }
+            sdz = wave_sum(sdz);
+            const float df = sdz - zk;
+            s_clo = g_clo[r] * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));     // d|x| = sign(x), 0 at 0 like torch.abs
+            gd += s_clo;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = c * 64 + lane;
+        const bool ok = i < N;
         float g = gd * z[c] + gcr * cr[c] + gcg * cg[c] + gcb * cb[c];
         if (g_weights && ok) g += g_weights[base + i];
+        if (i == kci) g += gwat;
         gw[c] = ok ? g : 0.f;
     }
     // the sampler's part: per-gaussian sums of (dL/ddist_i + dL/dz_i * unit_z) over the samples that came from that gaussian
@@ -1221,6 +1249,7 @@ __global__ __launch_bounds__(256) void ray_tail_bwd_kernel(const float* __restri
             *(float4*)(d_logits + (base + i) * 4) = o;
             float gz = gd * w[c];
             if (g_zvol) gz += g_zvol[base + i];
+            if (i == kci) gz -= s_clo;
             const float gdist = gdelta - ((i + 1 < N) ? after : 0.f);
             if (d_z) d_z[base + i] = gz;
             if (d_dist) d_dist[base + i] = gdist;
@@ -1599,6 +1628,7 @@ int scenerf_hip_ray_tail_backward(const scenerf_cfg* cfg, const float* logits, c
                                   const float* noise_g, const float* unit_dir, const float* gmeans, const float* gstds,
                                   const int32_t* perm, const float* kl_saved, const float* g_loss_kl, const float* g_gmeans,
                                   const float* g_gstds, float* d_logits, float* d_offsets, float* d_dist, float* d_z,
+                                  const float* g_weights_at_depth, const float* g_closest, const int32_t* closest_idx,
                                   scenerf_stream_t stream) {
     if (check_cfg(cfg)) return 1;
     SRF_CHECK(logits && dist_sorted && z_sorted && g_depth && g_color && d_logits && offsets && anchors && noise_g && unit_dir && gmeans &&
@@ -1607,7 +1637,8 @@ int scenerf_hip_ray_tail_backward(const scenerf_cfg* cfg, const float* logits, c
     hipStream_t s = as_stream(stream);
     dim3 grid(cdiv(R, 4));
     SrfLaunchScope ps(s, "ray_tail_bwd", 0, (double)R * (44.0 * N + 40.0));
-#define TB(C) ray_tail_bwd_kernel<C><<<grid, 256, 0, s>>>(logits, dist_sorted, z_sorted, R, N, g_depth, g_color, g_weights, g_alphas, g_densities, g_zvol, d_logits, d_dist, d_z, offsets, anchors, noise_g, unit_dir, gmeans, gstds, perm, kl_saved, g_loss_kl, g_gmeans, g_gstds, cfg->n_pts_uni, cfg->n_gaussians, cfg->n_pts_per_gaussian, cfg->base_std, d_offsets)
+#define TB(C) ray_tail_bwd_kernel<C><<<grid, 256, 0, s>>>(logits, dist_sorted, z_sorted, R, N, g_depth, g_color, g_weights, g_alphas, g_densities, g_zvol, d_logits, d_dist, d_z, offsets, anchors, noise_g, unit_dir, gmeans, gstds, perm, kl_saved, g_loss_kl, g_gmeans, g_gstds, cfg->n_pts_uni, cfg->n_gaussians, cfg->n_pts_per_gaussian, cfg->base_std, d_offsets, g_weights_at_depth, g_closest, closest_idx)
+    SRF_CHECK(!(g_weights_at_depth || g_closest) || closest_idx, "ray_tail_backward: gradients of weights_at_depth / closest_pts_to_depth need closest_idx");
     if (N <= 64) TB(1);
     else if (N <= 128) TB(2);
     else if (N <= 256) TB(4);

@@ -819,8 +819,8 @@ class RenderChunk(torch.autograd.Function):
         # keep what backward needs (plain attributes: these are internal buffers, not graph tensors)
         ctx.cfg, ctx.ccfg, ctx.maps, ctx.mlp, ctx.mlpg = cfg, ccfg, maps, mlp, mlpg
         ctx.keep = dict(R=R, anchors=anchors, noise_g=noise_g, unit_dir=unit_dir, gmeans=gmeans, gstds=gstds, perm=perm,
-                        dist_s=dist_s, z_s=z_s, kl_saved=kl_saved, run_g=run_g, run_m=run_m)
-        ctx.mark_non_differentiable(w_at, closest, som_vars, som_means)
+                        dist_s=dist_s, z_s=z_s, kl_saved=kl_saved, run_g=run_g, run_m=run_m, closest_idx=closest_idx)
+        ctx.mark_non_differentiable(som_vars, som_means)    # (made from detached inputs in the reference too: ray_som_kl.py:17-19)
         if maps.debug_aux is not None:
             # opt-in debug hook (RenderSession(debug_aux=True)): stage intermediates of the LAST chunk of this session, for the
             # per-stage parity tests.  Off by default: it would pin logits / xenc / indices of a chunk (GBs at N = 512) for as long
@@ -845,7 +845,7 @@ class RenderChunk(torch.autograd.Function):
             return RenderChunk._backward(ctx, *grads)
 
     @staticmethod
-    def _backward(ctx, g_depth, g_color, g_gmeans, g_gstds, _g_wat, _g_closest, g_kl, g_alphas, _g_somv, g_dens, g_weights,
+    def _backward(ctx, g_depth, g_color, g_gmeans, g_gstds, g_wat, g_closest, g_kl, g_alphas, _g_somv, g_dens, g_weights,
                   g_zvol, _g_somm):
         lib = _capi.load()
         k = ctx.keep
@@ -860,8 +860,8 @@ class RenderChunk(torch.autograd.Function):
 
         g_depth = c(g_depth) if g_depth is not None else torch.zeros((R,), **f32)
         g_color = c(g_color) if g_color is not None else torch.zeros((R, 3), **f32)
-        g_gmeans, g_gstds, g_kl, g_alphas, g_dens, g_weights, g_zvol = map(c, (g_gmeans, g_gstds, g_kl, g_alphas, g_dens,
-                                                                              g_weights, g_zvol))
+        g_gmeans, g_gstds, g_kl, g_alphas, g_dens, g_weights, g_zvol, g_wat, g_closest = map(c, (g_gmeans, g_gstds, g_kl, g_alphas, g_dens,
+                                                                                                   g_weights, g_zvol, g_wat, g_closest))
         run_m, run_g = k["run_m"], k["run_g"]
         d_logits = torch.empty((R * N, 4), **f32)
         d_off = torch.empty((R, G, 2), **f32)
@@ -872,7 +872,8 @@ class RenderChunk(torch.autograd.Function):
                                                       k["anchors"].data_ptr(), k["noise_g"].data_ptr(), k["unit_dir"].data_ptr(),
                                                       k["gmeans"].data_ptr(), k["gstds"].data_ptr(), k["perm"].data_ptr(),
                                                       k["kl_saved"].data_ptr(), _capi.ptr(g_kl), _capi.ptr(g_gmeans), _capi.ptr(g_gstds),
-                                                      d_logits.data_ptr(), d_off.data_ptr(), None, None, st), "ray_tail_backward")
+                                                      d_logits.data_ptr(), d_off.data_ptr(), None, None, _capi.ptr(g_wat), _capi.ptr(g_closest),
+                                                      k["closest_idx"].data_ptr(), st), "ray_tail_backward")
         want_maps = bool(ctx.needs_input_grad[10])
         if PREFILL_AT == 3 and want_maps and getattr(ctx.maps, "_want_prefill", False):
             ctx.maps._want_prefill = False

@@ -397,6 +397,45 @@ def test_optional_output_gradients_match_oracle():
         assert rel < 2e-2, "mlp_gaussian.%s rel %.3e" % (name, rel)
 
 
+def test_weights_at_depth_and_closest_point_gradients_match_oracle():
+    """weights_at_depth = weights[k] and closest_pts_to_depths = |depth - z_k| at k = argmin |depth - z| are differentiable in the
+    reference (scenerf.py:729-736: a gather and a min over values with autograd; the index carries none): the same here, through the
+    per-ray tail's backward.  Rays whose k differs from the oracle's (a tie in the min) are left out of the loss on both sides."""
+    from scenerf_amd import synth
+    kw = dict(sphere_W=376, sphere_H=114)
+    R = 48
+    ocfg = orc.OracleConfig.kitti(**kw)
+    mlp, mlpg = synth.mlp_state(61, 4), synth.mlp_state(62, 2, out_scale=4.0)
+    maps = synth.feature_maps(376, 114, 63, smooth=True)
+    pix = synth.stride2_pixels((1220, 370), R, 64)
+    nu, ng = synth.sampling_noise(R, 32, 32, 65)
+    K, T = synth.kitti_cam_K(), synth.rel_pose(2.0, 5.0)
+    gen = torch.Generator().manual_seed(4)
+    cw, cc = torch.randn(R, generator=gen), torch.randn(R, generator=gen)
+    po = {k: v.clone().requires_grad_(True) for k, v in mlp.items()}
+    pg = {k: v.clone().requires_grad_(True) for k, v in mlpg.items()}
+    ref = orc.render_chunk(ocfg, po, pg, K, T, maps, pix, nu, ng, keep_intermediates=True)
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="fp32", **kw).to(DEV)
+    m.mlp.load_state_dict(mlp)
+    m.mlp_gaussian.load_state_dict(mlpg)
+    m.debug_aux = True
+    out = m.render_rays_batch(K.to(DEV), T.to(DEV), {k: v.to(DEV) for k, v in maps.items()}, sampled_pixels=pix.to(DEV),
+                              ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
+    assert out["weights_at_depth"].requires_grad and out["closest_pts_to_depths"].requires_grad
+    same = (m.last_aux["closest_idx"].cpu().long() == ref["_closest_idx"]).float()
+    assert float(same.mean()) > 0.9
+    cw, cc = cw * same, cc * same
+    ((ref["weights_at_depth"] * cw).sum() + (ref["closest_pts_to_depths"] * cc).sum()).backward()
+    ((out["weights_at_depth"] * cw.to(DEV)).sum() + (out["closest_pts_to_depths"] * cc.to(DEV)).sum()).backward()
+    for net, ps, names in ((m.mlp, po, ("lin_out.weight", "blocks.1.fc_0.weight", "lin_z.0.weight", "lin_in.weight")),
+                           (m.mlp_gaussian, pg, ("lin_out.weight", "blocks.2.fc_1.weight"))):
+        for name in names:
+            got, want = dict(net.named_parameters())[name].grad.cpu(), ps[name].grad
+            assert float(want.norm()) > 0
+            rel = float((got - want).norm() / want.norm())
+            assert rel < 2e-2, "%s rel %.3e" % (name, rel)
+
+
 # ------------------------------------------------------------------------------------------------ BASELINE full size
 def test_full_size_config2_properties_and_subset_parity():
     """BASELINE.json configs[1] at full size (KITTI 1500x452 sphere, R=1200, N=128): size-independent properties of the

@@ -576,7 +576,7 @@ def test_fused_ray_tail_equals_the_stage_kernels(N, U, P):
                                                       gw.data_ptr(), ga.data_ptr(), gden.data_ptr(), gz.data_ptr(), OF.data_ptr(), AN.data_ptr(),
                                                       NZ.data_ptr(), UN.data_ptr(), GM.data_ptr(), GS.data_ptr(), PM.data_ptr(), a["ks"].data_ptr(),
                                                       gkl.data_ptr(), ggm.data_ptr(), ggs.data_ptr(), dl2.data_ptr(), o_.data_ptr(),
-                                                      _capi.ptr(dd_), _capi.ptr(dz_), _st()), "ray_tail_backward")
+                                                      _capi.ptr(dd_), _capi.ptr(dz_), None, None, None, _st()), "ray_tail_backward")
     assert torch.equal(dl1, dl2) and torch.equal(dd1, dd2) and torch.equal(dz1, dz2)
     assert torch.equal(do1, do2) and torch.equal(do1, do3)
     assert bool(torch.isfinite(do1).all()) and float(do1.abs().max()) > 0

@@ -1,5 +1,3 @@
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_render.py tests/test_gpu_graph.py tests/test_gpu_dp.py tests/test_gpu_loss_side.py -m gpu -x -q 2>&1 | tail -2
-export SRF_COMMIT=e1da126
-bash tools/profile_round.sh r04_n > gpurun_out/r04_n_profile_round.log 2>&1
-tail -1 gpurun_out/r04_n_profile_round.log | cut -c1-260
+timeout 600 python -m pytest tests/test_gpu_parity_full.py tests/test_gpu_graph.py tests/test_gpu_loss_side.py -m gpu -x -q -k "(kitti_c2_r1200_n128 and bf16) or graphed_step_replays or channels_last or source_loss" 2>&1 | tail -3
+python bench.py --gpus 1 --steps 20 --warmup 5 --headline-only 2>/dev/null | tail -1 | cut -c1-200
