@@ -28,6 +28,12 @@ import os
 import sys
 import time
 
+# ranks of a process group (N > 1, or --force-dist): more hardware queues than the runtime's default 4 BEFORE the runtime initialises -- with
+# RCCL's stream in the process the renderer's three streams otherwise share queues and the eagerly issued step serialises (scenerf_amd.dist.
+# more_hw_queues: 3.02 -> 2.65 ms per step); the one-process line is left as the runtime comes
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-dist" in sys.argv:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -1004,7 +1010,8 @@ def main():
                                          "device generator (RenderConfig.device_rng=True; --host-rng gives the reference's host-side draw: +0.1-0.25 ms per step)",
                        "loss": "reference per-source loss (colour L1 + reprojection on synthetic images, KL, closest gaussian; scenerf_amd.loss_side."
                                "source_loss, one launch each way)" if args.loss == "source" else "proxy: four means in eager torch",
-                       "numa_pin": pinned, "device_warm_steps": args.device_warm_steps},
+                       "numa_pin": pinned, "device_warm_steps": args.device_warm_steps,
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")},
             "eager_step": eager_leg, "other_entry": other, "other_rng": rng_other, "drop_in": drop_in, "steady_state": steady,
             "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager, "fp32_mode": fp32,
             "bundlefusion_c4": bf_leg, "infer_c5": inf_leg, "kitti_default_n64": n64_leg,
