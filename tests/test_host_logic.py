@@ -304,3 +304,18 @@ def test_parity_regression_gate_fires_between_1_2_and_1_3_times_the_measured_val
     rep = {"matched": {"out": {k: {"max_abs": 1.5e-6, "max_rel": 1.5e-6} for k in r32["out"]}, "grad": {}, "loss": {"rel": 1.5e-6}},
            "head_offsets": {"rel_l2": 9e-7}}
     assert [f for f in pf._regression_fails(k32, rep) if "output" in f and "depth_volumes" in f] == []
+
+
+def test_more_hw_queues_respects_the_user_and_the_initialised_runtime(monkeypatch):
+    """scenerf_amd.dist.more_hw_queues: GPU_MAX_HW_QUEUES = 8 for ranks of a process group, only if the user has not set it and the HIP
+    runtime has not initialised yet (the variable is read once, at initialisation)."""
+    import os
+    from scenerf_amd import dist as sdist
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    assert sdist.more_hw_queues() is True and os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "5")
+    assert sdist.more_hw_queues() is True and os.environ["GPU_MAX_HW_QUEUES"] == "5"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    assert sdist.more_hw_queues() is False and "GPU_MAX_HW_QUEUES" not in os.environ
