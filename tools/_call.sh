@@ -1,2 +1,2 @@
 mkdir -p gpurun_out
-python bench.py --gpus 1 --force-dist --graph off --steps 200 --warmup 20 --headline-only --device-warm-steps 50 > gpurun_out/fdq_default.out 2>/dev/null
+timeout 200 python -m pytest tests/test_gpu_parity_full.py -m gpu -x -q -k "kitti_default_r1200_n64 and fp32" 2>&1 | tail -2
