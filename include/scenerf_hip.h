@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SCENERF_HIP_ABI_VERSION 7
+#define SCENERF_HIP_ABI_VERSION 8
 #define SCENERF_N_SCALES 5          /* feature maps "1_1","1_2","1_4","1_8","1_16" */
 #define SCENERF_D_LATENT 2480       /* 80+160+320+640+1280 (resnetfc d_latent, scenerf.py:100-114) */
 #define SCENERF_D_HIDDEN 512
@@ -222,6 +222,14 @@ int scenerf_hip_encode_points(const scenerf_cfg* cfg, const float* dist, int dis
                                          (set scenerf_mlp_acts.x3_ready); the slack row M is zero-filled*/,
                               scenerf_stream_t stream);
 
+/* SphericalMapping.from_pixels (spherical_mapping.py:80-97 -> cam_pts_2_sphere_coords :99-115) for M pixels (u, v): unproject at depth 1
+ * with inv_K, angles, `round().long()`.  The rule for the two angles is the one scenerf_hip_encode_points uses for the per-sample index
+ * (csrc/sphere_exact.h: torch-CPU's operation sequence with SLEEF's 1.0-ULP acosf / atan2f), so the sphere map the encoder fills and the
+ * texels the renderer reads agree.  dist (may be NULL) = the norm of the unprojected point, the reference's third return value. */
+int scenerf_hip_pixels_to_sphere(const float* pix /*[M][2]*/, const float* inv_K /*[9]*/, float v_min, float v_fov, float h_min,
+                                 float h_fov, int sphere_W, int sphere_H, int64_t M, int64_t* sphere_idx /*[M][2]*/,
+                                 float* dist /*[M] or NULL*/, scenerf_stream_t stream);
+
 /* utils.py:232-247 x5 (scenerf.py:522-527): bilinear 2x2 gather of the 5 maps at idx/div*2-1 with zeros
  * padding.  Writes Z rows only for (128-row tile, scale) pairs that have at least one in-range tap and
  * records that in tile_mask (bit s); taps = {texel index or -1, weight} per (row, scale, tap) for backward. */
@@ -367,6 +375,9 @@ int scenerf_hip_test_gemm_nt(int precision, const void* A, const void* W, const 
 /* C[N][K] += D[M][N]^T @ relu?(A[M][K]); colsum[N] += column sums of D (may be NULL); fp32 atomics. */
 int scenerf_hip_test_gemm_tn(int precision, const void* D, const void* A, int M, int N, int K, int relu_a,
                              float* C, float* colsum, scenerf_stream_t stream);
+
+/* csrc/sphere_exact.h's two routines on their own: acos_a[i] = acos(a[i]) (may be NULL), atan2_ab[i] = atan2(a[i], b[i]) (may be NULL). */
+int scenerf_hip_test_acos_atan2(const float* a, const float* b, int64_t n, float* acos_a, float* atan2_ab, scenerf_stream_t stream);
 
 /* Host-only (no GPU needed): the chunk-descriptor tables the fused ResnetFC kernels walk -- kind 0: fused.hip (33 sets: one per
  * scale mask for the forward, set 32 = backward chain), kind 2: wide.hip (33 sets: 32 forward masks + the backward chain; kind 1 is refused).  A set is SCENERF_CHUNK_TABLE_STRIDE ints:

@@ -55,6 +55,11 @@ class OracleConfig:
     gauss_floor: float = 1.5       # scenerf.py:591-594 (+1.5); scenerf_bf.py:606-608 (+0.5)
     kl_std_floor: float = 1.5      # ray_som_kl.py:83 (same in BF)
     uni_fallback: int = 0          # uniform samples drawn when n_pts_uni == 0: scenerf_bf.py:623-626 substitutes 2; scenerf.py has no substitute
+    # which routine stands behind `torch.acos` in the sphere index (spherical_mapping.py:106).  "torch": the reference's call as this
+    # host executes it -- MKL VML's vmsAcos(HA), whose last bit depends on the CPU's instruction set (oracle/sleef_acos.py).  "sleef_u10":
+    # the pinned rule of this project, torch's own SLEEF build (what torch.atan2 already is, and what torch.acos is without MKL); the GPU
+    # parity tests select it and then require EVERY sphere index to be equal.  `torch.atan2` is SLEEF under both settings.
+    acos_rule: str = "torch"
 
     @property
     def fov(self):
@@ -133,8 +138,17 @@ def sphere_coords(pix: torch.Tensor, inv_K: torch.Tensor, cfg: OracleConfig, ret
     c = torch.ones(pix.shape[0], device=pix.device).view(-1, 1) * c
     x, y, z = c[:, 0], c[:, 1], c[:, 2]
     dist = torch.linalg.norm(c, ord=2, dim=1)
-    v_angle = torch.acos(-y / dist) / math.pi * 180
-    h_angle = 180 - torch.atan2(z, x) / math.pi * 180
+    if cfg.acos_rule == "sleef_u10":
+        import sleef_acos          # (oracle/ is on sys.path: the oracle modules are imported top-level)
+        v_angle = sleef_acos.acos(-y / dist) / math.pi * 180
+        # (torch.atan2 is already SLEEF where ATen runs its AVX2 / AVX-512 kernels; calling the routine by name makes the rule
+        # independent of ATEN_CPU_CAPABILITY)
+        h_angle = 180 - sleef_acos.atan2(z.contiguous(), x.contiguous()) / math.pi * 180
+    elif cfg.acos_rule == "torch":
+        v_angle = torch.acos(-y / dist) / math.pi * 180
+        h_angle = 180 - torch.atan2(z, x) / math.pi * 180
+    else:
+        raise ValueError("acos_rule %r" % (cfg.acos_rule,))
     out = torch.zeros((pix.shape[0], 2), device=pix.device)
     out[:, 0] = (h_angle - h_min) / h_fov * (cfg.sphere_W - 1)
     out[:, 1] = (v_angle - v_min) / v_fov * (cfg.sphere_H - 1)

@@ -23,7 +23,7 @@ D_HIDDEN = 512
 D_XENC = 48
 TILE_ROWS = 128
 W_STREAM_BLOCKS = (3 * D_XENC + D_LATENT) // 16 + 2 * ((512 + D_LATENT) // 16) + 10 * (512 // 16)   # scenerf_hip.h
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 vp = C.c_void_p
 
@@ -125,6 +125,8 @@ _PROTOS = {
     "scenerf_hip_composite_backward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_raysom_forward": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_sampler_backward": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+    "scenerf_hip_pixels_to_sphere": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, i32, i32, C.c_int64, vp, vp, vp]),
+    "scenerf_hip_test_acos_atan2": (C.c_int, [vp, vp, C.c_int64, vp, vp, vp]),
     "scenerf_hip_test_gemm_nt": (C.c_int, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "scenerf_hip_test_chunk_table": (C.c_int, [C.POINTER(Cfg), i32, vp, i32]),
     "scenerf_hip_test_gemm_tn": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, vp, vp, vp]),

@@ -19,7 +19,7 @@ SOURCES = ["runtime.hip", "rays.hip", "gemm.hip", "wgrad.hip", "fused.hip", "wid
 # wide.hip owns the whole accumulator file (a[0:255] by name in inline-asm MFMAs): the compiler must not park spilled VGPRs there
 # (a spill then shows up as scratch usage, which tools/asmcheck.sh and the build's resource check refuse)
 EXTRA = {"wide.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
-HEADERS = ["common.h", "gemm.h", "fused.h", os.path.join("..", "..", "include", "scenerf_hip.h")]
+HEADERS = ["common.h", "gemm.h", "fused.h", "sphere_exact.h", os.path.join("..", "..", "include", "scenerf_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"] + os.environ.get("SRF_EXTRA_FLAGS", "").split()
 

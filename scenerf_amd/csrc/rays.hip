@@ -5,17 +5,15 @@
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf, so the rounding
 // sequence is the one documented next to each formula (it follows the reference's eager torch ops).
 #include "common.h"
+#include "sphere_exact.h"
 
 #define PI_F 3.14159265358979323846f
 #define HALF_PI_F 1.57079632679489661923f
 
-// k-ordered fma chain == what a BLAS sgemm micro-kernel does for a length-3/4 dot product
-__device__ static inline float dot3(float a0, float a1, float a2, float x, float y, float z) {
-    return fmaf(a2, z, fmaf(a1, y, a0 * x));
-}
-__device__ static inline float dot4(float a0, float a1, float a2, float a3, float x, float y, float z, float w) {
-    return fmaf(a3, w, fmaf(a2, z, fmaf(a1, y, a0 * x)));
-}
+// k-ordered fma chain == what a BLAS sgemm micro-kernel does for a length-3/4 dot product (sphere_exact.h: checked bit for bit against
+// torch's `K @ p` on the CPU by tests/test_sphere_exact.py)
+#define dot3 srf_dot3
+#define dot4 srf_dot4
 
 // ------------------------------------------------------------------------------------------------ ray setup
 // one thread per (ray, j): j < U writes dist_u; j == 0 also writes unit_dir / viewdir.
@@ -44,18 +42,8 @@ __global__ void ray_setup_kernel(const float* __restrict__ pixels, const float* 
         dist_u[(size_t)r * U + j] = lin_u[j] + nu * step;  // utils.py:84-85
     }
     if (j == 0) {
-        float u = pixels[2 * r], v = pixels[2 * r + 1];
-        float dx = dot3(iK[0], iK[1], iK[2], u, v, 1.f);
-        float dy = dot3(iK[3], iK[4], iK[5], u, v, 1.f);
-        float dz = dot3(iK[6], iK[7], iK[8], u, v, 1.f);
-        float n = sqrtf(dx * dx + dy * dy + dz * dz);
-        n = fmaxf(n, 1e-12f);  // F.normalize eps
-        unit_dir[3 * r + 0] = dx / n;
-        unit_dir[3 * r + 1] = dy / n;
-        unit_dir[3 * r + 2] = dz / n;
-        viewdir[3 * r + 0] = dot3(T[0], T[1], T[2], dx, dy, dz);   // utils.py:170 (un-normalised)
-        viewdir[3 * r + 1] = dot3(T[4], T[5], T[6], dx, dy, dz);
-        viewdir[3 * r + 2] = dot3(T[8], T[9], T[10], dx, dy, dz);
+        // utils.py:177-182 (unit dirs), :170 (un-normalised view direction): sphere_exact.h, torch-CPU's operation sequence
+        srf_ray_dir(iK, T, pixels[2 * r], pixels[2 * r + 1], unit_dir + 3 * r, viewdir + 3 * r);
     }
 }
 
@@ -93,42 +81,25 @@ __global__ __launch_bounds__(256) void encode_points_kernel(const float* __restr
     int r = m / ppr, j = m - r * ppr;
     float d = dist[(size_t)r * dist_ray_stride + j];
     // source-frame point = dist * unit_dir (utils.py:87 / 217), then T @ [p,1] (utils.py:161-166)
-    float px = d * unit_dir[3 * r], py = d * unit_dir[3 * r + 1], pz = d * unit_dir[3 * r + 2];
-    float qx = dot4(T[0], T[1], T[2], T[3], px, py, pz, 1.f);
-    float qy = dot4(T[4], T[5], T[6], T[7], px, py, pz, 1.f);
-    float qz = dot4(T[8], T[9], T[10], T[11], px, py, pz, 1.f);
+    float qv[3];
+    srf_sample_point(T, unit_dir + 3 * r, d, qv);
+    const float qx = qv[0], qy = qv[1], qz = qv[2];
     if (part == 0) {
         if (pts_out && live) {
             pts_out[3 * (size_t)m] = qx;
             pts_out[3 * (size_t)m + 1] = qy;
             pts_out[3 * (size_t)m + 2] = qz;
         }
-        // cam_pts_2_pix, utils.py:298-315
-        float h0 = dot3(K[0], K[1], K[2], qx, qy, qz);
-        float h1 = dot3(K[3], K[4], K[5], qx, qy, qz);
-        float h2 = dot3(K[6], K[7], K[8], qx, qy, qz);
-        float u = -1.f, v = -1.f;
-        if (h2 > 0.f) {
-            u = h0 / h2;
-            v = h1 / h2;
-        }
-        // SphericalMapping.from_pixels at depth 1, spherical_mapping.py:80-115
-        float cx = dot3(iK[0], iK[1], iK[2], u, v, 1.f);
-        float cy = dot3(iK[3], iK[4], iK[5], u, v, 1.f);
-        float cz = dot3(iK[6], iK[7], iK[8], u, v, 1.f);
-        float cd = sqrtf(cx * cx + cy * cy + cz * cz);
-        float v_angle = acosf(-cy / cd) / PI_F * 180.f;
-        float h_angle = 180.f - atan2f(cz, cx) / PI_F * 180.f;
-        float ox = (h_angle - sc.h_min) / sc.h_fov * (float)(sc.W - 1);
-        float oy = (v_angle - sc.v_min) / sc.v_fov * (float)(sc.H - 1);
-        // torch.round = half-to-even = rintf; clamp so the int conversion is defined for far-out points
-        ox = fminf(fmaxf(rintf(ox), -1.0e9f), 1.0e9f);
-        oy = fminf(fmaxf(rintf(oy), -1.0e9f), 1.0e9f);
-        if (!(ox == ox)) ox = -1.0e9f;
-        if (!(oy == oy)) oy = -1.0e9f;
+        // cam_pts_2_pix (utils.py:298-315), then SphericalMapping.from_pixels at depth 1 (spherical_mapping.py:80-115): the operation
+        // sequence of torch's CPU kernels, acos / atan2 included (sphere_exact.h) -- the rounded index is the reference's, bit for bit
+        float u, v, ox, oy;
+        srf_cam_pt_to_pix(K, qx, qy, qz, &u, &v);
+        srf_sphere_consts sxc;
+        sxc.v_min = sc.v_min; sxc.v_fov = sc.v_fov; sxc.h_min = sc.h_min; sxc.h_fov = sc.h_fov; sxc.W = sc.W; sxc.H = sc.H;
+        srf_pix_to_sphere_f(iK, sxc, u, v, &ox, &oy);
         if (live) {
-            sphere_idx[2 * (size_t)m] = (int32_t)ox;
-            sphere_idx[2 * (size_t)m + 1] = (int32_t)oy;
+            sphere_idx[2 * (size_t)m] = srf_round_index(ox);
+            sphere_idx[2 * (size_t)m + 1] = srf_round_index(oy);
         }
     }
     // PositionalEncoding pe.py:32-43: [x, sin(f0 x), sin(f0 x + pi/2), ...] then viewdir, zero pad to 48.  Columns of this thread:
@@ -1480,6 +1451,51 @@ int scenerf_hip_encode_points(const scenerf_cfg* cfg, const float* dist, int dis
     encode_points_kernel<<<cdiv(M, ENC_ROWS), 256, 0, s>>>(dist, dist_ray_stride, pts_per_ray, unit_dir, viewdir, K, inv_K, T_s2i,
                                                       sc, M, pts, sphere_idx, xenc, (bf16_t*)x3);
     SRF_LAUNCH_CHECK("encode_points_kernel");
+    return 0;
+}
+
+// SphericalMapping.from_pixels (spherical_mapping.py:80-97) for a list of pixels: the encoder's image->sphere grid.  Same operation
+// sequence as the renderer's per-sample index (sphere_exact.h), so the map the encoder writes and the texels the renderer reads follow one rule.
+__global__ void pixels_to_sphere_kernel(const float* __restrict__ pix, const float* __restrict__ iK, srf_sphere_consts sc, int64_t M,
+                                        int64_t* __restrict__ idx, float* __restrict__ dist) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float u = pix[2 * m], v = pix[2 * m + 1];
+    float ox, oy;
+    srf_pix_to_sphere_f(iK, sc, u, v, &ox, &oy);
+    idx[2 * m] = (int64_t)srf_round_index(ox);
+    idx[2 * m + 1] = (int64_t)srf_round_index(oy);
+    if (dist) {
+        const float cx = srf_dot3(iK[0], iK[1], iK[2], u, v, 1.0f), cy = srf_dot3(iK[3], iK[4], iK[5], u, v, 1.0f),
+                    cz = srf_dot3(iK[6], iK[7], iK[8], u, v, 1.0f);
+        dist[m] = srf_norm3(cx, cy, cz);
+    }
+}
+int scenerf_hip_pixels_to_sphere(const float* pix, const float* inv_K, float v_min, float v_fov, float h_min, float h_fov, int sphere_W,
+                                 int sphere_H, int64_t M, int64_t* sphere_idx, float* dist, scenerf_stream_t stream) {
+    SRF_CHECK(pix && inv_K && sphere_idx && M > 0 && sphere_W > 1 && sphere_H > 1, "pixels_to_sphere: bad argument");
+    hipStream_t s = as_stream(stream);
+    srf_sphere_consts sc;
+    sc.v_min = v_min; sc.v_fov = v_fov; sc.h_min = h_min; sc.h_fov = h_fov; sc.W = sphere_W; sc.H = sphere_H;
+    SrfLaunchScope ps(s, "pixels_to_sphere", 0, (double)M * (8 + 16 + (dist ? 4 : 0)));
+    pixels_to_sphere_kernel<<<(unsigned)((M + 255) / 256), 256, 0, s>>>(pix, inv_K, sc, M, sphere_idx, dist);
+    SRF_LAUNCH_CHECK("pixels_to_sphere_kernel");
+    return 0;
+}
+
+// test hook: the two device routines on their own (tests hold them to torch's own SLEEF build, bit for bit)
+__global__ void test_acos_atan2_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ acos_a,
+                                       float* __restrict__ atan2_ab) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (acos_a) acos_a[i] = srf_acosf_u10(a[i]);
+    if (atan2_ab) atan2_ab[i] = srf_atan2f_u10(a[i], b[i]);
+}
+int scenerf_hip_test_acos_atan2(const float* a, const float* b, int64_t n, float* acos_a, float* atan2_ab, scenerf_stream_t stream) {
+    SRF_CHECK(a && n > 0 && (acos_a || atan2_ab) && (!atan2_ab || b), "test_acos_atan2: bad argument");
+    hipStream_t s = as_stream(stream);
+    test_acos_atan2_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a, b, n, acos_a, atan2_ab);
+    SRF_LAUNCH_CHECK("test_acos_atan2_kernel");
     return 0;
 }
 

@@ -210,8 +210,23 @@ class SphericalMapping(nn.Module):
         return cache[key]
 
     def from_pixels(self, inv_K, pix_coords=None):
+        """spherical_mapping.py:80-115.  On the GPU: one launch of the library's rule (``scenerf_hip_pixels_to_sphere``, the same
+        operation sequence -- torch-CPU's, with SLEEF's 1.0-ULP acos / atan2 -- the renderer uses for its per-sample index, so the map
+        the encoder fills and the texels the renderer reads agree).  CPU tensors take the reference's torch ops unchanged."""
         if pix_coords is None:
             pix_coords = self._full_grid(inv_K)
+        if inv_K.is_cuda:
+            from . import _capi
+            lib = _capi.load()
+            pix = pix_coords.to(torch.float32).contiguous()
+            ik = inv_K.to(torch.float32).contiguous()
+            M = pix.shape[0]
+            idx = torch.empty((M, 2), dtype=torch.int64, device=pix.device)
+            dist = torch.empty((M,), dtype=torch.float32, device=pix.device)
+            _capi.check(lib.scenerf_hip_pixels_to_sphere(pix.data_ptr(), ik.data_ptr(), self.v_angle_min, self.v_fov, self.h_angle_min,
+                                                         self.h_fov, self.out_img_W, self.out_img_H, M, idx.data_ptr(), dist.data_ptr(),
+                                                         torch.cuda.current_stream(pix.device).cuda_stream), "pixels_to_sphere")
+            return pix_coords, idx, dist.type_as(inv_K)
         homo = torch.cat([pix_coords, torch.ones_like(pix_coords[:, :1])], dim=1)
         cam = (inv_K @ homo.T).T
         dist = torch.linalg.norm(cam, ord=2, dim=1)

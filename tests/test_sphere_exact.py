@@ -1,0 +1,174 @@
+"""The sphere-index rule, held without a GPU ("sphere indices bit-exact").
+
+``scenerf_amd/csrc/sphere_exact.h`` is one source for two compilers.  Here gcc builds it for the host (``tests/csrc/sphere_exact_host.c``,
+``-ffp-contract=off`` like rays.hip) and every stage of the chain pixel -> ray -> sample point -> projected pixel -> angles -> rounded
+sphere pixel is compared BIT FOR BIT with what torch-CPU / the oracle computes:
+
+  * the two SLEEF routines against torch's own SLEEF build (``oracle/sleef_acos.py``) and, for atan2, against ``torch.atan2`` itself;
+  * ray directions, sample points and projected pixels against the oracle's torch ops (matmul, F.normalize, division);
+  * the rounded indices against ``oracle.sphere_coords`` under the pinned rule (``acos_rule="sleef_u10"``): zero differences, KITTI and
+    BundleFusion constants, points behind the camera included;
+  * how far the pinned rule is from the reference as THIS host runs it (``acos_rule="torch"``: MKL's vmsAcos): rows only, a few per million.
+
+The GPU side (``tests/test_gpu_stages.py::test_device_acos_atan2_*``, ``test_encode_points_*``) then only has to show that the device
+executes the same sequence.
+"""
+import ctypes as C
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import scenerf_oracle as orc  # noqa: E402
+import sleef_acos  # noqa: E402
+
+vp = C.c_void_p
+
+
+@pytest.fixture(scope="module")
+def host(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("sx") / "libsphere_exact_host.so")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-shared", "-fPIC", "-o", out,
+                           os.path.join(HERE, "csrc", "sphere_exact_host.c"), "-lm"])
+    lib = C.CDLL(out)
+    lib.srf_host_acosf.argtypes = [vp, vp, C.c_size_t]
+    lib.srf_host_atan2f.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.srf_host_acosf_range_mismatch.argtypes = [C.c_uint32, C.c_uint32, vp]
+    lib.srf_host_acosf_range_mismatch.restype = C.c_size_t
+    lib.srf_host_points_to_sphere.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    lib.srf_host_rays.argtypes = [vp, C.c_size_t, vp, vp, vp, vp]
+    lib.srf_host_sample_points.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, vp]
+    return lib
+
+
+def bits_differ(a, b):
+    return int((a.contiguous().view(torch.int32) != b.contiguous().view(torch.int32)).sum())
+
+
+def special_values():
+    f = [0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 1e-30, -1e-30, 1e-40, -1e-40, 3e-39, -3e-39, 0.49999997, 0.50000006, 0.99999994, -0.99999994,
+         float("inf"), float("-inf"), 1e38, -1e38, 2.0, -2.0, 0.70710678, 1e-8]
+    return torch.tensor(f, dtype=torch.float32)
+
+
+def test_acos_is_torchs_own_sleef(host):
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.rand(1 << 22, generator=g) * 2 - 1, special_values().clamp(-1, 1), torch.linspace(-1, 1, 100001)])
+    y = torch.empty_like(x)
+    host.srf_host_acosf(x.data_ptr(), y.data_ptr(), x.numel())
+    assert bits_differ(y, sleef_acos.acos(x)) == 0
+
+
+@pytest.mark.skipif(not os.environ.get("SRF_EXHAUSTIVE"), reason="all 2^31 floats of [-1, 1]: ~2 min; run once per change of sphere_exact.h "
+                                                                "(SRF_EXHAUSTIVE=1); result recorded in profiles/r05_acos_exhaustive.txt")
+def test_acos_exhaustive(host):
+    bad = 0
+    step = 1 << 26
+    for sign in (0, 0x80000000):
+        for lo in range(0, 0x3f800001, step):
+            hi = min(lo + step, 0x3f800001)
+            b = torch.arange(lo, hi, dtype=torch.int64).to(torch.int32)
+            x = b.view(torch.float32)
+            if sign:
+                x = -x                      # bit pattern b | 0x80000000
+            ref = sleef_acos.acos(x)
+            bad += host.srf_host_acosf_range_mismatch(lo | sign, hi | sign, ref.data_ptr())
+    print("acos: every float32 in [-1, 1] (2 x %d values): %d differ from torch's SLEEF build" % (0x3f800001, bad))
+    assert bad == 0
+
+
+def test_atan2_is_torch_atan2(host):
+    g = torch.Generator().manual_seed(1)
+    n = 1 << 22
+    a = torch.randn(n, generator=g) * torch.exp(torch.randn(n, generator=g) * 4)
+    b = torch.randn(n, generator=g) * torch.exp(torch.randn(n, generator=g) * 4)
+    s = special_values()
+    a = torch.cat([a, s.repeat_interleave(s.numel()), torch.ones(1000), torch.rand(1000, generator=g)])
+    b = torch.cat([b, s.repeat(s.numel()), torch.rand(1000, generator=g) * 3 - 1.5, torch.ones(1000)])
+    y = torch.empty_like(a)
+    host.srf_host_atan2f(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel())
+    assert bits_differ(y, sleef_acos.atan2(a, b)) == 0
+    if torch.backends.cpu.get_cpu_capability() in ("AVX2", "AVX512"):
+        # torch.atan2 itself: ATen's vector loop calls SLEEF, but the last (n mod 32) elements of every thread's chunk go through the
+        # SCALAR lambda (std::atan2 of the C library) -- the reference's own result depends on where in the tensor an element sits
+        # (seen here: 2 of 4,196,880 elements, the tails of two OpenMP chunks).  Compare on one thread and a multiple of 32 elements.
+        nt = torch.get_num_threads()
+        try:
+            torch.set_num_threads(1)
+            m = a.numel() // 32 * 32
+            assert bits_differ(y[:m], torch.atan2(a[:m].contiguous(), b[:m].contiguous())) == 0
+        finally:
+            torch.set_num_threads(nt)
+
+
+def _cam(cfg):
+    if cfg.sphere_W == 1500:
+        K = torch.tensor([[707.0912, 0, 601.8873], [0, 707.0912, 183.1104], [0, 0, 1]])
+    else:
+        K = torch.tensor([[583.0, 0, 320.0], [0, 583.0, 240.0], [0, 0, 1]])
+    return K, torch.inverse(K).contiguous().clone()
+
+
+T_CASES = [torch.eye(4),
+           torch.tensor([[0.9848077, 0, 0.1736482, 0.3], [0, 1, 0, -0.1], [-0.1736482, 0, 0.9848077, 5.0], [0, 0, 0, 1]]),
+           torch.tensor([[0.9848077, 0, -0.1736482, -0.2], [0, 1, 0, 0.05], [0.1736482, 0, 0.9848077, 10.0], [0, 0, 0, 1]])]
+
+
+@pytest.mark.parametrize("variant", ["kitti", "bundlefusion"])
+def test_chain_equals_the_oracle_bit_for_bit(host, variant):
+    cfg = getattr(orc.OracleConfig, variant)(acos_rule="sleef_u10")
+    K, iK = _cam(cfg)
+    W, H = cfg.img_size
+    g = torch.Generator().manual_seed(7)
+    R, S = 20000, 24
+    pix = torch.stack([torch.randint(0, W, (R,), generator=g).float(), torch.randint(0, H, (R,), generator=g).float()], 1).contiguous()
+    for ti, T in enumerate(T_CASES):
+        T = T.contiguous()
+        dirs, unit = orc.ray_directions(pix, iK)
+        vd = (T[:3, :3] @ dirs.T).T
+        hu, hv = torch.empty(R, 3), torch.empty(R, 3)
+        host.srf_host_rays(pix.data_ptr(), R, iK.data_ptr(), T.data_ptr(), hu.data_ptr(), hv.data_ptr())
+        assert bits_differ(hu, unit) == 0, "unit directions (utils.py:177-182)"
+        assert bits_differ(hv, vd) == 0, "view directions (utils.py:170)"
+        dist = (torch.rand(R, S, generator=g) * cfg.max_sample_depth * 1.5 - 0.3 * cfg.max_sample_depth).contiguous()
+        pts = orc.to_frame((dist.unsqueeze(-1) * unit.reshape(R, 1, 3)).reshape(-1, 3), T)
+        hp = torch.empty(R * S, 3)
+        host.srf_host_sample_points(hu.data_ptr(), dist.data_ptr(), R, S, T.data_ptr(), hp.data_ptr())
+        assert bits_differ(hp, pts) == 0, "sample points (utils.py:161-166)"
+        opix = orc.project_to_pixels(pts, K)
+        idx, coords = orc.sphere_coords(opix, iK, cfg, return_float=True)
+        hi, hc, hx = torch.empty(R * S, 2, dtype=torch.int32), torch.empty(R * S, 2), torch.empty(R * S, 2)
+        consts = torch.tensor(cfg.fov, dtype=torch.float32)
+        host.srf_host_points_to_sphere(hp.data_ptr(), R * S, K.data_ptr(), iK.data_ptr(), consts.data_ptr(), cfg.sphere_W, cfg.sphere_H,
+                                       hi.data_ptr(), hc.data_ptr(), hx.data_ptr())
+        assert bits_differ(hx, opix) == 0, "projected pixels (utils.py:298-315)"
+        front = (opix[:, 0] != -1) | (opix[:, 1] != -1)
+        assert ti > 0 or int((~front).sum()) > 0, "the case should hold points behind the camera"
+        assert bits_differ(hc, coords) == 0, "float sphere coordinates (spherical_mapping.py:99-113)"
+        assert torch.equal(hi.long(), idx), "rounded sphere pixels"
+
+
+def test_pinned_rule_against_the_reference_as_this_host_runs_it(host):
+    """acos_rule="torch" (MKL's vmsAcos on an MKL build) against the pinned SLEEF rule: columns (atan2) never differ; rows differ on a few
+    samples per million -- those are the samples a reference-minted golden may place on the neighbouring texel row."""
+    cfg_s, cfg_t = orc.OracleConfig.kitti(acos_rule="sleef_u10"), orc.OracleConfig.kitti(acos_rule="torch")
+    K, iK = _cam(cfg_s)
+    g = torch.Generator().manual_seed(3)
+    M = 1 << 21
+    z = torch.rand(M, generator=g) * 100 + 0.1
+    pts = torch.stack([(torch.rand(M, generator=g) * 2 - 1) * z * 1.2, (torch.rand(M, generator=g) * 2 - 1) * z * 0.4, z], 1)
+    pix = orc.project_to_pixels(pts, K)
+    a, b = orc.sphere_coords(pix, iK, cfg_s), orc.sphere_coords(pix, iK, cfg_t)
+    dx, dy = int((a[:, 0] != b[:, 0]).sum()), int((a[:, 1] != b[:, 1]).sum())
+    print("pinned rule vs torch.acos on this host: %d column and %d row differences in %d samples" % (dx, dy, M))
+    if torch.backends.cpu.get_cpu_capability() in ("AVX2", "AVX512"):
+        assert dx == 0
+    assert dy <= M * 2e-5
+    assert int((a - b).abs().max()) <= 1
