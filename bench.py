@@ -123,9 +123,11 @@ def parse():
                     help="AdamW of the step: 'fused' = scenerf_amd.optim.FusedAdamW (one HIP launch over all 40 parameter tensors), 'torch' = "
                          "torch.optim.AdamW(fused=True)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="train, one GPU: issue the step as ONE hipGraph replay (scenerf_amd.graph.GraphedStep: forward, loss, backward, fused "
-                         "AdamW captured once); 'auto' = on when it can be captured (bf16, device noise, the fused optimizer, one rank), the "
-                         "eagerly issued step is then reported next to it as `eager_step`; 'off' = the eager step is the headline")
+                    help="train: issue the step as ONE hipGraph replay per rank (scenerf_amd.graph.GraphedStep: forward, loss, backward with the "
+                         "gradient all-reduces, fused AdamW captured once); 'auto' = on when it can be captured (bf16, device noise, the fused "
+                         "optimizer) and EVERY rank's capture succeeded -- otherwise all ranks step eagerly; one GPU: the eagerly issued step is "
+                         "reported next to it as `eager_step`; 'off' = the eager step is the headline")
+    ap.add_argument("--dry-fail-capture", type=int, default=-1, help=argparse.SUPPRESS)   # --dry-run: the rank whose stub capture fails
     ap.add_argument("--loss", default="source", choices=["source", "proxy"],
                     help="what stands between the renderer's forward and backward in a step: 'source' = the reference's loss of one source frame "
                          "(scenerf.py:203-238 around process_single_source: colour L1 + photometric reprojection against synthetic source / target "
@@ -251,6 +253,12 @@ def cpu_baseline(args):
             "what": "oracle/scenerf_oracle.py, the CPU restatement of the reference's eager path pinned on reference-minted goldens (the "
                     "reference itself is not on this box), render + proxy loss fwd+bwd",
             "threads_used": threads, "threads_available": cores,
+            # the REAL reference (imported unmodified from /root/reference, which does not exist on the GPU box) at this very configuration,
+            # measured once in the survey container and recorded in BASELINE.md section 2 -- a constant of the repository, not of this run
+            "reference_measured": {"value": 39.8, "unit": "rays/s", "cores": 8, "kind": "reference",
+                                   "what": "astra-vision/SceneRF's own modules, SceneRF.render_rays_batch + backward, 1200 rays x 128 samples, fp32, one "
+                                           "chunk: 11.80 s forward + 18.34 s backward on 8 cores of an Intel Xeon @ 2.10 GHz, torch 2.10 CPU",
+                                   "source": "BASELINE.md section 2 (survey container; not measurable on the GPU box)"},
             "sample": "%d rays x %d samples fwd+bwd on %d of %d host threads (torch's CPU kernels regress beyond a few dozen), full KITTI maps, "
                       "best of %d (%s s)" % (R, args.samples, threads, cores, len(times), ", ".join("%.1f" % t for t in times))}
 
@@ -731,6 +739,36 @@ def inference_leg(args, dev, frames=2, stride=2, chunk=4096, samples=512):
             "roofline": roof, "roofline_composite": roof_c}
 
 
+def graph_wanted(args, collectives):
+    """(attempt a captured step?, reason if not).  One GPU and N > 1 alike: the timed step is ONE hipGraph replay per rank
+    (scenerf_amd.graph.GraphedStep: forward + loss + backward with the gradient collectives + fused AdamW), attempted on every rank and
+    kept only if every rank's capture succeeded (scenerf_amd.graph.build_on_all_ranks); otherwise all ranks issue the step eagerly."""
+    if args.graph == "off":
+        return False, "--graph off"
+    if args.sync == "step" and collectives:
+        return False, "--sync step (its end-of-backward callback is host code)"
+    if args.precision != "bf16" and args.graph == "auto":
+        return False, "fp32 mode"
+    if getattr(args, "host_rng", False):
+        return False, "--host-rng (the host-side draw cannot be captured)"
+    if args.optimizer != "fused":
+        return False, "--optimizer torch"
+    return True, None
+
+
+class _StubGraphed:
+    """--dry-run stand-in for GraphedStep: 'captures' the stub step, or fails on the rank --dry-fail-capture names (tests/test_dist_gloo.py:
+    the rank-consistent fallback of scenerf_amd.graph.build_on_all_ranks over gloo, without a GPU)."""
+
+    def __init__(self, model, rank, fail_rank):
+        if rank == fail_rank:
+            raise RuntimeError("dry run: capture refused on rank %d" % rank)
+        self.model = model
+
+    def __call__(self):
+        return self.model.step()
+
+
 def main():
     args = parse()
     if args.dry_run:
@@ -749,7 +787,7 @@ def main():
             raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible: one process per GPU is the contract" % (
                 env_world, torch.cuda.device_count()))
     # (a captured step with collectives needs the NCCL watchdog's event polling off: scenerf_amd.dist.init_from_env)
-    cap = (args.graph == "on" or (args.graph == "auto" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.force_dist)) and not dry
+    cap = graph_wanted(args, env_world > 1 or args.force_dist)[0] and (env_world > 1 or args.force_dist) and not dry
     rank, world, local = sdist.init_from_env(force=args.force_dist and not dry, graph_capture=cap)
     assert world == args.gpus
     forced = bool(args.force_dist and world == 1 and not dry)
@@ -805,34 +843,35 @@ def main():
         return step
 
     step = make_step(model, opt)
-    # one GPU: the step as ONE hipGraph replay (the product's GraphedStep); the eagerly issued step is measured right after it and
-    # reported as `eager_step`.  N > 1: eager unless --graph on.  A step WITH its collectives does capture and replay on RCCL
-    # (tests/test_gpu_graph.py::test_graphed_step_with_nccl_world1, one rank), but a multi-rank captured all-reduce has never run on this
-    # code, and a capture that goes wrong on some ranks only is a hang, not a fallback: the scaling run is not where to find out.
+    # The timed step is ONE hipGraph replay per rank (the product's GraphedStep), on one GPU and on N alike: with its gradient collectives
+    # captured (tests/test_gpu_graph.py::test_graphed_step_with_nccl_world1 runs that on RCCL with one rank; `--gpus 1 --force-dist` is the
+    # same line through bench.py).  Every rank attempts its capture, then the ranks agree over a gloo side group: if ANY capture failed, ALL
+    # ranks issue the step eagerly (scenerf_amd.graph.build_on_all_ranks; control flow under tests/test_dist_gloo.py with two gloo ranks) --
+    # a rank-consistent fallback, never a mix and never a hang on a half-captured world.  One GPU: the eagerly issued step is measured
+    # right after the replayed one and reported as `eager_step`.
     graphed = eager_leg = None
     graph_note = "eager (one launch call per kernel)"
-    want_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
-    if want_graph and not dry:
-        why = None
-        if world > 1 and args.graph != "on": why = "more than one rank"
-        elif args.sync == "step" and collectives: why = "--sync step (its end-of-backward callback is host code)"
-        elif args.precision != "bf16" and args.graph == "auto": why = "fp32 mode"
-        elif getattr(args, "host_rng", False): why = "--host-rng (the host-side draw cannot be captured)"
-        elif args.optimizer != "fused": why = "--optimizer torch"
-        if why is None:
-            try:
-                from scenerf_amd.graph import GraphedStep
-                args.capturable = True
-                opt_g = make_optimizer(args, params)
-                args.capturable = False
-                graphed = GraphedStep(model, opt_g, loss_fn, K, T, maps, pix, ray_batch_size=R, warmup=max(1, args.warmup))
-                graph_note = "one hipGraph replay per step (scenerf_amd.graph.GraphedStep: forward + loss + backward + fused AdamW captured once)"
-            except Exception as e:      # (a capture that fails must not cost the line: the eager step is the fallback, and the line says so)
-                graphed = None
-                graph_note = "eager (graph capture failed: %s)" % repr(e)[:200]
-                torch.cuda.synchronize()
+    want_graph, why = graph_wanted(args, collectives)
+    if want_graph:
+        from scenerf_amd.graph import build_on_all_ranks
+        if dry:
+            factory = lambda: _StubGraphed(model, rank, args.dry_fail_capture)      # noqa: E731
         else:
-            graph_note = "eager (%s)" % why
+            from scenerf_amd.graph import GraphedStep
+            args.capturable = True
+            opt_g = make_optimizer(args, params)
+            args.capturable = False
+            factory = lambda: GraphedStep(model, opt_g, loss_fn, K, T, maps, pix, ray_batch_size=R, warmup=max(1, args.warmup))     # noqa: E731
+        graphed, note = build_on_all_ranks(factory)
+        if graphed is not None:
+            graph_note = "one hipGraph replay per step (scenerf_amd.graph.GraphedStep: forward + loss + backward%s + fused AdamW captured once; %s)" % (
+                " + the gradient all-reduces" if collectives else "", note)
+        else:
+            graph_note = "eager (%s)" % note
+            if not dry:
+                torch.cuda.synchronize()
+    else:
+        graph_note = "eager (%s)" % why
     if not dry:
         for _ in range(max(0, args.device_warm_steps)):     # setup: the device at its sustained clocks before W + K (see --device-warm-steps)
             (graphed or step)()
@@ -842,7 +881,7 @@ def main():
         if not args.headline_only:
             dt_e, last_e = _timed(step, args, world, dev, sync)
             assert torch.isfinite(last_e).item(), "loss is not finite (eager step)"
-            eager_leg = {"value": round(R * args.steps / dt_e, 1), "unit": "rays/s", "ms_per_step": round(dt_e / args.steps * 1e3, 3),
+            eager_leg = {"value": round(world * R * args.steps / dt_e, 1), "unit": "rays/s", "ms_per_step": round(dt_e / args.steps * 1e3, 3),
                          "host_issue_ms_per_step": round(_timed.host_s / args.steps * 1e3, 3),
                          "note": "the same step issued eagerly (~50 launch calls per step from Python), same process, right after the timed region"}
         step_main = graphed

@@ -55,11 +55,16 @@ class OracleConfig:
     gauss_floor: float = 1.5       # scenerf.py:591-594 (+1.5); scenerf_bf.py:606-608 (+0.5)
     kl_std_floor: float = 1.5      # ray_som_kl.py:83 (same in BF)
     uni_fallback: int = 0          # uniform samples drawn when n_pts_uni == 0: scenerf_bf.py:623-626 substitutes 2; scenerf.py has no substitute
-    # which routine stands behind `torch.acos` in the sphere index (spherical_mapping.py:106).  "torch": the reference's call as this
-    # host executes it -- MKL VML's vmsAcos(HA), whose last bit depends on the CPU's instruction set (oracle/sleef_acos.py).  "sleef_u10":
-    # the pinned rule of this project, torch's own SLEEF build (what torch.atan2 already is, and what torch.acos is without MKL); the GPU
-    # parity tests select it and then require EVERY sphere index to be equal.  `torch.atan2` is SLEEF under both settings.
-    acos_rule: str = "torch"
+    # The arithmetic behind the sphere index (ray direction -> sample point -> projected pixel -> angles -> round()).  "torch": the
+    # reference's calls as THIS host executes them.  That is not one function of the inputs: `torch.acos` is MKL VML's vmsAcos(HA), whose last
+    # bit depends on the instruction set MKL dispatches to; `A @ x.T` is MKL's sgemm, whose summation order depends on the CPU vendor and the
+    # operand layout (on the AMD EPYC hosts of the MI355X boxes `K @ pts.T` differs from the same call on the Intel build container in a
+    # third of its elements: profiles/r05_oracle_vs_host_epyc.txt); `torch.atan2` sends the last n mod 32 elements of every OpenMP chunk
+    # through the C library instead of SLEEF (oracle/sleef_acos.py, tools/sleef_check/).  "pinned": the rule this project fixes (DESIGN.md
+    # section 2) -- 3x3 / 4x4 products as k-ordered fma chains (what MKL does on the Intel container the golden vectors were minted on),
+    # acos / atan2 = torch's own SLEEF u10 build; everything else (division, 2-norm, scaling, round) is ATen's and already host-independent.
+    # The GPU parity tests select "pinned" and then require EVERY sphere index, sample point and ray direction to be equal, bit for bit.
+    index_rule: str = "torch"
 
     @property
     def fov(self):
@@ -97,16 +102,42 @@ def _homog(pix: torch.Tensor) -> torch.Tensor:
     return torch.cat([pix, torch.ones_like(pix[:, :1])], dim=1)
 
 
-def ray_directions(pixels: torch.Tensor, inv_K: torch.Tensor):
+class _PinnedMatvec(torch.autograd.Function):
+    """(A @ X.T).T with every output element the k-ordered fma chain fma(a_k, x_k, ... fma(a_1, x_1, a_0 * x_0)) (oracle/sleef_shim.c);
+    the gradient w.r.t. X is the plain product (A is a constant of the path)."""
+
+    @staticmethod
+    def forward(ctx, A, X):
+        import sleef_acos          # (oracle/ is on sys.path: the oracle modules are imported top-level)
+        ctx.save_for_backward(A)
+        return sleef_acos.matvec_fma(A, X)
+
+    @staticmethod
+    def backward(ctx, g):
+        (A,) = ctx.saved_tensors
+        return None, g @ A
+
+
+def _matvec(A: torch.Tensor, X: torch.Tensor, rule: str = "torch") -> torch.Tensor:
+    """(A @ X.T).T for X (M, k): the reference's call (rule "torch": whatever this host's BLAS makes of it) or the pinned k-ordered fma
+    chain (OracleConfig.index_rule)."""
+    if rule == "pinned":
+        return _PinnedMatvec.apply(A.detach().float().contiguous(), X.float())
+    if rule != "torch":
+        raise ValueError("index_rule %r" % (rule,))
+    return (A @ X.T).T
+
+
+def ray_directions(pixels: torch.Tensor, inv_K: torch.Tensor, rule: str = "torch"):
     """utils.py:177-182 (unit dirs) and utils.py:131-135,170 (un-normalised dir)."""
-    d = (inv_K[:3, :3] @ _homog(pixels).T).T
+    d = _matvec(inv_K[:3, :3], _homog(pixels), rule)
     return d, F.normalize(d, dim=1)
 
 
-def to_frame(pts: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
+def to_frame(pts: torch.Tensor, T: torch.Tensor, rule: str = "torch") -> torch.Tensor:
     """utils.py:161-166 / 268-279: homogeneous 4x4 transform of (M,3) points."""
     h = torch.cat([pts, torch.ones(pts.shape[0], 1, dtype=pts.dtype, device=pts.device)], dim=1).float()
-    return (T @ h.T).T[:, :3]
+    return _matvec(T, h, rule)[:, :3]
 
 
 def uniform_distances(n_rays: int, U: int, D: float, noise_u: torch.Tensor) -> torch.Tensor:
@@ -122,9 +153,9 @@ def gaussian_anchor_distances(cfg: OracleConfig) -> torch.Tensor:
     return torch.linspace(step / 2, cfg.max_sample_depth - step / 2, steps=cfg.n_gaussians)
 
 
-def project_to_pixels(pts: torch.Tensor, K: torch.Tensor) -> torch.Tensor:
+def project_to_pixels(pts: torch.Tensor, K: torch.Tensor, rule: str = "torch") -> torch.Tensor:
     """utils.py:298-315: K @ p, perspective divide where z>0, else (-1,-1)."""
-    h = (K @ pts.T).T
+    h = _matvec(K, pts, rule)
     ok = h[:, 2] > 0
     pix = torch.full((pts.shape[0], 2), -1.0, device=pts.device)
     pix = torch.where(ok[:, None], h[:, :2] / h[:, 2:3], pix)
@@ -134,21 +165,21 @@ def project_to_pixels(pts: torch.Tensor, K: torch.Tensor) -> torch.Tensor:
 def sphere_coords(pix: torch.Tensor, inv_K: torch.Tensor, cfg: OracleConfig, return_float: bool = False):
     """spherical_mapping.py:80-115: pixel -> unit-depth cam point -> (acos, atan2) -> rounded sphere pixel."""
     v_min, v_fov, h_min, h_fov = cfg.fov
-    c = (inv_K @ _homog(pix).T).T
+    c = _matvec(inv_K, _homog(pix), cfg.index_rule)
     c = torch.ones(pix.shape[0], device=pix.device).view(-1, 1) * c
     x, y, z = c[:, 0], c[:, 1], c[:, 2]
     dist = torch.linalg.norm(c, ord=2, dim=1)
-    if cfg.acos_rule == "sleef_u10":
+    if cfg.index_rule == "pinned":
         import sleef_acos          # (oracle/ is on sys.path: the oracle modules are imported top-level)
         v_angle = sleef_acos.acos(-y / dist) / math.pi * 180
         # (torch.atan2 is already SLEEF where ATen runs its AVX2 / AVX-512 kernels; calling the routine by name makes the rule
         # independent of ATEN_CPU_CAPABILITY)
         h_angle = 180 - sleef_acos.atan2(z.contiguous(), x.contiguous()) / math.pi * 180
-    elif cfg.acos_rule == "torch":
+    elif cfg.index_rule == "torch":
         v_angle = torch.acos(-y / dist) / math.pi * 180
         h_angle = 180 - torch.atan2(z, x) / math.pi * 180
     else:
-        raise ValueError("acos_rule %r" % (cfg.acos_rule,))
+        raise ValueError("index_rule %r" % (cfg.index_rule,))
     out = torch.zeros((pix.shape[0], 2), device=pix.device)
     out[:, 0] = (h_angle - h_min) / h_fov * (cfg.sphere_W - 1)
     out[:, 1] = (v_angle - v_min) / v_fov * (cfg.sphere_H - 1)
@@ -181,7 +212,7 @@ def point_inputs(pts: torch.Tensor, viewdir_rows: torch.Tensor, x_rgb: Dict[str,
                  K: torch.Tensor, cfg: OracleConfig, idx_use: Optional[torch.Tensor] = None):
     """scenerf.py:505-531: (M,3) infer-frame points -> x_in (M, 2480+39+3) and the sphere indices.
     ``idx_use`` (parity tests only, see render_chunk): gather at these indices instead of the ones computed here (still returned)."""
-    pix = project_to_pixels(pts, K)
+    pix = project_to_pixels(pts, K, cfg.index_rule)
     idx = sphere_coords(pix, torch.inverse(K), cfg)
     use = idx if idx_use is None else idx_use.to(idx.dtype).reshape(idx.shape)
     pe = positional_encoding(pts)
@@ -331,8 +362,9 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
         raise ZeroDivisionError("float division by zero (utils.py:77: step = (d_max - d_min) / n_pts_per_ray with n_pts_uni == 0)")
     # (U == 0 with P > 1: the KITTI reference divides by zero here as well; the product renders the gaussian samples alone -- a superset
     # of the reference -- and this restatement follows it so that the configuration can be checked: no uniform samples are drawn)
-    dirs, unit = ray_directions(pixels, inv_K)
-    viewdir = (T_source2infer[:3, :3] @ dirs.T).T                                  # utils.py:170
+    rule = cfg.index_rule
+    dirs, unit = ray_directions(pixels, inv_K, rule)
+    viewdir = _matvec(T_source2infer[:3, :3], dirs, rule)                          # utils.py:170
 
     # uniform samples (utils.py:112-173); with n_pts_uni == 0 and P > 1 they are drawn and not rendered (noise_u may then be empty)
     if noise_u.shape[1] == 0 and cfg.n_pts_uni == 0 and P != 1:
@@ -341,14 +373,14 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
         dist_u = uniform_distances(R, U, D, noise_u)
         pts_u_src = dist_u.unsqueeze(-1) * unit.reshape(R, 1, 3)
         z_u = pts_u_src[:, :, 2]
-        pts_u = to_frame(pts_u_src.reshape(-1, 3), T_source2infer).reshape(R, U, 3)
+        pts_u = to_frame(pts_u_src.reshape(-1, 3), T_source2infer, rule).reshape(R, U, 3)
     else:
         dist_u = z_u = torch.zeros(R, 0, device=pixels.device)
         pts_u = torch.zeros(R, 0, 3, device=pixels.device)
 
     # gaussian heads (scenerf.py:549-596)
     anchors = gaussian_anchor_distances(cfg).type_as(cam_K).reshape(1, G, 1).expand(R, -1, 1)
-    apts = to_frame((anchors * unit.reshape(R, 1, 3)).reshape(-1, 3), T_source2infer)
+    apts = to_frame((anchors * unit.reshape(R, 1, 3)).reshape(-1, 3), T_source2infer, rule)
     vd_g = viewdir.unsqueeze(1).expand(-1, G, -1).reshape(-1, 3)
     xin_g, idx_g = point_inputs(apts, vd_g, x_rgb, cam_K, cfg, None if sphere_idx is None else sphere_idx[1])
     keep_g = {} if keep_intermediates else None
@@ -364,7 +396,7 @@ def render_chunk(cfg: OracleConfig, mlp: Dict[str, torch.Tensor], mlp_gaussian: 
     dist_g = torch.where(dist_g < 0.1, torch.full_like(dist_g, 0.1), dist_g)
     pts_g_src = dist_g.unsqueeze(-1) * unit.reshape(R, 1, 3)
     z_g = pts_g_src[:, :, 2]
-    pts_g = to_frame(pts_g_src.reshape(-1, 3), T_source2infer).reshape(R, G * P, 3)
+    pts_g = to_frame(pts_g_src.reshape(-1, 3), T_source2infer, rule).reshape(R, G * P, 3)
 
     # merge + sort (scenerf.py:636-659)
     if cfg.n_pts_uni > 0:

@@ -8,8 +8,9 @@ AVX2 kernels disagree on 207 of 4,194,304 inputs, the SSE4.2 kernel on 11,570 (`
 ``profiles/r05_acos_isa_probe.txt``), and a torch built without MKL (aarch64 wheels) calls SLEEF's ``Sleef_acosf*_u10`` instead.  The
 reference therefore has no single answer in the last bit of acos, and a sample within an ulp of a .5 boundary lands on either texel
 depending on the host.  The rule this project pins: **acos = SLEEF u10**, the open routine torch itself ships and uses
-for the sibling op, identical across its AVX2 / AVX-512 builds.  ``OracleConfig.acos_rule = "sleef_u10"`` selects it; the default
-(``"torch"``) stays the reference's call, whatever the host makes of it.
+for the sibling op, identical across its AVX2 / AVX-512 builds.  ``OracleConfig.index_rule = "pinned"`` selects it (together with the k-ordered fma
+chains for the path's 3x3 / 4x4 products: MKL's sgemm sums them in another order on other CPUs, see OracleConfig); the default (``"torch"``)
+stays the reference's calls, whatever the host makes of them.
 
 The functions below call the routine inside torch's own ``libtorch_cpu.so`` (exported symbols ``Sleef_acosf8_u10avx2`` /
 ``Sleef_atan2f8_u10avx2``) through ``oracle/sleef_shim.c``: the oracle does not restate SLEEF, it runs it.  Needs gcc and an AVX2 host.
@@ -33,7 +34,8 @@ def build(force: bool = False) -> str:
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
         os.makedirs(OUT, exist_ok=True)
         tl = os.path.join(os.path.dirname(torch.__file__), "lib")
-        subprocess.check_call(["gcc", "-O2", "-mavx2", "-shared", "-fPIC", "-o", LIB, src, "-L" + tl, "-ltorch_cpu", "-Wl,-rpath," + tl])
+        subprocess.check_call(["gcc", "-O2", "-mavx2", "-mfma", "-ffp-contract=off", "-shared", "-fPIC", "-o", LIB, src, "-L" + tl, "-ltorch_cpu",
+                               "-Wl,-rpath," + tl, "-lm"])
     return LIB
 
 
@@ -46,6 +48,7 @@ def _load():
             _lib = C.CDLL(build(force=True))
         _lib.oracle_sleef_acosf.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         _lib.oracle_sleef_atan2f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        _lib.oracle_matvec_fma.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     return _lib
 
 
@@ -67,6 +70,16 @@ def atan2(p: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
     if pc.numel():
         _load().oracle_sleef_atan2f(pc.data_ptr(), qc.data_ptr(), y.data_ptr(), pc.numel())
     return y.reshape(p.shape)
+
+
+def matvec_fma(A: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
+    """(A @ X.T).T for A (rows, k), X (M, k), float32 on the CPU, every element a k-ordered fma chain (sleef_shim.c: oracle_matvec_fma)."""
+    assert A.dtype == torch.float32 and X.dtype == torch.float32 and A.dim() == 2 and X.dim() == 2 and A.shape[1] == X.shape[1]
+    Ac, Xc = A.detach().contiguous(), X.detach().contiguous()
+    out = torch.empty((Xc.shape[0], Ac.shape[0]), dtype=torch.float32)
+    if Xc.shape[0]:
+        _load().oracle_matvec_fma(Ac.data_ptr(), Ac.shape[0], Ac.shape[1], Xc.data_ptr(), Xc.shape[0], out.data_ptr())
+    return out
 
 
 if __name__ == "__main__":

@@ -26,3 +26,16 @@ void oracle_sleef_atan2f(const float* p, const float* q, float* y, size_t n) {
         for (size_t j = i; j < n; ++j) y[j] = b[j - i];
     }
 }
+
+/* The pinned rule's small matrix products: out[m][r] = fma(A[r][k-1], x[m][k-1], ... fma(A[r][1], x[m][1], A[r][0] * x[m][0])), the
+ * k-ordered chain of a BLAS sgemm micro-kernel (what MKL runs for these shapes on the Intel container the golden vectors were minted on;
+ * MKL on other CPUs sums some layouts in another order).  A is (rows, k) row-major, x is (M, k) row-major, out is (M, rows). */
+#include <math.h>
+void oracle_matvec_fma(const float* A, int rows, int k, const float* x, size_t M, float* out) {
+    for (size_t m = 0; m < M; ++m)
+        for (int r = 0; r < rows; ++r) {
+            float acc = A[r * k] * x[m * k];
+            for (int j = 1; j < k; ++j) acc = fmaf(A[r * k + j], x[m * k + j], acc);
+            out[m * rows + r] = acc;
+        }
+}

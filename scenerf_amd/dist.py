@@ -56,7 +56,10 @@ def more_hw_queues(n: int = 8) -> bool:
     its kernels in order.  The renderer overlaps three streams (the caller's, its side stream, the library's weight-gradient stream); with
     RCCL's stream in the process two of them end up on ONE queue and the step serialises -- measured with a one-rank RCCL group, eagerly
     issued: 3.016 ms per step with 4 queues, 2.646 with 8 (16: the same).  The variable is read when the runtime initialises, so this must
-    run before the first GPU call of the process: returns False (and changes nothing) if that has already happened or the user set it."""
+    run before the first GPU call of the process -- best of all before ``import torch`` (bench.py's first lines do that for its ranks):
+    ``torch.cuda.is_initialized()`` is only a lower bound, ``torch.cuda.device_count()`` can already have brought the HIP runtime up while
+    it still says False.  Returns False (and changes nothing) if torch's CUDA state is initialised; True means "the variable is set", which
+    is a promise about the runtime only if no GPU call came first."""
     if "GPU_MAX_HW_QUEUES" in os.environ:
         return True
     if torch.cuda.is_available() and torch.cuda.is_initialized():
@@ -75,10 +78,11 @@ def init_from_env(backend: Optional[str] = None, force: bool = False, graph_capt
     if graph_capture:
         os.environ["TORCH_NCCL_ASYNC_ERROR_HANDLING"] = "0"
         os.environ["NCCL_ASYNC_ERROR_HANDLING"] = "0"
-    more_hw_queues()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or force:
+        more_hw_queues()       # (ranks of a process group only: a plain one-process run is left as the runtime comes)
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -93,6 +97,24 @@ def init_from_env(backend: Optional[str] = None, force: bool = False, graph_capt
         except TypeError:       # older torch without device_id
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+_SIDE_GROUP = None
+
+
+def all_ranks_agree(ok: bool) -> bool:
+    """AND of ``ok`` over the ranks, over a gloo SIDE group (CPU tensors, TCP): for decisions that must not touch the gradient
+    communicator -- e.g. "did every rank's hipGraph capture succeed?" (GraphedStep.build_on_all_ranks), where a failed capture may have
+    left the RCCL stream of that rank in an undefined state and a rank that failed before reaching a collective would leave the others
+    waiting inside one.  Every rank must call it the same number of times.  One process: returns ``ok``."""
+    global _SIDE_GROUP
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(ok)
+    if _SIDE_GROUP is None:
+        _SIDE_GROUP = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=_SIDE_GROUP)
+    return bool(int(t[0]))
 
 
 def shard_rays(n_rays_total: int, rank: int, world: int) -> Tuple[int, int]:

@@ -18,23 +18,57 @@ its autograd graph alive) before building another.
 Construction has side effects: it runs ``warmup`` real optimizer steps on whatever the static inputs hold at that moment (allocator
 pools, one-time setup and the optimizer state must exist before the capture) and then one more while capturing, whose kernels do
 not execute.  Parameters, AdamW moments, the step count and the device RNG have therefore advanced by ``warmup`` steps when the
-constructor returns (``steps_warmup``); pass ``restore=True`` to have parameters, optimizer state and RNG state put back afterwards,
-so that the first replay is step 1 on the data the caller copies into the static tensors.
+constructor returns (``steps_warmup``); pass ``restore=True`` to have all of that put back afterwards IN PLACE (the graph holds the
+addresses): parameters, every tensor of ``optimizer.state`` (moments and step counts as they were -- an optimizer resumed from a
+checkpoint or stepped before keeps its state; entries the warm-up created are zeroed), ``FusedAdamW``'s device-side [lr, t], the model's
+in-kernel sampler state ``{seed, calls}`` (``model._device_rng_state``: created before the snapshot, so the seed is the one the first
+replay uses), torch's CUDA generator, and any tensor listed in ``restore_tensors`` (e.g. the ``[seed, calls]`` tensor of a loss that calls
+``source_loss(rng_state=...)``).  The first replay is then step 1 from the caller's state: ``tests/test_gpu_graph.py`` holds it equal to an
+eager first step.
+
+More than one rank: ``GraphedStep.build_on_all_ranks`` attempts the capture on every rank and lets the ranks AGREE on the outcome over a
+gloo side group -- if any rank's capture failed, every rank drops its graph and steps eagerly (a step captured on some ranks only would
+still match the others' collectives one for one, but a bench line or a training log must not describe two kinds of rank).
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Optional
+from typing import Callable, Dict, Optional, Sequence
 
 import torch
+
+
+def _wait_for_pending_collectives(timeout_s: float = 10.0) -> None:
+    """Block until the process group's watchdog has retired every finished collective.  The warm-up steps' collectives stay on
+    ProcessGroupNCCL's work list until its next sweep; a completion query that thread makes while this one is capturing is an error inside
+    the watchdog (observed on RCCL, ~1 run in 10: the process aborts).  All of that work HAS finished (the caller synchronised the device):
+    ask the backend to report an empty list (ProcessGroup._wait_for_pending_works: it returns when the watchdog's list is empty) instead of
+    hoping that a fixed sleep outlasts one sweep; without that API, poll the group's sequence of sweeps with a bounded sleep loop."""
+    import time
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"):
+        return
+    pg = dist.group.WORLD
+    f = getattr(pg, "_wait_for_pending_works", None)
+    if f is not None:
+        try:
+            f()
+            return
+        except Exception:      # (a backend that does not implement it raises: fall through)
+            pass
+    t0 = time.time()           # older torch: the watchdog sweeps every 100 ms; wait for several sweeps
+    while time.time() - t0 < min(timeout_s, 1.0):
+        time.sleep(0.1)
 
 
 class GraphedStep:
     def __init__(self, model, optimizer: Optional[torch.optim.Optimizer], loss_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
                  cam_K: torch.Tensor, T_source2infer: torch.Tensor, x_rgb: Dict[str, torch.Tensor], pixels: torch.Tensor,
-                 ray_batch_size: Optional[int] = None, warmup: int = 3, noise=None, restore: bool = False):
+                 ray_batch_size: Optional[int] = None, warmup: int = 3, noise=None, restore: bool = False,
+                 restore_tensors: Sequence[torch.Tensor] = ()):
         """``noise``: optional static ``(noise_u, noise_g)`` tensors handed to ``render_rays_batch`` (the caller refills them between
         replays); without it the sampler draws on the device inside the graph.  ``restore``: undo the warm-up steps' effect on
-        parameters, optimizer state and the device RNG (module docstring)."""
+        parameters, optimizer state and every RNG state (module docstring); ``restore_tensors``: further device tensors the step
+        advances, put back with them."""
         if noise is None and not getattr(model.render_cfg, "device_rng", False):
             raise RuntimeError("GraphedStep: the sampler noise must be drawn on the device (render_cfg.device_rng = True); the "
                                "reference's host-side draw cannot be captured")
@@ -50,9 +84,7 @@ class GraphedStep:
         self._params = [p for g in optimizer.param_groups for p in g["params"]] if optimizer is not None else \
             [p for p in model.parameters() if p.requires_grad]
         self._map_leaves = [v for v in x_rgb.values() if v.requires_grad]
-        snap = None
-        if restore:
-            snap = ([p.detach().clone() for p in self._params], torch.cuda.get_rng_state(dev))
+        snap = self._snapshot(dev, restore_tensors) if restore else None
         # warm-up on a side stream (allocator pools, one-time setup, optimizer state), as torch's capture recipe asks
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -61,29 +93,69 @@ class GraphedStep:
                 self._eager()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl":
-            # the warm-up steps' collectives are still on ProcessGroupNCCL's watchdog list until its next sweep; a completion query that
-            # thread makes while this one is capturing is an error inside the watchdog (observed on RCCL, ~1 run in 10: the process
-            # aborts).  All of that work has finished (synchronize above): give the sweep time to retire it before the capture starts
-            import time
-            time.sleep(0.6)
+        _wait_for_pending_collectives()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._eager()
         self.map_grads = {k: v.grad for k, v in x_rgb.items() if v.requires_grad}
         self.steps_warmup = max(1, warmup)
         if snap is not None:
-            # parameters and moments back IN PLACE (the graph holds their addresses), step counts to zero, the RNG where it was
-            with torch.no_grad():
-                for p, v in zip(self._params, snap[0]):
-                    p.copy_(v)
-                if optimizer is not None:
-                    for st in optimizer.state.values():
-                        for k, v in st.items():
-                            if torch.is_tensor(v):
-                                v.zero_()
-            torch.cuda.set_rng_state(snap[1], dev)
+            self._restore(snap, dev)
             self.steps_warmup = 0
+
+    # ---- restore=True: everything the warm-up steps advanced, put back in place -----------------------------------------------
+    def _snapshot(self, dev, extra):
+        opt = self.optimizer
+        rng_model = None
+        if self.noise is None and hasattr(self.model, "_device_rng_state"):
+            rng_model = self.model._device_rng_state(dev)          # (created now if need be: the seed the replays will use)
+        st = {}
+        if opt is not None:
+            for p, d in opt.state.items():
+                st[p] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+        hyper = {gi: h[0].detach().clone() for gi, h in getattr(opt, "_hyper", {}).items()} if opt is not None else {}
+        return dict(params=[p.detach().clone() for p in self._params], opt_state=st, hyper=hyper,
+                    cuda_rng=torch.cuda.get_rng_state(dev), rng_model=(rng_model, rng_model.clone()) if rng_model is not None else None,
+                    extra=[(t, t.detach().clone()) for t in extra])
+
+    def _restore(self, snap, dev):
+        opt = self.optimizer
+        with torch.no_grad():
+            for p, v in zip(self._params, snap["params"]):
+                p.copy_(v)
+            if opt is not None:
+                for p, d in opt.state.items():
+                    was = snap["opt_state"].get(p, {})
+                    for k, v in list(d.items()):
+                        if torch.is_tensor(v):
+                            if k in was and torch.is_tensor(was[k]):
+                                v.copy_(was[k])
+                            elif k in was:
+                                v.fill_(float(was[k]))
+                            else:
+                                v.zero_()               # state the warm-up created: as if it had never stepped
+                        elif k in was:
+                            d[k] = was[k]
+                        elif isinstance(v, (int, float)):
+                            d[k] = type(v)(0)
+                for gi, h in getattr(opt, "_hyper", {}).items():        # FusedAdamW's device-side [lr, t, scratch]
+                    if gi in snap["hyper"]:
+                        h[0].copy_(snap["hyper"][gi])
+                    else:
+                        steps = [float(s["step"]) for s in (snap["opt_state"].get(p) for p in opt.param_groups[gi]["params"]) if s and "step" in s]
+                        h[0][1:].zero_()
+                        h[0][1:2].fill_(max(steps) if steps else 0.0)
+            if snap["rng_model"] is not None:
+                snap["rng_model"][0].copy_(snap["rng_model"][1])
+            for t, v in snap["extra"]:
+                t.copy_(v)
+        torch.cuda.set_rng_state(snap["cuda_rng"], dev)
+
+    # ---- more than one rank: every rank captures, then all agree ----------------------------------------------------------------
+    @classmethod
+    def build_on_all_ranks(cls, *args, agree: Optional[Callable[[bool], bool]] = None, **kw):
+        """(GraphedStep or None, note): ``build_on_all_ranks(lambda: cls(*args, **kw), agree)`` (module function below)."""
+        return build_on_all_ranks(lambda: cls(*args, **kw), agree)
 
     def _eager(self) -> torch.Tensor:
         for p in self._params:
@@ -106,3 +178,30 @@ class GraphedStep:
             self.optimizer.sync_hyper()     # a scheduler may have moved the learning rate
         self.graph.replay()
         return self.loss
+
+
+def build_on_all_ranks(factory: Callable[[], object], agree: Optional[Callable[[bool], bool]] = None):
+    """(graphed step or None, note).  Every rank calls this; each attempts its capture (``factory()``: normally ``lambda:
+    GraphedStep(...)``); ``agree(ok)`` returns the AND over ranks (default: ``scenerf_amd.dist.all_ranks_agree``, a gloo side group -- never
+    the gradient communicator, whose stream a failed capture may have left in an undefined state).  If any rank failed, EVERY rank drops
+    its graph and the caller steps eagerly everywhere: no rank is left replaying a graph whose collectives the others issue by hand, and a
+    log line describes one kind of rank.  (What this cannot catch: a rank that dies or hangs inside its warm-up steps -- those are real
+    collectives, and the others wait in them until the process group's timeout.)"""
+    from . import dist as sdist
+    err = None
+    try:
+        g = factory()
+    except Exception as e:           # noqa: BLE001 -- whatever went wrong, the other ranks must hear about it
+        g, err = None, repr(e)[:200]
+        try:
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                torch.cuda.synchronize()
+        except Exception:            # noqa: BLE001
+            pass
+    ok = (agree or sdist.all_ranks_agree)(g is not None)
+    if ok:
+        return g, "captured on every rank"
+    if g is not None:
+        del g
+        return None, "capture failed on another rank: all ranks step eagerly"
+    return None, "capture failed on this rank (%s): all ranks step eagerly" % err

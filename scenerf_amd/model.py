@@ -296,13 +296,16 @@ class SceneRF(TrainingMixin, _Base):
 
     # ---- the hot path ---------------------------------------------------------------------------------------
     def _inv_K(self, cam_K: torch.Tensor) -> torch.Tensor:
-        """torch.inverse(cam_K) as the reference computes it (scenerf.py:400), cached per intrinsics tensor: rocSOLVER's LU is ~8
-        tiny launches and is not stream-capturable.  The cache key is the tensor OBJECT and its version counter (never the address:
-        a new tensor may reuse it), so a loop that passes the same K tensor pays once and anything else recomputes."""
+        """torch.inverse(cam_K) (scenerf.py:400), cached per intrinsics tensor.  Computed by the HOST's LAPACK and uploaded: the GPU's LU
+        (rocSOLVER: ~8 tiny launches, not stream-capturable) returns an inverse that differs from the CPU's in the last bit of single
+        entries (BundleFusion's -cy/fy: seen as 6 of 108,000 sphere rows off the oracle's), and everything downstream of the sphere index
+        is held bit-exact to torch-CPU's operation sequence (csrc/sphere_exact.h).  One small D2H + H2D per NEW intrinsics tensor; the
+        cache key is the tensor OBJECT and its version counter (never the address: a new tensor may reuse it), so a loop -- or a
+        captured graph -- that passes the same K tensor pays once."""
         hit = getattr(self, "_inv_K_cache", None)
         if hit is None or hit[0] is not cam_K or hit[1] != cam_K._version:
-            hit = (cam_K, cam_K._version, torch.inverse(cam_K).contiguous())    # (torch.inverse hands back a column-major view: every
-                                                                                 #  consumer's .contiguous() would be a copy launch per chunk)
+            inv = torch.inverse(cam_K.detach().to("cpu", torch.float32)).contiguous()   # (torch.inverse hands back a column-major view)
+            hit = (cam_K, cam_K._version, inv.to(cam_K.device))
             object.__setattr__(self, "_inv_K_cache", hit)
         return hit[2]
 

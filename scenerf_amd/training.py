@@ -194,13 +194,13 @@ class TrainingMixin:
         bs = img_input.shape[0]
         T_cam2velo = torch.inverse(batch["T_velo_2_cam"][0]) if "T_velo_2_cam" in batch else None
         cam_K0 = batch["cam_K"][0]
-        pix, pix_sphere, _ = self.spherical_mapping.from_pixels(inv_K=torch.inverse(cam_K0))
+        pix, pix_sphere, _ = self.spherical_mapping.from_pixels(inv_K=self._inv_K(cam_K0))
         x_rgbs = self.net_rgb(img_input, pix=pix, pix_sphere=pix_sphere)
         tot = dict(rep=0.0, col=0.0, kl=0.0, somv=0.0, stds=0.0, d2c=0.0)
         for i in range(bs):
             x_rgb = {k: x_rgbs[k][i] for k in x_rgbs}
             cam_K = batch["cam_K"][i]
-            inv_K = torch.inverse(cam_K).contiguous()
+            inv_K = self._inv_K(cam_K)       # (the host's LAPACK: model.py)
             for sid in range(len(batch["img_sources"][i])):
                 T_s2i = batch["T_source2infers"][i][sid]
                 ret = self.process_single_source(self.n_rays, x_rgb=x_rgb, cam_K=cam_K, inv_K=inv_K,
@@ -243,7 +243,7 @@ class BundleFusionTrainingMixin(TrainingMixin):
         img_input = batch["img_inputs"]
         bs = img_input.shape[0]
         cam_K = batch["cam_K_depth"][0]
-        inv_K = torch.inverse(cam_K).contiguous()
+        inv_K = self._inv_K(cam_K)           # (the host's LAPACK: model.py)
         pix, pix_sphere, _ = self.spherical_mapping.from_pixels(inv_K=inv_K)
         x_rgbs = self.net_rgb(img_input, pix=pix, pix_sphere=pix_sphere)
         n_grids = self.n_rays // (self.sample_grid_size ** 2)

@@ -127,6 +127,66 @@ def test_bench_control_flow_over_gloo():
     assert len(d["allreduce"]["per_rank_ms_per_step"]) == 2
 
 
+def test_bench_falls_back_on_every_rank_when_one_capture_fails():
+    """The rank-consistent fallback of the captured step (scenerf_amd.graph.build_on_all_ranks) in bench.py's own control flow: rank 1's
+    (stub) capture fails, rank 0's succeeds -- both must step eagerly (the line says so), the collectives still pair up (no hang), one
+    JSON line, clean exit.  And without the failure the line reports the replayed step."""
+    import json
+    import subprocess
+    for fail, want in ((1, "eager (capture failed on another rank"), (0, "eager (capture failed on this rank"), (-1, "one hipGraph replay per step")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1",
+               "--dry-fail-capture", str(fail)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["value"] > 0
+        assert d["config"]["step_issue"].startswith(want), d["config"]["step_issue"]
+
+
+def _worker_agree(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from scenerf_amd import dist as sdist
+    from scenerf_amd.graph import build_on_all_ranks
+    sdist.init_from_env(backend="gloo")
+    res = []
+    assert sdist.all_ranks_agree(True) is True
+    assert sdist.all_ranks_agree(rank == 0) is False          # one dissenting rank: False on EVERY rank
+
+    def factory_ok():
+        return "graph of rank %d" % rank
+
+    def factory_fail_on_1():
+        if rank == 1:
+            raise RuntimeError("hipErrorStreamCaptureInvalidated (pretend)")
+        return "graph of rank %d" % rank
+
+    g, note = build_on_all_ranks(factory_ok)
+    res.append((g, note))
+    g, note = build_on_all_ranks(factory_fail_on_1)
+    res.append((g, note))
+    t = torch.tensor([float(rank)])                             # the default group still works after the side group's traffic
+    dist.all_reduce(t)
+    res.append(float(t))
+    torch.save(res, out % rank)
+    dist.destroy_process_group()
+
+
+def test_capture_outcome_is_agreed_over_a_side_group(tmp_path):
+    world = 2
+    out = str(tmp_path / "a%d.pt")
+    mp.spawn(_worker_agree, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = [torch.load(out % r) for r in range(world)]
+    for r in range(world):
+        assert res[r][0] == ("graph of rank %d" % r, "captured on every rank")
+        assert res[r][1][0] is None                              # nobody keeps a graph
+        assert res[r][2] == 1.0
+    assert "on another rank" in res[0][1][1] and "on this rank" in res[1][1][1] and "pretend" in res[1][1][1]
+
+
 def _bench(*argv, env=None, timeout=240):
     import subprocess
     e = dict(os.environ)

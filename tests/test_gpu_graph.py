@@ -192,6 +192,67 @@ def test_graphed_step_with_the_device_draw_inside_the_graph():
     assert float(opt.state[opt.param_groups[0]["params"][0]]["step"]) == 6.0
 
 
+def test_restore_true_first_replay_is_an_eager_first_step():
+    """GraphedStep(restore=True): after construction (2 warm-up steps + the capture) parameters, AdamW moments and step count, the
+    in-kernel sampler state and a listed extra tensor are what they were -- here an optimizer that had ALREADY stepped twice (a resumed
+    run: its moments must come back, not zeros).  The first replay then equals the next eager step from the same state up to the run-to-run
+    spread of two eager steps (fp32 atomics), the device draw included (same seed, same call counter)."""
+    from scenerf_amd.graph import GraphedStep
+
+    def start():
+        m, opt, maps, K, T, pix, _ = _setup(9)
+        m.reseed_device_rng(1234) if m.__dict__.get("_rng_states") else None
+        st = m._device_rng_state(torch.device(DEV))
+        st.copy_(torch.tensor([1234, 0, 0], dtype=torch.int64))
+        for _ in range(2):                       # the optimizer has a history
+            opt.zero_grad(set_to_none=True)
+            for v in maps.values():
+                v.grad = None
+            _loss(m.render_rays_batch(K, T, maps, T_cam2velo=None, sampled_pixels=pix, ray_batch_size=256)).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return m, opt, maps, K, T, pix
+
+    def eager_next(m, opt, maps, K, T, pix):
+        opt.zero_grad(set_to_none=True)
+        for v in maps.values():
+            v.grad = None
+        loss = _loss(m.render_rays_batch(K, T, maps, T_cam2velo=None, sampled_pixels=pix, ray_batch_size=256))
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        return float(loss), [p.detach().clone() for p in opt.param_groups[0]["params"]]
+
+    la, pa = eager_next(*start())
+    lb, pb = eager_next(*start())
+    m, opt, maps, K, T, pix = start()
+    params = opt.param_groups[0]["params"]
+    before = dict(p=[p.detach().clone() for p in params], m=[opt.state[p]["exp_avg"].clone() for p in params],
+                  v=[opt.state[p]["exp_avg_sq"].clone() for p in params], rng=m._device_rng_state(torch.device(DEV)).clone(),
+                  hyper=opt._hyper[0][0].clone())
+    extra = torch.tensor([7, 3], dtype=torch.int64, device=DEV)
+
+    def loss_fn(out):
+        extra.add_(1)                             # a tensor the step advances (stands for source_loss's [seed, calls])
+        return _loss(out)
+
+    gs = GraphedStep(m, opt, loss_fn, K, T, maps, pix, ray_batch_size=256, warmup=2, restore=True, restore_tensors=[extra])
+    torch.cuda.synchronize()
+    assert gs.steps_warmup == 0
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before["p"], params))
+    assert all(torch.equal(a, opt.state[p]["exp_avg"]) for a, p in zip(before["m"], params)) and float(before["m"][0].abs().max()) > 0
+    assert all(torch.equal(a, opt.state[p]["exp_avg_sq"]) for a, p in zip(before["v"], params))
+    assert torch.equal(before["rng"][:2], m._device_rng_state(torch.device(DEV))[:2])
+    assert torch.equal(before["hyper"], opt._hyper[0][0]) and float(opt.state[params[0]]["step"]) == 2.0
+    assert extra.tolist() == [7, 3]
+    lg = float(gs())
+    torch.cuda.synchronize()
+    assert float(opt.state[params[0]]["step"]) == 3.0 and extra.tolist() == [8, 4]
+    spread = _rel(pa, pb)
+    assert _rel(pa, [p.detach() for p in params]) <= 3 * spread + 1e-6, (spread, _rel(pa, [p.detach() for p in params]))
+    assert abs(lg - la) <= 3 * abs(la - lb) + 1e-3 * (1 + abs(la)), (la, lb, lg)
+
+
 def test_graphed_step_refuses_what_cannot_be_captured():
     from scenerf_amd.graph import GraphedStep
     from scenerf_amd.optim import FusedAdamW

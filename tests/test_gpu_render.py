@@ -45,30 +45,31 @@ def frac_within(a, b, tol, absolute=False):
     return float(ok.float().mean()), ok
 
 
-def clean_mask(aux, o, ocfg, K, n_rays):
+def clean_mask(aux, o, ocfg, K, n_rays, T):
     """Rays (the first ``n_rays`` of the render) whose every sample and anchor got the sphere index the FREE-RUNNING oracle ``o`` computed
-    (reference rule as this host runs it) -- the rays a stored / free-running output vector can be compared on.
+    (the reference's calls as this host runs them) -- the rays a stored / free-running output vector can be compared on.
 
-    Round 5: the geometry chain is bit-exact (csrc/sphere_exact.h), so an index can differ from the free-running oracle's for two
-    reasons only, and both are checked here instead of being waved through by a window around the .5 boundaries:
-      * the acos routine (rows only): the pinned rule (SLEEF u10) against torch.acos = MKL's vmsAcos on this host.  The oracle's OWN
-        points under the pinned rule must give the GPU's index wherever the GPU's sample sits at the oracle's position;
-      * a gaussian sample that moved: its distance carries the gaussian head's fp32 output, which is MLP arithmetic (accumulation order)
-        and not bit-exact.  Only main samples, only those whose sorted distance differs from the oracle's in its bits; anchors never."""
+    Round 5: the geometry chain is bit-exact (csrc/sphere_exact.h), so before the mask is built EVERY index of the GPU is required to be the
+    pinned rule (OracleConfig.index_rule) applied to the GPU's own sample distances and ray directions -- no window around the .5 boundaries.
+    What is left to differ from the free-running oracle, and is masked: gaussian samples whose distance carries the gaussian head's fp32
+    output (MLP arithmetic: accumulation order, not bit-exact), and what the host makes of torch.acos / `K @ p` (oracle/sleef_acos.py)."""
     import dataclasses
     n_main, n_head = o["_idx"].shape[0], o["_idx_g"].shape[0]
     iK = torch.inverse(K)
-    rule = dataclasses.replace(ocfg, acos_rule="sleef_u10")
+    rule = dataclasses.replace(ocfg, index_rule="pinned")
     got, got_g = aux["sphere_idx"].cpu().long()[:n_main], aux["sphere_idx_g"].cpu().long()[:n_head]
-    idx_g_rule = orc.sphere_coords(orc.project_to_pixels(o["_anchor_pts"].detach(), K), iK, rule)
+    unit = aux["unit_dir"].cpu()[:n_rays]
+    G = n_head // n_rays
+    anchors = orc.gaussian_anchor_distances(ocfg).reshape(1, G, 1)
+    apts = orc.to_frame((anchors * unit.reshape(n_rays, 1, 3)).reshape(-1, 3), T, "pinned")
+    idx_g_rule = orc.sphere_coords(orc.project_to_pixels(apts, K, "pinned"), iK, rule)
     assert torch.equal(got_g, idx_g_rule), "anchor sphere indices differ from the pinned rule (%d rows)" % int((got_g != idx_g_rule).any(1).sum())
-    idx_rule = orc.sphere_coords(orc.project_to_pixels(o["_pts_sorted"].detach().reshape(-1, 3), K), iK, rule)
-    same_pos = (aux["dist_sorted"].cpu().reshape(-1)[:n_main].view(torch.int32) == o["_dist_sorted"].detach().reshape(-1).view(torch.int32))
-    assert torch.equal(got[same_pos], idx_rule[same_pos]), \
-        "%d samples at the oracle's own position have another sphere index than the pinned rule" % int((got[same_pos] != idx_rule[same_pos]).any(1).sum())
-    assert int((got - idx_rule).abs().max()) <= 1          # (a moved gaussian sample: the neighbouring texel at most)
+    ds = aux["dist_sorted"].cpu()[:n_rays]
+    pts = orc.to_frame((ds.unsqueeze(-1) * unit.reshape(n_rays, 1, 3)).reshape(-1, 3), T, "pinned")
+    idx_rule = orc.sphere_coords(orc.project_to_pixels(pts, K, "pinned"), iK, rule)
+    assert torch.equal(got.clamp(-10**9, 10**9), idx_rule.clamp(-10**9, 10**9)), \
+        "%d sample sphere indices differ from the pinned rule at the GPU's own sample positions" % int((got != idx_rule).any(1).sum())
     dm, dh = got - o["_idx"], got_g - o["_idx_g"]
-    assert int((dm[:, 0][same_pos] != 0).sum()) == 0 and int((dh[:, 0] != 0).sum()) == 0, "a column (atan2) differs from torch's at the oracle's position"
     assert int(dm.abs().max()) <= 1 and int(dh.abs().max()) <= 1
     flipped = (dm != 0).any(dim=1).reshape(n_rays, -1).any(dim=1) | (dh != 0).any(dim=1).reshape(n_rays, -1).any(dim=1)
     assert int(flipped.sum()) <= max(1, n_rays // 16), "too many rays with a sphere index off the free-running oracle's: %d of %d" % (int(flipped.sum()), n_rays)
@@ -81,8 +82,8 @@ def _clean_rays(m, g: Golden, R):
     mlp, mlpg = g.mlp_states()
     outs = [orc.render_chunk(ocfg, mlp, mlpg, g.cam_K, g.T, g.feature_maps(), g.pixels[s:s + g.chunk], g.noise_u[s:s + g.chunk],
                              g.noise_g[s:s + g.chunk], keep_intermediates=True) for s in range(0, R, g.chunk)]
-    o = {k: torch.cat([c[k] for c in outs], dim=0) for k in ("_idx", "_idx_g", "_pts_sorted", "_anchor_pts", "_dist_sorted")}
-    return clean_mask(m.last_aux, o, ocfg, g.cam_K, R)
+    o = {k: torch.cat([c[k] for c in outs], dim=0) for k in ("_idx", "_idx_g")}
+    return clean_mask(m.last_aux, o, ocfg, g.cam_K, R, g.T)
 
 
 def _loss_kl_at_the_gpus_choices(m, g: Golden, R):
@@ -90,7 +91,7 @@ def _loss_kl_at_the_gpus_choices(m, g: Golden, R):
     choices (BMU per sample, mask per gaussian: render_chunk(head_offsets=, som_choices=)) under the pinned acos rule -- the sphere indices
     are NOT handed over: they must come out equal -- after checking that every differing RaySOM choice sits on a tie of the oracle's own
     (argmax margin / threshold distance)."""
-    ocfg = (orc.OracleConfig.kitti if g.variant == "kitti" else orc.OracleConfig.bundlefusion)(acos_rule="sleef_u10", **g.cfg_kwargs())
+    ocfg = (orc.OracleConfig.kitti if g.variant == "kitti" else orc.OracleConfig.bundlefusion)(index_rule="pinned", **g.cfg_kwargs())
     mlp, mlpg = g.mlp_states()
     aux = m.last_aux
     N, G = aux["bmu"].shape[1], aux["kl_mask"].shape[1]
@@ -227,7 +228,7 @@ def test_larger_chunk_against_oracle_bf16_and_fp32():
             out = m.render_rays_batch(K.to(DEV), T.to(DEV), {k: v.to(DEV) for k, v in maps.items()}, sampled_pixels=pix.to(DEV),
                                       ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
         t = TOL[precision]
-        clean = clean_mask(m.last_aux, ref, ocfg, K, R) if m.debug_aux else torch.ones(R, dtype=torch.bool)
+        clean = clean_mask(m.last_aux, ref, ocfg, K, R, T) if m.debug_aux else torch.ones(R, dtype=torch.bool)
         _, okd = frac_within(out["depth"].cpu(), ref["depth"].detach(), t["depth"])
         _, okc = frac_within(out["color"].cpu(), ref["color"].detach(), t["color"], True)
         fd, fc = float(okd[clean].float().mean()), float(okc[clean].float().mean())
@@ -266,7 +267,7 @@ def test_edge_cases_against_oracle_fp32(name, over, R, chunk, pose):
         nu = torch.zeros(R, 0, 1)
     chunks = [orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix[s:s + chunk], nu[s:s + chunk], ng[s:s + chunk], keep_intermediates=True)
               for s in range(0, R, chunk)]
-    ref = {k: torch.cat([c[k] for c in chunks], dim=0) for k in OUT_KEYS + ["_idx", "_idx_g", "_pts_sorted", "_anchor_pts", "_dist_sorted"]}
+    ref = {k: torch.cat([c[k] for c in chunks], dim=0) for k in OUT_KEYS + ["_idx", "_idx_g"]}
     m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="fp32", **kw).to(DEV)
     m.mlp.load_state_dict(mlp)
     m.mlp_gaussian.load_state_dict(mlpg)
@@ -274,7 +275,7 @@ def test_edge_cases_against_oracle_fp32(name, over, R, chunk, pose):
     x = {k: v.to(DEV).requires_grad_(True) for k, v in maps.items()}
     out = m.render_rays_batch(K.to(DEV), T.to(DEV), x, sampled_pixels=pix.to(DEV), ray_batch_size=chunk,
                               noise=(nu.to(DEV), ng.to(DEV)))
-    clean = clean_mask(m.last_aux, ref, ocfg, K, R)   # every ray except those with a +-1 sphere index at a rounding boundary
+    clean = clean_mask(m.last_aux, ref, ocfg, K, R, T)   # every ray whose indices are the free-running oracle's
     for k in OUT_KEYS:
         got, want = out[k].detach().cpu(), ref[k].detach()
         assert got.shape == want.shape, (k, got.shape, want.shape)
@@ -476,7 +477,7 @@ def test_full_size_config2_properties_and_subset_parity():
                                     ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
         outs[precision] = {k: v.cpu() for k, v in o.items()}
         if precision == "fp32":
-            aux32 = {k: m.last_aux[k].cpu() for k in ("sphere_idx", "sphere_idx_g", "dist_sorted")}
+            aux32 = {k: m.last_aux[k].cpu() for k in ("sphere_idx", "sphere_idx_g", "dist_sorted", "unit_dir")}
     o = outs["fp32"]
     w, a, z, dep = o["weights"], o["alphas"], o["depth_volumes"], o["depth"]
     assert w.shape == (R, N)
@@ -497,7 +498,7 @@ def test_full_size_config2_properties_and_subset_parity():
     S = 40
     ocfg = orc.OracleConfig.kitti(**kw)
     ref = orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix[:S], nu[:S], ng[:S], keep_intermediates=True)
-    clean = clean_mask(aux32, ref, ocfg, K, S)
+    clean = clean_mask(aux32, ref, ocfg, K, S, T)
     for k in ("depth", "color", "weights", "alphas", "densities", "gaussian_means", "gaussian_stds", "depth_volumes"):
         _, ok = frac_within(o[k][:S], ref[k].detach(), TOL["fp32"]["color"] if k == "color" else 1e-4, k in ABS_KEYS)
         assert bool(ok[clean].all()), "%s: %.3f of the subset rays within tolerance" % (k, float(ok[clean].float().mean()))
@@ -574,7 +575,7 @@ def test_full_size_config3_bundlefusion_fused_vs_layers_and_subset_parity():
             o = m.render_rays_batch(K.to(DEV), T.to(DEV), x, sampled_pixels=pix.to(DEV), ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
         grads = None
         if m.debug_aux:
-            auxs[precision] = {k: m.last_aux[k].cpu() for k in ("sphere_idx", "sphere_idx_g", "dist_sorted")}
+            auxs[precision] = {k: m.last_aux[k].cpu() for k in ("sphere_idx", "sphere_idx_g", "dist_sorted", "unit_dir")}
         if grad:
             (o["depth"].mean() + o["color"].mean() + o["loss_kl"].mean() + o["gaussian_means"].mean()).backward()
             grads = {"mlp." + n: p.grad.cpu() for n, p in m.mlp.named_parameters()}
@@ -587,7 +588,7 @@ def test_full_size_config3_bundlefusion_fused_vs_layers_and_subset_parity():
     S = 24
     ocfg = orc.OracleConfig.bundlefusion(**{k: v for k, v in kw.items()})
     ref = orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix[:S], nu[:S], ng[:S], keep_intermediates=True)
-    clean = clean_mask(auxs["fp32"], ref, ocfg, K, S)
+    clean = clean_mask(auxs["fp32"], ref, ocfg, K, S, T)
     for k in ("depth", "color", "weights", "alphas", "gaussian_means", "gaussian_stds", "depth_volumes"):
         _, ok = frac_within(o32[k][:S], ref[k].detach(), TOL["fp32"]["color"] if k == "color" else 1e-4, k in ABS_KEYS)
         assert bool(ok[clean].all()), "%s: %.3f of the subset rays within tolerance" % (k, float(ok[clean].float().mean()))

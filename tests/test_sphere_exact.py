@@ -6,9 +6,9 @@ sphere pixel is compared BIT FOR BIT with what torch-CPU / the oracle computes:
 
   * the two SLEEF routines against torch's own SLEEF build (``oracle/sleef_acos.py``) and, for atan2, against ``torch.atan2`` itself;
   * ray directions, sample points and projected pixels against the oracle's torch ops (matmul, F.normalize, division);
-  * the rounded indices against ``oracle.sphere_coords`` under the pinned rule (``acos_rule="sleef_u10"``): zero differences, KITTI and
+  * the rounded indices against ``oracle.sphere_coords`` under the pinned rule (``index_rule="pinned"``): zero differences, KITTI and
     BundleFusion constants, points behind the camera included;
-  * how far the pinned rule is from the reference as THIS host runs it (``acos_rule="torch"``: MKL's vmsAcos): rows only, a few per million.
+  * how far the pinned rule is from the reference as THIS host runs it (``index_rule="torch"``: MKL's vmsAcos): rows only, a few per million.
 
 The GPU side (``tests/test_gpu_stages.py::test_device_acos_atan2_*``, ``test_encode_points_*``) then only has to show that the device
 executes the same sequence.
@@ -123,7 +123,7 @@ T_CASES = [torch.eye(4),
 
 @pytest.mark.parametrize("variant", ["kitti", "bundlefusion"])
 def test_chain_equals_the_oracle_bit_for_bit(host, variant):
-    cfg = getattr(orc.OracleConfig, variant)(acos_rule="sleef_u10")
+    cfg = getattr(orc.OracleConfig, variant)(index_rule="pinned")
     K, iK = _cam(cfg)
     W, H = cfg.img_size
     g = torch.Generator().manual_seed(7)
@@ -131,18 +131,18 @@ def test_chain_equals_the_oracle_bit_for_bit(host, variant):
     pix = torch.stack([torch.randint(0, W, (R,), generator=g).float(), torch.randint(0, H, (R,), generator=g).float()], 1).contiguous()
     for ti, T in enumerate(T_CASES):
         T = T.contiguous()
-        dirs, unit = orc.ray_directions(pix, iK)
-        vd = (T[:3, :3] @ dirs.T).T
+        dirs, unit = orc.ray_directions(pix, iK, "pinned")
+        vd = orc._matvec(T[:3, :3], dirs, "pinned")
         hu, hv = torch.empty(R, 3), torch.empty(R, 3)
         host.srf_host_rays(pix.data_ptr(), R, iK.data_ptr(), T.data_ptr(), hu.data_ptr(), hv.data_ptr())
         assert bits_differ(hu, unit) == 0, "unit directions (utils.py:177-182)"
         assert bits_differ(hv, vd) == 0, "view directions (utils.py:170)"
         dist = (torch.rand(R, S, generator=g) * cfg.max_sample_depth * 1.5 - 0.3 * cfg.max_sample_depth).contiguous()
-        pts = orc.to_frame((dist.unsqueeze(-1) * unit.reshape(R, 1, 3)).reshape(-1, 3), T)
+        pts = orc.to_frame((dist.unsqueeze(-1) * unit.reshape(R, 1, 3)).reshape(-1, 3), T, "pinned")
         hp = torch.empty(R * S, 3)
         host.srf_host_sample_points(hu.data_ptr(), dist.data_ptr(), R, S, T.data_ptr(), hp.data_ptr())
         assert bits_differ(hp, pts) == 0, "sample points (utils.py:161-166)"
-        opix = orc.project_to_pixels(pts, K)
+        opix = orc.project_to_pixels(pts, K, "pinned")
         idx, coords = orc.sphere_coords(opix, iK, cfg, return_float=True)
         hi, hc, hx = torch.empty(R * S, 2, dtype=torch.int32), torch.empty(R * S, 2), torch.empty(R * S, 2)
         consts = torch.tensor(cfg.fov, dtype=torch.float32)
@@ -156,19 +156,28 @@ def test_chain_equals_the_oracle_bit_for_bit(host, variant):
 
 
 def test_pinned_rule_against_the_reference_as_this_host_runs_it(host):
-    """acos_rule="torch" (MKL's vmsAcos on an MKL build) against the pinned SLEEF rule: columns (atan2) never differ; rows differ on a few
-    samples per million -- those are the samples a reference-minted golden may place on the neighbouring texel row."""
-    cfg_s, cfg_t = orc.OracleConfig.kitti(acos_rule="sleef_u10"), orc.OracleConfig.kitti(acos_rule="torch")
+    """index_rule="torch" (the reference's calls as this host executes them) against the pinned rule, on one set of points.  Where the
+    host's sgemm runs the 3x3 products as k-ordered fma chains (the Intel build container the golden vectors were minted on: checked here,
+    not assumed), columns (atan2 = SLEEF in torch itself) never differ and rows differ on a few samples per million (MKL's vmsAcos against
+    SLEEF's acosf) -- the samples a reference-minted golden may place on the neighbouring texel row.  On a host whose BLAS sums in another
+    order (the AMD EPYC hosts of the MI355X boxes) the count is printed and only bounded."""
+    cfg_s, cfg_t = orc.OracleConfig.kitti(index_rule="pinned"), orc.OracleConfig.kitti(index_rule="torch")
     K, iK = _cam(cfg_s)
     g = torch.Generator().manual_seed(3)
     M = 1 << 21
     z = torch.rand(M, generator=g) * 100 + 0.1
-    pts = torch.stack([(torch.rand(M, generator=g) * 2 - 1) * z * 1.2, (torch.rand(M, generator=g) * 2 - 1) * z * 0.4, z], 1)
-    pix = orc.project_to_pixels(pts, K)
-    a, b = orc.sphere_coords(pix, iK, cfg_s), orc.sphere_coords(pix, iK, cfg_t)
+    p0 = torch.stack([(torch.rand(M, generator=g) * 2 - 1) * z * 1.2, (torch.rand(M, generator=g) * 2 - 1) * z * 0.4, z], 1)
+    pts = orc.to_frame(p0, T_CASES[1], "pinned")              # (the layout the path hands to `K @ pts.T`: a column slice of a (4, M) product)
+    pts_layout = (T_CASES[1] @ torch.cat([p0, torch.ones(M, 1)], 1).T).T[:, :3]
+    same_T = bits_differ(pts, pts_layout) == 0
+    pix_s, pix_t = orc.project_to_pixels(pts, K, "pinned"), orc.project_to_pixels(pts_layout if same_T else pts, K, "torch")
+    blas_is_pinned = same_T and bits_differ(pix_s, pix_t) == 0
+    a, b = orc.sphere_coords(pix_s, iK, cfg_s), orc.sphere_coords(pix_t, iK, cfg_t)
     dx, dy = int((a[:, 0] != b[:, 0]).sum()), int((a[:, 1] != b[:, 1]).sum())
-    print("pinned rule vs torch.acos on this host: %d column and %d row differences in %d samples" % (dx, dy, M))
-    if torch.backends.cpu.get_cpu_capability() in ("AVX2", "AVX512"):
+    print("this host's `A @ x.T` is the k-ordered fma chain: %s; pinned rule vs the reference's calls on this host: %d column and %d row "
+          "differences in %d samples" % (blas_is_pinned, dx, dy, M))
+    if blas_is_pinned and torch.backends.cpu.get_cpu_capability() in ("AVX2", "AVX512"):
         assert dx == 0
-    assert dy <= M * 2e-5
+        assert dy <= M * 2e-5
+    assert dx + dy <= M * 2e-4
     assert int((a - b).abs().max()) <= 1
