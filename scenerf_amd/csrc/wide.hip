@@ -195,8 +195,15 @@ extern "C" int scenerf_hip_test_wide_cyc(unsigned long long* ptr) { return (int)
 #define H_STAMP()
 #endif
 
-template <int MODE>
+// MODE_T: 0 / 3 = forward, 1 / 4 = backward chain with lin_out's prologue, 2 = backward chain on a staged dH3 tile.  0 and 1 are the
+// instantiations for launches whose every block is full (M a multiple of 128) and whose every layer is saved (training): the stream-out's
+// stores are then CERTAIN -- one 16-byte store (+ one sign-bit byte store, forward) per resident chunk -- and the K loop's waits count
+// them (WSK, H_WAITW); 3 and 4 are the same kernels with the load-only count and the stores behind their row / pointer checks
+// (inference, partial blocks); 2 (tests, A/B runs) starts with a run that streams nothing out and keeps the load-only count too.
+template <int MODE_T>
 __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
+    constexpr int MODE = MODE_T == 3 ? 0 : MODE_T == 4 ? 1 : MODE_T;
+    constexpr int WSK = MODE_T == 0 ? 2 : MODE_T == 1 ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // the accumulator file is this kernel's: a[0:255] are written by name in the MFMA statements
     asm volatile("" ::: "a0", "a15", "a16", "a31", "a32", "a63", "a64", "a95", "a96", "a127", "a128", "a159", "a160", "a191", "a192", "a223",
@@ -446,12 +453,19 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
 // 15 - j vector-memory operations are younger -- the rest of its chunk and the next three chunks' loads; stores and DMA in between
 // only add to that -- and loads retire in order, so vmcnt(15 - j) in front of the first MFMA that reads fragment j is safe.)
 #ifdef H_VAR_CLD
-#define H_WAITW(I, J)
+#define H_WAITW(I, J, WS)
 #else
-#define H_WAITW(I, J) if ((I) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(15 - (J)));
+// WS = vector-memory operations a chunk issues BESIDES its four ring loads (round 5).  The counter is shared: with the stream-out's
+// stores in the loop (training forward: one 16-byte store + one sign-bit byte store per chunk; backward chain: one store) the operations
+// younger than load j of chunk c number 15 - j + 3 WS, and vmcnt(15 - j) made the wave wait for ~1.5 chunks' worth of YOUNGER operations
+// as well -- the ring's four chunks of slack shrank to about two and a half, and every store had to be acknowledged by L2 within two
+// chunks instead of four (the same kernel without stores, inference, ran at 0.48 of peak against 0.34).  The exact count holds where the
+// three chunks in front are known to have issued WS operations each: chunks 4.. of a resident run in the instantiations whose stores are
+// certain (WSK); a run's first four chunks (what ran before them is the previous run's tail or an epilogue) keep the load-only count.
+#define H_WAITW(I, J, WS) if ((I) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(15 - (J) + 3 * (WS)));
 #endif
 #define H_M(I, J, S, ZERO)                                                          \
-    H_WAITW(I, J)                                                                   \
+    H_WAITW(I, J, WS_)                                                              \
     if (ZERO) h_mfma0<16 * (4 * (I) + (J))>(wr[S][J], af[I]);                       \
     else h_mfma<16 * (4 * (I) + (J))>(wr[S][J], af[I]);
 #define H_SB() __builtin_amdgcn_sched_barrier(0);
@@ -475,7 +489,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     { \
         const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
         const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
-        const bool sok_ = sv_run && (m0 + srow_ < p.M);                                                                                                \
+        const bool sok_ = WSK > 0 || (sv_run && (m0 + srow_ < p.M));                                                                                                \
         H_M(0, 0, S, ZERO)                                                                                                                             \
         const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
         H_SB()                                                                                                                                         \
@@ -499,7 +513,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
         H_SB()                                                                                                                                         \
         H_M(2, 0, S, ZERO)                                                                                                                             \
-        if (MODE == 0 && sok_ && sg_base) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
+        if (MODE == 0 && sok_ && (WSK > 0 || sg_base)) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
         H_SB()                                                                                                                                         \
         H_M(2, 1, S, ZERO)                                                                                                                             \
         const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
@@ -529,7 +543,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     { \
         const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
         const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
-        const bool sok_ = sv_run && (m0 + srow_ < p.M);                                                                                                \
+        const bool sok_ = WSK > 0 || (sv_run && (m0 + srow_ < p.M));                                                                                                \
         H_M(0, 0, S, ZERO) H_M(0, 1, S, ZERO)                                                                                                          \
         const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
         H_SB()                                                                                                                                         \
@@ -545,7 +559,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
         H_SB()                                                                                                                                         \
         H_M(2, 0, S, ZERO) H_M(2, 1, S, ZERO)                                                                                                          \
-        if (MODE == 0 && sok_ && sg_base) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
+        if (MODE == 0 && sok_ && (WSK > 0 || sg_base)) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
         const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
         H_SB()                                                                                                                                         \
         H_M(2, 2, S, ZERO) H_M(2, 3, S, ZERO)                                                                                                          \
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     { \
         const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
         const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
-        const bool sok_ = sv_run && (m0 + srow_ < p.M);                                                                                                \
+        const bool sok_ = WSK > 0 || (sv_run && (m0 + srow_ < p.M));                                                                                                \
         H_M(0, 0, S, ZERO) H_M(0, 1, S, ZERO) H_M(0, 2, S, ZERO) H_M(0, 3, S, ZERO)                                                                    \
         const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
         af[0] = *(lds_frag_p)(uintptr_t)(x0_);                                                                                                         \
@@ -579,7 +593,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
         H_SB()                                                                                                                                         \
         H_M(2, 0, S, ZERO) H_M(2, 1, S, ZERO) H_M(2, 2, S, ZERO) H_M(2, 3, S, ZERO)                                                                    \
-        if (MODE == 0 && sok_ && sg_base) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
+        if (MODE == 0 && sok_ && (WSK > 0 || sg_base)) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
         const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
         H_TOUCH(DP)                                                                                                                                    \
         const unsigned x1_ = x0_ + 65536u; af[2] = *(lds_frag_p)(uintptr_t)(x1_);                                                                      \
@@ -597,7 +611,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     { \
         const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
         const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
-        const bool sok_ = sv_run && (m0 + srow_ < p.M);                                                                                                \
+        const bool sok_ = WSK > 0 || (sv_run && (m0 + srow_ < p.M));                                                                                                \
         H_M(0, 0, S, ZERO) H_M(0, 1, S, ZERO) H_M(0, 2, S, ZERO) H_M(0, 3, S, ZERO) H_M(1, 0, S, ZERO) H_M(1, 1, S, ZERO) H_M(1, 2, S, ZERO) H_M(1, 3, S, ZERO) \
         const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
         af[0] = *(lds_frag_p)(uintptr_t)(x0_);                                                                                                         \
@@ -607,7 +621,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
         H_SB()                                                                                                                                         \
         H_M(2, 0, S, ZERO) H_M(2, 1, S, ZERO) H_M(2, 2, S, ZERO) H_M(2, 3, S, ZERO) H_M(3, 0, S, ZERO) H_M(3, 1, S, ZERO) H_M(3, 2, S, ZERO) H_M(3, 3, S, ZERO) \
-        if (MODE == 0 && sok_ && sg_base) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
+        if (MODE == 0 && sok_ && (WSK > 0 || sg_base)) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
         const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
         H_TOUCH(DP)                                                                                                                                    \
         const unsigned x1_ = x0_ + 65536u; af[2] = *(lds_frag_p)(uintptr_t)(x1_);                                                                      \
@@ -623,7 +637,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     { \
         const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
         const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
-        const bool sok_ = sv_run && (m0 + srow_ < p.M);                                                                                                \
+        const bool sok_ = WSK > 0 || (sv_run && (m0 + srow_ < p.M));                                                                                                \
         H_M(0, 0, S, ZERO) H_M(0, 1, S, ZERO) H_M(0, 2, S, ZERO) H_M(0, 3, S, ZERO) H_M(1, 0, S, ZERO) H_M(1, 1, S, ZERO) H_M(1, 2, S, ZERO) H_M(1, 3, S, ZERO) H_M(2, 0, S, ZERO) H_M(2, 1, S, ZERO) H_M(2, 2, S, ZERO) H_M(2, 3, S, ZERO) H_M(3, 0, S, ZERO) H_M(3, 1, S, ZERO) H_M(3, 2, S, ZERO) H_M(3, 3, S, ZERO) \
         const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
         af[0] = *(lds_frag_p)(uintptr_t)(x0_);                                                                                                         \
@@ -631,7 +645,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         uint32_t su_ = 0; if (MODE == 0) { su_ = h_pk_min_u16(sv_.x, 0x00010001u); su_ |= h_pk_min_u16(sv_.y, 0x00010001u) << 2; }                     \
         if (MODE == 0) { su_ |= h_pk_min_u16(sv_.z, 0x00010001u) << 4; su_ |= h_pk_min_u16(sv_.w, 0x00010001u) << 6; }                                 \
         af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
-        if (MODE == 0 && sok_ && sg_base) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
+        if (MODE == 0 && sok_ && (WSK > 0 || sg_base)) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
         const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
         H_TOUCH(DP)                                                                                                                                    \
         const unsigned x1_ = x0_ + 65536u; af[2] = *(lds_frag_p)(uintptr_t)(x1_);                                                                      \
@@ -657,16 +671,25 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         af[2] = *(lds_frag_p)(uintptr_t)(ag + 65536u);
         af[3] = *(lds_frag_p)(uintptr_t)(ag + 98304u);
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int WS_ = WSK;
+        // (a run's first four chunks: what ran before them is not this loop -- the load-only count, all four fragments at once, behind a
+        // scalar branch.  Two whole copies of the chunks with different immediates were tried: the register allocator parks the joined
+        // live ranges in accumulator registers.)
+#define H_RUN_HEAD() if (WSK > 0 && g == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #pragma unroll 1
         for (int g = 0; g < 4; ++g) {
             H_LANE();
             if (g == 0) {
+                H_RUN_HEAD()
                 H_RES_CHUNK(0, 0, true, e0, dnv.x)
             } else {
                 H_RES_CHUNK(0, 0, false, e0, dnv.x)
             }
+            H_RUN_HEAD()
             H_RES_CHUNK(1, 1, false, e1, dnv.y)
+            H_RUN_HEAD()
             H_RES_CHUNK(2, 2, false, e2, dnv.z)
+            H_RUN_HEAD()
             H_RES_CHUNK(3, 3, false, e3, dnv.w)
             H_GROUP_TOP()
             H_RES_CHUNK(0, 4, false, e0, dnv.x)
@@ -676,6 +699,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
             H_GROUP_TOP()
             ag += 256u;
         }
+#undef H_RUN_HEAD
     };
 
     // ---- STAGED chunks (forward only): `ns` list entries (multiple of H_D, padding at the end), `nreal` of them real, staged in rounds
@@ -1023,6 +1047,8 @@ static int wide_attrs() {
         SRF_HIP(hipFuncSetAttribute((const void*)mlp_wide_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS));
         SRF_HIP(hipFuncSetAttribute((const void*)mlp_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS));
         SRF_HIP(hipFuncSetAttribute((const void*)mlp_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS)));
+        SRF_HIP(hipFuncSetAttribute((const void*)mlp_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS));
+        SRF_HIP(hipFuncSetAttribute((const void*)mlp_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS));
     return 0;
 }
 
@@ -1068,8 +1094,12 @@ int launch_mlp_fwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, co
         }
     }
     SrfLaunchScope ps(s, w->d_out == 2 ? "mlp_fwd_fused/g" : "mlp_fwd_fused", flops, 0);
-    mlp_wide_kernel<0><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);
-    SRF_LAUNCH_CHECK("mlp_wide_kernel<0>");
+    // every block full and every layer + its sign bits saved: the instantiation whose K loop counts the stream-out's stores (kernel header)
+    bool certain = M % H_BM == 0 && a->sign_bits != nullptr;
+    for (int l = 0; l < 7; ++l) certain = certain && p.layer[l].save != nullptr;
+    if (certain) mlp_wide_kernel<0><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);
+    else mlp_wide_kernel<3><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);
+    SRF_LAUNCH_CHECK("mlp_wide_kernel<fwd>");
     return 0;
 }
 
@@ -1101,7 +1131,8 @@ int launch_mlp_bwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, in
     p.desc = desc + 32 * F_MAXCH;
     p.M = M;
     SrfLaunchScope ps(s, w->d_out == 2 ? "mlp_bwd_fused/g" : "mlp_bwd_fused", 2.0 * M * 512.0 * (6.0 * 512.0 + (d_logits ? 48.0 : 0.0)), 0);
-    if (d_logits) mlp_wide_kernel<1><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);
+    if (d_logits && M % H_BM == 0) mlp_wide_kernel<1><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);    // (full blocks: the stores are certain)
+    else if (d_logits) mlp_wide_kernel<4><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);
     else mlp_wide_kernel<2><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);
     SRF_LAUNCH_CHECK("mlp_wide_kernel<bwd>");
     return 0;
