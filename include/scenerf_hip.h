@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SCENERF_HIP_ABI_VERSION 8
+#define SCENERF_HIP_ABI_VERSION 9
 #define SCENERF_N_SCALES 5          /* feature maps "1_1","1_2","1_4","1_8","1_16" */
 #define SCENERF_D_LATENT 2480       /* 80+160+320+640+1280 (resnetfc d_latent, scenerf.py:100-114) */
 #define SCENERF_D_HIDDEN 512
@@ -366,6 +366,30 @@ int scenerf_hip_source_loss_backward(const float* color, const float* col_src, c
                                      const float* gmeans, const float* depth, const int32_t* closest, const float* out8, const float* g_total,
                                      int R, int G, float w_rep, float w_col, float w_d2c, float* g_color, float* g_depth, float* g_loss_kl,
                                      float* g_gmeans, scenerf_stream_t stream);
+
+/* ---- ResnetFC of any shape, forward only (fp32) ---------------------------------------------------------------- */
+/* resnetfc.py:67-164 is generic in n_blocks / d_hidden; SceneRF instantiates 3 x 512 (scenerf.py:100-114) and the fast kernels above are
+ * built for that.  BASELINE.json configs[0] names a 1-block, 128-wide net: this entry evaluates ANY ResnetFC(d_in=42, d_latent=2480) on the
+ * outputs of scenerf_hip_encode_points / _gather_features with one fp32-MFMA GEMM per nn.Linear, in the reference's order of additions.
+ * Parameters in the reference's layout (nn.Linear.weight = [out][in], row-major fp32) except: w_in zero-padded 42 -> 48 input columns,
+ * w_out / b_out zero-padded to d_out_pad rows (a multiple of 8).  h_a, h_b, n_buf: [M][d_hidden] fp32 scratch; logits [M][d_out_pad]. */
+#define SCENERF_RESNETFC_MAX_BLOCKS 8
+typedef struct {
+    int32_t n_blocks, d_hidden, d_out_pad;
+    const float* w_in;  /* [d_hidden][48] */
+    const float* b_in;
+    const float* w_z[SCENERF_RESNETFC_MAX_BLOCKS];    /* lin_z.b.weight [d_hidden][2480] */
+    const float* b_z[SCENERF_RESNETFC_MAX_BLOCKS];
+    const float* w_fc0[SCENERF_RESNETFC_MAX_BLOCKS];  /* blocks.b.fc_0.weight [d_hidden][d_hidden] */
+    const float* b_fc0[SCENERF_RESNETFC_MAX_BLOCKS];
+    const float* w_fc1[SCENERF_RESNETFC_MAX_BLOCKS];
+    const float* b_fc1[SCENERF_RESNETFC_MAX_BLOCKS];
+    const float* w_out; /* [d_out_pad][d_hidden] */
+    const float* b_out; /* [d_out_pad] */
+} scenerf_resnetfc;
+int scenerf_hip_resnetfc_forward(const scenerf_cfg* cfg, const scenerf_resnetfc* net, const float* xenc /*[M][48]*/,
+                                 const float* Z /*[Mpad][2480] fp32, as scenerf_hip_gather_features wrote it*/, const uint8_t* tile_mask,
+                                 int M, float* h_a, float* h_b, float* n_buf, float* logits, scenerf_stream_t stream);
 
 /* ---- generic building blocks exported for unit tests ------------------------------------------------------- */
 /* C[M][N] = relu?(A[M][K]) @ W[N][K]^T (+bias); act operands per `precision`, fp32 output.

@@ -23,7 +23,7 @@ D_HIDDEN = 512
 D_XENC = 48
 TILE_ROWS = 128
 W_STREAM_BLOCKS = (3 * D_XENC + D_LATENT) // 16 + 2 * ((512 + D_LATENT) // 16) + 10 * (512 // 16)   # scenerf_hip.h
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 vp = C.c_void_p
 
@@ -54,6 +54,19 @@ class MlpWeights(C.Structure):
         ("w_stream", vp),
         ("clear", vp), ("clear_floats", C.c_int64),
     ]
+
+
+RESNETFC_MAX_BLOCKS = 8
+
+
+class ResnetFCNet(C.Structure):
+    """scenerf_resnetfc (scenerf_hip.h): a ResnetFC of any block count / width, forward only."""
+    _fields_ = [("n_blocks", C.c_int32), ("d_hidden", C.c_int32), ("d_out_pad", C.c_int32),
+                ("w_in", vp), ("b_in", vp),
+                ("w_z", vp * RESNETFC_MAX_BLOCKS), ("b_z", vp * RESNETFC_MAX_BLOCKS),
+                ("w_fc0", vp * RESNETFC_MAX_BLOCKS), ("b_fc0", vp * RESNETFC_MAX_BLOCKS),
+                ("w_fc1", vp * RESNETFC_MAX_BLOCKS), ("b_fc1", vp * RESNETFC_MAX_BLOCKS),
+                ("w_out", vp), ("b_out", vp)]
 
 
 class MlpParams(C.Structure):
@@ -127,6 +140,7 @@ _PROTOS = {
     "scenerf_hip_sampler_backward": (C.c_int, [C.POINTER(Cfg), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
     "scenerf_hip_pixels_to_sphere": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, i32, i32, C.c_int64, vp, vp, vp]),
     "scenerf_hip_test_acos_atan2": (C.c_int, [vp, vp, C.c_int64, vp, vp, vp]),
+    "scenerf_hip_resnetfc_forward": (C.c_int, [C.POINTER(Cfg), C.POINTER(ResnetFCNet), vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "scenerf_hip_test_gemm_nt": (C.c_int, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "scenerf_hip_test_chunk_table": (C.c_int, [C.POINTER(Cfg), i32, vp, i32]),
     "scenerf_hip_test_gemm_tn": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, vp, vp, vp]),

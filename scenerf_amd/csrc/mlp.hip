@@ -415,6 +415,75 @@ int scenerf_hip_mlp_forward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w
     return launch_linout_fwd<float>(w->d_out, a->H[3], w->w_out, w->b_out, M, a->logits, s);
 }
 
+// ResnetFC.forward (resnetfc.py:133-164) for ANY block count / hidden width, fp32, forward only: one fp32-MFMA GEMM per nn.Linear, the
+// reference's order of additions (h = lin_in(x); per block: h += lin_z.b(z); h += fc_1(relu(fc_0(relu(h)))); out = lin_out(relu(h))).
+// The product's fast kernels are specialised to the trunk SceneRF instantiates (3 blocks x 512); this entry is what makes every other
+// ResnetFC shape -- BASELINE.json configs[0]'s 1 block x 128 -- run through the same ray pipeline on the GPU.
+int scenerf_hip_resnetfc_forward(const scenerf_cfg* cfg, const scenerf_resnetfc* net, const float* xenc, const float* Z,
+                                 const uint8_t* tile_mask, int M, float* h_a, float* h_b, float* n_buf, float* logits,
+                                 scenerf_stream_t stream) {
+    SRF_CHECK(cfg && net && xenc && Z && tile_mask && h_a && h_b && n_buf && logits && M > 0, "resnetfc_forward: NULL argument");
+    SRF_CHECK(net->n_blocks >= 1 && net->n_blocks <= SCENERF_RESNETFC_MAX_BLOCKS, "resnetfc_forward: n_blocks=%d (1..%d)", net->n_blocks,
+              SCENERF_RESNETFC_MAX_BLOCKS);
+    SRF_CHECK(net->d_hidden >= 16 && net->d_hidden % 16 == 0 && net->d_out_pad >= 8 && net->d_out_pad % 8 == 0,
+              "resnetfc_forward: d_hidden=%d must be a multiple of 16, d_out_pad=%d of 8", net->d_hidden, net->d_out_pad);
+    SRF_CHECK(net->w_in && net->b_in && net->w_out && net->b_out, "resnetfc_forward: NULL parameter");
+    hipStream_t s = as_stream(stream);
+    const int H = net->d_hidden;
+    float* cur = h_a;
+    float* nxt = h_b;
+    {
+        GemmNT g;
+        g.name = "gemm_generic_lin_in";
+        g.A1 = xenc; g.lda1 = SCENERF_D_XENC; g.K1 = SCENERF_D_XENC;
+        g.W = net->w_in; g.ldw = SCENERF_D_XENC;
+        g.M = M; g.N = H; g.bias = net->b_in;
+        g.out = cur; g.ldout = H; g.out_f32 = 1;
+        if (int e = launch_gemm_nt(0, g, s)) return e;
+    }
+    for (int b = 0; b < net->n_blocks; ++b) {
+        SRF_CHECK(net->w_z[b] && net->b_z[b] && net->w_fc0[b] && net->b_fc0[b] && net->w_fc1[b] && net->b_fc1[b], "resnetfc_forward: NULL parameter (block %d)", b);
+        {   // h = h + lin_z.b(z)
+            GemmNT g;
+            g.name = "gemm_generic_linz";
+            set_segments(g, cfg, Z, tile_mask);
+            g.W = net->w_z[b]; g.ldw = SCENERF_D_LATENT;
+            g.M = M; g.N = H; g.bias = net->b_z[b];
+            g.res = cur; g.ldres = H; g.res_f32 = 1;
+            g.out = nxt; g.ldout = H; g.out_f32 = 1;
+            if (int e = launch_gemm_nt(0, g, s)) return e;
+            float* t = cur; cur = nxt; nxt = t;
+        }
+        {   // net = fc_0(relu(h))
+            GemmNT g;
+            g.name = "gemm_generic_fc0";
+            g.A1 = cur; g.lda1 = H; g.K1 = H; g.relu1 = 1;
+            g.W = net->w_fc0[b]; g.ldw = H;
+            g.M = M; g.N = H; g.bias = net->b_fc0[b];
+            g.out = n_buf; g.ldout = H; g.out_f32 = 1;
+            if (int e = launch_gemm_nt(0, g, s)) return e;
+        }
+        {   // h = h + fc_1(relu(net))
+            GemmNT g;
+            g.name = "gemm_generic_fc1";
+            g.A1 = n_buf; g.lda1 = H; g.K1 = H; g.relu1 = 1;
+            g.W = net->w_fc1[b]; g.ldw = H;
+            g.M = M; g.N = H; g.bias = net->b_fc1[b];
+            g.res = cur; g.ldres = H; g.res_f32 = 1;
+            g.out = nxt; g.ldout = H; g.out_f32 = 1;
+            if (int e = launch_gemm_nt(0, g, s)) return e;
+            float* t = cur; cur = nxt; nxt = t;
+        }
+    }
+    GemmNT g;   // out = lin_out(relu(h)), the output columns zero-padded to a multiple of 8 by the caller
+    g.name = "gemm_generic_lin_out";
+    g.A1 = cur; g.lda1 = H; g.K1 = H; g.relu1 = 1;
+    g.W = net->w_out; g.ldw = H;
+    g.M = M; g.N = net->d_out_pad; g.bias = net->b_out;
+    g.out = logits; g.ldout = net->d_out_pad; g.out_f32 = 1;
+    return launch_gemm_nt(0, g, s);
+}
+
 int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const scenerf_mlp_grads* g_,
                              const void* Z, const float* xenc, const uint8_t* tile_mask, const int32_t* tap_texel,
                              const float* tap_weight, int M, const scenerf_mlp_acts* a, const float* d_logits, void* dH,

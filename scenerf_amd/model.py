@@ -133,13 +133,19 @@ class ResnetBlockFC(nn.Module):
 class ResnetFC(nn.Module):
     """Parameter container with the reference's names/shapes/init (resnetfc.py:67-131).
 
-    It has no ``forward``: evaluation happens inside the HIP MLP pass (``scenerf_hip_mlp_forward``).
+    It has no ``forward``: evaluation happens inside the HIP MLP pass.  The shape SceneRF instantiates (``n_blocks=3, d_hidden=512``,
+    scenerf.py:100-114) runs on the fused kernels, forward and backward; every other block count / hidden width (the reference class is
+    generic: BASELINE.json configs[0] names 1 block x 128) runs forward-only, in fp32, one MFMA GEMM per ``nn.Linear``
+    (``scenerf_hip_resnetfc_forward``) -- assign such a net to ``model.mlp`` / ``model.mlp_gaussian`` and render under ``torch.no_grad()``.
     """
 
     def __init__(self, d_in: int = 42, d_out: int = 4, n_blocks: int = 3, d_latent: int = 2480, d_hidden: int = 512):
         super().__init__()
-        if (d_in, n_blocks, d_latent, d_hidden) != (42, 3, 2480, 512) or d_out not in (2, 4):
-            raise ValueError("the HIP MLP pass is built for ResnetFC(d_in=42, n_blocks=3, d_latent=2480, d_hidden=512, d_out in {2,4})")
+        if (d_in, d_latent) != (42, 2480) or d_out not in (2, 4):
+            raise ValueError("the HIP ray pipeline feeds a ResnetFC(d_in=42, d_latent=2480, d_out in {2,4}) (positional encoding + view direction, "
+                             "the five feature maps' 2480 channels)")
+        if not (1 <= n_blocks <= 8) or d_hidden < 16 or d_hidden % 16:
+            raise ValueError("ResnetFC: n_blocks in 1..8 and d_hidden a multiple of 16 (the MFMA GEMM's K granularity)")
         self.d_in, self.d_out, self.n_blocks, self.d_latent, self.d_hidden = d_in, d_out, n_blocks, d_latent, d_hidden
         self.lin_in = nn.Linear(d_in, d_hidden)
         nn.init.constant_(self.lin_in.bias, 0.0)
@@ -153,9 +159,22 @@ class ResnetFC(nn.Module):
             nn.init.constant_(self.lin_z[i].bias, 0.0)
             nn.init.kaiming_normal_(self.lin_z[i].weight, a=0, mode="fan_in")
 
+    @property
+    def is_standard(self) -> bool:
+        """The trunk SceneRF instantiates: the shape the fused kernels (forward + backward) are built for."""
+        return self.n_blocks == 3 and self.d_hidden == 512
+
     def ordered_params(self):
+        """Parameters in the order the renderer's pack expects: ``MLP_PARAM_NAMES`` for the standard shape; the same pattern over
+        ``n_blocks`` blocks otherwise (lin_in, lin_out, then per block fc_0, fc_1, lin_z: weight, bias)."""
         p = dict(self.named_parameters())
-        return [p[n] for n in MLP_PARAM_NAMES]
+        if self.is_standard:
+            return [p[n] for n in MLP_PARAM_NAMES]
+        names = ["lin_in.weight", "lin_in.bias", "lin_out.weight", "lin_out.bias"]
+        for b in range(self.n_blocks):
+            names += ["blocks.%d.fc_0.weight" % b, "blocks.%d.fc_0.bias" % b, "blocks.%d.fc_1.weight" % b, "blocks.%d.fc_1.bias" % b,
+                      "lin_z.%d.weight" % b, "lin_z.%d.bias" % b]
+        return [p[n] for n in names]
 
     def forward(self, *a, **k):
         raise RuntimeError("ResnetFC is evaluated by the HIP MLP pass; call SceneRF.render_rays_batch")
@@ -335,7 +354,8 @@ class SceneRF(TrainingMixin, _Base):
         if sampled_pixels.shape[0] == 0:
             raise ValueError("sampled_pixels is empty (the reference fails in torch.cat over zero chunks here, scenerf.py:459-470)")
         self.ray_som  # noqa: B018  (attribute kept for parity with the reference module tree)
-        if (self.static_inference and not torch.is_grad_enabled() and sampled_pixels.shape[0] > ray_batch_size and not self.debug_aux):
+        if (self.static_inference and not torch.is_grad_enabled() and sampled_pixels.shape[0] > ray_batch_size and not self.debug_aux
+                and self.mlp.is_standard and self.mlp_gaussian.is_standard):
             # the evaluation / reconstruction callers (render_colors.py:114-119, generate_novel_depths.py:116-122: 50k-450k rays in
             # chunks of 4000-8000 under no_grad): static chunk shape, one captured hipGraph per input frame (scenerf_amd/inference.py)
             return self.render_image(cam_K, T_source2infer, x_rgb, sampled_pixels=sampled_pixels, ray_batch_size=ray_batch_size, noise=noise)

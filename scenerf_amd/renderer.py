@@ -554,6 +554,73 @@ class PackedMLP:
         return [out[n] for n in MLP_PARAM_NAMES]
 
 
+class GenericPackedMLP:
+    """A ResnetFC of a shape the fused kernels are not built for (anything but 3 blocks x 512; ``ResnetFC.ordered_params`` order): the
+    reference's parameter layout, lin_in's input columns zero-padded 42 -> 48 and lin_out's rows to a multiple of 8, for
+    ``scenerf_hip_resnetfc_forward`` (fp32, forward only).  Same interface as ``PackedMLP`` where a forward pass touches it."""
+    generic = True
+
+    def __init__(self, params: Sequence[torch.Tensor], d_out: int, cfg: RenderConfig):
+        if cfg.precision_code != 0:
+            raise RuntimeError("a ResnetFC other than 3 blocks x 512 runs on the per-layer fp32 GEMM path only: construct the model with "
+                               "precision='fp32' (the bf16 kernels are built for the trunk SceneRF instantiates)")
+        ps = [_f32c(t.detach()) for t in params]
+        if len(ps) < 10 or (len(ps) - 4) % 6:
+            raise RuntimeError("GenericPackedMLP: expected lin_in, lin_out and six tensors per block (ResnetFC.ordered_params)")
+        for i, t in enumerate(ps):
+            _require_cuda(t, "ResnetFC parameter %d" % i)
+        nb = (len(ps) - 4) // 6
+        H = ps[0].shape[0]
+        if tuple(ps[0].shape) != (H, 42) or tuple(ps[2].shape) != (d_out, H) or nb > _capi.RESNETFC_MAX_BLOCKS or H % 16:
+            raise RuntimeError("ResnetFC parameter shapes do not match d_in=42, d_hidden=%d, d_out=%d" % (H, d_out))
+        self.d_out, self.d_hidden, self.n_blocks, self.device = d_out, H, nb, ps[0].device
+        self.d_out_pad = (d_out + 7) // 8 * 8
+        dev = self.device
+        w_in = torch.zeros((H, D_X), dtype=torch.float32, device=dev)
+        w_in[:, :42] = ps[0]
+        w_out = torch.zeros((self.d_out_pad, H), dtype=torch.float32, device=dev)
+        w_out[:d_out] = ps[2]
+        b_out = torch.zeros((self.d_out_pad,), dtype=torch.float32, device=dev)
+        b_out[:d_out] = ps[3]
+        self._keep = ps + [w_in, w_out, b_out]        # (the struct below holds raw pointers)
+        n = _capi.ResnetFCNet()
+        n.n_blocks, n.d_hidden, n.d_out_pad = nb, H, self.d_out_pad
+        n.w_in, n.b_in, n.w_out, n.b_out = w_in.data_ptr(), ps[1].data_ptr(), w_out.data_ptr(), b_out.data_ptr()
+        for b in range(nb):
+            w0, b0, w1, b1, wz, bz = ps[4 + 6 * b: 10 + 6 * b]
+            if tuple(w0.shape) != (H, H) or tuple(w1.shape) != (H, H) or tuple(wz.shape) != (H, D_L):
+                raise RuntimeError("ResnetFC block %d: parameter shapes do not match d_hidden=%d, d_latent=%d" % (b, H, D_L))
+            n.w_fc0[b], n.b_fc0[b], n.w_fc1[b], n.b_fc1[b], n.w_z[b], n.b_z[b] = (w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                                                                                 wz.data_ptr(), bz.data_ptr())
+        self.c = n
+
+    def launch_pack(self, upto: int = 2) -> None:
+        pass
+
+    def wait_ready(self, backward: bool = False) -> None:
+        if backward:
+            raise RuntimeError("a ResnetFC other than 3 blocks x 512 is forward only")
+
+
+class _GenericRun:
+    """Buffers of one generic ResnetFC evaluation (forward only): what the rest of the chunk reads of an ``_MlpRun``."""
+
+    def __init__(self, M: int, pk: GenericPackedMLP, dev):
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.M = M
+        self.Mpad = (M + _capi.TILE_ROWS - 1) // _capi.TILE_ROWS * _capi.TILE_ROWS
+        self.sphere_idx = torch.empty((M, 2), dtype=torch.int32, device=dev)
+        self.xenc = torch.empty((M, D_X), **f32)
+        self.Z = torch.empty((self.Mpad, D_L), **f32)
+        self.tile_mask = torch.empty((self.Mpad // _capi.TILE_ROWS,), dtype=torch.uint8, device=dev)
+        self.tap_texel = torch.empty((M, 5, 4), dtype=torch.int32, device=dev)
+        self.tap_weight = torch.empty((M, 5, 4), **f32)
+        self.h = [torch.empty((M, pk.d_hidden), **f32) for _ in range(3)]
+        self.logits_pad = torch.empty((M, pk.d_out_pad), **f32)
+        self.logits = None
+        self.sign_bits = None
+
+
 class MlpHolder:
     def __init__(self, grad_sync=None, grad_sync_async=None):
         self.packed: Optional[PackedMLP] = None
@@ -564,6 +631,7 @@ class MlpHolder:
         self.single_chunk = False    # set by render_rays_batch when the whole call is one chunk
         self.defer_pack = False      # pack on the side stream (the radiance MLP: first used after the gaussian head's chain)
         self.split_pack = False      # ... in two calls, a forward's operands first (the gaussian head: its forward is the step's first GEMM)
+        self.grad_mode = True        # torch.is_grad_enabled() where the session was opened (inside Function.forward it is always off)
 
 
 class PackMLP(torch.autograd.Function):
@@ -571,6 +639,15 @@ class PackMLP(torch.autograd.Function):
     def forward(ctx, holder: MlpHolder, d_out: int, cfg: RenderConfig, *params):
         # training sessions (a parameter gradient will be asked for): the radiance MLP is packed on the side stream
         side = _side_stream(params[0].device) if (holder.defer_pack and any(ctx.needs_input_grad[3:])) else None
+        if len(params) != len(MLP_PARAM_NAMES) or params[0].shape[0] != D_H:
+            # any other ResnetFC shape: the per-layer fp32 GEMM path, forward only (scenerf_hip_resnetfc_forward)
+            # (needs_input_grad reports the parameters' requires_grad flags whatever the grad mode: the session recorded the mode)
+            if holder.grad_mode and any(ctx.needs_input_grad[3:]):
+                raise RuntimeError("scenerf_amd: a ResnetFC other than 3 blocks x 512 is forward only -- render under torch.no_grad() "
+                                   "(or with parameters that do not require gradients)")
+            holder.packed = GenericPackedMLP(params, d_out, cfg)
+            ctx.holder = holder
+            return torch.empty(1, device=params[0].device)
         holder.packed = PackedMLP(params, d_out, cfg, pack_stream=side, defer=CHAIN_FIRST, split=CHAIN_FIRST and holder.split_pack)
         ctx.holder = holder
         return torch.empty(1, device=params[0].device)   # autograd token: its value is never read (no fill launch)
@@ -651,6 +728,26 @@ def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dis
               K, inv_K, T, M, keep_acts: bool = True, before_forward=None, before_wait=None) -> _MlpRun:
     lib = _capi.load()
     st = _stream(dist.device)
+    if getattr(pk, "generic", False):
+        if keep_acts:
+            raise RuntimeError("scenerf_amd: a ResnetFC other than 3 blocks x 512 is forward only -- render under torch.no_grad()")
+        run = _GenericRun(M, pk, dist.device)
+        _capi.check(lib.scenerf_hip_encode_points(C.byref(ccfg), dist.data_ptr(), dist_ray_stride, ppr, unit_dir.data_ptr(),
+                                                  viewdir.data_ptr(), K.data_ptr(), inv_K.data_ptr(), T.data_ptr(), M, None,
+                                                  run.sphere_idx.data_ptr(), run.xenc.data_ptr(), None, st), "encode_points")
+        _capi.check(lib.scenerf_hip_gather_features(C.byref(ccfg), C.byref(maps.map_ptr_array()), run.sphere_idx.data_ptr(), M,
+                                                    run.Z.data_ptr(), run.tile_mask.data_ptr(), run.tap_texel.data_ptr(),
+                                                    run.tap_weight.data_ptr(), st), "gather_features")
+        if before_wait is not None:
+            before_wait()
+        if before_forward is not None:
+            before_forward()
+        _capi.check(lib.scenerf_hip_resnetfc_forward(C.byref(ccfg), C.byref(pk.c), run.xenc.data_ptr(), run.Z.data_ptr(),
+                                                     run.tile_mask.data_ptr(), M, run.h[0].data_ptr(), run.h[1].data_ptr(),
+                                                     run.h[2].data_ptr(), run.logits_pad.data_ptr(), st), "resnetfc_forward")
+        run.logits = run.logits_pad[:, :pk.d_out].contiguous()     # (the tail and the sampler read [M][d_out])
+        run.h = None
+        return run
     run = _MlpRun(M, pk.d_out, cfg.precision_code, dist.device, lean=(not keep_acts) and cfg.uses_fused(M),
                   x3_direct=cfg.precision_code == 1, keep_xenc=maps.debug_aux is not None)
     _capi.check(lib.scenerf_hip_encode_points(C.byref(ccfg), dist.data_ptr(), dist_ray_stride, ppr, unit_dir.data_ptr(),
@@ -977,6 +1074,7 @@ class RenderSession:
         # training sessions pack both MLPs on the side stream: the gaussian head's operands (needed first) are packed while the main
         # stream sets up the rays and gathers the head's features (~55 us before its first GEMM), the radiance MLP's behind them
         # (first read ~0.3 ms into the step).  The side stream runs them in this order: head, then radiance MLP.
+        self.mlp.grad_mode = self.mlpg.grad_mode = torch.is_grad_enabled()
         self.mlp.defer_pack = True
         self.mlpg.defer_pack = DEFER_HEAD_PACK
         self.mlpg.split_pack = SPLIT_HEAD_PACK

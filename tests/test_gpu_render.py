@@ -207,6 +207,58 @@ def test_inference_no_grad_and_determinism():
     assert not a["depth"].requires_grad
 
 
+def test_plumbing_config_c1_runs_through_the_product():
+    """BASELINE.json configs[0] -- 4k rays x 64 samples through a 4-layer 128-wide ResnetFC (n_blocks = 1), forward only -- through the
+    PRODUCT on the GPU: the same ray pipeline (ray setup, both samplers, sort, encode, gather, per-ray tail) with the MLPs evaluated by
+    ``scenerf_hip_resnetfc_forward`` (one fp32 MFMA GEMM per nn.Linear: the fused kernels are built for 3 x 512), against the golden
+    vector the reference's own render_rays_batch produced with its mlp / mlp_gaussian swapped for that shape (make_golden.py)."""
+    from scenerf_amd.model import ResnetFC
+    g = Golden("c1_plumbing_r4096_n64")
+    assert g.meta["mlp"] == dict(n_blocks=1, d_hidden=128) and g.meta["R"] == 4096 and g.chunk == 1024
+    m = SceneRF(precision="fp32", **g.ctor)
+    m.mlp = ResnetFC(d_in=42, d_out=4, n_blocks=1, d_hidden=128)
+    m.mlp_gaussian = ResnetFC(d_in=42, d_out=2, n_blocks=1, d_hidden=128)
+    mlp, mlpg = g.mlp_states()
+    m.mlp.load_state_dict(mlp)
+    m.mlp_gaussian.load_state_dict(mlpg)
+    m = m.to(DEV)
+    R = g.pixels.shape[0]
+    m.debug_aux = True
+    with torch.no_grad():
+        out, _ = run_model(m, g, g.feature_maps(), grad=False)
+    assert set(out) == set(OUT_KEYS)
+    clean = _clean_rays(m, g, R)
+    assert int(clean.sum()) >= R - max(1, R // 16)
+    tol = TOL["fp32"]
+    for k in OUT_KEYS:
+        got = out[k].detach().float().cpu()
+        assert bool(torch.isfinite(got).all()), k
+        if k in ("loss_kl", "som_vars", "closest_pts_to_depths", "weights_at_depth"):
+            continue   # argmax / argmin / threshold outputs: ties (test_render_matches_reference_golden gates them at matched choices)
+        t = tol["depth"] if k in ("depth", "depth_volumes", "gaussian_means", "gaussian_stds") else tol["color"] if k == "color" else tol["other"]
+        if ("out/" + k) in g.z.files:
+            ref = g.out(k)
+            assert got.shape == ref.shape, k
+            _, ok = frac_within(got, ref, t, k in ABS_KEYS)
+            assert bool(ok[clean].all()), "%s: %.4f of the clean rays within tolerance (max err %.2e)" % (
+                k, float(ok[clean].float().mean()), float(((got - ref).abs() / (1.0 if k in ABS_KEYS else 1.0 + ref.abs())).reshape(R, -1)[clean].max()))
+        else:       # the (R, N) outputs are stored as digests: the reference's 256 largest entries
+            d = g.out_digest(k)
+            N = got.shape[1]
+            rows = d["idx"] // N
+            keep = clean[rows]
+            gv, rv = got.reshape(-1)[d["idx"]][keep], d["val"][keep]
+            if k == "alphas":      # alpha = 1 - exp(-sigma delta): the absolute gate was set at N = 128 and scales with the sample spacing
+                t = t * max(1.0, 128.0 / N)     # (tests/test_gpu_parity_full.py::_out_gate; measured here 1.16e-4 at N = 64)
+            lim = t if k in ABS_KEYS else t * (1.0 + rv.abs())
+            assert bool(((gv - rv).abs() <= lim).all()), "%s digest: max err %.2e" % (k, float((gv - rv).abs().max()))
+    # ... and a gradient cannot be asked of these shapes: refused by name, not a crash
+    x = {k: v.to(DEV) for k, v in g.feature_maps().items()}
+    with pytest.raises(RuntimeError, match="forward only"):
+        m.render_rays_batch(g.cam_K.to(DEV), g.T.to(DEV), x, sampled_pixels=g.pixels[:64].to(DEV), ray_batch_size=64,
+                            noise=(g.noise_u[:64].to(DEV), g.noise_g[:64].to(DEV)))
+
+
 def test_larger_chunk_against_oracle_bf16_and_fp32():
     """R=256 rays x N=128 (config-2 sampling) on the small sphere, vs the CPU oracle run here."""
     from scenerf_amd import synth

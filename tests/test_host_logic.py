@@ -319,3 +319,21 @@ def test_more_hw_queues_respects_the_user_and_the_initialised_runtime(monkeypatc
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
     assert sdist.more_hw_queues() is False and "GPU_MAX_HW_QUEUES" not in os.environ
+
+
+def test_resnetfc_container_is_generic_like_the_reference():
+    """resnetfc.py:67-131 is generic in n_blocks / d_hidden; the container mirrors that (state_dict names, shapes, init) and says which
+    shapes the fused kernels take (``is_standard``); what the ray pipeline fixes (d_in = 42, d_latent = 2480, d_out in {2, 4}) is refused."""
+    from scenerf_amd.model import ResnetFC
+    std = ResnetFC()
+    assert std.is_standard and len(std.ordered_params()) == 22
+    small = ResnetFC(d_in=42, d_out=4, n_blocks=1, d_hidden=128)
+    assert not small.is_standard
+    sd = small.state_dict()
+    assert sd["lin_in.weight"].shape == (128, 42) and sd["lin_z.0.weight"].shape == (128, 2480) and sd["lin_out.weight"].shape == (4, 128)
+    assert "blocks.1.fc_0.weight" not in sd and float(sd["blocks.0.fc_1.weight"].abs().max()) == 0.0      # fc_1 starts at zero (resnetfc.py:40)
+    assert [tuple(p.shape) for p in small.ordered_params()] == [(128, 42), (128,), (4, 128), (4,), (128, 128), (128,), (128, 128), (128,),
+                                                                (128, 2480), (128,)]
+    for bad in (dict(d_in=3), dict(d_latent=512), dict(d_out=3), dict(d_hidden=100), dict(n_blocks=0)):
+        with pytest.raises(ValueError):
+            ResnetFC(**bad)
