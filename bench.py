@@ -475,11 +475,42 @@ def _rooflines(kernels, args, nprof, value_per_gpu, world):
         try:
             pr = _composite_probe(65536, args.samples)
             roof_c["at_inference_chunk"] = pr
-            for nm in ("fwd", "bwd", "tail_fwd", "tail_bwd"):
+            for nm in ("fwd", "bwd", "tail_fwd", "tail_fwd_nosom", "tail_bwd"):
                 roof_c["frac_65536_rays_" + nm] = pr[nm]["frac"]
+            roof_c["traffic"] = _tail_traffic(args.samples)
         except Exception as e:   # never let the extra leg break the bench line
             roof_c["at_inference_chunk"] = {"error": str(e)}
     return roof, roof_c
+
+
+def _tail_traffic(N):
+    """HBM bytes per launch of the per-ray tail kernels at 65,536 rays from the committed rocprofv3 --pmc passes (tools/profile_tail.sh:
+    FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE), next to the algorithmic bytes -- counters cannot be read from inside the process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_tail_pmc_hbm.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+    except Exception:
+        return None
+    meta = d.pop("_meta", {})
+    C_ = 1 if N <= 64 else 2 if N <= 128 else 4 if N <= 256 else 8
+    out = {"source": os.path.basename(files[-1]), "collected_at": meta.get("commit") or "unknown", "rays": 65536}
+    try:
+        from scenerf_amd import build as _b
+        out["fresh"] = bool(meta.get("src_digest")) and meta.get("src_digest") == _b._digest()
+    except Exception:
+        out["fresh"] = False
+    for key, fn, alg in (("tail_fwd", "ray_tail_fwd_kernel<%d, 4, true>" % C_, 32 * N + 24), ("tail_fwd_nosom", "ray_tail_fwd_kernel<%d, 4, false>" % C_, None),
+                         ("tail_bwd", "ray_tail_bwd_kernel<%d>" % C_, 44 * N + 40)):
+        v = d.get(fn + " @grid=%d" % (65536 * 64)) or d.get(fn)
+        if v:
+            out[key] = {"bytes_per_launch": round(v["hbm_bytes_per_launch"]), "fetch": round(v["fetch_bytes_per_launch"]), "write": round(v["write_bytes_per_launch"])}
+            if alg:
+                out[key]["algorithmic_bytes_per_launch"] = 65536 * alg
+                out[key]["ratio"] = round(v["hbm_bytes_per_launch"] / (65536.0 * alg), 3)
+    return out
 
 
 def _composite_probe(R, N, reps=20):
@@ -515,6 +546,9 @@ def _composite_probe(R, N, reps=20):
                                                     None, None, None, None, offs.data_ptr(), anchors.data_ptr(), noise.data_ptr(), unit.data_ptr(),
                                                     gm.data_ptr(), gs.data_ptr(), perm.data_ptr(), ks.data_ptr(), None, None, None, dl.data_ptr(),
                                                     do.data_ptr(), None, None, None, None, None, st)
+    nosom = lambda: lib.scenerf_hip_ray_tail_forward(C.byref(cc), logits.data_ptr(), dist.data_ptr(), z.data_ptr(), None, None, R,
+                                                     dens.data_ptr(), al.data_ptr(), w.data_ptr(), dep.data_ptr(), col.data_ptr(), clo.data_ptr(),
+                                                     wat.data_ptr(), ci.data_ptr(), None, None, None, None, None, st)
     dd, dz = f(R, N), f(R, N)
     cfwd = lambda: lib.scenerf_hip_composite_forward(logits.data_ptr(), dist.data_ptr(), z.data_ptr(), R, N, dens.data_ptr(), al.data_ptr(),
                                                      w.data_ptr(), dep.data_ptr(), col.data_ptr(), clo.data_ptr(), wat.data_ptr(), ci.data_ptr(), st)
@@ -524,8 +558,10 @@ def _composite_probe(R, N, reps=20):
            "note": "fwd / bwd = the compositing pass proper (composite_fwd / composite_bwd stage kernels: alpha compositing only, the pass the "
                    "HBM roofline of SURVEY 8d is defined on); tail_fwd / tail_bwd = what a training chunk launches (ray_tail_*: compositing + "
                    "RaySOM, compositing + sampler / KL backward), priced on the same compositing bytes -- the SOM update's exp / log per "
-                   "(sample, gaussian) makes the fused forward compute-bound"}
-    for name, fn, bpr in (("fwd", cfwd, 32 * N + 24), ("bwd", cbwd, 48 * N + 40), ("tail_fwd", fwd, 32 * N + 24), ("tail_bwd", bwd, 44 * N + 40)):
+                   "(sample, gaussian) makes the fused forward compute-bound; tail_fwd_nosom = the compositing-only instantiation of the "
+                   "same kernel (loss_kl = NULL): what a no_grad render that does not ask for loss_kl / som_vars launches (full-frame inference)"}
+    for name, fn, bpr in (("fwd", cfwd, 32 * N + 24), ("bwd", cbwd, 48 * N + 40), ("tail_fwd", fwd, 32 * N + 24), ("tail_fwd_nosom", nosom, 32 * N + 24),
+                          ("tail_bwd", bwd, 44 * N + 40)):
         for _ in range(3):
             assert fn() == 0, lib.scenerf_hip_last_error()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

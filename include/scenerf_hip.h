@@ -304,7 +304,10 @@ int scenerf_hip_raysom_forward(const scenerf_cfg* cfg, const float* gmeans, cons
  * ray_som_kl.py:10-87 -- the sorted distances and fresh alphas stay in the wave's registers for the SOM update), and their autograd
  * together with the sampler's (compositing backward + reparameterisation / relu / kl_gauss backward: the gradients w.r.t. the sorted
  * distances and depths never leave the wave; d_dist / d_z are written only if non-NULL).  Results are bit-identical to the stage
- * entries above and below, which remain for per-stage use.  Algorithmic HBM bytes per ray: 32 N + 24 forward, 44 N + 40 backward. */
+ * entries above and below, which remain for per-stage use.  Algorithmic HBM bytes per ray: 32 N + 24 forward, 44 N + 40 backward.
+ * Forward, optional parts (a no_grad render that asked for a subset of the outputs): loss_kl == NULL (then som_means, som_vars, kl_saved
+ * and bmu_out must be NULL too; gmeans / gstds are not read) = compositing only, no RaySOM pass; densities / alphas / weights are each
+ * written only if non-NULL (alphas is required with the RaySOM half): a depth + colour render moves 20 N + 24 bytes per ray. */
 int scenerf_hip_ray_tail_forward(const scenerf_cfg* cfg, const float* logits, const float* dist_sorted, const float* z_sorted,
                                  const float* gmeans, const float* gstds, int R, float* densities, float* alphas, float* weights,
                                  float* depth, float* color, float* closest, float* weights_at_depth, int32_t* closest_idx,

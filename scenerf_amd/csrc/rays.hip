@@ -834,7 +834,11 @@ __device__ __forceinline__ void raysom_sample(const float d, const float dens, c
     }
 }
 
-template <int C, int GM>
+// SOM = false (round 5): the compositing alone -- no RaySOM tables, no barriers, no second and third pass over the registers -- for callers
+// that do not ask for loss_kl / som_vars (full-frame inference, keys = depth / colour: the SOM update was computed and thrown away).
+// densities / alphas / weights are written only where their pointer is non-NULL: a depth + colour render moves 20 N + 24 bytes per ray
+// instead of 32 N + 24.
+template <int C, int GM, bool SOM>
 __global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ dist,
                                                            const float* __restrict__ zv, const float* __restrict__ gmeans,
                                                            const float* __restrict__ gstds, int R, int N, int G, float som_sigma,
@@ -845,12 +849,13 @@ __global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restri
                                                            float* __restrict__ loss_kl, float* __restrict__ som_means,
                                                            float* __restrict__ som_vars, float* __restrict__ kl_saved,
                                                            uint8_t* __restrict__ bmu_out) {
-    __shared__ float s_nb[4][GM][GM], s_p12[4][GM][GM];
+    __shared__ float s_nb[SOM ? 4 : 1][GM][GM], s_p12[SOM ? 4 : 1][GM][GM];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + wv;
     const bool active = r < R;
     // ---- RaySOM tables of this ray (ray_som_kl.py:30-38), before anything else: the barriers are block-wide
     float m[GM], s[GM], var[GM];
+    if (SOM) {
 #pragma unroll
     for (int g = 0; g < GM; ++g) {
         bool ok = active && g < G;
@@ -878,6 +883,7 @@ __global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restri
         s_p12[wv][c2][c1] = (c2 < G && c1 < G) ? s_nb[wv][c2][c1] / sum : 0.f;
     }
     __syncthreads();
+    }
     if (!active) return;
     // ---- compositing (composite_fwd_kernel)
     const size_t base = (size_t)r * N;
@@ -916,9 +922,9 @@ __global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restri
         sgc += w[c] * cg;
         sb += w[c] * cb;
         if (ok) {
-            densities[base + i] = sg;
-            alphas[base + i] = a;
-            weights[base + i] = w[c];
+            if (densities) densities[base + i] = sg;
+            if (alphas) alphas[base + i] = a;
+            if (weights) weights[base + i] = w[c];
         }
     }
     sd = wave_sum(sd);
@@ -952,6 +958,7 @@ __global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restri
         w_at[r] = bw;
         closest_idx[r] = bi;
     }
+    if (!SOM) return;
     // ---- RaySOM update + KL (raysom_fwd_kernel) on the registers' (distance, alpha)
     // (the per-sample update weights of pass 1 are kept for pass 2 -- C x G registers -- instead of being recomputed: the stage kernel
     // evaluates the same expressions twice, the values are identical)
@@ -1620,20 +1627,23 @@ int scenerf_hip_ray_tail_forward(const scenerf_cfg* cfg, const float* logits, co
                                  float* loss_kl, float* som_means, float* som_vars, float* kl_saved, uint8_t* bmu_out,
                                  scenerf_stream_t stream) {
     if (check_cfg(cfg)) return 1;
-    SRF_CHECK(logits && dist_sorted && z_sorted && gmeans && gstds && densities && alphas && weights && depth && color && closest &&
-                  weights_at_depth && closest_idx && loss_kl && som_means && som_vars && kl_saved && R > 0, "ray_tail_forward: NULL argument");
+    SRF_CHECK(logits && dist_sorted && z_sorted && depth && color && closest && weights_at_depth && closest_idx && R > 0, "ray_tail_forward: NULL argument");
+    const bool som = loss_kl != nullptr;      // the RaySOM half: all of its outputs or none
+    SRF_CHECK(som ? (gmeans && gstds && som_means && som_vars && kl_saved && alphas) : (!som_means && !som_vars && !kl_saved && !bmu_out),
+              "ray_tail_forward: loss_kl, som_means, som_vars, kl_saved (and gmeans, gstds, alphas) go together");
     const int N = cfg->n_samples;
     hipStream_t s = as_stream(stream);
     dim3 grid(cdiv(R, 4));
-    SrfLaunchScope ps(s, "ray_tail_fwd", 0, (double)R * (32.0 * N + 24.0));
-#define TF2(C, GB) ray_tail_fwd_kernel<C, GB><<<grid, 256, 0, s>>>(logits, dist_sorted, z_sorted, gmeans, gstds, R, N, cfg->n_gaussians, cfg->som_sigma, cfg->kl_std_floor, densities, alphas, weights, depth, color, closest, weights_at_depth, closest_idx, loss_kl, som_means, som_vars, kl_saved, bmu_out)
-#define TF(C) { if (cfg->n_gaussians <= 4) TF2(C, 4); else TF2(C, MAXG); }
+    SrfLaunchScope ps(s, som ? "ray_tail_fwd" : "ray_tail_fwd_nosom", 0,
+                      (double)R * ((20.0 + (densities ? 4.0 : 0.0) + (alphas ? 4.0 : 0.0) + (weights ? 4.0 : 0.0)) * N + 24.0));
+#define TF3(C, GB, SM) ray_tail_fwd_kernel<C, GB, SM><<<grid, 256, 0, s>>>(logits, dist_sorted, z_sorted, gmeans, gstds, R, N, cfg->n_gaussians, cfg->som_sigma, cfg->kl_std_floor, densities, alphas, weights, depth, color, closest, weights_at_depth, closest_idx, loss_kl, som_means, som_vars, kl_saved, bmu_out)
+#define TF(C) { if (!som) TF3(C, 4, false); else if (cfg->n_gaussians <= 4) TF3(C, 4, true); else TF3(C, MAXG, true); }
     if (N <= 64) TF(1)
     else if (N <= 128) TF(2)
     else if (N <= 256) TF(4)
     else TF(8)
 #undef TF
-#undef TF2
+#undef TF3
     SRF_LAUNCH_CHECK("ray_tail_fwd_kernel");
     return 0;
 }

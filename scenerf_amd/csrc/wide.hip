@@ -658,7 +658,9 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     }
 #endif
     // 32 resident chunks (a K = 512 operand in the A buffer): four groups of eight; the very first chunk starts the accumulators at 0
-    auto resident_run = [&]() __attribute__((always_inline)) {
+    // head_cons: the chunks in front of this run were not a resident run's (a staged run, the prologue): its first four chunks wait on the
+    // load-only count.  Behind another resident run (the epilogue in between only adds younger operations) the exact count holds from chunk 0.
+    auto resident_run = [&](const bool head_cons) __attribute__((always_inline)) {
         H_LANE();
         const unsigned wl = w_lane();
         unsigned ag = a_lane();
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         // (a run's first four chunks: what ran before them is not this loop -- the load-only count, all four fragments at once, behind a
         // scalar branch.  Two whole copies of the chunks with different immediates were tried: the register allocator parks the joined
         // live ranges in accumulator registers.)
-#define H_RUN_HEAD() if (WSK > 0 && g == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#define H_RUN_HEAD() if (WSK > 0 && g == 0 && head_cons) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #pragma unroll 1
         for (int g = 0; g < 4; ++g) {
             H_LANE();
@@ -779,7 +781,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         for (int b = 0; b < 3; ++b) {
             const bool tail = b < 2 && nz > 0;
             xb_dma(1 + 2 * b);
-            resident_run();
+            resident_run(true);        // (behind layer 0's / the previous block's staged chunks -- or, without a lin_z tail, a resident run: rare)
             epilogue(std::false_type(), 1 + 2 * b);
             if (tail && !zres) dma_round(c + 32, 0, min(H_ZCAP, nzr));   // round 0 of this layer's lin_z tail: the stage is idle until then
             if (b == 2 && p.logits) {
@@ -790,7 +792,7 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
                     h_glds16((const char*)p.w_out + k * 1024, (unsigned)(ln << 4), __builtin_amdgcn_readfirstlane(lds0 + H_ZS + k * 1024));
             }
             xb_dma(2 + 2 * b);
-            resident_run();
+            resident_run(false);       // (behind fc_0's resident run)
             if (tail) staged_run(nz, nzr, H_ZCAP, zres ? 2 : 1, false);
             epilogue(std::true_type(), 2 + 2 * b);
         }
@@ -874,10 +876,10 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
 #pragma unroll 1
         for (int l = 0; l < 6; l += 2) {
             xb_dma(l);
-            resident_run();
+            resident_run(l == 0);                 // (the first run follows the prologue)
             epilogue(std::false_type(), l);       // dN_b = ...
             xb_dma(l + 1);
-            resident_run();
+            resident_run(false);
             epilogue(std::true_type(), l + 1);    // dH_b = dH_{b+1} + ...
         }
     }

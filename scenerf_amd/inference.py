@@ -52,6 +52,7 @@ class ImageRenderer:
         with torch.no_grad(), _on(dev):
             self.session = RenderSession(self.cfg, {k: v.detach() for k, v in x_rgb.items()}, [p.detach() for p in model.mlp.ordered_params()],
                                          [p.detach() for p in model.mlp_gaussian.ordered_params()], debug_aux=bool(getattr(model, "debug_aux", False)))
+            self.session.maps.want_keys = set(self.keys)     # (the per-ray tail skips what nobody asked for: RenderChunk._forward)
             f32 = dict(dtype=torch.float32, device=dev)
             # static inputs of the captured chunk
             self.pix = torch.zeros((self.chunk, 2), **f32)

@@ -894,25 +894,32 @@ class RenderChunk(torch.autograd.Function):
         if PREFILL_AT == 2 and getattr(maps, "_want_prefill", False):
             maps._want_prefill = False
             maps.prefill_grad_accumulators()
-        dens = torch.empty((R, N), **f32)
-        alphas = torch.empty((R, N), **f32)
-        weights = torch.empty((R, N), **f32)
+        # a no_grad session that asked for a subset of the outputs (ImageRenderer(keys=...): RenderSession.want_keys): the (R, N) outputs
+        # nobody reads are not written, and without loss_kl / som_vars the per-ray tail runs its compositing-only instantiation
+        want = getattr(maps, "want_keys", None) if (not keep and maps.debug_aux is None) else None
+        need = (lambda k: True) if want is None else (lambda k: k in want)
+        som = need("loss_kl") or need("som_vars")
+        nothing = torch.empty((0,), **f32)
+        dens = torch.empty((R, N), **f32) if need("densities") else nothing
+        alphas = torch.empty((R, N), **f32) if (need("alphas") or som) else nothing
+        weights = torch.empty((R, N), **f32) if need("weights") else nothing
         depth = torch.empty((R,), **f32)
         color = torch.empty((R, 3), **f32)
         closest = torch.empty((R,), **f32)
         w_at = torch.empty((R,), **f32)
         closest_idx = torch.empty((R,), dtype=torch.int32, device=dev)
-        loss_kl = torch.empty((R,), **f32)
-        som_means = torch.empty((R, G), **f32)
-        som_vars = torch.empty((R, G), **f32)
-        kl_saved = torch.empty((R, G, 3), **f32)
+        loss_kl = torch.empty((R,), **f32) if som else nothing
+        som_means = torch.empty((R, G), **f32) if som else nothing
+        som_vars = torch.empty((R, G), **f32) if som else nothing
+        kl_saved = torch.empty((R, G, 3), **f32) if som else nothing
         bmu = torch.empty((R, N), dtype=torch.uint8, device=dev) if maps.debug_aux is not None else None
+        opt = lambda t: t.data_ptr() if t.numel() else None     # noqa: E731
         # compositing + RaySOM: one launch, the alphas stay in the wave's registers for the SOM update (scenerf_hip.h: ray_tail)
         _capi.check(lib.scenerf_hip_ray_tail_forward(C.byref(ccfg), run_m.logits.data_ptr(), dist_s.data_ptr(), z_s.data_ptr(),
-                                                     gmeans.data_ptr(), gstds.data_ptr(), R, dens.data_ptr(), alphas.data_ptr(),
-                                                     weights.data_ptr(), depth.data_ptr(), color.data_ptr(), closest.data_ptr(),
-                                                     w_at.data_ptr(), closest_idx.data_ptr(), loss_kl.data_ptr(), som_means.data_ptr(),
-                                                     som_vars.data_ptr(), kl_saved.data_ptr(), _capi.ptr(bmu), st), "ray_tail_forward")
+                                                     gmeans.data_ptr(), gstds.data_ptr(), R, opt(dens), opt(alphas),
+                                                     opt(weights), depth.data_ptr(), color.data_ptr(), closest.data_ptr(),
+                                                     w_at.data_ptr(), closest_idx.data_ptr(), opt(loss_kl), opt(som_means),
+                                                     opt(som_vars), opt(kl_saved), _capi.ptr(bmu), st), "ray_tail_forward")
         # keep what backward needs (plain attributes: these are internal buffers, not graph tensors)
         ctx.cfg, ctx.ccfg, ctx.maps, ctx.mlp, ctx.mlpg = cfg, ccfg, maps, mlp, mlpg
         ctx.keep = dict(R=R, anchors=anchors, noise_g=noise_g, unit_dir=unit_dir, gmeans=gmeans, gstds=gstds, perm=perm,

@@ -616,6 +616,20 @@ def test_fused_ray_tail_equals_the_stage_kernels(N, U, P):
                                                  b["sv"].data_ptr(), b["ks"].data_ptr(), b["bmu"].data_ptr(), _st()), "ray_tail_forward")
     for k_ in a:
         assert torch.equal(a[k_], b[k_]), "forward output %s differs" % k_
+    # ... and the compositing-only instantiation (loss_kl == NULL: what a depth / colour render under no_grad launches): the same values,
+    # the (R, N) outputs written only where asked for
+    c = outs()
+    c["w"].fill_(-7.0)
+    _capi.check(lib.scenerf_hip_ray_tail_forward(C.byref(cc), L.data_ptr(), D.data_ptr(), Z.data_ptr(), None, None, R,
+                                                 None, c["al"].data_ptr(), None, c["dep"].data_ptr(), c["col"].data_ptr(),
+                                                 c["clo"].data_ptr(), c["wat"].data_ptr(), c["ci"].data_ptr(), None, None, None, None, None, _st()),
+                "ray_tail_forward (no SOM)")
+    for k_ in ("al", "dep", "col", "clo", "wat", "ci"):
+        assert torch.equal(a[k_], c[k_]), "compositing-only output %s differs" % k_
+    assert float(c["w"].min()) == -7.0 and float(c["w"].max()) == -7.0
+    assert lib.scenerf_hip_ray_tail_forward(C.byref(cc), L.data_ptr(), D.data_ptr(), Z.data_ptr(), GM.data_ptr(), GS.data_ptr(), R, None, None, None,
+                                            c["dep"].data_ptr(), c["col"].data_ptr(), c["clo"].data_ptr(), c["wat"].data_ptr(), c["ci"].data_ptr(),
+                                            None, c["sm"].data_ptr(), None, None, None, _st()) != 0       # half of the RaySOM outputs: refused
     dl1, dd1, dz1, do1 = f(R * N, 4), f(R, N), f(R, N), f(R, G, 2)
     dl2, dd2, dz2, do2, do3 = f(R * N, 4), f(R, N), f(R, N), f(R, G, 2), f(R, G, 2)
     _capi.check(lib.scenerf_hip_composite_backward(L.data_ptr(), D.data_ptr(), Z.data_ptr(), R, N, gd.data_ptr(), gc.data_ptr(), gw.data_ptr(),
