@@ -203,7 +203,11 @@ extern "C" int scenerf_hip_test_wide_cyc(unsigned long long* ptr) { return (int)
 template <int MODE_T>
 __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     constexpr int MODE = MODE_T == 3 ? 0 : MODE_T == 4 ? 1 : MODE_T;
+#ifdef H_VAR_WS0      // (development: the load-only count everywhere = the kernels as they were before round 5, for same-box A/B runs)
+    constexpr int WSK = 0;
+#else
     constexpr int WSK = MODE_T == 0 ? 2 : MODE_T == 1 ? 1 : 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // the accumulator file is this kernel's: a[0:255] are written by name in the MFMA statements
     asm volatile("" ::: "a0", "a15", "a16", "a31", "a32", "a63", "a64", "a95", "a96", "a127", "a128", "a159", "a160", "a191", "a192", "a223",

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
 for tag in "$@"; do
     for rep in 1; do
-        SRF_LIB_TAG=$tag python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-eager-baseline --kernels-json gpurun_out/var_k.json \
+        SRF_LIB_TAG=$tag python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-eager-baseline --no-extra-legs --no-fp32-mode --kernels-json gpurun_out/var_k.json \
             > gpurun_out/var_b.json 2> gpurun_out/var_err.log || { echo "variant '$tag' FAILED"; tail -5 gpurun_out/var_err.log; continue; }
         python - "$tag" <<'PY'
 import json, sys
