@@ -53,8 +53,6 @@ d = idx.cpu() != hi
 print("sphere idx differing: columns %d rows %d of %d" % (int(d[:, 0].sum()), int(d[:, 1].sum()), M))
 # the two routines alone on the chain's own arguments
 c = (iK @ torch.cat([hx, torch.ones(M, 1)], 1).T).T.contiguous()
-cd = torch.sqrt(torch.zeros(1))  # placeholder
-arg_a = torch.empty(M); 
 n = torch.linalg.norm(c, ord=2, dim=1)
 arg = (-c[:, 1] / n).contiguous()
 out = torch.empty(M, device=dev); out2 = torch.empty(M, device=dev)

@@ -5,8 +5,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import scenerf_oracle as orc
-import importlib
-os.environ.setdefault("SRF_NO_GPU_IMPORT", "1")
 from scenerf_amd import synth
 
 name = sys.argv[1] if len(sys.argv) > 1 else "kitti_c2_r1200_n128"
@@ -57,8 +55,6 @@ bad = (hx.view(torch.int32) != opix.contiguous().view(torch.int32)).any(1)
 if bool(bad.any()):
     j = bad.nonzero()[:, 0]
     print("pix mismatch rows:", j[:10].tolist(), "(M = %d; M mod 16 = %d)" % (M, M % 16))
-c = (iK @ orc._homog(opix).T).T
-hcx = torch.stack([torch.tensor(0.)]);
 bad = (hc.view(torch.int32) != coords.contiguous().view(torch.int32))
 if bool(bad.any()):
     print("coords mismatch rows:", bad.any(1).nonzero()[:10, 0].tolist())
