@@ -4,7 +4,8 @@ step costs what its kernels cost whatever the host is doing (the eager step is i
 time on an idle host; a busy host makes it host-bound).
 
 What a captured step fixes, as with any CUDA / HIP graph: tensor ADDRESSES and shapes.  Camera, pose and pixels are read from the
-static tensors ``cam_K`` / ``T_source2infer`` / ``pixels`` of the object (``copy_`` new values into them between replays); the feature
+static tensors ``cam_K`` / ``T_source2infer`` / ``pixels`` of the object (``copy_`` new values into them between replays; or hand
+``pixels`` over as a callable that draws them on the device inside the step, like the reference's per-step ``randperm``); the feature
 maps are the caller's tensors, captured by address (write new features into the same storage); their gradients land in
 ``map_grads`` (the ``.grad`` of the captured leaves, zeroed by the graph itself at the top of each replay).  The gaussian sampler's
 noise must be drawn on the device (``RenderConfig.device_rng``: the generator state advances inside the graph); the optimizer must be
@@ -75,6 +76,12 @@ class GraphedStep:
         for g in (optimizer.param_groups if optimizer is not None else ()):
             if not g.get("capturable", False):
                 raise RuntimeError("GraphedStep: the optimizer must be capturable (FusedAdamW(capturable=True))")
+        # ``pixels``: a static (R, 2) tensor, or a zero-argument callable evaluated INSIDE the captured step (e.g. the reference's per-step draw
+        # ``grid[torch.randperm(len(grid), device=dev)[:R]]``, scenerf.py:253-264: torch's CUDA generator is graph-safe, every replay
+        # draws fresh pixels); the callable must return the same shape on the same device every time and launch only capturable work
+        self._pixels_fn = pixels if callable(pixels) else None
+        if self._pixels_fn is not None:
+            pixels = self._pixels_fn()
         dev = pixels.device
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         self.cam_K, self.T_source2infer, self.pixels, self.x_rgb = cam_K, T_source2infer, pixels, x_rgb
@@ -162,6 +169,8 @@ class GraphedStep:
             p.grad = None
         for v in self._map_leaves:
             v.grad = None
+        if self._pixels_fn is not None:
+            self.pixels = self._pixels_fn()      # (captured: the draw is part of the replayed step; ``self.pixels`` = the last replay's)
         out = self.model.render_rays_batch(self.cam_K, self.T_source2infer, self.x_rgb, T_cam2velo=None, sampled_pixels=self.pixels,
                                            ray_batch_size=self.ray_batch_size, **({"noise": self.noise} if self.noise is not None else {}))
         loss = self.loss_fn(out)

@@ -253,6 +253,30 @@ def test_restore_true_first_replay_is_an_eager_first_step():
     assert abs(lg - la) <= 3 * abs(la - lb) + 1e-3 * (1 + abs(la)), (la, lb, lg)
 
 
+def test_graphed_step_draws_fresh_pixels_inside_the_graph():
+    """``pixels`` as a callable: the reference's per-step draw (a random subset of the stride-2 grid, scenerf.py:253-264) made on the device
+    INSIDE the captured step -- every replay renders another pixel set (torch's CUDA generator is graph-safe), with a static sampler noise the
+    loss still moves from replay to replay, and the object exposes the last replay's pixels."""
+    from scenerf_amd.graph import GraphedStep
+    m, opt, maps, K, T, pix, noise = _setup(11)
+    xs, ys = torch.arange(0, 1220, 2, device=DEV, dtype=torch.float32), torch.arange(0, 370, 2, device=DEV, dtype=torch.float32)
+    grid = torch.stack(torch.meshgrid(xs, ys, indexing="ij"), dim=2).reshape(-1, 2)
+
+    def draw():
+        return grid[torch.randperm(grid.shape[0], device=DEV)[:256]]
+
+    gs = GraphedStep(m, opt, _loss, K, T, maps, draw, ray_batch_size=256, warmup=2, noise=noise)
+    seen, losses = [], []
+    for _ in range(3):
+        losses.append(float(gs()))
+        torch.cuda.synchronize()
+        seen.append(gs.pixels.clone())
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    assert len(set(round(x, 7) for x in losses)) > 1, losses
+    assert all(bool(((p[:, 0] % 2 == 0) & (p[:, 1] % 2 == 0) & (p[:, 0] < 1220) & (p[:, 1] < 370)).all()) for p in seen)
+
+
 def test_graphed_step_refuses_what_cannot_be_captured():
     from scenerf_amd.graph import GraphedStep
     from scenerf_amd.optim import FusedAdamW
