@@ -163,15 +163,35 @@ def _mark():
     return e
 
 
+_AVG_OK = None      # does the backend average inside the collective (RCCL: ncclAvg)?  None = not tried yet
+
+
+def _native_avg() -> bool:
+    """The mean taken INSIDE the all-reduce (``ReduceOp.AVG`` = ncclAvg on RCCL): no 21.7-MB division kernel behind each of the step's two
+    collectives.  gloo has no AVG: sum, then divide."""
+    global _AVG_OK
+    if _AVG_OK is None:
+        _AVG_OK = dist.get_backend() == "nccl" and hasattr(dist.ReduceOp, "AVG")
+    return _AVG_OK
+
+
 def allreduce_mean_(flat: torch.Tensor) -> None:
     """In-place mean over ranks of a flat gradient buffer (no-op for a single process).  Installed as
     ``model.grad_sync``: the renderer calls it once per MLP on the packed fp32 gradient sink (21.7 MB)."""
-    global _ISSUED
+    global _ISSUED, _AVG_OK
     if _active():
         _ISSUED += 1
         t0 = _mark() if (TIMING is not None and flat.is_cuda) else None
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(dist.get_world_size())
+        if _native_avg():
+            try:
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+            except RuntimeError:      # a backend build without ncclAvg: remember, and take the mean by hand (nothing was reduced yet)
+                _AVG_OK = False
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat.div_(dist.get_world_size())
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.div_(dist.get_world_size())
         if t0 is not None:
             TIMING.append(("sync", t0, _mark()))
 
@@ -183,7 +203,8 @@ def allreduce_mean_async(flat: torch.Tensor):
     if not _active():
         return None
     _ISSUED += 1
-    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    avg = _native_avg()
+    work = dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
     world = dist.get_world_size()
 
     def finish():
@@ -191,7 +212,8 @@ def allreduce_mean_async(flat: torch.Tensor):
         work.wait()          # the current stream waits for the collective
         if t0 is not None:
             TIMING.append(("wait", t0, _mark()))
-        flat.div_(world)
+        if not avg:
+            flat.div_(world)
     return finish
 
 
