@@ -53,7 +53,9 @@ def pmc_traffic(logical_name, rows=None):
     (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/pmc_hbm.py).  PMC counters cannot be read from inside the
     process, so this is the last profiled value of the same bench command, not a live reading; None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    # (the step's counters: not the per-ray tail's or the compositing probe's files, which match the same pattern)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json"))
+                   if "_tail_" not in os.path.basename(f) and "composite" not in os.path.basename(f))
     if not files:
         return None
     try:
