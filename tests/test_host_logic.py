@@ -337,3 +337,20 @@ def test_resnetfc_container_is_generic_like_the_reference():
     for bad in (dict(d_in=3), dict(d_latent=512), dict(d_out=3), dict(d_hidden=100), dict(n_blocks=0)):
         with pytest.raises(ValueError):
             ResnetFC(**bad)
+
+
+def test_bench_reads_each_roofline_from_its_own_counter_file():
+    """bench.py quotes PMC bytes from the committed rocprofv3 passes: the step's kernels from profiles/r*_pmc_hbm.json, the per-ray tail from
+    r*_tail_pmc_hbm.json -- two files matching one glob (round 5: the tail's file shadowed the step's and `roofline.traffic` came out null)."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    fwd = bench.pmc_traffic("mlp_fwd_fused", 153600)
+    wg = bench.pmc_traffic("gemm_wgrad_fc", 153600)
+    assert fwd and fwd["kernel_fn"].startswith("mlp_wide_kernel<0>") and "_tail_" not in fwd["source"] and fwd["bytes_per_launch"] > 1e9
+    assert wg and wg["kernel_fn"].startswith("wgrad_tr_kernel") and wg["bytes_per_launch"] > 1e9
+    tail = bench._tail_traffic(128)
+    assert tail and "_tail_" in tail["source"] and 1.0 <= tail["tail_fwd"]["ratio"] <= 1.3 and 1.0 <= tail["tail_bwd"]["ratio"] <= 1.3
