@@ -111,7 +111,20 @@ def all_ranks_agree(ok: bool) -> bool:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return bool(ok)
     if _SIDE_GROUP is None:
-        _SIDE_GROUP = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+        if dist.get_backend() == "gloo":
+            _SIDE_GROUP = dist.group.WORLD
+        else:
+            # one node (the rendezvous address is loopback): gloo on the loopback interface -- a container's hostname need not resolve
+            if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            try:
+                _SIDE_GROUP = dist.new_group(backend="gloo")
+            except Exception:        # noqa: BLE001 -- no gloo transport here: agree over the default group (device tensor) instead
+                _SIDE_GROUP = False
+    if _SIDE_GROUP is False:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t[0]))
     t = torch.tensor([1 if ok else 0], dtype=torch.int32)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=_SIDE_GROUP)
     return bool(int(t[0]))
