@@ -473,29 +473,24 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     if (ZERO) h_mfma0<16 * (4 * (I) + (J))>(wr[S][J], af[I]);                       \
     else h_mfma<16 * (4 * (I) + (J))>(wr[S][J], af[I]);
 #define H_SB() __builtin_amdgcn_sched_barrier(0);
-// H_PLACE = MFMAs issued back to back before the fillers that become legal behind them (development knob; measured with
-// tools/wide_cycles.py: see the kernel header)
-#ifndef H_PLACE
-#define H_PLACE 1
-#endif
+// (round 6: the chunk's address arithmetic is kept off the vector unit and out of 64 bits -- the weight loads and the stream-out's
+// stores are the SGPR-base forms (uniform 64-bit base + 32-bit lane offset + immediate): one address register per lane instead of two,
+// no v_lshl_add_u64 / s_mul per chunk; the stream-out's row pointer is a running scalar, its sign-bit rows are reached by the store's
+// immediate offset within a group of eight chunks, the piece's LDS address is one XOR of a per-group register)
 #ifdef H_VAR_NOW
 #define H_LW(S, J, OFF)
-#elif defined(H_VAR_HALF)     // (development: half the weight loads)
-#define H_LW(S, J, OFF) if ((J) < 2) wr[S][J] = *(glb_frag_p)(uintptr_t)(wp_ + OFF);
-#elif defined(H_VAR_CLD)    // (development: the ring loads as plain loads, waits placed by the compiler)
-#define H_LW(S, J, OFF) wr[S][J] = *(glb_frag_p)(uintptr_t)(wp_ + OFF);
+#elif defined(H_VAR_HALF)
+#define H_LW(S, J, OFF) if ((J) < 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(wr[S][J]) : "v"(wo_), "s"(Wb));
 #else
-#define H_LW(S, J, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(wr[S][J]) : "v"(wp_));
+#define H_LW(S, J, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(wr[S][J]) : "v"(wo_), "s"(Wb));
 #endif
-#define H_TOUCH(DP)
-#if H_PLACE == 1
-#define H_RES_CHUNK(S, KK, ZERO, DW, DP) \
+#define H_RES_CHUNK(S, KK, ZERO, DW) \
     { \
         const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
-        const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
-        const bool sok_ = WSK > 0 || (sv_run && (m0 + srow_ < p.M));                                                                                                \
+        const bool sok_ = WSK > 0 || (sv_run && (m0 + 4 * (8 * g + (KK)) + wvu < p.M));                                                                \
         H_M(0, 0, S, ZERO)                                                                                                                             \
-        const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
+        const u32x4_h svv_ = *(lds_u4r_p)(uintptr_t)((svl ^ (unsigned)(((KK) & 3) << 6)) + (unsigned)((KK) * 4 * F_AROW));                              \
+        const uint4 sv_ = make_uint4(svv_.x, svv_.y, svv_.z, svv_.w);                                                                                  \
         H_SB()                                                                                                                                         \
         H_M(0, 1, S, ZERO)                                                                                                                             \
         H_SB()                                                                                                                                         \
@@ -505,7 +500,8 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         af[0] = *(lds_frag_p)(uintptr_t)(x0_);                                                                                                         \
         H_SB()                                                                                                                                         \
         H_M(1, 0, S, ZERO)                                                                                                                             \
-        if (sok_) h_store16(sv_base + (size_t)(m0 + srow_) * sv_ld2 + ln * 16, sv_);                                                                   \
+        if (sok_) h_store16(svp + l16, sv_);                                                                                                           \
+        svp += svs;                                                                                                                                    \
         H_SB()                                                                                                                                         \
         H_M(1, 1, S, ZERO)                                                                                                                             \
         uint32_t su_ = 0; if (MODE == 0) { su_ = h_pk_min_u16(sv_.x, 0x00010001u); su_ |= h_pk_min_u16(sv_.y, 0x00010001u) << 2; }                     \
@@ -517,13 +513,12 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
         H_SB()                                                                                                                                         \
         H_M(2, 0, S, ZERO)                                                                                                                             \
-        if (MODE == 0 && sok_ && (WSK > 0 || sg_base)) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
+        if (MODE == 0 && sok_ && (WSK > 0 || sg_base)) h_store1(sgp + l1 + (KK) * 256, (su_ | (su_ >> 15)) & 0xffu);                                   \
         H_SB()                                                                                                                                         \
         H_M(2, 1, S, ZERO)                                                                                                                             \
-        const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
+        const unsigned wo_ = wl + ((unsigned)FD_Z(DW) << 14);                                                                                          \
         H_SB()                                                                                                                                         \
         H_M(2, 2, S, ZERO)                                                                                                                             \
-        H_TOUCH(DP)                                                                                                                                    \
         H_SB()                                                                                                                                         \
         H_M(2, 3, S, ZERO)                                                                                                                             \
         const unsigned x1_ = x0_ + 65536u; af[2] = *(lds_frag_p)(uintptr_t)(x1_);                                                                      \
@@ -542,125 +537,6 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         af[3] = *(lds_frag_p)(uintptr_t)(x1_ + 32768u);                                                                                                \
         H_SB()                                                                                                                                         \
     }
-#elif H_PLACE == 2
-#define H_RES_CHUNK(S, KK, ZERO, DW, DP) \
-    { \
-        const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
-        const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
-        const bool sok_ = WSK > 0 || (sv_run && (m0 + srow_ < p.M));                                                                                                \
-        H_M(0, 0, S, ZERO) H_M(0, 1, S, ZERO)                                                                                                          \
-        const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
-        H_SB()                                                                                                                                         \
-        H_M(0, 2, S, ZERO) H_M(0, 3, S, ZERO)                                                                                                          \
-        af[0] = *(lds_frag_p)(uintptr_t)(x0_);                                                                                                         \
-        H_SB()                                                                                                                                         \
-        H_M(1, 0, S, ZERO) H_M(1, 1, S, ZERO)                                                                                                          \
-        if (sok_) h_store16(sv_base + (size_t)(m0 + srow_) * sv_ld2 + ln * 16, sv_);                                                                   \
-        uint32_t su_ = 0; if (MODE == 0) { su_ = h_pk_min_u16(sv_.x, 0x00010001u); su_ |= h_pk_min_u16(sv_.y, 0x00010001u) << 2; }                     \
-        H_SB()                                                                                                                                         \
-        H_M(1, 2, S, ZERO) H_M(1, 3, S, ZERO)                                                                                                          \
-        if (MODE == 0) { su_ |= h_pk_min_u16(sv_.z, 0x00010001u) << 4; su_ |= h_pk_min_u16(sv_.w, 0x00010001u) << 6; }                                 \
-        af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
-        H_SB()                                                                                                                                         \
-        H_M(2, 0, S, ZERO) H_M(2, 1, S, ZERO)                                                                                                          \
-        if (MODE == 0 && sok_ && (WSK > 0 || sg_base)) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
-        const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
-        H_SB()                                                                                                                                         \
-        H_M(2, 2, S, ZERO) H_M(2, 3, S, ZERO)                                                                                                          \
-        H_TOUCH(DP)                                                                                                                                    \
-        const unsigned x1_ = x0_ + 65536u; af[2] = *(lds_frag_p)(uintptr_t)(x1_);                                                                      \
-        H_SB()                                                                                                                                         \
-        H_M(3, 0, S, ZERO) H_M(3, 1, S, ZERO)                                                                                                          \
-        H_LW(S, 0, 0)                                                                                                                                  \
-        H_LW(S, 1, 1024)                                                                                                                               \
-        H_SB()                                                                                                                                         \
-        H_M(3, 2, S, ZERO) H_M(3, 3, S, ZERO)                                                                                                          \
-        H_LW(S, 2, 2048)                                                                                                                               \
-        H_LW(S, 3, 3072)                                                                                                                               \
-        af[3] = *(lds_frag_p)(uintptr_t)(x1_ + 32768u);                                                                                                \
-        H_SB()                                                                                                                                         \
-    }
-#elif H_PLACE == 4
-#define H_RES_CHUNK(S, KK, ZERO, DW, DP) \
-    { \
-        const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
-        const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
-        const bool sok_ = WSK > 0 || (sv_run && (m0 + srow_ < p.M));                                                                                                \
-        H_M(0, 0, S, ZERO) H_M(0, 1, S, ZERO) H_M(0, 2, S, ZERO) H_M(0, 3, S, ZERO)                                                                    \
-        const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
-        af[0] = *(lds_frag_p)(uintptr_t)(x0_);                                                                                                         \
-        H_SB()                                                                                                                                         \
-        H_M(1, 0, S, ZERO) H_M(1, 1, S, ZERO) H_M(1, 2, S, ZERO) H_M(1, 3, S, ZERO)                                                                    \
-        if (sok_) h_store16(sv_base + (size_t)(m0 + srow_) * sv_ld2 + ln * 16, sv_);                                                                   \
-        uint32_t su_ = 0; if (MODE == 0) { su_ = h_pk_min_u16(sv_.x, 0x00010001u); su_ |= h_pk_min_u16(sv_.y, 0x00010001u) << 2; }                     \
-        if (MODE == 0) { su_ |= h_pk_min_u16(sv_.z, 0x00010001u) << 4; su_ |= h_pk_min_u16(sv_.w, 0x00010001u) << 6; }                                 \
-        af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
-        H_SB()                                                                                                                                         \
-        H_M(2, 0, S, ZERO) H_M(2, 1, S, ZERO) H_M(2, 2, S, ZERO) H_M(2, 3, S, ZERO)                                                                    \
-        if (MODE == 0 && sok_ && (WSK > 0 || sg_base)) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
-        const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
-        H_TOUCH(DP)                                                                                                                                    \
-        const unsigned x1_ = x0_ + 65536u; af[2] = *(lds_frag_p)(uintptr_t)(x1_);                                                                      \
-        H_SB()                                                                                                                                         \
-        H_M(3, 0, S, ZERO) H_M(3, 1, S, ZERO) H_M(3, 2, S, ZERO) H_M(3, 3, S, ZERO)                                                                    \
-        H_LW(S, 0, 0)                                                                                                                                  \
-        H_LW(S, 1, 1024)                                                                                                                               \
-        H_LW(S, 2, 2048)                                                                                                                               \
-        H_LW(S, 3, 3072)                                                                                                                               \
-        af[3] = *(lds_frag_p)(uintptr_t)(x1_ + 32768u);                                                                                                \
-        H_SB()                                                                                                                                         \
-    }
-#elif H_PLACE == 8
-#define H_RES_CHUNK(S, KK, ZERO, DW, DP) \
-    { \
-        const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
-        const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
-        const bool sok_ = WSK > 0 || (sv_run && (m0 + srow_ < p.M));                                                                                                \
-        H_M(0, 0, S, ZERO) H_M(0, 1, S, ZERO) H_M(0, 2, S, ZERO) H_M(0, 3, S, ZERO) H_M(1, 0, S, ZERO) H_M(1, 1, S, ZERO) H_M(1, 2, S, ZERO) H_M(1, 3, S, ZERO) \
-        const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
-        af[0] = *(lds_frag_p)(uintptr_t)(x0_);                                                                                                         \
-        if (sok_) h_store16(sv_base + (size_t)(m0 + srow_) * sv_ld2 + ln * 16, sv_);                                                                   \
-        uint32_t su_ = 0; if (MODE == 0) { su_ = h_pk_min_u16(sv_.x, 0x00010001u); su_ |= h_pk_min_u16(sv_.y, 0x00010001u) << 2; }                     \
-        if (MODE == 0) { su_ |= h_pk_min_u16(sv_.z, 0x00010001u) << 4; su_ |= h_pk_min_u16(sv_.w, 0x00010001u) << 6; }                                 \
-        af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
-        H_SB()                                                                                                                                         \
-        H_M(2, 0, S, ZERO) H_M(2, 1, S, ZERO) H_M(2, 2, S, ZERO) H_M(2, 3, S, ZERO) H_M(3, 0, S, ZERO) H_M(3, 1, S, ZERO) H_M(3, 2, S, ZERO) H_M(3, 3, S, ZERO) \
-        if (MODE == 0 && sok_ && (WSK > 0 || sg_base)) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
-        const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
-        H_TOUCH(DP)                                                                                                                                    \
-        const unsigned x1_ = x0_ + 65536u; af[2] = *(lds_frag_p)(uintptr_t)(x1_);                                                                      \
-        H_LW(S, 0, 0)                                                                                                                                  \
-        H_LW(S, 1, 1024)                                                                                                                               \
-        H_LW(S, 2, 2048)                                                                                                                               \
-        H_LW(S, 3, 3072)                                                                                                                               \
-        af[3] = *(lds_frag_p)(uintptr_t)(x1_ + 32768u);                                                                                                \
-        H_SB()                                                                                                                                         \
-    }
-#else
-#define H_RES_CHUNK(S, KK, ZERO, DW, DP) \
-    { \
-        const unsigned x0_ = (KK) == 7 ? ag + 256u : ag ^ (unsigned)((((KK) + 1) & 7) << 5);                                                           \
-        const int srow_ = 4 * (8 * g + (KK)) + wvu;                                                                                                    \
-        const bool sok_ = WSK > 0 || (sv_run && (m0 + srow_ < p.M));                                                                                                \
-        H_M(0, 0, S, ZERO) H_M(0, 1, S, ZERO) H_M(0, 2, S, ZERO) H_M(0, 3, S, ZERO) H_M(1, 0, S, ZERO) H_M(1, 1, S, ZERO) H_M(1, 2, S, ZERO) H_M(1, 3, S, ZERO) H_M(2, 0, S, ZERO) H_M(2, 1, S, ZERO) H_M(2, 2, S, ZERO) H_M(2, 3, S, ZERO) H_M(3, 0, S, ZERO) H_M(3, 1, S, ZERO) H_M(3, 2, S, ZERO) H_M(3, 3, S, ZERO) \
-        const uint4 sv_ = *(const uint4*)(Abuf + srow_ * F_AROW + ((ln ^ (srow_ & 15)) << 4));                                                         \
-        af[0] = *(lds_frag_p)(uintptr_t)(x0_);                                                                                                         \
-        if (sok_) h_store16(sv_base + (size_t)(m0 + srow_) * sv_ld2 + ln * 16, sv_);                                                                   \
-        uint32_t su_ = 0; if (MODE == 0) { su_ = h_pk_min_u16(sv_.x, 0x00010001u); su_ |= h_pk_min_u16(sv_.y, 0x00010001u) << 2; }                     \
-        if (MODE == 0) { su_ |= h_pk_min_u16(sv_.z, 0x00010001u) << 4; su_ |= h_pk_min_u16(sv_.w, 0x00010001u) << 6; }                                 \
-        af[1] = *(lds_frag_p)(uintptr_t)(x0_ + 32768u);                                                                                                \
-        if (MODE == 0 && sok_ && (WSK > 0 || sg_base)) h_store1(sg_base + (size_t)(m0 + srow_) * 64 + ln, (su_ | (su_ >> 15)) & 0xffu);                             \
-        const char* const wp_ = H_WPTR(DW) + wl;                                                                                                       \
-        H_TOUCH(DP)                                                                                                                                    \
-        const unsigned x1_ = x0_ + 65536u; af[2] = *(lds_frag_p)(uintptr_t)(x1_);                                                                      \
-        H_LW(S, 0, 0)                                                                                                                                  \
-        H_LW(S, 1, 1024)                                                                                                                               \
-        H_LW(S, 2, 2048)                                                                                                                               \
-        H_LW(S, 3, 3072)                                                                                                                               \
-        af[3] = *(lds_frag_p)(uintptr_t)(x1_ + 32768u);                                                                                                \
-        H_SB()                                                                                                                                         \
-    }
-#endif
     // 32 resident chunks (a K = 512 operand in the A buffer): four groups of eight; the very first chunk starts the accumulators at 0
     // head_cons: the chunks in front of this run were not a resident run's (a staged run, the prologue): its first four chunks wait on the
     // load-only count.  Behind another resident run (the epilogue in between only adds younger operations) the exact count holds from chunk 0.
@@ -671,6 +547,13 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
         // (a resident run starts with all 32 pieces of the previous layer's output still to stream out, or with none)
         const bool sv_run = save_i == 0 && sv_base != nullptr;
         save_i = 32;
+        // the stream-out of chunk k: row 4 k + wvu of the block, one 16-byte slot per lane.  LDS address of the piece: row * 1 KiB + ((lane ^
+        // (row & 15)) << 4), and row & 15 = (4 k & 12) | wvu: a per-group register XOR ((k & 3) << 6), + k * 4 KiB as the read's immediate;
+        // HBM: a running uniform row pointer + (lane << 4); sign bits: a per-group uniform pointer + lane + 256 k as the store's immediate
+        typedef const __attribute__((address_space(3))) u32x4_h* lds_u4r_p;
+        char* svp = sv_base + (size_t)(m0 + wvu) * sv_ld2;
+        const size_t svs = (size_t)4 * sv_ld2;
+        uint8_t* sgp = sg_base + (size_t)(m0 + wvu) * 64;
         // fragments of chunk 0 (the A buffer was completed behind the epilogue's second barrier)
         af[0] = *(lds_frag_p)(uintptr_t)(ag);
         af[1] = *(lds_frag_p)(uintptr_t)(ag + 32768u);
@@ -685,25 +568,30 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
 #pragma unroll 1
         for (int g = 0; g < 4; ++g) {
             H_LANE();
+            // (per-lane addresses of the group's stream-out pieces, re-derived from the opaque lane copy: nothing lane-derived is carried
+            // around the loop except the fragment base and the weight offset)
+            const unsigned l16 = (unsigned)ln << 4, l1 = (unsigned)ln;
+            const unsigned svl = lds0 + (unsigned)((32 * g + wvu) * F_AROW) + (unsigned)((ln ^ wvu) << 4);
             if (g == 0) {
                 H_RUN_HEAD()
-                H_RES_CHUNK(0, 0, true, e0, dnv.x)
+                H_RES_CHUNK(0, 0, true, e0)
             } else {
-                H_RES_CHUNK(0, 0, false, e0, dnv.x)
+                H_RES_CHUNK(0, 0, false, e0)
             }
             H_RUN_HEAD()
-            H_RES_CHUNK(1, 1, false, e1, dnv.y)
+            H_RES_CHUNK(1, 1, false, e1)
             H_RUN_HEAD()
-            H_RES_CHUNK(2, 2, false, e2, dnv.z)
+            H_RES_CHUNK(2, 2, false, e2)
             H_RUN_HEAD()
-            H_RES_CHUNK(3, 3, false, e3, dnv.w)
+            H_RES_CHUNK(3, 3, false, e3)
             H_GROUP_TOP()
-            H_RES_CHUNK(0, 4, false, e0, dnv.x)
-            H_RES_CHUNK(1, 5, false, e1, dnv.y)
-            H_RES_CHUNK(2, 6, false, e2, dnv.z)
-            H_RES_CHUNK(3, 7, false, e3, dnv.w)
+            H_RES_CHUNK(0, 4, false, e0)
+            H_RES_CHUNK(1, 5, false, e1)
+            H_RES_CHUNK(2, 6, false, e2)
+            H_RES_CHUNK(3, 7, false, e3)
             H_GROUP_TOP()
             ag += 256u;
+            sgp += 32 * 64;
         }
 #undef H_RUN_HEAD
     };
@@ -892,7 +780,6 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
 #undef H_RES_CHUNK
 #undef H_M
 #undef H_SB
-#undef H_TOUCH
 #undef H_LW
 #undef H_GROUP_TOP
 #undef H_WPTR

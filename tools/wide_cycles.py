@@ -57,6 +57,18 @@ for name, call, labels in (("forward", fwd, ["setup", "dma0"] + sum([["K%d" % l,
     span = (t[:, n - 1].max() - t[:, 0].min()).item()
     print("%s: %d stamps, block total mean %.0f cycles (min %.0f max %.0f); first start -> last end %.0f cycles (= %.2f blocks deep)" % (
         name, n, tot.mean().item(), tot.min().item(), tot.max().item(), span, span / tot.mean().item()))
+    # per dispatch round (blocks are handed out in id order, 256 at a time): start offset from the kernel's first stamp, mean length --
+    # do the first round's blocks (every CU in the same phase at the same time) run slower than the later, desynchronised ones?
+    # (s_memtime is per XCD: block b runs on XCD b % 8; offsets are taken against the first stamp of the same XCD)
+    xcd = torch.arange(nb) % 8
+    t0 = torch.stack([t[xcd == x, 0].min() for x in range(8)])[xcd]
+    st_, en_ = t[:, 0] - t0, t[:, n - 1] - t0
+    print("  kernel span per XCD (first start -> last end): " + " ".join("%.0f" % en_[xcd == x].max().item() for x in range(8)))
+    for r_ in range((nb + 255) // 256):
+        sl = slice(256 * r_, min(nb, 256 * r_ + 256))
+        print("  round %d (%d blocks): start %.0f..%.0f, length mean %.0f (min %.0f max %.0f), end mean %.0f max %.0f" % (
+            r_, sl.stop - sl.start, st_[sl].min().item(), st_[sl].max().item(), tot[sl].mean().item(), tot[sl].min().item(),
+            tot[sl].max().item(), en_[sl].mean().item(), en_[sl].max().item()))
     for m_ in sorted(set(pat)):
         sel = (masks == m_)
         print("  mask %d (%d blocks): " % (m_, int(sel.sum())) + "  ".join("%s %.0f" % (labels[i] if i < len(labels) else "?", d[sel, i].mean().item()) for i in range(n - 1)))
