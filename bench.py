@@ -453,6 +453,7 @@ def _rooflines(kernels, args, nprof, value_per_gpu, world):
             if k["name"] in short:
                 roof["frac_" + short[k["name"]]] = round(k["flops"] / (k["total_ms"] * 1e-3) / 1e12 / peak, 4)
                 roof["us_" + short[k["name"]]] = round(k["avg_us"], 1)
+        roof.update(_roofline_extras(mfma, peak, nprof, args))
         if value_per_gpu is not None:
             # with zero-K-block skipping, utilisation is reported on the FLOPs issued (above) and the rays/s are
             # quoted separately against the dense algorithmic count of the reference: fwd 2(N*5,405,696 + G*5,404,672), x3 fwd+bwd
@@ -483,6 +484,44 @@ def _rooflines(kernels, args, nprof, value_per_gpu, world):
         except Exception as e:   # never let the extra leg break the bench line
             roof_c["at_inference_chunk"] = {"error": str(e)}
     return roof, roof_c
+
+
+def padding_flops(name, flops_per_launch, rows):
+    """FLOPs of a launch that multiply padding (operand columns that exist only to fill a tile), so that a fraction of the peak can be quoted
+    on USEFUL work too.  The batched weight-gradient launch (csrc/mlp.hip) carries two padded problems: lin_in's K = 42 real input
+    columns ride in a 256-column tile (SCENERF_WIN_LD), and nothing else -- lin_z's 256 dense columns of Z are all real latent columns
+    (80 + 160 + the first 16 of the third level).  Every other MFMA kernel issues exactly what it reports."""
+    if name.split("/")[0] == "gemm_wgrad_fc" and rows:
+        return 2.0 * rows * 512.0 * (256 - 42)
+    return 0.0
+
+
+def _roofline_extras(mfma, peak, nprof, args, big=0.10):
+    """``roofline_min``: the WORST big kernel (lowest fraction of the MFMA peak among the kernels that take more than ``big`` of the
+    profiled steps' kernel time) -- the line's ``roofline`` names the LONGEST kernel, and two kernels 2 % apart in time trade that place
+    without either getting faster.  ``roofline_useful_frac``: the dominant kernel's fraction on useful FLOPs (padding excluded)."""
+    out = {}
+    tot_t = sum(k["total_ms"] for k in mfma)
+    step_ms = getattr(args, "step_ms_for_roofline", None)
+    ref_t = step_ms * nprof if step_ms else tot_t
+    bigk = [k for k in mfma if k["total_ms"] >= big * ref_t]
+    frac = lambda k, f=None: (k["flops"] if f is None else f) / (k["total_ms"] * 1e-3) / 1e12 / peak
+    if bigk:
+        w = min(bigk, key=frac)
+        out["roofline_min"] = {"bound": "mfma", "kernel": w["name"], "frac": round(frac(w), 4), "achieved": round(frac(w) * peak, 2), "peak": peak,
+                               "unit": "TFLOP/s", "avg_launch_us": round(w["total_ms"] * 1e3 / max(w["launches"], 1), 2),
+                               "share_of_step": round(w["total_ms"] / ref_t, 3),
+                               "rule": "lowest fraction among MFMA kernels above %.0f %% of the step" % (100 * big),
+                               "candidates": {k["name"]: round(frac(k), 4) for k in bigk}}
+        out["roofline_min_frac"] = out["roofline_min"]["frac"]
+        out["roofline_min_kernel"] = w["name"]
+    dom = max(mfma, key=lambda k: k["total_ms"])
+    rows = getattr(args, "rows_per_launch", None)
+    pad = padding_flops(dom["name"], dom["flops"] / max(dom["launches"], 1), rows) * dom["launches"]
+    out["roofline_useful_frac"] = round(frac(dom, dom["flops"] - pad), 4)
+    out["roofline_useful_note"] = "dominant kernel on useful FLOPs: %.1f of %.1f GFLOP per launch are tile padding" % (
+        pad / max(dom["launches"], 1) / 1e9, dom["flops"] / max(dom["launches"], 1) / 1e9)
+    return out
 
 
 def _tail_traffic(N):
@@ -783,6 +822,11 @@ def graph_wanted(args, collectives):
     kept only if every rank's capture succeeded (scenerf_amd.graph.build_on_all_ranks); otherwise all ranks issue the step eagerly."""
     if args.graph == "off":
         return False, "--graph off"
+    if collectives and args.graph == "auto" and not getattr(args, "force_dist", False):
+        # a replayed step whose all-reduces run BETWEEN GPUs has never executed on this code (one RCCL rank and two gloo ranks have): a
+        # capture that raises is caught (build_on_all_ranks), a replay that hangs or reduces wrongly is not -- so more than one rank steps
+        # eagerly unless `--graph on` asks for the captured step, which is then checked on its first replays (replay_agrees_across_ranks)
+        return False, "more than one rank: the replayed step with its collectives is opt-in (--graph on) until it has run between GPUs"
     if args.sync == "step" and collectives:
         return False, "--sync step (its end-of-backward callback is host code)"
     if args.precision != "bf16" and args.graph == "auto":
@@ -792,6 +836,25 @@ def graph_wanted(args, collectives):
     if args.optimizer != "fused":
         return False, "--optimizer torch"
     return True, None
+
+
+def replay_agrees_across_ranks(tensors, world, dev=None):
+    """First-replay check of a captured step that carries gradient collectives: after a replayed optimizer step every rank must
+    hold the SAME parameters -- data-parallel ranks start equal and apply the same averaged gradients, so two checksums per rank (sum and
+    sum of squares, float64) must be bit-equal everywhere.  A captured all-reduce that was not replayed, or reduced over the wrong ranks,
+    leaves them different.  Every rank computes the same verdict from the gathered values: (ok, spread)."""
+    acc = torch.zeros(2, dtype=torch.float64, device=tensors[0].device)
+    for t in tensors:
+        d = t.detach().double()
+        acc[0] += d.sum()
+        acc[1] += (d * d).sum()
+    if world == 1:
+        return True, 0.0
+    got = [torch.zeros_like(acc) for _ in range(world)]
+    torch.distributed.all_gather(got, acc)
+    g = torch.stack(got)
+    spread = float((g.max(0).values - g.min(0).values).abs().max())
+    return spread == 0.0, spread
 
 
 class _StubGraphed:
@@ -901,6 +964,15 @@ def main():
             args.capturable = False
             factory = lambda: GraphedStep(model, opt_g, loss_fn, K, T, maps, pix, ray_batch_size=R, warmup=max(1, args.warmup))     # noqa: E731
         graphed, note = build_on_all_ranks(factory)
+        if graphed is not None and collectives and world > 1:
+            # the replayed collectives are checked before anything is timed: two replays, then the parameters must be equal on every rank
+            for _ in range(2):
+                graphed()
+            ok, spread = replay_agrees_across_ranks([model.head, model.main] if dry else params, world)
+            if not ok:        # (every rank computed this from the same gathered values: all drop their graphs together)
+                graphed, note = None, "replayed step left the ranks' parameters %.3e apart: all ranks step eagerly" % spread
+            else:
+                note += "; parameters bit-equal across ranks after the first replays"
         if graphed is not None:
             graph_note = "one hipGraph replay per step (scenerf_amd.graph.GraphedStep: forward + loss + backward%s + fused AdamW captured once; %s)" % (
                 " + the gradient all-reduces" if collectives else "", note)

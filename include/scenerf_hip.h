@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SCENERF_HIP_ABI_VERSION 9
+#define SCENERF_HIP_ABI_VERSION 10
 #define SCENERF_N_SCALES 5          /* feature maps "1_1","1_2","1_4","1_8","1_16" */
 #define SCENERF_D_LATENT 2480       /* 80+160+320+640+1280 (resnetfc d_latent, scenerf.py:100-114) */
 #define SCENERF_D_HIDDEN 512
@@ -96,6 +96,11 @@ typedef struct scenerf_cfg {
                                             * pass reads (untransposed operands, their w_stream blocks, biases) ... */
 #define SCENERF_FLAG_PACK_REST     1024u  /* ... this one the rest (transposed operands, their w_stream blocks, w_z_t, the `clear` zeroes): a forward
                                             * can be ordered behind the first call alone */
+
+#define SCENERF_FLAG_BWD_CHAIN_ONLY 2048u /* scenerf_hip_mlp_backward in two calls (fused dgrad chain only; without one the first call does everything and
+                                            * the second nothing): this one runs lin_out's backward and the dgrad chain ... */
+#define SCENERF_FLAG_BWD_GRADS_ONLY 4096u /* ... this one the weight and feature-map gradients that consume the chain's dH / dN: the caller may order
+                                            * other work of its own (another stream's kernels) between the two */
 
 /* Packed ResnetFC operands (built by the host from the nn.Linear parameters).
  * T = float (precision 0) or bf16 (precision 1).  reference scenerf/models/resnetfc.py:88-118,133-164 */
@@ -411,6 +416,16 @@ int scenerf_hip_test_acos_atan2(const float* a, const float* b, int64_t n, float
  * entry 0 = number of descriptors, then the descriptors, zero-padded.  Returns the number of ints written (<= cap) or < 0. */
 #define SCENERF_CHUNK_TABLE_STRIDE 704
 int scenerf_hip_test_chunk_table(const scenerf_cfg* cfg, int kind, int32_t* out, int cap);
+
+/* Two tuning knobs with measured defaults, exported for same-box A/B runs (< 0 leaves a value as it is; results do not depend on either):
+ *  warm_wide (default 1): L2 warm-up of the 128-row fused ResnetFC kernels (csrc/wide.hip) -- the blocks of a launch's first dispatch round,
+ *    one per CU, all starting together on an L2 that does not hold the launch's weight stream, each touch a slice of that stream before they
+ *    start, so that the XCD's L2 holds all of it after one memory round trip instead of missing chunk by chunk in lockstep;
+ *  dfeat_delay_us (default 12): scenerf_hip_mlp_backward with SCENERF_FLAG_WGRAD_OVERLAP holds the feature-gradient launch back by this many
+ *    microseconds behind the batched weight-gradient launch it runs beside -- that launch is ONE round of workgroups that each need most of a
+ *    CU's LDS, and if the 1,200 smaller feature-gradient workgroups reach the CUs first its last workgroups are placed only as those
+ *    drain (measured: 1,040 us instead of 675). */
+int scenerf_hip_test_set_tuning(int warm_wide, int dfeat_delay_us);
 
 /* ---- in-library kernel timing (bench.py's roofline leg) ----------------------------------------------------- */
 /* While enabled every kernel launch is bracketed by hipEvents on its own stream. */

@@ -23,7 +23,7 @@ D_HIDDEN = 512
 D_XENC = 48
 TILE_ROWS = 128
 W_STREAM_BLOCKS = (3 * D_XENC + D_LATENT) // 16 + 2 * ((512 + D_LATENT) // 16) + 10 * (512 // 16)   # scenerf_hip.h
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 vp = C.c_void_p
 
@@ -143,6 +143,7 @@ _PROTOS = {
     "scenerf_hip_resnetfc_forward": (C.c_int, [C.POINTER(Cfg), C.POINTER(ResnetFCNet), vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "scenerf_hip_test_gemm_nt": (C.c_int, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "scenerf_hip_test_chunk_table": (C.c_int, [C.POINTER(Cfg), i32, vp, i32]),
+    "scenerf_hip_test_set_tuning": (C.c_int, [i32, i32]),
     "scenerf_hip_test_gemm_tn": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "scenerf_hip_profile_enable": (C.c_int, [i32]),
     "scenerf_hip_profile_collect": (C.c_int, [C.POINTER(ProfRec), i32]),
@@ -169,6 +170,8 @@ def load() -> C.CDLL:
     v = lib.scenerf_hip_abi_version()
     if v != ABI_VERSION:
         raise RuntimeError("libscenerf_hip.so ABI %d != binding ABI %d: rebuild" % (v, ABI_VERSION))
+    if os.environ.get("SRF_TUNING"):   # development only (same-box A/B): "warm_wide,dfeat_delay_us" (scenerf_hip_test_set_tuning; -1 = default)
+        lib.scenerf_hip_test_set_tuning(*[int(x) for x in os.environ["SRF_TUNING"].split(",")])
     _lib = lib
     return lib
 
@@ -178,6 +181,7 @@ FLAG_NO_FUSED_BWD, FLAG_NO_WGRAD_TR, FLAG_DFEAT_PER_SCALE, FLAG_WGRAD_OVERLAP, F
 FLAG_UNIFORM_ONLY = 128
 FLAG_WIDE_BWD_STAGED = 256
 FLAG_PACK_FORWARD, FLAG_PACK_REST = 512, 1024
+FLAG_BWD_CHAIN_ONLY, FLAG_BWD_GRADS_ONLY = 2048, 4096
 ADAMW_SCRATCH = 65        # SCENERF_ADAMW_SCRATCH: words behind [lr, t] in scenerf_hip_adamw_step_dev's hyper
 WIN_LD = 256            # SCENERF_WIN_LD: row stride of scenerf_mlp_grads.w_in
 

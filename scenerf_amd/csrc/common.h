@@ -8,6 +8,15 @@
 #include "../../include/scenerf_hip.h"
 
 #define WAVE 64
+// L2 warm-up of the 128-row fused kernels' first dispatch round (wide.hip; scenerf_hip_test_set_tuning overrides)
+#ifndef SRF_WARM_WIDE_DEFAULT
+#define SRF_WARM_WIDE_DEFAULT 1
+#endif
+// microseconds the feature-gradient launch is held back behind the batched weight-gradient launch it runs beside (mlp.hip: srf_delay_kernel)
+#ifndef SRF_DFEAT_DELAY_US_DEFAULT
+#define SRF_DFEAT_DELAY_US_DEFAULT 12
+#endif
+int srf_dfeat_delay_us();
 
 // ---- error plumbing: never abort, report through the C ABI ---------------------------------------------
 void srf_set_error(const char* fmt, ...);

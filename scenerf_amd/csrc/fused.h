@@ -37,7 +37,10 @@ struct FusedArgs {
     const float* b_out;
     float* logits;       // [M][d_out]
     int d_out;
+    int warm;            // > 0: the blocks of the first dispatch round touch the launch's weight blocks (srf L2 warm-up, wide.hip)
 };
+
+int srf_warm_wide();     // scenerf_hip_test_set_tuning(): 0 = off, 1 = on (default)
 
 // One 32-bit descriptor per 16-wide K chunk (host-built per tile mask, read with scalar loads one step ahead):
 //   [0:9] w_stream block   [10:17] A column / 16   [18:19] src (0 = resident A buffer, 1 = X3, 2 = Z)   [20:22] layer

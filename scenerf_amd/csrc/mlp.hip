@@ -291,6 +291,12 @@ static int feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, c
     return 0;
 }
 
+// one wave that sleeps ~`us` microseconds (s_sleep 31 = 1,984 cycles, the clock holds ~2 GHz under load): a stream-ordered head start for
+// a launch on another stream
+__global__ void srf_delay_kernel(int us) {
+    for (int i = 0; i < us; ++i) __builtin_amdgcn_s_sleep(31);
+}
+
 // blocks 0..5: dst[0:512] = a, dst[512:1024] = b, dst[1024:1536] = c ; blocks 6..: w_dense[512][42] = w_in[512][SCENERF_WIN_LD][:, 0:42]
 // (lin_in.weight's gradient as the dense tensor autograd wants: handed over as a column slice of the 256-wide sink, AccumulateGrad
 // cloned it -- one more launch per MLP on the step's critical path, in front of the optimizer)
@@ -524,8 +530,23 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     // weight / bias gradients are then all linout_bwd is asked for: 157 MB of H3 to read instead of a 314 MB round trip
     const bool dh3_in_chain = wide_chain && !(cfg->flags & SCENERF_FLAG_WIDE_BWD_STAGED);
     const int allow_tr = (cfg->flags & SCENERF_FLAG_NO_WGRAD_TR) ? 0 : 1;
+    // Two-call form (round 6: SCENERF_FLAG_BWD_CHAIN_ONLY / _GRADS_ONLY, fused chain only): the caller may put a stream dependency between
+    // the dgrad chain and the weight / feature-map gradients -- the renderer orders the radiance MLP's gradient phase behind the gaussian
+    // head's whole backward, whose small kernels run beside the chain on another stream: when the chain got faster than they are (r06),
+    // the batched weight-gradient launch (one workgroup per CU, 128 KiB of LDS each) met the head's last kernels AND the feature-gradient
+    // launch on the CUs it needs, its last workgroups were placed only as those drained, and the launch took 1,036 us instead of 675.
+    // Without a fused chain the layers' dgrad and weight-gradient GEMMs interleave: the CHAIN_ONLY call then does everything and the
+    // GRADS_ONLY call nothing.
+    const bool chain_only = (cfg->flags & SCENERF_FLAG_BWD_CHAIN_ONLY) != 0 && fused_chain;
+    const bool grads_only = (cfg->flags & SCENERF_FLAG_BWD_GRADS_ONLY) != 0;
+    SRF_CHECK(!((cfg->flags & SCENERF_FLAG_BWD_CHAIN_ONLY) && grads_only), "mlp_backward: CHAIN_ONLY and GRADS_ONLY are two calls, not one");
+    if (grads_only && !fused_chain) return 0;
+    if (grads_only) {
+        if (int e = fork()) return e;
+    }
     // lin_out backward -> dH3, dw_out, db_out
-    if (dh3_in_chain) {
+    if (grads_only) {
+    } else if (dh3_in_chain) {
         // (measured, r04_b: the same reduction queued beside or behind the chain, on a side stream of equal or of lowest priority, with a
         // scratch buffer of its own -- nothing can share a CU with a block of the chain (all of its LDS and registers), so its workgroups
         // displace chain blocks by what they save in front of it: chain 537 -> 577 / 611 us, step time unchanged.  In stream order.)
@@ -535,14 +556,15 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
     } else {
         if (int e = launch_linout_bwd<float>(w->d_out, a->H[3], w->w_out, d_logits, M, dHcol(3), LDH, g_->w_out, g_->b_out, (float*)dN, s)) return e;
     }
-    if (!dh3_in_chain) {
+    if (!dh3_in_chain && !grads_only) {
         if (int e = fork()) return e;
     }
     // (r04: the feature-map gradients launched in FRONT of the side stream's weight gradients -- so that, as the first-captured successor
     // of the chain kernel, they keep its queue in a replayed graph -- cost 36 us: the batched weight-gradient launch is one round of 240
     // long-lived workgroups, and behind dfeat's 1,200 it gets its CUs late and staggered: 742 against 593 us.  Weight gradients first.)
-    if (fused_chain) {
+    if (fused_chain && !grads_only) {
         if (int e = wide_chain ? launch_mlp_bwd_wide(cfg, w, M, a, dH, dN, dh3_in_chain ? d_logits : nullptr, s) : launch_mlp_bwd_fused(cfg, w, M, a, dH, dN, s)) return e;
+        if (chain_only) return 0;
         if (int e = fork()) return e;
     }
     GemmTN wg[8];   // the six fc weight gradients (+ lin_z, below): batched into one launch when the chain kernel already produced every dH / dN
@@ -664,6 +686,16 @@ int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* 
         g_->b_z, g_->b_in, g_->b_fc1[0], g_->b_fc1[1], g_->w_in_dense, g_->w_in);
     SRF_LAUNCH_CHECK("copy3_kernel");
     if (gmaps_hwc) {
+        // the batched weight-gradient launch on s2 is ONE round of workgroups with 128 KiB of LDS each: it must find the CUs empty.  The
+        // feature-gradient workgroups (two per CU, 1,200+ of them) launched at the same moment on this stream take the CUs first or
+        // share them out, a weight-gradient workgroup then only fits when BOTH of a CU's feature-gradient workgroups have left -- and the
+        // dispatcher refills the holes with more of those: the launch took 1,036-1,048 us instead of 675 (profiles/r06_h_*, r06_i_*: r05 got
+        // away with a 6-us lead that the faster chain kernel of r06 no longer left).  A one-wave kernel that sleeps a few microseconds in
+        // front of the feature gradients gives the other launch its head start, replayed graph or not.
+        if (sc_ && nwg && srf_dfeat_delay_us() > 0 && !head) {
+            srf_delay_kernel<<<1, 64, 0, s>>>(srf_dfeat_delay_us());
+            SRF_LAUNCH_CHECK("srf_delay_kernel");
+        }
         if (int e = feature_grads(cfg, w, tile_mask, tap_texel, tap_weight, M, dH, gmaps_hwc, s)) return e;
     }
     if (sc_) {  // join: the caller's stream continues only after the weight-gradient stream has drained

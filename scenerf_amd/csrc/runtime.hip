@@ -76,7 +76,19 @@ void srf_prof_end(hipStream_t s) {
     if (p.b) (void)hipEventRecord(p.b, s);
 }
 
+// tuning knobs with measured defaults (scenerf_hip_test_set_tuning overrides, for same-box A/B runs): the L2 warm-up of the 128-row fused
+// kernels' first dispatch round (wide.hip), the head start the batched weight-gradient launch gets over the feature-gradient launch (mlp.hip)
+static int g_warm_wide = SRF_WARM_WIDE_DEFAULT, g_dfeat_delay_us = SRF_DFEAT_DELAY_US_DEFAULT;
+int srf_warm_wide() { return g_warm_wide; }
+int srf_dfeat_delay_us() { return g_dfeat_delay_us; }
+
 extern "C" {
+
+int scenerf_hip_test_set_tuning(int warm_wide, int dfeat_delay_us) {
+    if (warm_wide >= 0) g_warm_wide = warm_wide;
+    if (dfeat_delay_us >= 0) g_dfeat_delay_us = dfeat_delay_us;
+    return 0;
+}
 
 int scenerf_hip_abi_version(void) { return SCENERF_HIP_ABI_VERSION; }
 const char* scenerf_hip_last_error(void) { return g_err; }

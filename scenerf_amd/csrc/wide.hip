@@ -230,6 +230,27 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     const int nz = tab[2];     // a lin_z tail's staged chunks, incl. padding
     const int nzr = tab[3];    // ... real ones
     const bool zres = nzr <= H_ZCAP;                           // the stage keeps layer 0's Z chunks for layers 2 and 4
+    // ---- L2 warm-up (round 6).  The first dispatch round puts one block on every CU at the same instant, on an L2 that the previous
+    // kernels have filled with their own streams: every CU of an XCD then misses on the SAME weight block at the same time, chunk after
+    // chunk, and the four-chunk ring cannot cover a trip to memory -- blocks of round 0 took 302k / 307k cycles (forward / dgrad chain)
+    // against 236k / 192k for the later rounds, whose weights are L2 hits (tools/wide_cycles.py, profiles/r06_c_*).  So the blocks of
+    // round 0 share the job of touching the launch's whole weight stream once, up front: block b sits on XCD b % 8 (dispatch order: a
+    // speed assumption only), position (b >> 3) inside that XCD's round; position q touches chunk pairs q, q + npos, ... of this block's
+    // own chunk table -- one 16-byte piece per 128-byte line, thread t line t & 127 of chunk 2 * pair + (wave >> 1).  The pieces go
+    // global -> LDS by DMA (no destination register that a late return could clobber) into the second half of H_XB, which nothing has
+    // written yet: whatever is staged there later is issued later and lands later (returns are in order), and every counted wait of the
+    // K loops covers these oldest entries of the queue.
+    // (launches of less than one full round -- the gaussian head's 38 blocks -- are slower with it, 103 against 98 us: each of their few
+    // blocks would fetch a fifth of the stream before it starts)
+    if (p.warm > 0 && gridDim.x >= 256 && blockIdx.x < 256) {
+        const int npos = 32;
+        const int nch = tab[0];
+        const unsigned wdst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + H_XB + 4096 + wvu * 1024);
+        for (int pr = (int)(blockIdx.x >> 3) % npos; 2 * pr < nch; pr += npos) {
+            const int cw = 2 * pr + (wvu >> 1);
+            if (cw < nch) h_glds16((const char*)p.Wst + ((size_t)FD_Z(tab[H_HDR + cw]) << 14), (unsigned)((tid & 127) << 7), wdst);
+        }
+    }
     // lin_out's bias, fetched now (scalar registers): a load at the tail would sit behind 128 KiB of stores in the in-order vmcnt queue
     float bo[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 0 && p.logits) {
@@ -973,6 +994,7 @@ int launch_mlp_fwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, co
     p.b_out = w->b_out;
     p.logits = a->logits;
     p.d_out = w->d_out;
+    p.warm = srf_warm_wide();
     double flops = 0;   // FLOPs actually issued (profile mode only; synchronises to read the scale-activity mask)
     if (srf_prof_on()) {
         const int tiles = cdiv(M, SCENERF_TILE_ROWS);
@@ -1023,6 +1045,7 @@ int launch_mlp_bwd_wide(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, in
     if (int e = srf_desc_cache_get(g_wide_table, cfg, s, wide_table_build, &desc)) return e;
     p.desc = desc + 32 * F_MAXCH;
     p.M = M;
+    p.warm = srf_warm_wide();
     SrfLaunchScope ps(s, w->d_out == 2 ? "mlp_bwd_fused/g" : "mlp_bwd_fused", 2.0 * M * 512.0 * (6.0 * 512.0 + (d_logits ? 48.0 : 0.0)), 0);
     if (d_logits && M % H_BM == 0) mlp_wide_kernel<1><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);    // (full blocks: the stores are certain)
     else if (d_logits) mlp_wide_kernel<4><<<cdiv(M, H_BM), H_THREADS, H_LDS, s>>>(p);

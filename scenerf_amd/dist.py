@@ -100,6 +100,7 @@ def init_from_env(backend: Optional[str] = None, force: bool = False, graph_capt
 
 
 _SIDE_GROUP = None
+_SIDE_GROUP_OWNER = [None]     # the default group the side group was made under (re-initialisation invalidates it)
 
 
 def all_ranks_agree(ok: bool) -> bool:
@@ -110,17 +111,27 @@ def all_ranks_agree(ok: bool) -> bool:
     global _SIDE_GROUP
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return bool(ok)
+    if _SIDE_GROUP is not None and _SIDE_GROUP_OWNER[0] is not dist.group.WORLD:
+        _SIDE_GROUP = None           # the process group was destroyed and re-initialised: the cached side group belongs to the old one
     if _SIDE_GROUP is None:
         if dist.get_backend() == "gloo":
             _SIDE_GROUP = dist.group.WORLD
+            _SIDE_GROUP_OWNER[0] = dist.group.WORLD
         else:
             # one node (the rendezvous address is loopback): gloo on the loopback interface -- a container's hostname need not resolve
             if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
                 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             try:
-                _SIDE_GROUP = dist.new_group(backend="gloo")
-            except Exception:        # noqa: BLE001 -- no gloo transport here: agree over the default group (device tensor) instead
-                _SIDE_GROUP = False
+                grp = dist.new_group(backend="gloo")
+            except Exception:        # noqa: BLE001 -- no gloo transport on this rank
+                grp = None
+            # the ranks must all take the SAME path: a rank whose gloo group failed would otherwise reduce on the default group while
+            # the others wait in the gloo one.  The outcome of new_group is itself agreed on over the default group -- the
+            # one exchange here that does use the gradient communicator, at set-up time, before any capture has been attempted.
+            flag = torch.tensor([1 if grp is not None else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            _SIDE_GROUP = grp if int(flag[0]) == 1 else False
+            _SIDE_GROUP_OWNER[0] = dist.group.WORLD
     if _SIDE_GROUP is False:
         t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
         dist.all_reduce(t, op=dist.ReduceOp.MIN)

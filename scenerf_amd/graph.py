@@ -4,7 +4,8 @@ step costs what its kernels cost whatever the host is doing (the eager step is i
 time on an idle host; a busy host makes it host-bound).
 
 What a captured step fixes, as with any CUDA / HIP graph: tensor ADDRESSES and shapes.  Camera, pose and pixels are read from the
-static tensors ``cam_K`` / ``T_source2infer`` / ``pixels`` of the object (``copy_`` new values into them between replays; or hand
+static tensors ``cam_K`` / ``T_source2infer`` / ``pixels`` of the object (``copy_`` new values into them between replays -- the
+host-made inverse of ``cam_K`` is refreshed in place by ``__call__`` when ``cam_K``'s version counter has moved; or hand
 ``pixels`` over as a callable that draws them on the device inside the step, like the reference's per-step ``randperm``); the feature
 maps are the caller's tensors, captured by address (write new features into the same storage); their gradients land in
 ``map_grads`` (the ``.grad`` of the captured leaves, zeroed by the graph itself at the top of each replay).  The gaussian sampler's
@@ -80,18 +81,21 @@ class GraphedStep:
         # ``grid[torch.randperm(len(grid), device=dev)[:R]]``, scenerf.py:253-264: torch's CUDA generator is graph-safe, every replay
         # draws fresh pixels); the callable must return the same shape on the same device every time and launch only capturable work
         self._pixels_fn = pixels if callable(pixels) else None
+        self.model, self.optimizer = model, optimizer
+        self.noise = noise
+        self._params = [p for g in optimizer.param_groups for p in g["params"]] if optimizer is not None else \
+            [p for p in model.parameters() if p.requires_grad]
+        # (restore=True: the snapshot -- torch's CUDA generator included -- is taken BEFORE the probe draw below, so the first replay's
+        # pixels are the caller's generator state's, as an eager first step's would be)
+        snap = self._snapshot(cam_K.device, restore_tensors) if restore else None
         if self._pixels_fn is not None:
             pixels = self._pixels_fn()
         dev = pixels.device
-        self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
+        self.loss_fn = loss_fn
         self.cam_K, self.T_source2infer, self.pixels, self.x_rgb = cam_K, T_source2infer, pixels, x_rgb
         self.ray_batch_size = int(ray_batch_size or pixels.shape[0])
-        self.noise = noise
         self._one = None
-        self._params = [p for g in optimizer.param_groups for p in g["params"]] if optimizer is not None else \
-            [p for p in model.parameters() if p.requires_grad]
         self._map_leaves = [v for v in x_rgb.values() if v.requires_grad]
-        snap = self._snapshot(dev, restore_tensors) if restore else None
         # warm-up on a side stream (allocator pools, one-time setup, optimizer state), as torch's capture recipe asks
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -105,6 +109,9 @@ class GraphedStep:
         with torch.cuda.graph(self.graph):
             self.loss = self._eager()
         self.map_grads = {k: v.grad for k, v in x_rgb.items() if v.requires_grad}
+        # the captured step reads the inverse intrinsics from the model's cached tensor (made on the host, SceneRF._inv_K): remember the
+        # version of cam_K it belongs to -- __call__ refreshes that tensor in place when the caller has copied new intrinsics in
+        self._cam_K_version = cam_K._version
         self.steps_warmup = max(1, warmup)
         if snap is not None:
             self._restore(snap, dev)
@@ -185,6 +192,12 @@ class GraphedStep:
         """Replay: one more training step.  Returns the (static) loss tensor of the captured step."""
         if self.optimizer is not None and hasattr(self.optimizer, "sync_hyper"):
             self.optimizer.sync_hyper()     # a scheduler may have moved the learning rate
+        if self.cam_K._version != self._cam_K_version:
+            # new intrinsics were copied into the static cam_K: their inverse is host-made and lives in a tensor the graph holds by address
+            # (ADVICE r05: a replay runs no Python, so without this the rays would keep the OLD inverse) -- refreshed in place, outside the graph
+            if hasattr(self.model, "_inv_K"):
+                self.model._inv_K(self.cam_K)
+            self._cam_K_version = self.cam_K._version
         self.graph.replay()
         return self.loss
 

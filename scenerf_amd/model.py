@@ -237,14 +237,20 @@ class SphericalMapping(nn.Module):
         if inv_K.is_cuda:
             from . import _capi
             lib = _capi.load()
-            pix = pix_coords.to(torch.float32).contiguous()
+            dev = inv_K.device
+            # the pixel list follows the intrinsics' device (a CPU list with CUDA intrinsics would hand the kernel a host pointer, a list
+            # on another GPU a foreign one); the launch is issued under that device's guard, on its current stream
+            pix = pix_coords.to(device=dev, dtype=torch.float32).contiguous()
             ik = inv_K.to(torch.float32).contiguous()
             M = pix.shape[0]
-            idx = torch.empty((M, 2), dtype=torch.int64, device=pix.device)
-            dist = torch.empty((M,), dtype=torch.float32, device=pix.device)
-            _capi.check(lib.scenerf_hip_pixels_to_sphere(pix.data_ptr(), ik.data_ptr(), self.v_angle_min, self.v_fov, self.h_angle_min,
-                                                         self.h_fov, self.out_img_W, self.out_img_H, M, idx.data_ptr(), dist.data_ptr(),
-                                                         torch.cuda.current_stream(pix.device).cuda_stream), "pixels_to_sphere")
+            idx = torch.empty((M, 2), dtype=torch.int64, device=dev)
+            dist = torch.empty((M,), dtype=torch.float32, device=dev)
+            if M == 0:              # (the reference returns empty tensors here)
+                return pix_coords, idx, dist.type_as(inv_K)
+            with torch.cuda.device(dev):
+                _capi.check(lib.scenerf_hip_pixels_to_sphere(pix.data_ptr(), ik.data_ptr(), self.v_angle_min, self.v_fov, self.h_angle_min,
+                                                             self.h_fov, self.out_img_W, self.out_img_H, M, idx.data_ptr(), dist.data_ptr(),
+                                                             torch.cuda.current_stream(dev).cuda_stream), "pixels_to_sphere")
             return pix_coords, idx, dist.type_as(inv_K)
         homo = torch.cat([pix_coords, torch.ones_like(pix_coords[:, :1])], dim=1)
         cam = (inv_K @ homo.T).T
@@ -323,8 +329,17 @@ class SceneRF(TrainingMixin, _Base):
         captured graph -- that passes the same K tensor pays once."""
         hit = getattr(self, "_inv_K_cache", None)
         if hit is None or hit[0] is not cam_K or hit[1] != cam_K._version:
+            if torch.cuda.is_available() and cam_K.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("render_rays_batch: new intrinsics inside a hipGraph capture (their inverse is made on the host: a "
+                                   "device-to-host copy cannot be captured) -- render once with this cam_K tensor before capturing")
             inv = torch.inverse(cam_K.detach().to("cpu", torch.float32)).contiguous()   # (torch.inverse hands back a column-major view)
-            hit = (cam_K, cam_K._version, inv.to(cam_K.device))
+            if hit is not None and hit[0] is cam_K and hit[2].device == cam_K.device:
+                # same tensor object, new values (cam_K.copy_(...)): refresh the cached inverse IN PLACE -- a captured step holds its
+                # address (GraphedStep.__call__ comes through here when the version counter of its static cam_K has moved)
+                hit[2].copy_(inv)
+                hit = (cam_K, cam_K._version, hit[2])
+            else:
+                hit = (cam_K, cam_K._version, inv.to(cam_K.device))
             object.__setattr__(self, "_inv_K_cache", hit)
         return hit[2]
 
@@ -396,6 +411,9 @@ class SceneRF(TrainingMixin, _Base):
         poses rendered from that frame.  Sampling noise follows ``device_rng`` as in the chunk loop.  Returns the dict of ``render_rays_batch``
         (``keys`` selects a subset: the (n, N) outputs of a 451,400-ray frame at N = 512 are 0.9 GB each)."""
         from .inference import ImageRenderer, pixel_grid
+        if not (self.mlp.is_standard and self.mlp_gaussian.is_standard):
+            raise NotImplementedError("render_image needs the 3 x 512 ResnetFC trunks (its static-chunk engine re-packs the fused kernels' operand "
+                                      "layouts in place); a model with another ResnetFC shape renders through render_rays_batch under no_grad")
         if sampled_pixels is None:
             sampled_pixels = pixel_grid(tuple(self.img_size), stride, x_rgb["1_1"].device)
         if sampled_pixels.shape[0] == 0:

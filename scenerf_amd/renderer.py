@@ -68,6 +68,7 @@ CHAIN_FIRST = True           # capture / issue order: at every fork the critical
                              # the packs are launched behind the chain's first kernels (below: "Launch order")
 MAIN_WGRAD_OVERLAP = True    # radiance MLP's weight gradients on the library's side stream, beside its feature-map gradients (-35 us/step)
 DEFER_HEAD_PACK = True     # (tools/ab_step.py toggles this)
+GRADS_BEHIND_HEAD = True   # the radiance MLP's weight / feature-map gradients start only when the gaussian head's backward kernels are done
 SPLIT_HEAD_PACK = True     # the head's pack in two calls, its forward's operands first
 
 
@@ -768,10 +769,11 @@ def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dis
 
 
 def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: _MlpRun, d_logits, want_map_grads: bool,
-                  sync_async=None):
+                  sync_async=None, before_grads=None):
     """``sync_async`` (data parallel, scenerf_amd.dist.allreduce_mean_async): the parameter gradients are final once the weight-
     gradient GEMMs are queued, so their all-reduce is started there and the feature-gradient GEMM + scatter (0.5 ms) runs while
-    the collective is in flight; returns the collective's finisher (or None)."""
+    the collective is in flight; returns the collective's finisher (or None).  ``before_grads``: called between the dgrad chain and the
+    weight / feature-map gradients (scenerf_hip_mlp_backward's two-call form): where the caller orders that phase behind other work."""
     lib = _capi.load()
     pk.wait_ready(backward=True)
     act = _act_dtype(cfg.precision_code)
@@ -781,10 +783,22 @@ def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: 
     g = pk.grad_sink()
     gm = C.byref(maps.gmap_ptr_array()) if want_map_grads else None
     split = sync_async is not None and gm is not None
-    _capi.check(lib.scenerf_hip_mlp_backward(C.byref(ccfg), C.byref(pk.c), C.byref(g), run.Z.data_ptr(), _capi.ptr(run.xenc),
-                                             run.tile_mask.data_ptr(), run.tap_texel.data_ptr(), run.tap_weight.data_ptr(),
-                                             run.M, C.byref(run.c), d_logits.data_ptr(), dH.data_ptr(), dN.data_ptr(),
-                                             None if split else gm, _stream(dev)), "mlp_backward")
+
+    def call(cc):
+        _capi.check(lib.scenerf_hip_mlp_backward(C.byref(cc), C.byref(pk.c), C.byref(g), run.Z.data_ptr(), _capi.ptr(run.xenc),
+                                                 run.tile_mask.data_ptr(), run.tap_texel.data_ptr(), run.tap_weight.data_ptr(),
+                                                 run.M, C.byref(run.c), d_logits.data_ptr(), dH.data_ptr(), dN.data_ptr(),
+                                                 None if split else gm, _stream(dev)), "mlp_backward")
+
+    if before_grads is None:
+        call(ccfg)
+    else:
+        for flag in (_capi.FLAG_BWD_CHAIN_ONLY, _capi.FLAG_BWD_GRADS_ONLY):
+            cc = type(ccfg).from_buffer_copy(ccfg)
+            cc.flags |= flag
+            if flag == _capi.FLAG_BWD_GRADS_ONLY:
+                before_grads()
+            call(cc)
     finish = sync_async(pk.gflat) if sync_async is not None else None
     if split:
         _capi.check(lib.scenerf_hip_mlp_feature_grads(C.byref(ccfg), C.byref(pk.c), run.tile_mask.data_ptr(), run.tap_texel.data_ptr(),
@@ -988,6 +1002,8 @@ class RenderChunk(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
         do_head = bool(ctx.needs_input_grad[12] or want_maps)
+        head_done = []
+
         def main_backward():
             if ctx.needs_input_grad[11] or want_maps:
                 early = ctx.mlp.grad_sync_async if (ctx.mlpg.single_chunk and ctx.needs_input_grad[11]) else None
@@ -995,12 +1011,17 @@ class RenderChunk(torch.autograd.Function):
                 if MAIN_WGRAD_OVERLAP:
                     ccm = type(ccfg).from_buffer_copy(ccfg)
                     ccm.flags |= _capi.FLAG_WGRAD_OVERLAP
-                ctx.mlp.pending = _mlp_backward(ccm, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps, sync_async=early)
+                # GRADS_BEHIND_HEAD: the radiance MLP's weight / feature-map gradient phase waits for the gaussian head's backward (its
+                # kernels, not its all-reduce) -- see SCENERF_FLAG_BWD_CHAIN_ONLY in csrc/mlp.hip for what happens when the two meet
+                join = (lambda: main.wait_event(head_done[0])) if (GRADS_BEHIND_HEAD and head_done) else None
+                ctx.mlp.pending = _mlp_backward(ccm, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps, sync_async=early,
+                                                before_grads=join)
 
         def head_backward():
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 _mlp_backward(ccfg, cfg, ctx.maps, ctx.mlpg.packed, run_g, d_off.view(R * G, 2), want_maps)
+                head_done.append(side.record_event())
                 # data parallel, one chunk per step (training): the head's parameter gradients are final here, ~2 ms before the
                 # radiance MLP's -- reduce them now, on the side stream, under the main backward (half of the step's all-reduce
                 # volume leaves the critical path).  Every rank takes this branch in the same order: head first, main MLP later.

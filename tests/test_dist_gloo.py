@@ -136,7 +136,7 @@ def test_bench_falls_back_on_every_rank_when_one_capture_fails():
     for fail, want in ((1, "eager (capture failed on another rank"), (0, "eager (capture failed on this rank"), (-1, "one hipGraph replay per step")):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1",
-               "--dry-fail-capture", str(fail)]
+               "--graph", "on", "--dry-fail-capture", str(fail)]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -144,6 +144,44 @@ def test_bench_falls_back_on_every_rank_when_one_capture_fails():
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["value"] > 0
         assert d["config"]["step_issue"].startswith(want), d["config"]["step_issue"]
+        if fail == -1:     # the replayed collectives were checked before the timed region (bench.replay_agrees_across_ranks)
+            assert "bit-equal across ranks" in d["config"]["step_issue"], d["config"]["step_issue"]
+
+
+def test_bench_steps_eagerly_on_more_than_one_rank_unless_asked():
+    """`--graph auto` (the default) with two ranks: the eager step, and the line says why (a replayed all-reduce between GPUs has never run:
+    opt-in with --graph on until it has -- ADVICE r05)."""
+    import json
+    r = _bench("--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["step_issue"].startswith("eager (more than one rank"), d["config"]["step_issue"]
+
+
+def test_replay_check_sees_ranks_that_drifted_apart(tmp_path):
+    """bench.replay_agrees_across_ranks: equal parameters pass, one rank one ulp off fails -- on EVERY rank."""
+    out = str(tmp_path / "r%d.pt")
+    mp.spawn(_worker_replay_check, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in range(2):
+        ok_same, ok_diff = torch.load(out % r)
+        assert ok_same[0] is True and ok_same[1] == 0.0
+        assert ok_diff[0] is False and ok_diff[1] > 0.0
+
+
+def _worker_replay_check(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from scenerf_amd import dist as sdist
+    import bench
+    sdist.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(5)
+    ps = [torch.randn(512, 512, generator=g), torch.randn(37, generator=g)]
+    same = bench.replay_agrees_across_ranks(ps, world)
+    if rank == 1:
+        ps[1][3] = torch.nextafter(ps[1][3], torch.tensor(10.0))
+    diff = bench.replay_agrees_across_ranks(ps, world)
+    torch.save((same, diff), out % rank)
+    dist.destroy_process_group()
 
 
 def _worker_agree(rank, world, port, out):

@@ -277,6 +277,59 @@ def test_graphed_step_draws_fresh_pixels_inside_the_graph():
     assert all(bool(((p[:, 0] % 2 == 0) & (p[:, 1] % 2 == 0) & (p[:, 0] < 1220) & (p[:, 1] < 370)).all()) for p in seen)
 
 
+def test_graphed_step_follows_new_intrinsics_copied_into_cam_K():
+    """The inverse of cam_K is made on the HOST (SceneRF._inv_K) and lives in a device tensor the captured step holds by address; a replay
+    runs no Python, so after ``cam_K.copy_(new)`` that tensor would keep the old inverse and every ray its old direction.
+    ``GraphedStep.__call__`` refreshes it in place when cam_K's version counter has moved: the replay then renders what an eager call with
+    the new intrinsics renders (optimizer-free steps: nothing else moves between the two)."""
+    from scenerf_amd.graph import GraphedStep
+    m, _, maps, K, T, pix, noise = _setup(13)
+    K = K.clone()
+    for v in maps.values():
+        v.requires_grad_(False)
+    outs = {}
+
+    def keep(out):
+        outs["depth"] = out["depth"]
+        return _loss(out)
+
+    gs = GraphedStep(m, None, keep, K, T, maps, pix, ray_batch_size=256, warmup=1, noise=noise)
+    gs(); torch.cuda.synchronize()
+    d_old = outs["depth"].detach().clone()
+    inv_addr = m._inv_K_cache[2].data_ptr()
+    K2 = K.clone(); K2[0, 0] *= 0.9; K2[1, 1] *= 0.9; K2[0, 2] += 7.0
+    K.copy_(K2)
+    gs(); torch.cuda.synchronize()
+    d_new = outs["depth"].detach().clone()
+    assert m._inv_K_cache[2].data_ptr() == inv_addr                                    # refreshed in place: the graph's address
+    assert torch.equal(m._inv_K_cache[2].cpu(), torch.inverse(K2.cpu().float()))        # ... with the host's inverse of the new values
+    with torch.no_grad():
+        ref = m.render_rays_batch(K2.clone(), T, maps, T_cam2velo=None, sampled_pixels=pix, ray_batch_size=256, noise=noise)["depth"]
+    assert not torch.allclose(d_old, d_new, rtol=1e-3), "the replay did not see the new intrinsics"
+    torch.testing.assert_close(d_new, ref, rtol=2e-3, atol=2e-3)                        # (bf16 run-to-run level)
+
+
+def test_restore_true_with_a_pixel_callable_gives_back_the_callers_generator_state():
+    """restore=True snapshots torch's CUDA generator BEFORE the constructor's probe draw of a ``pixels`` callable (it was taken
+    after it, so the first replay drew what an eager first step would have drawn second)."""
+    from scenerf_amd.graph import GraphedStep
+    m, opt, maps, K, T, pix, noise = _setup(15)
+    xs, ys = torch.arange(0, 1220, 2, device=DEV, dtype=torch.float32), torch.arange(0, 370, 2, device=DEV, dtype=torch.float32)
+    grid = torch.stack(torch.meshgrid(xs, ys, indexing="ij"), dim=2).reshape(-1, 2)
+
+    def draw():
+        return grid[torch.randperm(grid.shape[0], device=DEV)[:256]]
+
+    torch.cuda.manual_seed(4242)
+    state0 = torch.cuda.get_rng_state(torch.device(DEV))
+    expect = draw().clone()                     # what an eager first step draws from the caller's generator state
+    torch.cuda.set_rng_state(state0, torch.device(DEV))
+    gs = GraphedStep(m, opt, _loss, K, T, maps, draw, ray_batch_size=256, warmup=2, noise=noise, restore=True)
+    assert torch.equal(torch.cuda.get_rng_state(torch.device(DEV)), state0)
+    gs(); torch.cuda.synchronize()
+    assert torch.equal(gs.pixels, expect)
+
+
 def test_graphed_step_refuses_what_cannot_be_captured():
     from scenerf_amd.graph import GraphedStep
     from scenerf_amd.optim import FusedAdamW

@@ -1,5 +1,8 @@
 """End-to-end parity of SceneRF.render_rays_batch (HIP path, through the C ABI) against the golden vectors
 minted from the reference, and against the CPU oracle at a larger size, forward and backward."""
+import json
+import os
+
 import pytest
 import torch
 
@@ -45,7 +48,32 @@ def frac_within(a, b, tol, absolute=False):
     return float(ok.float().mean()), ok
 
 
-def clean_mask(aux, o, ocfg, K, n_rays, T):
+# rays per case whose sphere index differs from the free-running oracle's (the host's torch.acos / `K @ p` against the pinned rule, and
+# gaussian samples that carry the head's fp32 arithmetic): MEASURED on MI355X per call site (tests/golden/clean_mask_measured.json,
+# regenerated from the counts every run leaves in gpurun_out/clean_mask_counts.json) -- a run may mask at most measured + 1 rays
+# (round 6; before that n_rays // 16 for every case, two orders of magnitude above what is measured)
+_CLEAN_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clean_mask_measured.json")
+CLEAN_MEASURED = json.load(open(_CLEAN_PATH)) if os.path.exists(_CLEAN_PATH) else {}
+_CLEAN_SEEN = {}
+
+
+def _clean_gate(key, flipped, n_rays):
+    _CLEAN_SEEN[key] = {"flipped_rays": flipped, "rays": n_rays}
+    if os.path.isdir("gpurun_out"):
+        path = os.path.join("gpurun_out", "clean_mask_counts.json")
+        try:
+            cur = json.load(open(path)) if os.path.exists(path) else {}
+        except Exception:
+            cur = {}
+        cur.update(_CLEAN_SEEN)
+        json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
+    want = CLEAN_MEASURED.get(key)
+    limit = want["flipped_rays"] + 1 if want is not None else max(1, n_rays // 256)
+    assert flipped <= limit, "[%s] %d of %d rays carry a sphere index off the free-running oracle's; %s" % (
+        key, flipped, n_rays, "measured %d (+1 allowed)" % want["flipped_rays"] if want is not None else "no measured entry: limit %d" % limit)
+
+
+def clean_mask(aux, o, ocfg, K, n_rays, T, key=None):
     """Rays (the first ``n_rays`` of the render) whose every sample and anchor got the sphere index the FREE-RUNNING oracle ``o`` computed
     (the reference's calls as this host runs them) -- the rays a stored / free-running output vector can be compared on.
 
@@ -72,7 +100,7 @@ def clean_mask(aux, o, ocfg, K, n_rays, T):
     dm, dh = got - o["_idx"], got_g - o["_idx_g"]
     assert int(dm.abs().max()) <= 1 and int(dh.abs().max()) <= 1
     flipped = (dm != 0).any(dim=1).reshape(n_rays, -1).any(dim=1) | (dh != 0).any(dim=1).reshape(n_rays, -1).any(dim=1)
-    assert int(flipped.sum()) <= max(1, n_rays // 16), "too many rays with a sphere index off the free-running oracle's: %d of %d" % (int(flipped.sum()), n_rays)
+    _clean_gate(key or "rays%d_rows%d" % (n_rays, n_main), int(flipped.sum()), n_rays)
     return ~flipped
 
 
@@ -83,7 +111,7 @@ def _clean_rays(m, g: Golden, R):
     outs = [orc.render_chunk(ocfg, mlp, mlpg, g.cam_K, g.T, g.feature_maps(), g.pixels[s:s + g.chunk], g.noise_u[s:s + g.chunk],
                              g.noise_g[s:s + g.chunk], keep_intermediates=True) for s in range(0, R, g.chunk)]
     o = {k: torch.cat([c[k] for c in outs], dim=0) for k in ("_idx", "_idx_g")}
-    return clean_mask(m.last_aux, o, ocfg, g.cam_K, R, g.T)
+    return clean_mask(m.last_aux, o, ocfg, g.cam_K, R, g.T, key="golden_" + g.name)
 
 
 def _loss_kl_at_the_gpus_choices(m, g: Golden, R):
@@ -280,7 +308,7 @@ def test_larger_chunk_against_oracle_bf16_and_fp32():
             out = m.render_rays_batch(K.to(DEV), T.to(DEV), {k: v.to(DEV) for k, v in maps.items()}, sampled_pixels=pix.to(DEV),
                                       ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
         t = TOL[precision]
-        clean = clean_mask(m.last_aux, ref, ocfg, K, R, T) if m.debug_aux else torch.ones(R, dtype=torch.bool)
+        clean = clean_mask(m.last_aux, ref, ocfg, K, R, T, key="larger_chunk") if m.debug_aux else torch.ones(R, dtype=torch.bool)
         _, okd = frac_within(out["depth"].cpu(), ref["depth"].detach(), t["depth"])
         _, okc = frac_within(out["color"].cpu(), ref["color"].detach(), t["color"], True)
         fd, fc = float(okd[clean].float().mean()), float(okc[clean].float().mean())
@@ -327,7 +355,7 @@ def test_edge_cases_against_oracle_fp32(name, over, R, chunk, pose):
     x = {k: v.to(DEV).requires_grad_(True) for k, v in maps.items()}
     out = m.render_rays_batch(K.to(DEV), T.to(DEV), x, sampled_pixels=pix.to(DEV), ray_batch_size=chunk,
                               noise=(nu.to(DEV), ng.to(DEV)))
-    clean = clean_mask(m.last_aux, ref, ocfg, K, R, T)   # every ray whose indices are the free-running oracle's
+    clean = clean_mask(m.last_aux, ref, ocfg, K, R, T, key="edge_" + name)   # every ray whose indices are the free-running oracle's
     for k in OUT_KEYS:
         got, want = out[k].detach().cpu(), ref[k].detach()
         assert got.shape == want.shape, (k, got.shape, want.shape)
@@ -550,7 +578,7 @@ def test_full_size_config2_properties_and_subset_parity():
     S = 40
     ocfg = orc.OracleConfig.kitti(**kw)
     ref = orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix[:S], nu[:S], ng[:S], keep_intermediates=True)
-    clean = clean_mask(aux32, ref, ocfg, K, S, T)
+    clean = clean_mask(aux32, ref, ocfg, K, S, T, key="full_config2_subset")
     for k in ("depth", "color", "weights", "alphas", "densities", "gaussian_means", "gaussian_stds", "depth_volumes"):
         _, ok = frac_within(o[k][:S], ref[k].detach(), TOL["fp32"]["color"] if k == "color" else 1e-4, k in ABS_KEYS)
         assert bool(ok[clean].all()), "%s: %.3f of the subset rays within tolerance" % (k, float(ok[clean].float().mean()))
@@ -640,7 +668,7 @@ def test_full_size_config3_bundlefusion_fused_vs_layers_and_subset_parity():
     S = 24
     ocfg = orc.OracleConfig.bundlefusion(**{k: v for k, v in kw.items()})
     ref = orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix[:S], nu[:S], ng[:S], keep_intermediates=True)
-    clean = clean_mask(auxs["fp32"], ref, ocfg, K, S, T)
+    clean = clean_mask(auxs["fp32"], ref, ocfg, K, S, T, key="full_config3_subset")
     for k in ("depth", "color", "weights", "alphas", "gaussian_means", "gaussian_stds", "depth_volumes"):
         _, ok = frac_within(o32[k][:S], ref[k].detach(), TOL["fp32"]["color"] if k == "color" else 1e-4, k in ABS_KEYS)
         assert bool(ok[clean].all()), "%s: %.3f of the subset rays within tolerance" % (k, float(ok[clean].float().mean()))
@@ -1015,3 +1043,52 @@ def test_render_image_n512_bf16_against_position_matched_oracle():
         float(rel.max()), float(rel.median()), float(cerr.max())))
     assert torch.equal(out["gaussian_means"].cpu(), ref["gaussian_means"].detach())
     assert float(rel.max()) < 3e-2 and float(cerr.max()) < 3e-2
+
+
+@pytest.mark.gpu
+def test_render_image_n512_at_the_benched_chunk_against_the_oracle():
+    """BASELINE.json configs[4] AS BENCHED (bench.py's infer_c5 leg): N = 512 (U=256, G=4, P=64), bf16, ONE chunk of 4,096 rays =
+    2,097,152 rows = 16,384 row blocks of the 128-row forward, `keys=("depth", "color")` -- the compositing-only instantiation of the
+    per-ray tail (ray_tail_fwd_kernel<8, 4, false>, selective outputs), replayed from the captured graph -- against the CPU oracle under
+    no_grad, evaluated at the GPU's own gaussian-head offsets (identical sample positions: the comparison is the arithmetic of the
+    radiance MLP and the compositing, at the chunk shape the bench line is quoted on).  The oracle walks the chunk 128 rays at a time
+    (its gathered features are 10 KB per sample in fp32) over every ORACLE_STRIDE-th ray: 1,024 rays spread over all of the chunk."""
+    from scenerf_amd import synth
+    U, P, R = 256, 64, 4096
+    ORACLE_STRIDE = 4
+    kw = dict(n_pts_uni=U, n_pts_per_gaussian=P)
+    mlp, mlpg = synth.mlp_state(111, 4), synth.mlp_state(112, 2, out_scale=4.0)
+    maps = synth.feature_maps(1500, 452, 113, smooth=False)
+    pix = synth.stride2_pixels((1220, 370), R, 114)
+    nu, ng = synth.sampling_noise(R, U, 4 * P, 115)
+    K, T = synth.kitti_cam_K(), synth.rel_pose(2.0, 5.0)
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="bf16", **kw).to(DEV).eval()
+    m.mlp.load_state_dict(mlp)
+    m.mlp_gaussian.load_state_dict(mlpg)
+    m.debug_aux = True
+    with torch.no_grad():
+        out = m.render_image(K.to(DEV), T.to(DEV), {k: v.to(DEV) for k, v in maps.items()}, sampled_pixels=pix.to(DEV), ray_batch_size=R,
+                             keys=("depth", "color"), noise=(nu.to(DEV), ng.to(DEV)), use_graph=True)
+    assert set(out) == {"depth", "color"}
+    eng = m._image_renderer[1]
+    assert eng.graph is not None and m.render_cfg.uses_fused(R * (U + 4 * P))
+    off = eng.session.last_aux["offsets"].float().cpu().reshape(R, 4, 2)
+    sel = torch.arange(0, R, ORACLE_STRIDE)
+    ocfg = orc.OracleConfig.kitti(index_rule="pinned", **kw)
+    dref, cref = [], []
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        for s in range(0, len(sel), 128):
+            ii = sel[s:s + 128]
+            o = orc.render_chunk(ocfg, mlp, mlpg, K, T, maps, pix[ii], nu[ii], ng[ii], head_offsets=off[ii])
+            dref.append(o["depth"]); cref.append(o["color"])
+    dref, cref = torch.cat(dref), torch.cat(cref)
+    rel = (out["depth"].cpu()[sel] - dref).abs() / dref.abs()
+    cerr = (out["color"].cpu()[sel] - cref).abs()
+    print("N=512, one 4,096-ray chunk, depth + colour only, bf16 vs the oracle at matched positions (%d rays, oracle %.0f s): depth rel max %.2e "
+          "median %.2e p99 %.2e, colour abs max %.2e p99 %.2e" % (len(sel), time.time() - t0, float(rel.max()), float(rel.median()),
+                                                                 float(rel.quantile(0.99)), float(cerr.max()), float(cerr.quantile(0.99))))
+    # 2 x what the N = 512 parity_full case measures at matched positions (depth max rel 3.6e-4 ... at R = 32); the outer bound is SURVEY 8d's bf16 row
+    assert float(rel.max()) < 2e-3 and float(rel.median()) < 2e-4, (float(rel.max()), float(rel.median()))
+    assert float(cerr.max()) < 1e-3, float(cerr.max())

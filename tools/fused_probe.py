@@ -37,6 +37,23 @@ for name in kernels:
         call()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if os.environ.get("PROBE_WARM_SWEEP"):   # start stagger of the first dispatch round (64-cycle units), alternated in one process
+        import statistics
+        vals = [int(x) for x in os.environ["PROBE_WARM_SWEEP"].split(",")]
+        acc = {v: [] for v in vals}
+        for rnd in range(5):
+            for v in vals:
+                lib.scenerf_hip_test_set_tuning(v, -1)
+                call(); torch.cuda.synchronize()
+                e0.record()
+                for _ in range(reps):
+                    call()
+                e1.record()
+                torch.cuda.synchronize()
+                acc[v].append(e0.elapsed_time(e1) * 1e3 / reps)
+        for v in vals:
+            print("%-7s M=%d warm-up %d: median %.1f us (min %.1f)" % (name, M, v, statistics.median(acc[v]), min(acc[v])), flush=True)
+        lib.scenerf_hip_test_set_tuning(1, -1)
     e0.record()
     for _ in range(reps):
         call()

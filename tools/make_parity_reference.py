@@ -1,14 +1,18 @@
 """tests/golden/parity_full_measured.json from the parity_full_*.json files a GPU run of tests/test_gpu_parity_full.py leaves in
 gpurun_out/ (or profiles/r*_parity_full_*): per case the measured worst errors at matched discrete choices -- per output (max abs for the
 absolute-gated ones, max rel otherwise), per gradient group (worst tensor's relative L2), the proxy loss, the gaussian head's offsets.
-The test refuses results more than 1.25 x worse than these.
-usage: make_parity_reference.py [glob, default gpurun_out/parity_full_*.json]"""
+The test refuses results more than 1.25 x worse than these (free-running bf16 gradients: 2 x).
+usage: make_parity_reference.py [--only-free] [glob, default gpurun_out/parity_full_*.json]
+--only-free: keep the committed matched-choice entries (they move by up to 2 x from run to run at rounding level through the fp32 atomics'
+order: re-minting them from ONE run would turn the 1.25 x gate into a flake) and set only the free-running ones."""
 import glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ABS_KEYS = ("color", "alphas", "weights")
 GATED = ("depth", "color", "gaussian_means", "gaussian_stds", "depth_volumes", "alphas", "weights", "densities")
-pat = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity_full_*.json")
+only_free = "--only-free" in sys.argv
+argv = [a for a in sys.argv[1:] if a != "--only-free"]
+pat = argv[0] if argv else os.path.join(ROOT, "gpurun_out", "parity_full_*.json")
 out = {}
 for f in sorted(glob.glob(pat)):
     d = json.load(open(f))
@@ -21,6 +25,23 @@ for f in sorted(glob.glob(pat)):
             groups[g] = max(groups.get(g, 0.0), v["rel_l2"])
     out[key] = {"out": {k: (m["out"][k]["max_abs"] if k in ABS_KEYS else m["out"][k]["max_rel"]) for k in GATED if k in m["out"]},
                 "grad": groups, "loss": m["loss"]["rel"], "head": d["head_offsets"]["rel_l2"], "source": os.path.basename(f)}
+    # free-running bf16 (no teacher forcing: the oracle at ITS OWN head offsets, sample positions and RaySOM choices): worst tensor per
+    # gradient group -- the test holds a run to 2 x these (round 6; before that 0.2 / 0.4 / 0.4 for every case)
+    if "free" in d and "grad" in d["free"]:
+        fg = {}
+        for nm, v in d["free"]["grad"].items():
+            if "rel_l2" in v:
+                g = nm.split(".")[0] + "."
+                fg[g] = max(fg.get(g, 0.0), v["rel_l2"])
+        out[key]["free_grad"] = fg
+        out[key]["free_loss"] = d["free"]["loss"]["rel"]
 dst = os.path.join(ROOT, "tests", "golden", "parity_full_measured.json")
+if only_free and os.path.exists(dst):
+    old = json.load(open(dst))
+    for k, v in old.items():
+        for kk in ("free_grad", "free_loss"):
+            if k in out and kk in out[k]:
+                v[kk] = out[k][kk]
+    out = old
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
 print("wrote %s: %d cases" % (dst, len(out)))

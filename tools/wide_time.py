@@ -49,6 +49,37 @@ bwd = lambda: _capi.check(lib.scenerf_hip_mlp_backward(C.byref(cc), C.byref(pk.c
 for _ in range(3):
     fwd(); bwd()
 torch.cuda.synchronize()
+if os.environ.get("PROBE_WARM_SWEEP"):   # "0,4,8,12,...": the kernels' start stagger (64-cycle units per XCD position), alternated in ONE process
+    import statistics
+    vals = [int(x) for x in os.environ["PROBE_WARM_SWEEP"].split(",")]
+    acc = {v: ([], []) for v in vals}
+    for rnd in range(int(os.environ.get("PROBE_ROUNDS", "4"))):
+        for v in vals:
+            lib.scenerf_hip_test_set_tuning(v, -1)
+            fwd(); bwd(); torch.cuda.synchronize()
+            lib.scenerf_hip_profile_enable(1)
+            for _ in range(reps // 2):
+                fwd(); bwd()
+            torch.cuda.synchronize()
+            rows = {r["name"]: r for r in _capi.profile_collect()}
+            lib.scenerf_hip_profile_enable(0)
+            acc[v][0].append(rows["mlp_fwd_fused"]["total_ms"] * 1e3 / rows["mlp_fwd_fused"]["launches"])
+            acc[v][1].append(rows["mlp_bwd_fused"]["total_ms"] * 1e3 / rows["mlp_bwd_fused"]["launches"])
+    for v in vals:
+        print("warm-up %d: forward median %.1f us (min %.1f) | dgrad chain median %.1f us (min %.1f)" % (
+            v, statistics.median(acc[v][0]), min(acc[v][0]), statistics.median(acc[v][1]), min(acc[v][1])), flush=True)
+    sys.exit(0)
+if os.environ.get("PROBE_LOOP_S"):     # keep the GPU busy for a while (tools/clock_probe.sh reads clocks and power meanwhile)
+    import time
+    t_end = time.time() + float(os.environ["PROBE_LOOP_S"])
+    which = os.environ.get("PROBE_LOOP_WHAT", "fwd")
+    while time.time() < t_end:
+        for _ in range(50):
+            if which != "bwd":
+                fwd()
+            if which != "fwd":
+                bwd()
+        torch.cuda.synchronize()
 lib.scenerf_hip_profile_enable(1)
 for _ in range(reps):
     fwd(); bwd()
