@@ -94,9 +94,14 @@ __global__ __launch_bounds__(F_THREADS) void mlp_fused_kernel(FusedArgs p) {
         const unsigned wlane = q * 4096 + lane * 16;
         const int prow = lane >> 1;
         const int pls = ((lane & 1) ^ ((lane >> 4) & 1)) << 4;
-        const int gm_a = min(m0 + 32 * (q & 1) + prow, p.M - 1);
-        const unsigned ox3 = (unsigned)gm_a * (3 * SCENERF_D_XENC * 2) + pls;   // < 4 GiB: M * 4960 B fits 32 bits up to 865k rows
-        const unsigned oz = (unsigned)gm_a * (SCENERF_D_LATENT * 2) + pls;
+        // (row offsets RELATIVE to the block's first row -- the block's base goes into the 64-bit uniform address: as absolute 32-bit
+        //  offsets they wrapped beyond 865,900 rows of Z (4,960 B each), i.e. in every no_grad chunk of more than 1,691 rays at N = 512 --
+        //  found by tests/test_gpu_render.py::test_render_image_n512_at_the_benched_chunk_against_the_oracle, round 6)
+        const int lr_a = min(m0 + 32 * (q & 1) + prow, p.M - 1) - m0;
+        const unsigned ox3 = (unsigned)lr_a * (3 * SCENERF_D_XENC * 2) + pls;
+        const unsigned oz = (unsigned)lr_a * (SCENERF_D_LATENT * 2) + pls;
+        const char* const bx3 = (const char*)p.X3 + (size_t)m0 * (3 * SCENERF_D_XENC * 2);
+        const char* const bz = (const char*)p.Z + (size_t)m0 * (SCENERF_D_LATENT * 2);
         auto issue = [&](const int d) {
             const unsigned sb = ring0 + FD_STAGE(d) * F_STAGE;
             f_glds16x4((const char*)p.Wst + (size_t)FD_Z(d) * F_WSTG, wlane, __builtin_amdgcn_readfirstlane(sb + q * 4096));
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(F_THREADS) void mlp_fused_kernel(FusedArgs p) {
             if (MODE == 0) {
                 const int src = FD_SRC(d);
                 if (src != 0 && q < 2)
-                    f_glds16((const char*)(src == 1 ? p.X3 : p.Z) + (size_t)FD_Y(d) * 2, src == 1 ? ox3 : oz,
+                    f_glds16((src == 1 ? bx3 : bz) + (size_t)FD_Y(d) * 2, src == 1 ? ox3 : oz,
                              __builtin_amdgcn_readfirstlane(sb + F_WSTG + q * 1024));
                 if (FD_BEGIN(d) && q >= 2)   // the bias this layer's accumulators start from (read at the previous layer's end)
                     f_glds16((const char*)p.layer[FD_LAYER(d)].bias + (q - 2) * 1024, lane * 16,

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void linout_fwd_kernel(const void* __restrict_
 }
 
 // dH3[m][k] = [H3>0] * sum_j dl[m][j] w_out[j][k];  dw_out[j][k] += sum_m dl[m][j] relu(H3[m][k]);  db_out[j] += sum_m dl[m][j]
-// one wave per row, lane owns 8 of the 512 columns; 4 rows per iteration so 4 independent 16-byte loads are in flight
+// one wave per row, lane owns 8 of the 512 columns; 8 rows per iteration so 8 independent 16-byte loads are in flight (r06: 39.5 us against 42 with 4, 46.8 with 2, for lin_out's weight gradient at 153,600 rows)
 // DH = false: the weight / bias gradients only (the 128-row dgrad chain makes dH3 itself: wide.hip MODE 1), H3 is read and nothing but
 // the partial sums is written
 template <typename T, int DO, bool DH>
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void linout_bwd_kernel(const void* __restrict_
         }
     }
 #ifndef LOB_RU
-#define LOB_RU 4
+#define LOB_RU 8
 #endif
     constexpr int RU = LOB_RU;
     for (int mb = wave * RU; mb < M; mb += nwaves * RU) {
@@ -329,6 +329,12 @@ int scenerf_hip_mlp_feature_grads(const scenerf_cfg* cfg, const scenerf_mlp_weig
                                   const int32_t* tap_texel, const float* tap_weight, int M, const void* dH,
                                   float* const gmaps_hwc[SCENERF_N_SCALES], scenerf_stream_t stream) {
     SRF_CHECK(cfg && w && tile_mask && tap_texel && tap_weight && dH && gmaps_hwc && M > 0, "mlp_feature_grads: NULL argument");
+    // SCENERF_FLAG_WGRAD_OVERLAP here = "the caller runs this beside the batched weight gradients of the same pass, on another stream":
+    // the head start that launch needs (see scenerf_hip_mlp_backward) is given on this stream
+    if ((cfg->flags & SCENERF_FLAG_WGRAD_OVERLAP) && srf_dfeat_delay_us() > 0 && w->d_out != 2 && cfg->precision && cdiv(M, 128) >= SRF_WIDE_MIN_BLOCKS) {
+        srf_delay_kernel<<<1, 64, 0, as_stream(stream)>>>(srf_dfeat_delay_us());
+        SRF_LAUNCH_CHECK("srf_delay_kernel");
+    }
     return feature_grads(cfg, w, tile_mask, tap_texel, tap_weight, M, dH, gmaps_hwc, as_stream(stream));
 }
 

@@ -418,13 +418,15 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
     // ---- staged chunks: DMA of chunk descriptor d (X3 / Z columns FD_Y .. +15 of the block's 128 rows) into LDS offset `off`: this
     // wave's 32 rows = one 1-KiB piece; lane -> row lane / 2, physical 16-byte slot lane & 1, fetching the logical slot
     // physical ^ ((row >> 3) & 1) (swizzle on the source)
-    const char* const gX3 = (const char*)p.X3;
-    const char* const gZ = (const char*)p.Z;
+    // (the block's first row goes into the 64-bit uniform base, the lane offset is relative to it: as an absolute 32-bit offset it wrapped
+    //  beyond 865,900 rows of Z -- every no_grad chunk of more than 1,691 rays at N = 512; round 6, see fused.hip)
+    const char* const gX3 = (const char*)p.X3 + (size_t)m0 * (3 * SCENERF_D_XENC * 2);
+    const char* const gZ = (const char*)p.Z + (size_t)m0 * (SCENERF_D_LATENT * 2);
     auto dma = [&](const int d, const unsigned off) __attribute__((always_inline)) {
-        const int gm = min(m0 + 32 * wvu + (ln >> 1), p.M - 1);                // (rows past M: clamped, computed, dropped)
+        const int lr = min(m0 + 32 * wvu + (ln >> 1), p.M - 1) - m0;           // (rows past M: clamped, computed, dropped)
         const unsigned pls = (unsigned)(((ln & 1) ^ ((ln >> 4) & 1)) << 4);
         const bool x3 = FD_SRC(d) == 1;
-        const unsigned voff = (unsigned)gm * (x3 ? 3u * SCENERF_D_XENC * 2u : SCENERF_D_LATENT * 2u) + pls;   // < 4 GiB up to 865k rows
+        const unsigned voff = (unsigned)lr * (x3 ? 3u * SCENERF_D_XENC * 2u : SCENERF_D_LATENT * 2u) + pls;
         const char* sb = (x3 ? gX3 : gZ) + FD_Y(d) * 2;
         h_glds16(sb, voff, __builtin_amdgcn_readfirstlane(lds0 + off + wvu * 1024));
     };

@@ -62,6 +62,9 @@ def _wait_for_pending_collectives(timeout_s: float = 10.0) -> None:
         time.sleep(0.1)
 
 
+OPTIMIZER_BESIDE_MAP_GRADS = True     # (module knob for A/B runs: bench.py --set graph.OPTIMIZER_BESIDE_MAP_GRADS=False)
+
+
 class GraphedStep:
     def __init__(self, model, optimizer: Optional[torch.optim.Optimizer], loss_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
                  cam_K: torch.Tensor, T_source2infer: torch.Tensor, x_rgb: Dict[str, torch.Tensor], pixels: torch.Tensor,
@@ -95,6 +98,7 @@ class GraphedStep:
         self.cam_K, self.T_source2infer, self.pixels, self.x_rgb = cam_K, T_source2infer, pixels, x_rgb
         self.ray_batch_size = int(ray_batch_size or pixels.shape[0])
         self._one = None
+        self._opt_stream = None
         self._map_leaves = [v for v in x_rgb.values() if v.requires_grad]
         # warm-up on a side stream (allocator pools, one-time setup, optimizer state), as torch's capture recipe asks
         side = torch.cuda.Stream(device=dev)
@@ -183,9 +187,26 @@ class GraphedStep:
         loss = self.loss_fn(out)
         if self._one is None or self._one.shape != loss.shape or self._one.dtype != loss.dtype:
             self._one = torch.ones_like(loss)
+        ev_box = getattr(self.model, "_step_events", None)
+        if ev_box is not None:
+            ev_box.pop("param_grads_ready", None)
         loss.backward(self._one)        # (a cached root gradient: autograd's own ones_like is one more fill launch per step)
         if self.optimizer is not None:
-            self.optimizer.step()
+            ev = ev_box.get("param_grads_ready") if (ev_box is not None and OPTIMIZER_BESIDE_MAP_GRADS) else None
+            if ev is not None and getattr(self.model, "grad_sync", None) is None and getattr(self.model, "grad_sync_async", None) is None:
+                # the renderer left an event behind which every PARAMETER gradient is complete, while the feature-map gradients' tail
+                # (the coarse levels' scatter: ~75 us at KITTI) still runs on its side stream: the optimizer step goes to a stream of its
+                # own behind that event alone and runs beside that tail; this stream joins it before the step ends.  (Data parallel: the
+                # gradient all-reduces end in PackMLP.backward on this stream -- the step stays in stream order.)
+                main = torch.cuda.current_stream(self.pixels.device)
+                if self._opt_stream is None:
+                    self._opt_stream = torch.cuda.Stream(device=self.pixels.device)
+                self._opt_stream.wait_event(ev)
+                with torch.cuda.stream(self._opt_stream):
+                    self.optimizer.step()
+                main.wait_stream(self._opt_stream)
+            else:
+                self.optimizer.step()
         return loss.detach()
 
     def __call__(self) -> torch.Tensor:

@@ -379,7 +379,8 @@ class SceneRF(TrainingMixin, _Base):
         inv_K = self._inv_K(cam_K)
         sess = RenderSession(cfg, x_rgb, self.mlp.ordered_params(), self.mlp_gaussian.ordered_params(),
                              grad_sync=self.grad_sync, grad_sync_async=self.grad_sync_async, debug_aux=self.debug_aux,
-                             rng=self._device_rng_state(sampled_pixels.device) if (cfg.device_rng and noise is None) else None)
+                             rng=self._device_rng_state(sampled_pixels.device) if (cfg.device_rng and noise is None) else None,
+                             events=self.__dict__.setdefault("_step_events", {}))
         outs, auxs = [], []
         n = sampled_pixels.shape[0]
         sess.mlpg.single_chunk = n <= ray_batch_size   # training (scenerf.py:262-275): lets the head's gradient all-reduce start early

@@ -69,6 +69,7 @@ CHAIN_FIRST = True           # capture / issue order: at every fork the critical
 MAIN_WGRAD_OVERLAP = True    # radiance MLP's weight gradients on the library's side stream, beside its feature-map gradients (-35 us/step)
 DEFER_HEAD_PACK = True     # (tools/ab_step.py toggles this)
 GRADS_BEHIND_HEAD = True   # the radiance MLP's weight / feature-map gradients start only when the gaussian head's backward kernels are done
+MAP_GRADS_ON_SIDE = True   # ... and its feature-map gradients run on the side stream, unjoined until the accumulators' next consumer
 SPLIT_HEAD_PACK = True     # the head's pack in two calls, its forward's operands first
 
 
@@ -769,11 +770,15 @@ def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dis
 
 
 def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: _MlpRun, d_logits, want_map_grads: bool,
-                  sync_async=None, before_grads=None):
+                  sync_async=None, before_grads=None, maps_stream=None):
     """``sync_async`` (data parallel, scenerf_amd.dist.allreduce_mean_async): the parameter gradients are final once the weight-
     gradient GEMMs are queued, so their all-reduce is started there and the feature-gradient GEMM + scatter (0.5 ms) runs while
     the collective is in flight; returns the collective's finisher (or None).  ``before_grads``: called between the dgrad chain and the
-    weight / feature-map gradients (scenerf_hip_mlp_backward's two-call form): where the caller orders that phase behind other work."""
+    weight / feature-map gradients (scenerf_hip_mlp_backward's two-call form): where the caller orders that phase behind other work.
+    ``maps_stream``: run the feature-map gradients THERE, beside the weight gradients on the current stream, and do not join: the map
+    accumulators' next consumer waits (MapHolder._gmaps_ready -> grad_accumulators(): the next chunk's backward or PrepareMaps.backward) --
+    the current stream then carries only what the PARAMETER gradients need, so an optimizer step ordered behind ``param_grads_ready``
+    does not wait for the map gradients' tail (GraphedStep)."""
     lib = _capi.load()
     pk.wait_ready(backward=True)
     act = _act_dtype(cfg.precision_code)
@@ -782,7 +787,7 @@ def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: 
     dN = torch.empty((3, run.M, D_H), dtype=act, device=dev)
     g = pk.grad_sink()
     gm = C.byref(maps.gmap_ptr_array()) if want_map_grads else None
-    split = sync_async is not None and gm is not None
+    split = (sync_async is not None or maps_stream is not None) and gm is not None
 
     def call(cc):
         _capi.check(lib.scenerf_hip_mlp_backward(C.byref(cc), C.byref(pk.c), C.byref(g), run.Z.data_ptr(), _capi.ptr(run.xenc),
@@ -790,6 +795,7 @@ def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: 
                                                  run.M, C.byref(run.c), d_logits.data_ptr(), dH.data_ptr(), dN.data_ptr(),
                                                  None if split else gm, _stream(dev)), "mlp_backward")
 
+    chain_done = None
     if before_grads is None:
         call(ccfg)
     else:
@@ -798,9 +804,25 @@ def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: 
             cc.flags |= flag
             if flag == _capi.FLAG_BWD_GRADS_ONLY:
                 before_grads()
+                if maps_stream is not None:      # what the feature-map gradients wait for: the chain (and the join), NOT the weight gradients
+                    chain_done = torch.cuda.current_stream(dev).record_event()
             call(cc)
     finish = sync_async(pk.gflat) if sync_async is not None else None
-    if split:
+    if split and maps_stream is not None:
+        if chain_done is not None:
+            maps_stream.wait_event(chain_done)
+        else:
+            maps_stream.wait_stream(torch.cuda.current_stream(dev))
+        ccf = type(ccfg).from_buffer_copy(ccfg)
+        ccf.flags |= _capi.FLAG_WGRAD_OVERLAP
+        with torch.cuda.stream(maps_stream):
+            _capi.check(lib.scenerf_hip_mlp_feature_grads(C.byref(ccf), C.byref(pk.c), run.tile_mask.data_ptr(), run.tap_texel.data_ptr(),
+                                                          run.tap_weight.data_ptr(), run.M, dH.data_ptr(), gm, maps_stream.cuda_stream),
+                        "mlp_feature_grads")
+            maps._gmaps_ready = maps_stream.record_event()
+        for t in (dH, run.tile_mask, run.tap_texel, run.tap_weight):
+            t.record_stream(maps_stream)
+    elif split:
         _capi.check(lib.scenerf_hip_mlp_feature_grads(C.byref(ccfg), C.byref(pk.c), run.tile_mask.data_ptr(), run.tap_texel.data_ptr(),
                                                       run.tap_weight.data_ptr(), run.M, dH.data_ptr(), gm, _stream(dev)),
                     "mlp_feature_grads")
@@ -1007,15 +1029,21 @@ class RenderChunk(torch.autograd.Function):
         def main_backward():
             if ctx.needs_input_grad[11] or want_maps:
                 early = ctx.mlp.grad_sync_async if (ctx.mlpg.single_chunk and ctx.needs_input_grad[11]) else None
-                ccm = ccfg
-                if MAIN_WGRAD_OVERLAP:
-                    ccm = type(ccfg).from_buffer_copy(ccfg)
-                    ccm.flags |= _capi.FLAG_WGRAD_OVERLAP
                 # GRADS_BEHIND_HEAD: the radiance MLP's weight / feature-map gradient phase waits for the gaussian head's backward (its
                 # kernels, not its all-reduce) -- see SCENERF_FLAG_BWD_CHAIN_ONLY in csrc/mlp.hip for what happens when the two meet
                 join = (lambda: main.wait_event(head_done[0])) if (GRADS_BEHIND_HEAD and head_done) else None
+                # MAP_GRADS_ON_SIDE (single-chunk training sessions): the weight gradients stay on THIS stream, the feature-map
+                # gradients go to the side stream (the head's backward there is over: joined above) and are not waited for here
+                on_side = MAP_GRADS_ON_SIDE and want_maps and join is not None and ctx.mlpg.single_chunk and ctx.needs_input_grad[11]
+                ccm = ccfg
+                if MAIN_WGRAD_OVERLAP and not on_side:
+                    ccm = type(ccfg).from_buffer_copy(ccfg)
+                    ccm.flags |= _capi.FLAG_WGRAD_OVERLAP
                 ctx.mlp.pending = _mlp_backward(ccm, cfg, ctx.maps, ctx.mlp.packed, run_m, d_logits, want_maps, sync_async=early,
-                                                before_grads=join)
+                                                before_grads=join, maps_stream=side if on_side else None)
+                # both MLPs' parameter gradients are complete at this point of this stream (the head's: joined above)
+                if join is not None and getattr(ctx.maps, "events", None) is not None:
+                    ctx.maps.events["param_grads_ready"] = main.record_event()
 
         def head_backward():
             side.wait_stream(main)
@@ -1040,7 +1068,8 @@ class RenderChunk(torch.autograd.Function):
             #  at this fork instead of 5.)
             head_backward()
             main_backward()
-            main.wait_stream(side)
+            if ctx.mlpg.synced or not (GRADS_BEHIND_HEAD and head_done and (ctx.needs_input_grad[11] or want_maps)):
+                main.wait_stream(side)       # (the head's all-reduce, or no join inside main_backward)
             for t in (d_off, run_g.Z, run_g.xenc, run_g.h0pre, run_g.logits):
                 if t is not None:
                     t.record_stream(side)
@@ -1059,7 +1088,10 @@ class RenderSession:
 
     def __init__(self, cfg: RenderConfig, x_rgb: Dict[str, torch.Tensor], mlp_params: Sequence[torch.Tensor],
                  mlpg_params: Sequence[torch.Tensor], grad_sync=None, grad_sync_async=None, debug_aux: bool = False,
-                 rng: Optional[torch.Tensor] = None):
+                 rng: Optional[torch.Tensor] = None, events: Optional[dict] = None):
+        """``events``: a caller-owned dict; a training session's backward leaves ``events["param_grads_ready"]`` there -- an event of the
+        backward's stream behind which BOTH MLPs' parameter gradients are complete (the feature-map gradients may still be running on
+        the side stream: whoever reads them goes through PrepareMaps.backward, which waits)."""
         hwc, chw = self.classify_maps(x_rgb)
         if hwc or cfg.hwc_scales:   # per-call layout state (scenerf_cfg.map_chw): a copy, the model's config is not touched
             cfg = dataclasses.replace(cfg, hwc_scales=hwc, direct_scales=tuple(i for i in cfg.direct_scales if i not in hwc))
@@ -1071,6 +1103,7 @@ class RenderSession:
             if not (rng.is_cuda and rng.dtype == torch.int64 and rng.numel() == 3 and rng.device == self.device):
                 raise RuntimeError("rng must be a CUDA int64 tensor {seed, calls, scratch} on the maps' device")
             self.maps.rng = rng if cfg.device_rng else None
+        self.maps.events = events
 
     @staticmethod
     def classify_maps(x_rgb):

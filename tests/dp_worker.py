@@ -77,9 +77,64 @@ def main():
     dist.destroy_process_group()
 
 
+def main_benched_shape_and_capture():
+    """The combination an N > 1 bench line runs, on two gloo ranks sharing the test box's GPU: BASELINE configs[1]'s
+    shape per rank (R = 1,200 x N = 128 on the full KITTI sphere: the packed 21.7-MB gradient sinks, the head's early all-reduce on the side
+    stream, the radiance MLP's asynchronous one) through `build_on_all_ranks(GraphedStep)`.  gloo collectives cannot be captured (they
+    stage through the host), so EVERY rank's capture must fail and the rank-consistent fallback must fire on both -- nobody keeps a graph,
+    nobody hangs -- and the eager step that follows must still leave the mean of the ranks' local gradients on every rank."""
+    from scenerf_amd.graph import GraphedStep, build_on_all_ranks
+    from scenerf_amd.optim import FusedAdamW
+    rank, world, local = sdist.init_from_env("gloo")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    R, U, P = 1200, 64, 16
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, n_pts_uni=U, n_pts_per_gaussian=P, precision="bf16").to(dev)
+    m.mlp.load_state_dict(synth.mlp_state(81, 4))
+    m.mlp_gaussian.load_state_dict(synth.mlp_state(82, 2, out_scale=4.0))
+    maps = {k: v.to(dev).requires_grad_(True) for k, v in synth.feature_maps(1500, 452, 83 + rank, smooth=False).items()}
+    K, T = synth.kitti_cam_K().to(dev), synth.rel_pose(1.0, 0.0).to(dev)
+    pix = synth.stride2_pixels((1220, 370), R, 84 + rank).to(dev)
+    nu, ng = synth.sampling_noise(R, U, 4 * P, 85 + rank)
+    noise = (nu.to(dev), ng.to(dev))
+    params = list(m.mlp.parameters()) + list(m.mlp_gaussian.parameters())
+    loss_fn = lambda out: out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()   # noqa: E731
+
+    def grads(sync):
+        m.grad_sync = sdist.allreduce_mean_ if sync else None
+        m.grad_sync_async = sdist.allreduce_mean_async if sync else None
+        for p in params + list(maps.values()):
+            p.grad = None
+        loss_fn(m.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=R, noise=noise)).backward()
+        torch.cuda.synchronize()
+        return torch.cat([p.grad.reshape(-1) for p in params]).cpu()
+
+    m.grad_sync, m.grad_sync_async = sdist.allreduce_mean_, sdist.allreduce_mean_async
+    opt = FusedAdamW(params, lr=0.0, weight_decay=0.0, capturable=True)      # (lr = 0: the parameters stay where they are for the comparison)
+    g, note = build_on_all_ranks(lambda: GraphedStep(m, opt, loss_fn, K, T, maps, pix, ray_batch_size=R, warmup=1, noise=noise))
+    torch.cuda.synchronize()
+    fell_back = g is None
+    flags = [None] * world
+    dist.all_gather_object(flags, (fell_back, note))
+    g_sync = grads(True)
+    g_local = grads(False)
+    mean = g_local.clone()
+    dist.all_reduce(mean)
+    mean /= world
+    others = [torch.empty_like(g_sync) for _ in range(world)]
+    dist.all_gather(others, g_sync)
+    same = all(torch.equal(others[0], o) for o in others)
+    rel = float((g_sync - mean).norm() / mean.norm())
+    differs = float((g_local - mean).norm() / mean.norm())
+    if rank == 0:
+        print("DP_BENCHED fallback_on_all=%s same=%s rel=%.3e local_vs_mean=%.3e notes=%r" % (
+            all(f[0] for f in flags), same, rel, differs, [f[1][:60] for f in flags]))
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     try:
-        main()
+        main_benched_shape_and_capture() if "benched" in sys.argv[1:] else main()
     except Exception:
         import traceback
         print("DP_ERROR rank %s\n%s" % (os.environ.get("RANK"), traceback.format_exc()), flush=True)

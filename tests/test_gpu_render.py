@@ -1089,6 +1089,8 @@ def test_render_image_n512_at_the_benched_chunk_against_the_oracle():
     print("N=512, one 4,096-ray chunk, depth + colour only, bf16 vs the oracle at matched positions (%d rays, oracle %.0f s): depth rel max %.2e "
           "median %.2e p99 %.2e, colour abs max %.2e p99 %.2e" % (len(sel), time.time() - t0, float(rel.max()), float(rel.median()),
                                                                  float(rel.quantile(0.99)), float(cerr.max()), float(cerr.quantile(0.99))))
-    # 2 x what the N = 512 parity_full case measures at matched positions (depth max rel 3.6e-4 ... at R = 32); the outer bound is SURVEY 8d's bf16 row
-    assert float(rel.max()) < 2e-3 and float(rel.median()) < 2e-4, (float(rel.max()), float(rel.median()))
-    assert float(cerr.max()) < 1e-3, float(cerr.max())
+    # gates = 2 x measured on MI355X (depth rel max 2.09e-4, median 3.9e-5; colour abs max 8.9e-5).  This test found rows beyond 865,900
+    # reading other rows' features (32-bit row offsets in the fused kernels' operand DMA: every no_grad chunk of more than 1,691 rays at
+    # N = 512): depth rel 3.5e-2 on the chunk's later rays, 5e-5 on its first ones
+    assert float(rel.max()) < 4.5e-4 and float(rel.median()) < 8e-5, (float(rel.max()), float(rel.median()))
+    assert float(cerr.max()) < 2e-4, float(cerr.max())

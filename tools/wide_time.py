@@ -99,5 +99,5 @@ if chk:
     else:
         torch.save({k: v.cpu() for k, v in cur.items()}, chk)
         msg = " | saved %s" % chk
-print("lib %-8r M=%d: forward %.1f us (%.3f of 2.5 PF) | dgrad chain %.1f us (%.3f) | wgrad batch %.1f us%s" % (
-    os.environ.get("SRF_LIB_TAG", ""), M, tf, fl_f / tf / 1e6 / 2500, tb, fl_b / tb / 1e6 / 2500, us("gemm_wgrad_fc"), msg), flush=True)
+print("lib %-8r M=%d: forward %.1f us (%.3f of 2.5 PF) | dgrad chain %.1f us (%.3f) | wgrad batch %.1f us | linout wgrad %.1f us%s" % (
+    os.environ.get("SRF_LIB_TAG", ""), M, tf, fl_f / tf / 1e6 / 2500, tb, fl_b / tb / 1e6 / 2500, us("gemm_wgrad_fc"), us("linout_wgrad"), msg), flush=True)
