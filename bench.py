@@ -778,6 +778,97 @@ def default_n64_leg(args, dev, steps=10, warmup=3):
             "roofline": roof, "roofline_composite": roof_c}
 
 
+class _StaticEncoder(torch.nn.Module):
+    """Stands in for the image encoder of the trainer's step (net_rgb: EfficientNet-B7 U-Net, out of scope here and absent offline): hands
+    back the same five feature maps with a batch axis -- they are leaves that require gradients, so the step computes the map gradients an
+    encoder's backward would start from."""
+
+    def __init__(self, maps):
+        super().__init__()
+        self.maps = maps
+
+    def forward(self, img, pix=None, pix_sphere=None):
+        return {k: v.unsqueeze(0) for k, v in self.maps.items()}
+
+
+def kitti_training_step_leg(args, dev, steps=20, warmup=3, n_sources=2):
+    """The step the reference's TRAINER runs (scenerf.py:119-241 through scenerf_amd.training.TrainingMixin.forward): one
+    image, S source frames -- per source a trained render of n_rays = 1,200 rays, a metric-only render of 1,200 lidar pixels under no_grad and
+    the source's loss -- then ONE optimizer step; issued eagerly (what Lightning's loop gets) and as ONE hipGraph replay
+    (scenerf_amd.graph.GraphedFn, the per-source pixel subsets drawn on the device inside the graph).  rays/s counts the TRAINED rays."""
+    from scenerf_amd.graph import GraphedFn
+    R, S = args.rays, n_sources
+    maps = {k: v.to(dev).requires_grad_(True) for k, v in synth.feature_maps(1500, 452, 3).items()}
+
+    def build():
+        m = make_model(args, dev)
+        m.n_rays = R
+        m.net_rgb = _StaticEncoder(maps)
+        m.device_pixel_draw = True
+        return m
+
+    g = torch.Generator().manual_seed(7)
+    img = lambda: torch.rand(3, 370, 1220, generator=g).to(dev)          # noqa: E731
+    K = synth.kitti_cam_K().to(dev)
+    batch = {"img_inputs": torch.rand(1, 3, 370, 1220, generator=g).to(dev), "cam_K": [K], "T_velo_2_cam": [torch.eye(4, device=dev)],
+             "img_sources": [[img() for _ in range(S)]], "img_targets": [[img() for _ in range(S)]],
+             "T_source2targets": [[synth.rel_pose(0.5 + 0.5 * i, 2.0).to(dev) for i in range(S)]],
+             "T_source2infers": [[synth.rel_pose(1.0 + i, 0.0).to(dev) for i in range(S)]],
+             "loc2d_with_depths": [[synth.stride2_pixels((1220, 370), R, 300 + i).to(dev) for i in range(S)]],
+             "lidar_depths": [[torch.rand(R, generator=g).to(dev) * 60 + 2 for _ in range(S)]]}
+
+    def timed(step):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step()
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, host / steps, last
+
+    m = build()
+    params = list(m.mlp.parameters()) + list(m.mlp_gaussian.parameters())
+    opt = make_optimizer(args, params)
+
+    def eager_step():
+        for v in maps.values():
+            v.grad = None
+        loss = m.step(batch, "train")
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss.detach()
+
+    dt_e, host_e, last = timed(eager_step)
+    assert torch.isfinite(last).item()
+    out = {"metric": "rays/sec (the trainer's per-image step: %d source frames x (%d trained + %d metric-only rays), one optimizer step)" % (S, R, R),
+           "unit": "rays/s", "sources": S, "trained_rays_per_step": S * R, "metric_only_rays_per_step": S * R, "steps": steps,
+           "eager": {"value": round(S * R / dt_e, 1), "ms_per_step": round(dt_e * 1e3, 3), "host_issue_ms_per_step": round(host_e * 1e3, 3)}}
+    del m, opt
+    torch.cuda.empty_cache()
+    graphed = None
+    try:
+        m2 = build()
+        args.capturable = True
+        opt2 = make_optimizer(args, list(m2.mlp.parameters()) + list(m2.mlp_gaussian.parameters()))
+        args.capturable = False
+        gs = GraphedFn(m2, opt2, lambda: m2.step(batch, "train"), dev, grad_leaves=list(maps.values()), warmup=warmup)
+        dt_g, host_g, last = timed(gs)
+        assert torch.isfinite(last).item()
+        graphed = {"value": round(S * R / dt_g, 1), "ms_per_step": round(dt_g * 1e3, 3), "host_issue_ms_per_step": round(host_g * 1e3, 3)}
+    except Exception as e:      # noqa: BLE001 -- the eager numbers stand on their own
+        args.capturable = False
+        graphed = {"error": repr(e)[:300]}
+    out["graphed"] = graphed
+    out["value"] = graphed.get("value", out["eager"]["value"]) if graphed else out["eager"]["value"]
+    out["config"] = {"workload": "KITTI 370x1220, sphere 1500x452, %d samples/ray, 1 image x %d sources, %d trained + %d no_grad rays per source, "
+                                 "scenerf_amd.training.TrainingMixin.forward + fused source loss + AdamW; encoder replaced by static maps" % (
+                                     args.samples, S, R, R), "precision": args.precision}
+    return out
+
+
 def inference_leg(args, dev, frames=2, stride=2, chunk=4096, samples=512):
     """BASELINE.json configs[4]: KITTI novel-view inference, one stride-2 frame (112,850 px, generate_novel_depths.py:103-112), 512
     samples/ray (U=256, G=4, P=64), static chunks of 4,096 rays replayed from one captured hipGraph (scenerf_amd/inference.py)."""
@@ -1124,16 +1215,16 @@ def main():
         except Exception as e:  # never let the side measurement break the bench line
             eager = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
-    bf_leg = inf_leg = n64_leg = None
+    bf_leg = inf_leg = n64_leg = trainer_leg = None
     if rank == 0 and world == 1 and not dry and not args.no_extra_legs:
         legs = {}
-        for name, fn in (("bf", bundlefusion_leg), ("infer", inference_leg), ("n64", default_n64_leg)):
+        for name, fn in (("bf", bundlefusion_leg), ("infer", inference_leg), ("n64", default_n64_leg), ("trainer", kitti_training_step_leg)):
             try:
                 legs[name] = fn(args, dev)
             except Exception as e:  # never let a side leg break the bench line
                 legs[name] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()
-        bf_leg, inf_leg, n64_leg = legs["bf"], legs["infer"], legs["n64"]
+        bf_leg, inf_leg, n64_leg, trainer_leg = legs["bf"], legs["infer"], legs["n64"], legs["trainer"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
@@ -1163,7 +1254,7 @@ def main():
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")},
             "eager_step": eager_leg, "other_entry": other, "other_rng": rng_other, "drop_in": drop_in, "steady_state": steady,
             "roofline": roof, "roofline_composite": roof_c, "cpu_baseline": cpu, "eager_gpu_baseline": eager, "fp32_mode": fp32,
-            "bundlefusion_c4": bf_leg, "infer_c5": inf_leg, "kitti_default_n64": n64_leg,
+            "bundlefusion_c4": bf_leg, "infer_c5": inf_leg, "kitti_default_n64": n64_leg, "kitti_training_step": trainer_leg,
             "allreduce": allreduce, "ranks": census,
         }
         # flat copies of the side measurements (scalars inside `config` / `roofline` survive the driver's `parsed` copy of this line; nested
@@ -1176,9 +1267,12 @@ def main():
             cfgd["eager_issue_rays_per_s"], cfgd["eager_host_issue_ms_per_step"] = eager_leg["value"], eager_leg["host_issue_ms_per_step"]
         if steady:
             cfgd["steady_state_rays_per_s"] = steady["value"]
-        for nm, leg in (("bundlefusion_c4", bf_leg), ("infer_c5", inf_leg), ("kitti_default_n64", n64_leg)):
+        for nm, leg in (("bundlefusion_c4", bf_leg), ("infer_c5", inf_leg), ("kitti_default_n64", n64_leg), ("kitti_training_step", trainer_leg)):
             if leg and "value" in leg:
                 cfgd[nm + "_rays_per_s"] = leg["value"]
+        if trainer_leg and "eager" in trainer_leg:
+            cfgd["kitti_training_step_eager_rays_per_s"] = trainer_leg["eager"]["value"]
+            cfgd["kitti_training_step_eager_host_issue_ms"] = trainer_leg["eager"]["host_issue_ms_per_step"]
         if roof is not None:
             if roof_c:
                 roof["frac_tail_hbm_at_this_chunk"] = roof_c["frac"]

@@ -185,6 +185,10 @@ typedef struct scenerf_mlp_acts {
 
 int scenerf_hip_abi_version(void);
 const char* scenerf_hip_last_error(void);
+/* Returns and clears the HIP runtime's "last error" of the calling thread.  For callers that catch a FAILED stream capture and go on
+ * issuing eagerly: the capture's error otherwise stays behind as the last error and the next entry point of this library -- each checks
+ * hipGetLastError() behind its launches -- reports it for a launch that succeeded. */
+int scenerf_hip_clear_last_error(void);
 
 /* One-time setup for the CURRENT device (hipSetDevice) and this configuration: kernel attributes (dynamic LDS sizes), the chunk-descriptor
  * tables of the fused ResnetFC kernels (uploaded asynchronously on `stream`), the zero page.  Every entry point does this lazily on
@@ -398,6 +402,49 @@ typedef struct {
 int scenerf_hip_resnetfc_forward(const scenerf_cfg* cfg, const scenerf_resnetfc* net, const float* xenc /*[M][48]*/,
                                  const float* Z /*[Mpad][2480] fp32, as scenerf_hip_gather_features wrote it*/, const uint8_t* tile_mask,
                                  int M, float* h_a, float* h_b, float* n_buf, float* logits, scenerf_stream_t stream);
+
+/* ---- ResnetFC of any shape, trainable (fp32, per-layer GEMMs; round 6) -------------------------------------------------------
+ * resnetfc.py:133-164 with its autograd, for every block count / hidden width the class allows: the forward below additionally SAVES what a
+ * backward pass reads -- per block b the pre-activations hz[b] = h + lin_z.b(z) (the input of fc_0) and n[b] = fc_0(relu(hz[b])) (the input
+ * of fc_1), and h_fin (the input of lin_out), each [M][d_hidden] fp32 -- and the backward runs one fp32-MFMA GEMM per gradient:
+ *   lin_out:  dW_out += dlog^T relu(h_fin), db_out += colsum(dlog), dh = (dlog W_out) * [h_fin > 0]
+ *   block b (last to first):  dW1 += dh^T relu(n[b]), db1 += colsum(dh);  dn = (dh W1) * [n[b] > 0];  dW0 += dn^T relu(hz[b]), db0 += colsum(dn);
+ *                             dhz[b] = dh + (dn W0) * [hz[b] > 0];  dh = dhz[b]
+ *   lin_z:    dWz[b] += dhz[b]^T z (per pyramid level, row tiles without that level skipped), lin_in: dW_in += dhz[0]^T x, db_in += colsum(dhz[0])
+ *   maps:     dz = [dhz[0] | .. | dhz[nb-1]] Wz, scattered through the forward's bilinear taps (grid_sample backward)
+ * (db_z[b] equals db_in for b = 0 and db1 of block b - 1 otherwise -- the same column sums: the caller copies them.)
+ * `net` additionally needs the transposed operands of the input-gradient GEMMs.  Gradients ACCUMULATE into `grads` (the caller zeroes).
+ * dlog16: d_logits zero-padded to 16 columns; dhz: [M][n_blocks * d_hidden] (output, also scratch); dh, dn: [M][d_hidden] scratch. */
+typedef struct {
+    const float* w_fc0_t[SCENERF_RESNETFC_MAX_BLOCKS];  /* fc_0.weight^T: [d_hidden(in)][d_hidden(out)] -> as GEMM operand [n = in][k = out] */
+    const float* w_fc1_t[SCENERF_RESNETFC_MAX_BLOCKS];
+    const float* w_out_t;                               /* [d_hidden][16]: lin_out.weight^T, output columns zero-padded to 16 */
+    const float* w_z_t[SCENERF_N_SCALES];               /* per pyramid level: [map_C[s]][n_blocks * d_hidden] = columns of [Wz_0; ..; Wz_{nb-1}]^T */
+} scenerf_resnetfc_t;
+typedef struct {
+    float* hz[SCENERF_RESNETFC_MAX_BLOCKS];
+    float* n[SCENERF_RESNETFC_MAX_BLOCKS];
+    float* h_fin;
+} scenerf_resnetfc_acts;
+typedef struct {
+    float* w_in;  /* [d_hidden][48] */
+    float* b_in;
+    float* w_z;   /* [n_blocks * d_hidden][2480]: lin_z.b.weight's gradient = rows [b * d_hidden, (b + 1) * d_hidden) */
+    float* w_fc0[SCENERF_RESNETFC_MAX_BLOCKS];
+    float* b_fc0[SCENERF_RESNETFC_MAX_BLOCKS];
+    float* w_fc1[SCENERF_RESNETFC_MAX_BLOCKS];
+    float* b_fc1[SCENERF_RESNETFC_MAX_BLOCKS];
+    float* w_out; /* [16][d_hidden] (rows >= d_out: padding) */
+    float* b_out; /* [16] */
+} scenerf_resnetfc_grads;
+int scenerf_hip_resnetfc_forward_train(const scenerf_cfg* cfg, const scenerf_resnetfc* net, const float* xenc, const float* Z,
+                                       const uint8_t* tile_mask, int M, const scenerf_resnetfc_acts* acts, float* h_scratch /*[M][d_hidden]*/,
+                                       float* logits /*[M][d_out_pad]*/, scenerf_stream_t stream);
+int scenerf_hip_resnetfc_backward(const scenerf_cfg* cfg, const scenerf_resnetfc* net, const scenerf_resnetfc_t* net_t,
+                                  const scenerf_resnetfc_grads* grads, const float* xenc, const float* Z, const uint8_t* tile_mask,
+                                  const int32_t* tap_texel, const float* tap_weight, int M, const scenerf_resnetfc_acts* acts,
+                                  const float* dlog16 /*[M][16]*/, float* dhz, float* dh, float* dn,
+                                  float* const gmaps_hwc[SCENERF_N_SCALES] /*NULL: no map gradients*/, scenerf_stream_t stream);
 
 /* ---- generic building blocks exported for unit tests ------------------------------------------------------- */
 /* C[M][N] = relu?(A[M][K]) @ W[N][K]^T (+bias); act operands per `precision`, fp32 output.

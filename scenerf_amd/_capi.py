@@ -60,10 +60,26 @@ RESNETFC_MAX_BLOCKS = 8
 
 
 class ResnetFCNet(C.Structure):
-    """scenerf_resnetfc (scenerf_hip.h): a ResnetFC of any block count / width, forward only."""
+    """scenerf_resnetfc (scenerf_hip.h): a ResnetFC of any block count / width (fp32 GEMM path)."""
     _fields_ = [("n_blocks", C.c_int32), ("d_hidden", C.c_int32), ("d_out_pad", C.c_int32),
                 ("w_in", vp), ("b_in", vp),
                 ("w_z", vp * RESNETFC_MAX_BLOCKS), ("b_z", vp * RESNETFC_MAX_BLOCKS),
+                ("w_fc0", vp * RESNETFC_MAX_BLOCKS), ("b_fc0", vp * RESNETFC_MAX_BLOCKS),
+                ("w_fc1", vp * RESNETFC_MAX_BLOCKS), ("b_fc1", vp * RESNETFC_MAX_BLOCKS),
+                ("w_out", vp), ("b_out", vp)]
+
+
+class ResnetFCNetT(C.Structure):
+    """scenerf_resnetfc_t: the transposed operands of the generic net's input-gradient GEMMs."""
+    _fields_ = [("w_fc0_t", vp * RESNETFC_MAX_BLOCKS), ("w_fc1_t", vp * RESNETFC_MAX_BLOCKS), ("w_out_t", vp), ("w_z_t", vp * N_SCALES)]
+
+
+class ResnetFCActs(C.Structure):
+    _fields_ = [("hz", vp * RESNETFC_MAX_BLOCKS), ("n", vp * RESNETFC_MAX_BLOCKS), ("h_fin", vp)]
+
+
+class ResnetFCGrads(C.Structure):
+    _fields_ = [("w_in", vp), ("b_in", vp), ("w_z", vp),
                 ("w_fc0", vp * RESNETFC_MAX_BLOCKS), ("b_fc0", vp * RESNETFC_MAX_BLOCKS),
                 ("w_fc1", vp * RESNETFC_MAX_BLOCKS), ("b_fc1", vp * RESNETFC_MAX_BLOCKS),
                 ("w_out", vp), ("b_out", vp)]
@@ -104,6 +120,7 @@ i32 = C.c_int
 _PROTOS = {
     "scenerf_hip_abi_version": (C.c_int, []),
     "scenerf_hip_last_error": (C.c_char_p, []),
+    "scenerf_hip_clear_last_error": (C.c_int, []),
     "scenerf_hip_prepare": (C.c_int, [C.POINTER(Cfg), vp]),
     "scenerf_hip_maps_chw_to_hwc": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "scenerf_hip_grads_hwc_to_chw": (C.c_int, [vp, vp, i32, i32, i32, vp]),
@@ -141,6 +158,9 @@ _PROTOS = {
     "scenerf_hip_pixels_to_sphere": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, i32, i32, C.c_int64, vp, vp, vp]),
     "scenerf_hip_test_acos_atan2": (C.c_int, [vp, vp, C.c_int64, vp, vp, vp]),
     "scenerf_hip_resnetfc_forward": (C.c_int, [C.POINTER(Cfg), C.POINTER(ResnetFCNet), vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "scenerf_hip_resnetfc_forward_train": (C.c_int, [C.POINTER(Cfg), C.POINTER(ResnetFCNet), vp, vp, vp, i32, C.POINTER(ResnetFCActs), vp, vp, vp]),
+    "scenerf_hip_resnetfc_backward": (C.c_int, [C.POINTER(Cfg), C.POINTER(ResnetFCNet), C.POINTER(ResnetFCNetT), C.POINTER(ResnetFCGrads),
+                                                vp, vp, vp, vp, vp, i32, C.POINTER(ResnetFCActs), vp, vp, vp, vp, vp, vp]),
     "scenerf_hip_test_gemm_nt": (C.c_int, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "scenerf_hip_test_chunk_table": (C.c_int, [C.POINTER(Cfg), i32, vp, i32]),
     "scenerf_hip_test_set_tuning": (C.c_int, [i32, i32]),

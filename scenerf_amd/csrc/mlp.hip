@@ -496,6 +496,214 @@ int scenerf_hip_resnetfc_forward(const scenerf_cfg* cfg, const scenerf_resnetfc*
     return launch_gemm_nt(0, g, s);
 }
 
+// ---- the same net, trainable (round 6): the forward that saves what the backward reads, and the backward as one fp32-MFMA GEMM per
+// gradient (scenerf_hip.h).  resnetfc.py:133-164 and its autograd.
+static int resnetfc_check(const scenerf_cfg* cfg, const scenerf_resnetfc* net, const char* who) {
+    SRF_CHECK(cfg && net, "%s: NULL argument", who);
+    SRF_CHECK(net->n_blocks >= 1 && net->n_blocks <= SCENERF_RESNETFC_MAX_BLOCKS, "%s: n_blocks=%d (1..%d)", who, net->n_blocks,
+              SCENERF_RESNETFC_MAX_BLOCKS);
+    SRF_CHECK(net->d_hidden >= 16 && net->d_hidden % 16 == 0 && net->d_out_pad >= 8 && net->d_out_pad % 8 == 0,
+              "%s: d_hidden=%d must be a multiple of 16, d_out_pad=%d of 8", who, net->d_hidden, net->d_out_pad);
+    SRF_CHECK(net->w_in && net->b_in && net->w_out && net->b_out, "%s: NULL parameter", who);
+    for (int b = 0; b < net->n_blocks; ++b)
+        SRF_CHECK(net->w_z[b] && net->b_z[b] && net->w_fc0[b] && net->b_fc0[b] && net->w_fc1[b] && net->b_fc1[b], "%s: NULL parameter (block %d)", who, b);
+    return 0;
+}
+
+int scenerf_hip_resnetfc_forward_train(const scenerf_cfg* cfg, const scenerf_resnetfc* net, const float* xenc, const float* Z,
+                                       const uint8_t* tile_mask, int M, const scenerf_resnetfc_acts* acts, float* h_scratch,
+                                       float* logits, scenerf_stream_t stream) {
+    if (int e = resnetfc_check(cfg, net, "resnetfc_forward_train")) return e;
+    SRF_CHECK(xenc && Z && tile_mask && acts && h_scratch && logits && M > 0 && acts->h_fin, "resnetfc_forward_train: NULL argument");
+    hipStream_t s = as_stream(stream);
+    const int H = net->d_hidden, nb = net->n_blocks;
+    // h = lin_in(x) lands where the first block's residual is read from: the scratch for one block, h_fin's storage otherwise is free
+    // until the last block writes it -- the running h alternates between the scratch and h_fin so that the LAST block's output is h_fin
+    float* cur = (nb % 2) ? h_scratch : acts->h_fin;
+    {
+        GemmNT g;
+        g.name = "gemm_generic_lin_in";
+        g.A1 = xenc; g.lda1 = SCENERF_D_XENC; g.K1 = SCENERF_D_XENC;
+        g.W = net->w_in; g.ldw = SCENERF_D_XENC;
+        g.M = M; g.N = H; g.bias = net->b_in;
+        g.out = cur; g.ldout = H; g.out_f32 = 1;
+        if (int e = launch_gemm_nt(0, g, s)) return e;
+    }
+    for (int b = 0; b < nb; ++b) {
+        SRF_CHECK(acts->hz[b] && acts->n[b], "resnetfc_forward_train: NULL activation buffer (block %d)", b);
+        {   // hz[b] = h + lin_z.b(z)
+            GemmNT g;
+            g.name = "gemm_generic_linz";
+            set_segments(g, cfg, Z, tile_mask);
+            g.W = net->w_z[b]; g.ldw = SCENERF_D_LATENT;
+            g.M = M; g.N = H; g.bias = net->b_z[b];
+            g.res = cur; g.ldres = H; g.res_f32 = 1;
+            g.out = acts->hz[b]; g.ldout = H; g.out_f32 = 1;
+            if (int e = launch_gemm_nt(0, g, s)) return e;
+        }
+        {   // n[b] = fc_0(relu(hz[b]))
+            GemmNT g;
+            g.name = "gemm_generic_fc0";
+            g.A1 = acts->hz[b]; g.lda1 = H; g.K1 = H; g.relu1 = 1;
+            g.W = net->w_fc0[b]; g.ldw = H;
+            g.M = M; g.N = H; g.bias = net->b_fc0[b];
+            g.out = acts->n[b]; g.ldout = H; g.out_f32 = 1;
+            if (int e = launch_gemm_nt(0, g, s)) return e;
+        }
+        {   // h = hz[b] + fc_1(relu(n[b]))
+            float* nxt = cur == h_scratch ? acts->h_fin : h_scratch;
+            GemmNT g;
+            g.name = "gemm_generic_fc1";
+            g.A1 = acts->n[b]; g.lda1 = H; g.K1 = H; g.relu1 = 1;
+            g.W = net->w_fc1[b]; g.ldw = H;
+            g.M = M; g.N = H; g.bias = net->b_fc1[b];
+            g.res = acts->hz[b]; g.ldres = H; g.res_f32 = 1;
+            g.out = nxt; g.ldout = H; g.out_f32 = 1;
+            if (int e = launch_gemm_nt(0, g, s)) return e;
+            cur = nxt;
+        }
+    }
+    SRF_CHECK(cur == acts->h_fin, "resnetfc_forward_train: internal buffer parity");
+    GemmNT g;
+    g.name = "gemm_generic_lin_out";
+    g.A1 = cur; g.lda1 = H; g.K1 = H; g.relu1 = 1;
+    g.W = net->w_out; g.ldw = H;
+    g.M = M; g.N = net->d_out_pad; g.bias = net->b_out;
+    g.out = logits; g.ldout = net->d_out_pad; g.out_f32 = 1;
+    return launch_gemm_nt(0, g, s);
+}
+
+int scenerf_hip_resnetfc_backward(const scenerf_cfg* cfg, const scenerf_resnetfc* net, const scenerf_resnetfc_t* nt,
+                                  const scenerf_resnetfc_grads* gr, const float* xenc, const float* Z, const uint8_t* tile_mask,
+                                  const int32_t* tap_texel, const float* tap_weight, int M, const scenerf_resnetfc_acts* acts,
+                                  const float* dlog16, float* dhz, float* dh, float* dn, float* const gmaps_hwc[SCENERF_N_SCALES],
+                                  scenerf_stream_t stream) {
+    if (int e = resnetfc_check(cfg, net, "resnetfc_backward")) return e;
+    SRF_CHECK(nt && gr && xenc && Z && tile_mask && acts && dlog16 && dhz && dh && dn && M > 0 && acts->h_fin && nt->w_out_t,
+              "resnetfc_backward: NULL argument");
+    SRF_CHECK(!gmaps_hwc || (tap_texel && tap_weight), "resnetfc_backward: taps missing");
+    SRF_CHECK(gr->w_in && gr->b_in && gr->w_z && gr->w_out && gr->b_out, "resnetfc_backward: NULL gradient buffer");
+    hipStream_t s = as_stream(stream);
+    const int H = net->d_hidden, nb = net->n_blocks, LD = nb * H;
+    {   // lin_out: dW_out += dlog^T relu(h_fin), db_out += colsum(dlog)
+        GemmTN t;
+        t.name = "gemm_generic_wgrad_out";
+        t.D = dlog16; t.ldd = 16; t.A = acts->h_fin; t.lda = H; t.relu_a = 1;
+        t.M = M; t.N = 16; t.K = H; t.out = gr->w_out; t.ldo = H; t.colsum = gr->b_out;
+        t.allow_tr = 0;
+        if (int e = launch_gemm_tn(0, t, s)) return e;
+    }
+    {   // dh = (dlog W_out) * [h_fin > 0]
+        GemmNT g;
+        g.name = "gemm_generic_dgrad_out";
+        g.A1 = dlog16; g.lda1 = 16; g.K1 = 16;
+        g.W = nt->w_out_t; g.ldw = 16;
+        g.M = M; g.N = H;
+        g.maskp = acts->h_fin; g.ldmask = H;
+        g.out = dh; g.ldout = H; g.out_f32 = 1;
+        if (int e = launch_gemm_nt(0, g, s)) return e;
+    }
+    const float* dcur = dh;     // gradient w.r.t. the current block's output
+    int ldcur = H;
+    for (int b = nb - 1; b >= 0; --b) {
+        SRF_CHECK(acts->hz[b] && acts->n[b] && nt->w_fc0_t[b] && nt->w_fc1_t[b] && gr->w_fc0[b] && gr->b_fc0[b] && gr->w_fc1[b] && gr->b_fc1[b],
+                  "resnetfc_backward: NULL buffer (block %d)", b);
+        {   // dW1 += dh^T relu(n[b]), db1 += colsum(dh)
+            GemmTN t;
+            t.name = "gemm_generic_wgrad_fc1";
+            t.D = dcur; t.ldd = ldcur; t.A = acts->n[b]; t.lda = H; t.relu_a = 1;
+            t.M = M; t.N = H; t.K = H; t.out = gr->w_fc1[b]; t.ldo = H; t.colsum = gr->b_fc1[b];
+            t.allow_tr = 0;
+            if (int e = launch_gemm_tn(0, t, s)) return e;
+        }
+        {   // dn = (dh W1) * [n[b] > 0]
+            GemmNT g;
+            g.name = "gemm_generic_dgrad_fc1";
+            g.A1 = dcur; g.lda1 = ldcur; g.K1 = H;
+            g.W = nt->w_fc1_t[b]; g.ldw = H;
+            g.M = M; g.N = H;
+            g.maskp = acts->n[b]; g.ldmask = H;
+            g.out = dn; g.ldout = H; g.out_f32 = 1;
+            if (int e = launch_gemm_nt(0, g, s)) return e;
+        }
+        {   // dW0 += dn^T relu(hz[b]), db0 += colsum(dn)
+            GemmTN t;
+            t.name = "gemm_generic_wgrad_fc0";
+            t.D = dn; t.ldd = H; t.A = acts->hz[b]; t.lda = H; t.relu_a = 1;
+            t.M = M; t.N = H; t.K = H; t.out = gr->w_fc0[b]; t.ldo = H; t.colsum = gr->b_fc0[b];
+            t.allow_tr = 0;
+            if (int e = launch_gemm_tn(0, t, s)) return e;
+        }
+        {   // dhz[b] = dh + (dn W0) * [hz[b] > 0]   (column block b of dhz)
+            GemmNT g;
+            g.name = "gemm_generic_dgrad_fc0";
+            g.A1 = dn; g.lda1 = H; g.K1 = H;
+            g.W = nt->w_fc0_t[b]; g.ldw = H;
+            g.M = M; g.N = H;
+            g.maskp = acts->hz[b]; g.ldmask = H;
+            g.res2 = dcur; g.ldres2 = ldcur;
+            g.out = dhz + (size_t)b * H; g.ldout = LD; g.out_f32 = 1;
+            if (int e = launch_gemm_nt(0, g, s)) return e;
+        }
+        dcur = dhz + (size_t)b * H;
+        ldcur = LD;
+    }
+    // lin_z: dWz[b] += dhz[b]^T z, per pyramid level (row tiles without that level skipped: they multiply exact zeros)
+    int off = 0;
+    for (int sc = 0; sc < SCENERF_N_SCALES; ++sc) {
+        const int c = cfg->map_C[sc];
+        if (c > 0) {
+            GemmTN t;
+            t.name = "gemm_generic_wgrad_linz";
+            t.D = dhz; t.ldd = LD;
+            t.A = Z + off; t.lda = SCENERF_D_LATENT;
+            t.M = M; t.N = LD; t.K = c;
+            t.tile_mask = tile_mask; t.skip_bit = sc;
+            t.out = gr->w_z + off; t.ldo = SCENERF_D_LATENT;
+            t.allow_tr = 0;
+            if (int e = launch_gemm_tn(0, t, s)) return e;
+        }
+        off += c;
+    }
+    {   // lin_in: dW_in += dhz[0]^T x, db_in += colsum(dhz[0])
+        GemmTN t;
+        t.name = "gemm_generic_wgrad_in";
+        t.D = dhz; t.ldd = LD; t.A = xenc; t.lda = SCENERF_D_XENC;
+        t.M = M; t.N = H; t.K = SCENERF_D_XENC; t.out = gr->w_in; t.ldo = SCENERF_D_XENC; t.colsum = gr->b_in;
+        t.allow_tr = 0;
+        if (int e = launch_gemm_tn(0, t, s)) return e;
+    }
+    if (gmaps_hwc) {   // dz = dhz Wz scattered through the forward's taps: one launch for all levels (the GEMM family's scatter epilogue)
+        GemmNT g;
+        g.name = "gemm_generic_dfeat_scatter";
+        g.A1 = dhz; g.lda1 = LD; g.K1 = LD;
+        g.ldw = LD;
+        g.M = M;
+        g.tile_mask = tile_mask;
+        g.tap_texel = tap_texel; g.tap_weight = tap_weight;
+        bool any = false;
+        int t = 0;
+        for (int sc = 0; sc < 5; ++sc) {
+            SRF_CHECK(nt->w_z_t[sc] || !gmaps_hwc[sc], "resnetfc_backward: w_z_t[%d] missing", sc);
+            g.ms_t0[sc] = t;
+            g.ms_C[sc] = cfg->map_C[sc];
+            g.ms_W[sc] = nt->w_z_t[sc];
+            g.ms_gmap[sc] = gmaps_hwc[sc];
+            if (cfg->map_chw[sc] == 1) { g.ms_st[sc] = 1; g.ms_sc[sc] = (long)cfg->map_H[sc] * cfg->map_W[sc]; }
+            any = any || gmaps_hwc[sc];
+            t += cdiv(cfg->map_C[sc], 128);
+        }
+        if (any) {
+            g.ms_t0[5] = t;
+            g.ms_n = 5;
+            g.N = SCENERF_D_LATENT;
+            g.scatter_scale = 0;
+            if (int e = launch_gemm_nt(0, g, s)) return e;
+        }
+    }
+    return 0;
+}
+
 int scenerf_hip_mlp_backward(const scenerf_cfg* cfg, const scenerf_mlp_weights* w, const scenerf_mlp_grads* g_,
                              const void* Z, const float* xenc, const uint8_t* tile_mask, const int32_t* tap_texel,
                              const float* tap_weight, int M, const scenerf_mlp_acts* a, const float* d_logits, void* dH,

@@ -91,6 +91,10 @@ int scenerf_hip_test_set_tuning(int warm_wide, int dfeat_delay_us) {
 }
 
 int scenerf_hip_abi_version(void) { return SCENERF_HIP_ABI_VERSION; }
+// A failed stream capture leaves its error as the runtime's "last error" (hipErrorStreamCaptureInvalidated and friends); every entry
+// point of this library checks hipGetLastError() behind its launches and would report that stale error for a launch that succeeded.
+// Whoever catches a failed capture and carries on eagerly (scenerf_amd.graph.build_on_all_ranks) clears it here.  Returns the code.
+int scenerf_hip_clear_last_error(void) { return (int)hipGetLastError(); }
 const char* scenerf_hip_last_error(void) { return g_err; }
 
 int scenerf_hip_profile_enable(int on) {

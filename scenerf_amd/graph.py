@@ -80,6 +80,12 @@ class GraphedStep:
         for g in (optimizer.param_groups if optimizer is not None else ()):
             if not g.get("capturable", False):
                 raise RuntimeError("GraphedStep: the optimizer must be capturable (FusedAdamW(capturable=True))")
+        if (getattr(model, "grad_sync", None) is not None or getattr(model, "grad_sync_async", None) is not None) \
+                and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_backend() != "nccl":
+            # refused BEFORE anything is captured (a capture that fails half-way is expensive to recover from): only RCCL's collectives
+            # are stream operations; gloo's stage through the host
+            raise RuntimeError("GraphedStep: gradient collectives over the %r backend cannot be captured (they stage through the host); "
+                               "only nccl (= RCCL) collectives are stream operations" % torch.distributed.get_backend())
         # ``pixels``: a static (R, 2) tensor, or a zero-argument callable evaluated INSIDE the captured step (e.g. the reference's per-step draw
         # ``grid[torch.randperm(len(grid), device=dev)[:R]]``, scenerf.py:253-264: torch's CUDA generator is graph-safe, every replay
         # draws fresh pixels); the callable must return the same shape on the same device every time and launch only capturable work
@@ -100,6 +106,14 @@ class GraphedStep:
         self._one = None
         self._opt_stream = None
         self._map_leaves = [v for v in x_rgb.values() if v.requires_grad]
+        self._capture(dev, warmup, snap)
+        self.map_grads = {k: v.grad for k, v in x_rgb.items() if v.requires_grad}
+        # the captured step reads the inverse intrinsics from the model's cached tensor (made on the host, SceneRF._inv_K): remember the
+        # version of cam_K it belongs to -- __call__ refreshes that tensor in place when the caller has copied new intrinsics in
+        self._cam_K_version = cam_K._version
+
+    def _capture(self, dev, warmup, snap):
+        """Warm-up steps, then the capture of one more (``self._eager``); ``snap``: a ``_snapshot`` to put back afterwards (restore=True)."""
         # warm-up on a side stream (allocator pools, one-time setup, optimizer state), as torch's capture recipe asks
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -110,12 +124,27 @@ class GraphedStep:
         torch.cuda.synchronize(dev)
         _wait_for_pending_collectives()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._eager()
-        self.map_grads = {k: v.grad for k, v in x_rgb.items() if v.requires_grad}
-        # the captured step reads the inverse intrinsics from the model's cached tensor (made on the host, SceneRF._inv_K): remember the
-        # version of cam_K it belongs to -- __call__ refreshes that tensor in place when the caller has copied new intrinsics in
-        self._cam_K_version = cam_K._version
+        cur = torch.cuda.current_stream(dev)
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._eager()
+        except BaseException:
+            # a step that cannot be captured (a host sync inside it, a collective that stages through the host ...): leave no capture
+            # behind.  torch.cuda.graph's exit ends the capture, but when THAT raises too (it does for an invalidated capture) the
+            # capture stream stays current -- and on ROCm every later launch of the process then fails with "operation failed due to a
+            # previous error during capture" (tests/test_gpu_dp.py's benched-shape worker, round 6).
+            try:
+                self.graph.capture_end()
+            except Exception:            # noqa: BLE001 -- already ended
+                pass
+            torch.cuda.set_stream(cur)
+            # ... and the streams that were forked into the aborted capture are abandoned: the renderer's side stream fails its next launch
+            # with "invalid argument" (tools/capture_abort_probe.py: with fresh ones the eager step runs again)
+            from . import renderer
+            renderer.reset_side_streams()
+            self._opt_stream = None
+            self.graph = None
+            raise
         self.steps_warmup = max(1, warmup)
         if snap is not None:
             self._restore(snap, dev)
@@ -213,7 +242,7 @@ class GraphedStep:
         """Replay: one more training step.  Returns the (static) loss tensor of the captured step."""
         if self.optimizer is not None and hasattr(self.optimizer, "sync_hyper"):
             self.optimizer.sync_hyper()     # a scheduler may have moved the learning rate
-        if self.cam_K._version != self._cam_K_version:
+        if self.cam_K is not None and self.cam_K._version != self._cam_K_version:
             # new intrinsics were copied into the static cam_K: their inverse is host-made and lives in a tensor the graph holds by address
             # (ADVICE r05: a replay runs no Python, so without this the rays would keep the OLD inverse) -- refreshed in place, outside the graph
             if hasattr(self.model, "_inv_K"):
@@ -221,6 +250,49 @@ class GraphedStep:
             self._cam_K_version = self.cam_K._version
         self.graph.replay()
         return self.loss
+
+
+class GraphedFn(GraphedStep):
+    """ONE captured optimizer step of an arbitrary step function ``fn() -> loss`` -- e.g. the trainer's own per-image step
+    ``lambda: model.step(batch, "train")`` (scenerf.py:119-241: per source frame a trained render, a metric-only render under no_grad and
+    the source's loss, then ONE optimizer step), with several ``render_rays_batch`` sessions inside.  Everything ``fn`` reads is captured by
+    ADDRESS (write new images / poses / features into the same tensors between replays); what it draws must be drawn on the device
+    (``model.device_pixel_draw = True`` for the per-source pixel subset, ``render_cfg.device_rng`` for the sampler noise, the fused source
+    loss's in-kernel tie-breaking noise); the intrinsics tensors must be persistent objects (a list of tensors, not slices made per call:
+    their host-made inverses are cached per tensor object).  ``grad_leaves``: further leaves whose ``.grad`` the step produces (the
+    feature maps of a stub encoder); they are reset to None at the top of every step like the parameters'.  The optimizer step stays in
+    stream order here: with more than one session per step the parameter gradients are accumulated by autograd after each session's own."""
+
+    def __init__(self, model, optimizer: torch.optim.Optimizer, fn: Callable[[], torch.Tensor], device, grad_leaves: Sequence[torch.Tensor] = (),
+                 warmup: int = 3, restore: bool = False, restore_tensors: Sequence[torch.Tensor] = ()):
+        if not getattr(model.render_cfg, "device_rng", False):
+            raise RuntimeError("GraphedFn: the sampler noise must be drawn on the device (render_cfg.device_rng = True)")
+        for g in optimizer.param_groups:
+            if not g.get("capturable", False):
+                raise RuntimeError("GraphedFn: the optimizer must be capturable (FusedAdamW(capturable=True))")
+        if (getattr(model, "grad_sync", None) is not None or getattr(model, "grad_sync_async", None) is not None) \
+                and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_backend() != "nccl":
+            raise RuntimeError("GraphedFn: gradient collectives over the %r backend cannot be captured" % torch.distributed.get_backend())
+        dev = torch.device(device)
+        self.model, self.optimizer, self._fn = model, optimizer, fn
+        self.noise, self._pixels_fn, self.cam_K, self.pixels = None, None, None, None
+        self._params = [p for g in optimizer.param_groups for p in g["params"]]
+        self._map_leaves = list(grad_leaves)
+        self._one, self._opt_stream = None, None
+        snap = self._snapshot(dev, restore_tensors) if restore else None
+        self._capture(dev, warmup, snap)
+
+    def _eager(self) -> torch.Tensor:
+        for p in self._params:
+            p.grad = None
+        for v in self._map_leaves:
+            v.grad = None
+        loss = self._fn()
+        if self._one is None or self._one.shape != loss.shape or self._one.dtype != loss.dtype:
+            self._one = torch.ones_like(loss)
+        loss.backward(self._one)
+        self.optimizer.step()
+        return loss.detach()
 
 
 def build_on_all_ranks(factory: Callable[[], object], agree: Optional[Callable[[bool], bool]] = None):
@@ -239,6 +311,10 @@ def build_on_all_ranks(factory: Callable[[], object], agree: Optional[Callable[[
         try:
             if torch.cuda.is_available() and torch.cuda.is_initialized():
                 torch.cuda.synchronize()
+                # the failed capture's error stays behind as the HIP runtime's "last error": the library's next entry point would report
+                # it for a launch that succeeded (found by tests/test_gpu_dp.py's benched-shape worker, round 6) -- cleared here
+                from . import _capi
+                _capi.load().scenerf_hip_clear_last_error()
         except Exception:            # noqa: BLE001
             pass
     ok = (agree or sdist.all_ranks_agree)(g is not None)

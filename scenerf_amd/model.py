@@ -135,8 +135,9 @@ class ResnetFC(nn.Module):
 
     It has no ``forward``: evaluation happens inside the HIP MLP pass.  The shape SceneRF instantiates (``n_blocks=3, d_hidden=512``,
     scenerf.py:100-114) runs on the fused kernels, forward and backward; every other block count / hidden width (the reference class is
-    generic: BASELINE.json configs[0] names 1 block x 128) runs forward-only, in fp32, one MFMA GEMM per ``nn.Linear``
-    (``scenerf_hip_resnetfc_forward``) -- assign such a net to ``model.mlp`` / ``model.mlp_gaussian`` and render under ``torch.no_grad()``.
+    generic: BASELINE.json configs[0] names 1 block x 128) runs in fp32 with one MFMA GEMM per ``nn.Linear`` -- and, since round 6, one per
+    gradient: ``scenerf_hip_resnetfc_forward`` under ``no_grad``, ``_forward_train`` / ``_backward`` otherwise.  Assign such a net to
+    ``model.mlp`` / ``model.mlp_gaussian`` of a ``precision="fp32"`` model.
     """
 
     def __init__(self, d_in: int = 42, d_out: int = 4, n_blocks: int = 3, d_latent: int = 2480, d_hidden: int = 512):
@@ -327,7 +328,12 @@ class SceneRF(TrainingMixin, _Base):
         is held bit-exact to torch-CPU's operation sequence (csrc/sphere_exact.h).  One small D2H + H2D per NEW intrinsics tensor; the
         cache key is the tensor OBJECT and its version counter (never the address: a new tensor may reuse it), so a loop -- or a
         captured graph -- that passes the same K tensor pays once."""
+        # (a few entries: a batch of several images brings one intrinsics tensor per image -- scenerf.py:141-156 -- and alternates them)
+        multi = self.__dict__.setdefault("_inv_K_more", {})
         hit = getattr(self, "_inv_K_cache", None)
+        if (hit is None or hit[0] is not cam_K) and id(cam_K) in multi and multi[id(cam_K)][0] is cam_K:
+            hit = multi[id(cam_K)]
+            object.__setattr__(self, "_inv_K_cache", hit)
         if hit is None or hit[0] is not cam_K or hit[1] != cam_K._version:
             if torch.cuda.is_available() and cam_K.is_cuda and torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("render_rays_batch: new intrinsics inside a hipGraph capture (their inverse is made on the host: a "
@@ -341,6 +347,9 @@ class SceneRF(TrainingMixin, _Base):
             else:
                 hit = (cam_K, cam_K._version, inv.to(cam_K.device))
             object.__setattr__(self, "_inv_K_cache", hit)
+            if len(multi) >= 8 and id(cam_K) not in multi:
+                multi.pop(next(iter(multi)))
+            multi[id(cam_K)] = hit
         return hit[2]
 
     def _device_rng_state(self, dev) -> torch.Tensor:

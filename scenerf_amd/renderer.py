@@ -17,6 +17,7 @@ import ctypes as C
 import dataclasses
 from typing import Dict, List, Optional, Sequence
 
+import numpy as np
 import torch
 
 from . import _capi
@@ -72,6 +73,12 @@ GRADS_BEHIND_HEAD = True   # the radiance MLP's weight / feature-map gradients s
 MAP_GRADS_ON_SIDE = True   # ... and its feature-map gradients run on the side stream, unjoined until the accumulators' next consumer
 SPLIT_HEAD_PACK = True     # the head's pack in two calls, its forward's operands first
 
+
+
+def reset_side_streams() -> None:
+    """Forget the renderer's side streams (new ones are made on demand).  For whoever aborted a stream capture half-way: the side streams
+    that were forked into it stay unusable on ROCm ("invalid argument" at their next launch) -- GraphedStep calls this when a capture fails."""
+    _SIDE.clear()
 
 
 def _side_stream(dev) -> "torch.cuda.Stream":
@@ -559,10 +566,11 @@ class PackedMLP:
 class GenericPackedMLP:
     """A ResnetFC of a shape the fused kernels are not built for (anything but 3 blocks x 512; ``ResnetFC.ordered_params`` order): the
     reference's parameter layout, lin_in's input columns zero-padded 42 -> 48 and lin_out's rows to a multiple of 8, for
-    ``scenerf_hip_resnetfc_forward`` (fp32, forward only).  Same interface as ``PackedMLP`` where a forward pass touches it."""
+    ``scenerf_hip_resnetfc_forward`` / ``_forward_train`` / ``_backward`` (fp32, one MFMA GEMM per nn.Linear and per gradient: round 6 made
+    this path trainable).  Same interface as ``PackedMLP`` where the chunk touches it."""
     generic = True
 
-    def __init__(self, params: Sequence[torch.Tensor], d_out: int, cfg: RenderConfig):
+    def __init__(self, params: Sequence[torch.Tensor], d_out: int, cfg: RenderConfig, trainable: bool = False):
         if cfg.precision_code != 0:
             raise RuntimeError("a ResnetFC other than 3 blocks x 512 runs on the per-layer fp32 GEMM path only: construct the model with "
                                "precision='fp32' (the bf16 kernels are built for the trunk SceneRF instantiates)")
@@ -595,19 +603,86 @@ class GenericPackedMLP:
             n.w_fc0[b], n.b_fc0[b], n.w_fc1[b], n.b_fc1[b], n.w_z[b], n.b_z[b] = (w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(),
                                                                                  wz.data_ptr(), bz.data_ptr())
         self.c = n
+        self.trainable = trainable
+        self.gflat, self.gc, self.gviews = None, None, {}
+        self.ct = None
+        if trainable:
+            # transposed operands of the input-gradient GEMMs (scenerf_resnetfc_t): nn.Linear.weight^T per fc layer, lin_out.weight^T padded to 16
+            # output columns, and per pyramid level the columns of [Wz_0; ..; Wz_{nb-1}] as rows: [C_s][nb * H]
+            t = _capi.ResnetFCNetT()
+            keep = []
+            for b in range(nb):
+                w0t, w1t = ps[4 + 6 * b].t().contiguous(), ps[6 + 6 * b].t().contiguous()
+                keep += [w0t, w1t]
+                t.w_fc0_t[b], t.w_fc1_t[b] = w0t.data_ptr(), w1t.data_ptr()
+            w_out_t = torch.zeros((H, 16), dtype=torch.float32, device=dev)
+            w_out_t[:, :d_out] = ps[2].t()
+            t.w_out_t = w_out_t.data_ptr()
+            wz_all = torch.cat([ps[8 + 6 * b] for b in range(nb)], dim=0)          # [nb * H][2480]
+            off = 0
+            for sc, (c, _, _) in enumerate(cfg.map_shapes()):
+                wzt = wz_all[:, off:off + c].t().contiguous()                       # [C_s][nb * H]
+                keep.append(wzt)
+                t.w_z_t[sc] = wzt.data_ptr()
+                off += c
+            self._keep += keep + [w_out_t]
+            self.ct = t
 
     def launch_pack(self, upto: int = 2) -> None:
         pass
 
     def wait_ready(self, backward: bool = False) -> None:
-        if backward:
-            raise RuntimeError("a ResnetFC other than 3 blocks x 512 is forward only")
+        if backward and not self.trainable:
+            raise RuntimeError("this ResnetFC session was opened without gradients (a ResnetFC other than 3 blocks x 512 trains in fp32 "
+                               "when its parameters require them)")
+
+    # ---- gradient sink: one flat fp32 buffer (one all-reduce per MLP, like PackedMLP) carved into scenerf_resnetfc_grads
+    def _sink_fields(self):
+        H, nb = self.d_hidden, self.n_blocks
+        f = [("w_in", (H, D_X)), ("b_in", (H,)), ("w_z", (nb * H, D_L)), ("w_out", (16, H)), ("b_out", (16,))]
+        for b in range(nb):
+            f += [("w_fc0.%d" % b, (H, H)), ("b_fc0.%d" % b, (H,)), ("w_fc1.%d" % b, (H, H)), ("b_fc1.%d" % b, (H,))]
+        return f
+
+    def grad_sink(self) -> "_capi.ResnetFCGrads":
+        if self.gc is not None:
+            return self.gc
+        fields = self._sink_fields()
+        if self.gflat is None:
+            self.gflat = torch.zeros(sum(int(np.prod(shp)) for _, shp in fields), dtype=torch.float32, device=self.device)
+        off = 0
+        for name, shp in fields:
+            n = int(np.prod(shp))
+            self.gviews[name] = self.gflat[off:off + n].view(*shp)
+            off += n
+        g = _capi.ResnetFCGrads()
+        v = self.gviews
+        g.w_in, g.b_in, g.w_z, g.w_out, g.b_out = (v["w_in"].data_ptr(), v["b_in"].data_ptr(), v["w_z"].data_ptr(), v["w_out"].data_ptr(),
+                                                  v["b_out"].data_ptr())
+        for b in range(self.n_blocks):
+            g.w_fc0[b], g.b_fc0[b] = v["w_fc0.%d" % b].data_ptr(), v["b_fc0.%d" % b].data_ptr()
+            g.w_fc1[b], g.b_fc1[b] = v["w_fc1.%d" % b].data_ptr(), v["b_fc1.%d" % b].data_ptr()
+        self.gc = g
+        return g
+
+    def unpack_grads(self) -> List[Optional[torch.Tensor]]:
+        """Gradients in ``ResnetFC.ordered_params`` order (None if no chunk ran a backward)."""
+        nb, H = self.n_blocks, self.d_hidden
+        if self.gflat is None or not self.gviews:
+            return [None] * (4 + 6 * nb)
+        v = self.gviews
+        out = [v["w_in"][:, :42], v["b_in"], v["w_out"][:self.d_out], v["b_out"][:self.d_out]]
+        for b in range(nb):
+            # lin_z.b.bias is added where lin_in.bias (b = 0) / fc_1.(b-1).bias is: the same column sums of dhz[b] (scenerf_hip.h)
+            bz = v["b_in"] if b == 0 else v["b_fc1.%d" % (b - 1)]
+            out += [v["w_fc0.%d" % b], v["b_fc0.%d" % b], v["w_fc1.%d" % b], v["b_fc1.%d" % b], v["w_z"][b * H:(b + 1) * H], bz]
+        return out
 
 
 class _GenericRun:
-    """Buffers of one generic ResnetFC evaluation (forward only): what the rest of the chunk reads of an ``_MlpRun``."""
+    """Buffers of one generic ResnetFC evaluation: what the rest of the chunk reads of an ``_MlpRun`` (+ the saved activations of a training pass)."""
 
-    def __init__(self, M: int, pk: GenericPackedMLP, dev):
+    def __init__(self, M: int, pk: GenericPackedMLP, dev, keep_acts: bool = False):
         f32 = dict(dtype=torch.float32, device=dev)
         self.M = M
         self.Mpad = (M + _capi.TILE_ROWS - 1) // _capi.TILE_ROWS * _capi.TILE_ROWS
@@ -617,10 +692,22 @@ class _GenericRun:
         self.tile_mask = torch.empty((self.Mpad // _capi.TILE_ROWS,), dtype=torch.uint8, device=dev)
         self.tap_texel = torch.empty((M, 5, 4), dtype=torch.int32, device=dev)
         self.tap_weight = torch.empty((M, 5, 4), **f32)
-        self.h = [torch.empty((M, pk.d_hidden), **f32) for _ in range(3)]
         self.logits_pad = torch.empty((M, pk.d_out_pad), **f32)
         self.logits = None
         self.sign_bits = None
+        self.h0pre = None
+        self.acts = None
+        if keep_acts:      # what scenerf_hip_resnetfc_backward reads: hz[b], n[b] per block, h_fin (scenerf_resnetfc_acts)
+            nb = pk.n_blocks
+            self.saved = [torch.empty((M, pk.d_hidden), **f32) for _ in range(2 * nb + 1)]
+            self.h = [torch.empty((M, pk.d_hidden), **f32)]
+            a = _capi.ResnetFCActs()
+            for b in range(nb):
+                a.hz[b], a.n[b] = self.saved[2 * b].data_ptr(), self.saved[2 * b + 1].data_ptr()
+            a.h_fin = self.saved[2 * nb].data_ptr()
+            self.acts = a
+        else:
+            self.h = [torch.empty((M, pk.d_hidden), **f32) for _ in range(3)]
 
 
 class MlpHolder:
@@ -642,12 +729,10 @@ class PackMLP(torch.autograd.Function):
         # training sessions (a parameter gradient will be asked for): the radiance MLP is packed on the side stream
         side = _side_stream(params[0].device) if (holder.defer_pack and any(ctx.needs_input_grad[3:])) else None
         if len(params) != len(MLP_PARAM_NAMES) or params[0].shape[0] != D_H:
-            # any other ResnetFC shape: the per-layer fp32 GEMM path, forward only (scenerf_hip_resnetfc_forward)
+            # any other ResnetFC shape: the per-layer fp32 GEMM path (scenerf_hip_resnetfc_forward / _forward_train / _backward)
             # (needs_input_grad reports the parameters' requires_grad flags whatever the grad mode: the session recorded the mode)
-            if holder.grad_mode and any(ctx.needs_input_grad[3:]):
-                raise RuntimeError("scenerf_amd: a ResnetFC other than 3 blocks x 512 is forward only -- render under torch.no_grad() "
-                                   "(or with parameters that do not require gradients)")
-            holder.packed = GenericPackedMLP(params, d_out, cfg)
+            # (trainable whenever the session runs with autograd on: the maps' gradients pass through this net too)
+            holder.packed = GenericPackedMLP(params, d_out, cfg, trainable=bool(holder.grad_mode))
             ctx.holder = holder
             return torch.empty(1, device=params[0].device)
         holder.packed = PackedMLP(params, d_out, cfg, pack_stream=side, defer=CHAIN_FIRST, split=CHAIN_FIRST and holder.split_pack)
@@ -731,9 +816,8 @@ def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dis
     lib = _capi.load()
     st = _stream(dist.device)
     if getattr(pk, "generic", False):
-        if keep_acts:
-            raise RuntimeError("scenerf_amd: a ResnetFC other than 3 blocks x 512 is forward only -- render under torch.no_grad()")
-        run = _GenericRun(M, pk, dist.device)
+        keep_acts = keep_acts and pk.trainable
+        run = _GenericRun(M, pk, dist.device, keep_acts=keep_acts)
         _capi.check(lib.scenerf_hip_encode_points(C.byref(ccfg), dist.data_ptr(), dist_ray_stride, ppr, unit_dir.data_ptr(),
                                                   viewdir.data_ptr(), K.data_ptr(), inv_K.data_ptr(), T.data_ptr(), M, None,
                                                   run.sphere_idx.data_ptr(), run.xenc.data_ptr(), None, st), "encode_points")
@@ -744,9 +828,14 @@ def _mlp_eval(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, dist, dis
             before_wait()
         if before_forward is not None:
             before_forward()
-        _capi.check(lib.scenerf_hip_resnetfc_forward(C.byref(ccfg), C.byref(pk.c), run.xenc.data_ptr(), run.Z.data_ptr(),
-                                                     run.tile_mask.data_ptr(), M, run.h[0].data_ptr(), run.h[1].data_ptr(),
-                                                     run.h[2].data_ptr(), run.logits_pad.data_ptr(), st), "resnetfc_forward")
+        if keep_acts:
+            _capi.check(lib.scenerf_hip_resnetfc_forward_train(C.byref(ccfg), C.byref(pk.c), run.xenc.data_ptr(), run.Z.data_ptr(),
+                                                               run.tile_mask.data_ptr(), M, C.byref(run.acts), run.h[0].data_ptr(),
+                                                               run.logits_pad.data_ptr(), st), "resnetfc_forward_train")
+        else:
+            _capi.check(lib.scenerf_hip_resnetfc_forward(C.byref(ccfg), C.byref(pk.c), run.xenc.data_ptr(), run.Z.data_ptr(),
+                                                         run.tile_mask.data_ptr(), M, run.h[0].data_ptr(), run.h[1].data_ptr(),
+                                                         run.h[2].data_ptr(), run.logits_pad.data_ptr(), st), "resnetfc_forward")
         run.logits = run.logits_pad[:, :pk.d_out].contiguous()     # (the tail and the sampler read [M][d_out])
         run.h = None
         return run
@@ -781,6 +870,23 @@ def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: 
     does not wait for the map gradients' tail (GraphedStep)."""
     lib = _capi.load()
     pk.wait_ready(backward=True)
+    if getattr(pk, "generic", False):
+        # any other ResnetFC shape: one fp32 GEMM per gradient, all on the current stream (scenerf_hip_resnetfc_backward)
+        if before_grads is not None:
+            before_grads()
+        dev = d_logits.device
+        H, nb = pk.d_hidden, pk.n_blocks
+        dlog16 = torch.zeros((run.M, 16), dtype=torch.float32, device=dev)
+        dlog16[:, :pk.d_out] = d_logits
+        dhz = torch.empty((run.M, nb * H), dtype=torch.float32, device=dev)
+        dh, dn = torch.empty((run.M, H), dtype=torch.float32, device=dev), torch.empty((run.M, H), dtype=torch.float32, device=dev)
+        g = pk.grad_sink()
+        gm = C.byref(maps.gmap_ptr_array()) if want_map_grads else None
+        _capi.check(lib.scenerf_hip_resnetfc_backward(C.byref(ccfg), C.byref(pk.c), C.byref(pk.ct), C.byref(g), run.xenc.data_ptr(),
+                                                      run.Z.data_ptr(), run.tile_mask.data_ptr(), run.tap_texel.data_ptr(),
+                                                      run.tap_weight.data_ptr(), run.M, C.byref(run.acts), dlog16.data_ptr(), dhz.data_ptr(),
+                                                      dh.data_ptr(), dn.data_ptr(), gm, _stream(dev)), "resnetfc_backward")
+        return sync_async(pk.gflat) if sync_async is not None else None
     act = _act_dtype(cfg.precision_code)
     dev = d_logits.device
     dH = torch.empty((run.M, 4 * D_H), dtype=act, device=dev)

@@ -83,11 +83,20 @@ class TrainingMixin:
                               T_cam2velo, step_type) -> Dict[str, torch.Tensor]:
         """scenerf.py:243-320."""
         dev = cam_K.device
-        xs = torch.arange(0, self.img_size[0], 2, device=dev, dtype=cam_K.dtype)
-        ys = torch.arange(0, self.img_size[1], 2, device=dev, dtype=cam_K.dtype)
-        gx, gy = torch.meshgrid(xs, ys, indexing="ij")
-        grid = torch.stack([gx, gy], dim=2).reshape(-1, 2)
-        idx = torch.randperm(grid.shape[0])[:n_rays].to(dev)          # CPU generator like the reference (:262)
+        gkey = (dev, cam_K.dtype, tuple(self.img_size))
+        cache = self.__dict__.setdefault("_stride2_grids", {})
+        grid = cache.get(gkey)
+        if grid is None:      # the stride-2 pixel grid of scenerf.py:253-260: a function of the image size, built once per device
+            xs = torch.arange(0, self.img_size[0], 2, device=dev, dtype=cam_K.dtype)
+            ys = torch.arange(0, self.img_size[1], 2, device=dev, dtype=cam_K.dtype)
+            gx, gy = torch.meshgrid(xs, ys, indexing="ij")
+            grid = cache[gkey] = torch.stack([gx, gy], dim=2).reshape(-1, 2)
+        if getattr(self, "device_pixel_draw", False):
+            # the same draw on the DEVICE generator: no host round trip, and capturable (scenerf_amd.graph.GraphedFn replays the whole
+            # per-image step with fresh pixels per replay: torch's CUDA generator is graph-safe)
+            idx = torch.randperm(grid.shape[0], device=dev)[:n_rays]
+        else:
+            idx = torch.randperm(grid.shape[0])[:n_rays].to(dev)      # CPU generator like the reference (:262)
         pix_source = grid[idx]
         out = self.render_rays_batch(cam_K, T_source2infer, x_rgb, T_cam2velo=T_cam2velo,
                                      ray_batch_size=pix_source.shape[0], sampled_pixels=pix_source)

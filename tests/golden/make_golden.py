@@ -111,6 +111,14 @@ CASES = {
     "c1_plumbing_r4096_n64": dict(variant="kitti", ctor=dict(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8,
                                   sphere_W=376, sphere_H=114), R=4096, chunk=1024, pose=(2.0, -10.0), seed=505, smooth=True,
                                   mlp=dict(n_blocks=1, d_hidden=128), forward_only=True),
+    # the same net shape TRAINED (round 6: scenerf_hip_resnetfc_backward): outputs and the gradient digests of every parameter and map from
+    # the reference's autograd, and a second shape (2 blocks x 64) for the block loop
+    "c1_train_r256_n64": dict(variant="kitti", ctor=dict(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8,
+                              sphere_W=376, sphere_H=114), R=256, chunk=256, pose=(2.0, -10.0), seed=515, smooth=True,
+                              mlp=dict(n_blocks=1, d_hidden=128)),
+    "generic_train_2x64_r96": dict(variant="kitti", ctor=dict(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8,
+                                   sphere_W=376, sphere_H=114), R=96, chunk=48, pose=(1.0, 5.0), seed=525, smooth=True,
+                                   mlp=dict(n_blocks=2, d_hidden=64)),
 }
 
 OUT_KEYS = ["depth", "color", "gaussian_means", "gaussian_stds", "weights_at_depth", "closest_pts_to_depths",

@@ -174,7 +174,9 @@ def test_graphed_step_replays_the_eager_step():
     m0 = _setup(5)[0]       # the starting point: the optimizer did move the parameters
     assert _rel(ref, list(m0.mlp.parameters()) + list(m0.mlp_gaussian.parameters())) > 1e-4
     spread_p = _rel(ref, ref2)
-    assert _rel(ref, [p.detach() for p in opt2.param_groups[0]["params"]]) <= 3 * spread_p + 1e-5, (spread_p, losses, got)
+    # (+ 2e-4: the replayed kernels interleave differently from the eager ones, AdamW turns last-bit differences of tiny gradient entries
+    #  into full-size steps of those entries -- see test_restore_true_first_replay_is_an_eager_first_step)
+    assert _rel(ref, [p.detach() for p in opt2.param_groups[0]["params"]]) <= 3 * spread_p + 2e-4, (spread_p, losses, got)
     assert abs(got[-1] - losses[-1]) <= 3 * abs(losses2[-1] - losses[-1]) + 2e-3 * (1 + abs(losses[-1])), (losses, losses2, got)
     for k in gref:      # map gradients of the last replay land in the captured leaves' .grad
         spread = float((gref[k] - gref2[k]).norm())
@@ -248,8 +250,12 @@ def test_restore_true_first_replay_is_an_eager_first_step():
     lg = float(gs())
     torch.cuda.synchronize()
     assert float(opt.state[params[0]]["step"]) == 3.0 and extra.tolist() == [8, 4]
+    # (two eager runs from one start agree to ~1e-8 -- same launch timing, same order of the fp32 atomics -- but the replayed step runs its
+    #  kernels in another interleaving, and AdamW's m / sqrt(v) turns a last-bit difference of a tiny gradient entry into a full-size step
+    #  of that entry: measured 2e-5 .. 4e-5 relative over all parameters, depending on the stream plumbing.  A replay that was NOT step 1
+    #  from the caller's state -- stale moments, a step count off by one, the warm-up steps' parameters -- is off by >= 3e-3.)
     spread = _rel(pa, pb)
-    assert _rel(pa, [p.detach() for p in params]) <= 3 * spread + 1e-6, (spread, _rel(pa, [p.detach() for p in params]))
+    assert _rel(pa, [p.detach() for p in params]) <= 3 * spread + 2e-4, (spread, _rel(pa, [p.detach() for p in params]))
     assert abs(lg - la) <= 3 * abs(la - lb) + 1e-3 * (1 + abs(la)), (la, lb, lg)
 
 
@@ -328,6 +334,91 @@ def test_restore_true_with_a_pixel_callable_gives_back_the_callers_generator_sta
     assert torch.equal(torch.cuda.get_rng_state(torch.device(DEV)), state0)
     gs(); torch.cuda.synchronize()
     assert torch.equal(gs.pixels, expect)
+
+
+def _trainer_setup(seed, S=2, R=256):
+    """The trainer's per-image step on a small shape: SceneRF with a static stand-in encoder, one image, S source frames."""
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed(seed)
+    m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, n_pts_uni=32, n_pts_per_gaussian=8, precision="bf16",
+                device_rng=True, n_rays=R).to(DEV)
+    m.mlp.load_state_dict(synth.mlp_state(1, 4))
+    m.mlp_gaussian.load_state_dict(synth.mlp_state(2, 2, out_scale=4.0))
+    m._device_rng_state(torch.device(DEV)).copy_(torch.tensor([77, 0, 0], dtype=torch.int64))
+    maps = {k: v.to(DEV).requires_grad_(True) for k, v in synth.feature_maps(1500, 452, 3).items()}
+
+    class Enc(torch.nn.Module):
+        def forward(self, img, pix=None, pix_sphere=None):
+            return {k: v.unsqueeze(0) for k, v in maps.items()}
+
+    m.net_rgb = Enc()
+    m.device_pixel_draw = True
+    from scenerf_amd.loss_side import make_rng_state
+    object.__setattr__(m, "_loss_rng", make_rng_state(torch.device(DEV), seed=5))     # (the fused source loss's tie-breaking noise)
+    g = torch.Generator().manual_seed(seed + 1)
+    img = lambda: torch.rand(3, 370, 1220, generator=g).to(DEV)      # noqa: E731
+    K = synth.kitti_cam_K().to(DEV)
+    batch = {"img_inputs": torch.rand(1, 3, 370, 1220, generator=g).to(DEV), "cam_K": [K], "T_velo_2_cam": [torch.eye(4, device=DEV)],
+             "img_sources": [[img() for _ in range(S)]], "img_targets": [[img() for _ in range(S)]],
+             "T_source2targets": [[synth.rel_pose(0.5 + 0.5 * i, 2.0).to(DEV) for i in range(S)]],
+             "T_source2infers": [[synth.rel_pose(1.0 + i, 0.0).to(DEV) for i in range(S)]],
+             "loc2d_with_depths": [[synth.stride2_pixels((1220, 370), R, 300 + i).to(DEV) for i in range(S)]],
+             "lidar_depths": [[torch.rand(R, generator=g).to(DEV) * 60 + 2 for _ in range(S)]]}
+    from scenerf_amd.optim import FusedAdamW
+    opt = FusedAdamW(list(m.mlp.parameters()) + list(m.mlp_gaussian.parameters()), lr=1e-4, weight_decay=0.0, capturable=True)
+    return m, opt, maps, batch
+
+
+def test_graphed_fn_replays_the_trainers_multi_source_step():
+    """scenerf_amd.graph.GraphedFn around the trainer's OWN per-image step (TrainingMixin.forward: two source frames, per source a trained
+    render, a metric-only render under no_grad and the fused source loss; one optimizer step), the per-source pixel subsets drawn on the
+    device inside the graph: W warm-up steps + N replays against W + N eager steps from the same seeds -- every generator involved (torch's
+    CUDA generator for the pixels, the sampler's and the loss's in-kernel counters) advances per replay as it does per eager step, so the
+    parameters must agree to the run-to-run level of the fp32 atomics (through AdamW: see test_restore_true_...)."""
+    from scenerf_amd.graph import GraphedFn
+    N, W = 3, 2
+
+    def eager(steps):
+        m, opt, maps, batch = _trainer_setup(31)
+        losses = []
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            for v in maps.values():
+                v.grad = None
+            loss = m.step(batch, "train")
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in opt.param_groups[0]["params"]], losses
+
+    pa, la = eager(W + N)
+    pb, lb = eager(W + N)
+    m, opt, maps, batch = _trainer_setup(31)
+    gs = GraphedFn(m, opt, lambda: m.step(batch, "train"), DEV, grad_leaves=list(maps.values()), warmup=W)
+    got = [float(gs()) for _ in range(N)]
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(torch.tensor(got)))
+    assert float(opt.state[opt.param_groups[0]["params"][0]]["step"]) == float(W + N)
+    assert len(set(round(x, 6) for x in got)) > 1, got          # fresh pixels and noise per replay
+    spread = _rel(pa, pb)
+    rel = _rel(pa, [p.detach() for p in opt.param_groups[0]["params"]])
+    assert rel <= 3 * spread + 2e-4, (spread, rel, la, got)
+    assert abs(got[-1] - la[-1]) <= 3 * abs(lb[-1] - la[-1]) + 2e-3 * (1 + abs(la[-1])), (la, lb, got)
+    assert all(v.grad is not None and bool(torch.isfinite(v.grad).all()) for v in maps.values())
+
+
+def test_a_failed_capture_leaves_a_process_that_can_step_eagerly():
+    """`build_on_all_ranks` promises: if a capture fails, the step is issued eagerly instead.  A capture that fails HALF-WAY (here: a loss that
+    reads a value back to the host inside the captured step) must therefore leave no capture open, the caller's stream current, no stale
+    HIP error and no side stream that was forked into it in use -- on ROCm every later launch of the process otherwise fails (round 6:
+    tools/capture_abort_probe.py).  In its own process (tests/capture_abort_worker.py)."""
+    import os, re, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "capture_abort_worker.py")], capture_output=True, text=True, timeout=600)
+    m_ = re.search(r"CAPTURE_ABORT state_ok=(\w+) finite=(\w+)", r.stdout)
+    assert r.returncode == 0 and m_, r.stdout[-1500:] + r.stderr[-1500:]
+    assert m_.group(1) == "True" and m_.group(2) == "True", r.stdout[-500:]
 
 
 def test_graphed_step_refuses_what_cannot_be_captured():

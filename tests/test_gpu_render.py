@@ -255,8 +255,7 @@ def test_plumbing_config_c1_runs_through_the_product():
     with torch.no_grad():
         out, _ = run_model(m, g, g.feature_maps(), grad=False)
     assert set(out) == set(OUT_KEYS)
-    clean = _clean_rays(m, g, R)
-    assert int(clean.sum()) >= R - max(1, R // 16)
+    clean = _clean_rays(m, g, R)        # (at most measured + 1 rays masked: tests/golden/clean_mask_measured.json)
     tol = TOL["fp32"]
     for k in OUT_KEYS:
         got = out[k].detach().float().cpu()
@@ -280,11 +279,71 @@ def test_plumbing_config_c1_runs_through_the_product():
                 t = t * max(1.0, 128.0 / N)     # (tests/test_gpu_parity_full.py::_out_gate; measured here 1.16e-4 at N = 64)
             lim = t if k in ABS_KEYS else t * (1.0 + rv.abs())
             assert bool(((gv - rv).abs() <= lim).all()), "%s digest: max err %.2e" % (k, float((gv - rv).abs().max()))
-    # ... and a gradient cannot be asked of these shapes: refused by name, not a crash
+    # ... a gradient CAN be asked of these shapes since round 6 (test_generic_resnetfc_trains_against_the_reference below), in fp32: the
+    # bf16 kernels are built for the 3 x 512 trunk, and say so
+    mb = SceneRF(precision="bf16", **g.ctor)
+    mb.mlp = ResnetFC(d_in=42, d_out=4, n_blocks=1, d_hidden=128)
+    mb.mlp_gaussian = ResnetFC(d_in=42, d_out=2, n_blocks=1, d_hidden=128)
+    mb = mb.to(DEV)
     x = {k: v.to(DEV) for k, v in g.feature_maps().items()}
-    with pytest.raises(RuntimeError, match="forward only"):
-        m.render_rays_batch(g.cam_K.to(DEV), g.T.to(DEV), x, sampled_pixels=g.pixels[:64].to(DEV), ray_batch_size=64,
-                            noise=(g.noise_u[:64].to(DEV), g.noise_g[:64].to(DEV)))
+    with pytest.raises(RuntimeError, match="precision='fp32'"):
+        mb.render_rays_batch(g.cam_K.to(DEV), g.T.to(DEV), x, sampled_pixels=g.pixels[:64].to(DEV), ray_batch_size=64,
+                             noise=(g.noise_u[:64].to(DEV), g.noise_g[:64].to(DEV)))
+
+
+@pytest.mark.parametrize("name", ["c1_train_r256_n64", "generic_train_2x64_r96"])
+def test_generic_resnetfc_trains_against_the_reference(name):
+    """resnetfc.py:67-164 is generic AND differentiable: BASELINE configs[0]'s 1 block x 128 (and a 2 x 64 net over two chunks) through the
+    product WITH autograd -- `scenerf_hip_resnetfc_forward_train` / `_backward`, one fp32-MFMA GEMM per nn.Linear and per gradient -- against
+    the golden vectors the reference's own render_rays_batch + backward produced with its two MLPs swapped for that shape
+    (make_golden.py): all 12 outputs, and the norm + the reference's 256 largest entries of every parameter gradient and map gradient."""
+    from scenerf_amd.model import ResnetFC
+    g = Golden(name)
+    mk = g.meta["mlp"]
+    m = SceneRF(precision="fp32", **g.ctor)
+    m.mlp = ResnetFC(d_in=42, d_out=4, **mk)
+    m.mlp_gaussian = ResnetFC(d_in=42, d_out=2, **mk)
+    mlp, mlpg = g.mlp_states()
+    m.mlp.load_state_dict(mlp)
+    m.mlp_gaussian.load_state_dict(mlpg)
+    m = m.to(DEV)
+    R = g.pixels.shape[0]
+    m.debug_aux = True
+    out, x = run_model(m, g, g.feature_maps())
+    clean = _clean_rays(m, g, R)
+    tol = TOL["fp32"]
+    for k in ("depth", "color", "weights", "alphas", "densities", "gaussian_means", "gaussian_stds", "depth_volumes"):
+        ref, got = g.out(k), out[k].detach().float().cpu()
+        t = tol["depth"] if k in ("depth", "depth_volumes", "gaussian_means", "gaussian_stds") else tol["color"] if k == "color" else tol["other"]
+        _, ok = frac_within(got, ref, t, k in ABS_KEYS)
+        assert bool(ok[clean].all()), "%s: %.4f of the clean rays within tolerance" % (k, float(ok[clean].float().mean()))
+    loss = out["depth"].mean() + out["color"].mean() + out["loss_kl"].mean() + out["gaussian_means"].mean()
+    lrel = abs(loss.item() - float(g.z["loss"])) / abs(float(g.z["loss"]))
+    assert lrel <= 5e-4, lrel
+    loss.backward()
+    names = [n for n, _ in m.mlp.named_parameters()]
+    tensors = {}
+    for mod_name, mod in (("mlp", m.mlp), ("mlp_gaussian", m.mlp_gaussian)):
+        for pn, p in mod.named_parameters():
+            tensors["%s.%s" % (mod_name, pn)] = p.grad
+    for key, v in x.items():
+        tensors["x_rgb." + key] = v.grad if v.grad is not None else torch.zeros_like(v)
+    assert set(g.grad_names()) == set(tensors), (sorted(set(g.grad_names()) ^ set(tensors)), names)
+    gt = GRAD_TOL["fp32"]
+    bad, wn, wt = [], 0.0, 0.0
+    for nm, grad in tensors.items():
+        assert grad is not None, nm
+        d = g.grad_digest(nm)
+        flat = grad.detach().float().cpu().reshape(-1)
+        nrm = float(flat.double().norm())
+        en = abs(nrm - d["norm"]) / max(d["norm"], 1e-30) if d["norm"] > 0 else nrm
+        s = float(d["val"].abs().max())
+        et = float((flat[d["idx"]] - d["val"]).abs().max()) / max(s, 1e-30) if s > 0 else float(flat[d["idx"]].abs().max())
+        wn, wt = max(wn, en), max(wt, et)
+        if en > gt["norm"] or et > gt["topk"]:
+            bad.append((nm, "norm %.2e topk %.2e" % (en, et)))
+    print("\n%s: loss rel %.2e, %d/%d clean rays, worst gradient norm error %.2e, worst top-k error %.2e" % (name, lrel, int(clean.sum()), R, wn, wt))
+    assert not bad, bad
 
 
 def test_larger_chunk_against_oracle_bf16_and_fp32():

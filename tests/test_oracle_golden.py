@@ -11,7 +11,8 @@ def _cfg(g):
     return base(**g.cfg_kwargs())
 
 
-@pytest.mark.parametrize("name", CASES)
+# (+ the two trainable generic-ResnetFC cases of round 6: BASELINE configs[0]'s 1 x 128 net and a 2 x 64 net, with the reference's autograd)
+@pytest.mark.parametrize("name", CASES + ["c1_train_r256_n64", "generic_train_2x64_r96"])
 def test_oracle_matches_reference_outputs_and_grads(name):
     g = Golden(name)
     cfg = _cfg(g)
