@@ -143,7 +143,8 @@ def parse():
                          "capture and its clocks take a few hundred ms of load to settle (20 timed steps right after 5 warm-ups measure "
                          "2-4 %% slower than the 300-step steady_state of the same process); 0 = rounds 1-3 behaviour")
     ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE",
-                    help="development: set a module-level knob of scenerf_amd before the run, e.g. --set renderer.PREFILL_AT=3")
+                    help="development: set a module-level knob (or class attribute) of scenerf_amd before the run, e.g. --set renderer.PREFILL_AT=3, "
+                         "--set model.SceneRF.share_image_sessions=False")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed region (no eager / other-entry / drop-in / steady-state / roofline legs): what a profiler should see")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short BASELINE configs[3] (BundleFusion) and configs[4] (inference) legs")
@@ -158,8 +159,11 @@ def parse():
     for kv in a.set:
         import ast, importlib
         path, val = kv.split("=", 1)
-        modname, attr = path.rsplit(".", 1)
-        setattr(importlib.import_module("scenerf_amd." + modname), attr, ast.literal_eval(val))
+        parts = path.split(".")           # module[.Class].ATTR
+        obj = importlib.import_module("scenerf_amd." + parts[0])
+        for name in parts[1:-1]:
+            obj = getattr(obj, name)
+        setattr(obj, parts[-1], ast.literal_eval(val))
     if a.headline_only:
         a.no_roofline = a.no_extra_legs = a.no_cpu_baseline = a.no_eager_baseline = a.no_fp32_mode = True
     if a.steps is None:
@@ -1005,6 +1009,10 @@ def main():
         model, maps, K, T, pix, opt = _StubModel(rank), {}, None, None, None, None
     else:
         model = make_model(args, dev)
+        # one source frame per step in every leg of this model: each step is a new image for the renderer.  The cache of converted maps
+        # that serves the further source frames of ONE image (SceneRF.cache_converted_maps) would hit on the static bench maps every step:
+        # off here, on (the default) in the trainer's multi-source leg
+        model.cache_converted_maps = False
         params = list(model.mlp.parameters()) + list(model.mlp_gaussian.parameters())
         opt = make_optimizer(args, params)
         maps = _make_maps(args.maps, dev, rank)

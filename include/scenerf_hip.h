@@ -189,6 +189,10 @@ const char* scenerf_hip_last_error(void);
  * issuing eagerly: the capture's error otherwise stays behind as the last error and the next entry point of this library -- each checks
  * hipGetLastError() behind its launches -- reports it for a launch that succeeded. */
 int scenerf_hip_clear_last_error(void);
+/* The id of the stream capture `stream` is recording into, 0 when it is not capturing.  For host-side caches of device buffers: a buffer
+ * written inside a capture lives in that graph's memory and only has its contents during a replay, so a cache entry made under capture id
+ * X may be reused under X only (scenerf_amd/renderer.py: the converted feature maps of one image, shared by its S source frames). */
+int scenerf_hip_stream_capture_id(scenerf_stream_t stream, unsigned long long* id);
 
 /* One-time setup for the CURRENT device (hipSetDevice) and this configuration: kernel attributes (dynamic LDS sizes), the chunk-descriptor
  * tables of the fused ResnetFC kernels (uploaded asynchronously on `stream`), the zero page.  Every entry point does this lazily on

@@ -95,6 +95,15 @@ int scenerf_hip_abi_version(void) { return SCENERF_HIP_ABI_VERSION; }
 // point of this library checks hipGetLastError() behind its launches and would report that stale error for a launch that succeeded.
 // Whoever catches a failed capture and carries on eagerly (scenerf_amd.graph.build_on_all_ranks) clears it here.  Returns the code.
 int scenerf_hip_clear_last_error(void) { return (int)hipGetLastError(); }
+int scenerf_hip_stream_capture_id(scenerf_stream_t stream, unsigned long long* id) {
+    SRF_CHECK(id, "stream_capture_id: id is null");
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    hipError_t e = hipStreamGetCaptureInfo(as_stream(stream), &st, &cid);
+    SRF_CHECK(e == hipSuccess, "stream_capture_id: hipStreamGetCaptureInfo failed");
+    *id = st == hipStreamCaptureStatusActive ? (cid ? cid : ~0ull) : 0ull;
+    return 0;
+}
 const char* scenerf_hip_last_error(void) { return g_err; }
 
 int scenerf_hip_profile_enable(int on) {

@@ -386,13 +386,30 @@ class SceneRF(TrainingMixin, _Base):
         cfg = self.render_cfg
         cfg.som_sigma = float(self.ray_som.som_sigma)
         inv_K = self._inv_K(cam_K)
-        sess = RenderSession(cfg, x_rgb, self.mlp.ordered_params(), self.mlp_gaussian.ordered_params(),
-                             grad_sync=self.grad_sync, grad_sync_async=self.grad_sync_async, debug_aux=self.debug_aux,
-                             rng=self._device_rng_state(sampled_pixels.device) if (cfg.device_rng and noise is None) else None,
-                             events=self.__dict__.setdefault("_step_events", {}))
+        rng = self._device_rng_state(sampled_pixels.device) if (cfg.device_rng and noise is None) else None
+        # Inside the trainer's forward (training.TrainingMixin._params_fixed: no optimizer step in there, ONE backward over the returned
+        # total) the S trained renders of an image share one session, and so do its S metric-only renders: maps converted once, operands
+        # packed once, and -- the part the caches above cannot give -- ONE set of gradient accumulators: every source frame's backward adds
+        # into the same map-gradient and parameter-gradient sinks, handed to autograd once (no per-source zero fill / transpose back /
+        # unpack, no AccumulateGrad additions of 420 MB maps and 40 parameter tensors; N > 1: one gradient all-reduce per image instead
+        # of one per source frame).  A session renders chunks of any pose (RenderSession.render_chunk), which is all this needs
+        shared, skey, sess = self.__dict__.get("_image_sessions"), None, None
+        if shared is not None and not self.debug_aux and self.share_image_sessions:
+            skey = self._session_key(cfg, x_rgb, rng, sampled_pixels.device)
+            sess = shared.get(skey)
+        reused = sess is not None
+        if sess is None:
+            sess = RenderSession(cfg, x_rgb, self.mlp.ordered_params(), self.mlp_gaussian.ordered_params(),
+                                 grad_sync=self.grad_sync, grad_sync_async=self.grad_sync_async, debug_aux=self.debug_aux, rng=rng,
+                                 events=self.__dict__.setdefault("_step_events", {}),
+                                 convert_cache=self.__dict__.setdefault("_convert_cache", {}) if self.cache_converted_maps else None,
+                                 pack_cache=self.__dict__.get("_pack_cache"))
+            if skey is not None:
+                shared[skey] = sess
         outs, auxs = [], []
         n = sampled_pixels.shape[0]
-        sess.mlpg.single_chunk = n <= ray_batch_size   # training (scenerf.py:262-275): lets the head's gradient all-reduce start early
+        # training (scenerf.py:262-275), one chunk in the whole session: lets the head's gradient all-reduce start early
+        sess.mlpg.single_chunk = (n <= ray_batch_size) and not reused
         for s in range(0, n, ray_batch_size):
             e = min(s + ray_batch_size, n)
             nu = noise[0][s:e] if noise is not None else None
@@ -409,7 +426,22 @@ class SceneRF(TrainingMixin, _Base):
             ret = {k: torch.cat([o[k] for o in outs], dim=0) for k in outs[0]}
         return {k: ret[k] for k in OUTPUT_KEYS}
 
+    share_image_sessions = True     # see render_rays_batch: only ever in effect inside training.TrainingMixin.forward
+
+    def _session_key(self, cfg, x_rgb, rng, dev):
+        from . import _capi
+        import ctypes
+        cid = ctypes.c_ulonglong(0)
+        _capi.check(_capi.load().scenerf_hip_stream_capture_id(torch.cuda.current_stream(dev).cuda_stream, ctypes.byref(cid)), "stream_capture_id")
+        from .renderer import HWC
+        ts = [(k, v.t if isinstance(v, HWC) else v) for k, v in sorted(x_rgb.items())]
+        maps = tuple((k, id(v), v._version, v.data_ptr()) for k, v in ts)
+        return (torch.is_grad_enabled(), float(cfg.som_sigma), cid.value, None if rng is None else rng.data_ptr(), maps)
+
     # ---- full-frame inference (BASELINE.json configs[4]) -------------------------------------------------------------------------
+    # keep the (H,W,C) copies of the last image's contiguous (C,H,W) maps between calls (keyed by tensor identity + version counter): the S
+    # source frames of one image convert once.  Costs the copies' memory (210 MB in bf16 at KITTI) until the next image replaces them
+    cache_converted_maps = True
     static_inference = True     # no_grad multi-chunk render_rays_batch calls go through render_image (padded static chunks + hipGraph)
     inference_graph = True      # replay a captured hipGraph per chunk (False: the same static chunks, launched eagerly)
 

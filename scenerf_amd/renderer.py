@@ -178,6 +178,10 @@ class MapHolder:
         self._gflat: Optional[torch.Tensor] = None      # the one allocation the five accumulators are views of
         self.debug_aux: Optional[Dict[str, torch.Tensor]] = None   # dict when the session was opened with debug_aux=True
         self.rng: Optional[torch.Tensor] = None     # device int64 [3] {seed, calls, scratch}: in-kernel sampler noise (device_rng sessions)
+        # caller-owned dict (the model's): the converted (H,W,C) copies of the last image's maps, keyed by the source tensors' identity and
+        # version counters -- the S source frames of one image (scenerf.py:154-156: x_rgb is made once per image, rendered from S poses, plus
+        # the metric-only renders) then convert once instead of 2 S times (0.15 ms of 420 MB layout conversion per call)
+        self.convert_cache: Optional[dict] = None
 
     def convert(self, chw: Sequence[torch.Tensor]) -> None:
         """Also serves as the refresh of a long-lived session (inference.ImageRenderer): a second call writes into the SAME converted
@@ -205,9 +209,31 @@ class MapHolder:
             if i in self.cfg.direct_scales:
                 dst = self._in_place(src, old, i)   # read in place, (C,H,W) fp32 (RenderConfig.direct_scales)
             else:
-                dst = old[i] if old is not None else torch.empty((h, w, c), dtype=_act_dtype(prec), device=src.device)
-                _capi.check(lib.scenerf_hip_maps_chw_to_hwc(src.data_ptr(), dst.data_ptr(), c, h, w, prec, _stream(src.device)),
-                            "maps_chw_to_hwc")
+                hit = None
+                # (keyed on the caller's tensor; `src` is it, or its detached alias -- a converted temporary has no identity to key on)
+                cacheable = old is None and self.convert_cache is not None and src.data_ptr() == t.data_ptr() and t.dtype is torch.float32
+                if cacheable:
+                    # the capture this stream records into (0: none).  A buffer converted inside a capture is graph memory that only
+                    # holds the maps during a replay: its entry is reused by the later render calls of the SAME capture (the trainer's
+                    # per-image step under graph.GraphedFn) and by nothing else
+                    cid = C.c_ulonglong(0)
+                    _capi.check(lib.scenerf_hip_stream_capture_id(_stream(src.device), C.byref(cid)), "stream_capture_id")
+                    ckey = (prec, cid.value)
+                    ent = self.convert_cache.get(i)
+                    if ent is not None and ent[0] is t and ent[1] == t._version and ent[2] == t.data_ptr() and ent[3] == ckey \
+                            and tuple(ent[4].shape) == (h, w, c):
+                        hit = ent[4]
+                if hit is not None:
+                    # (the conversion that made it ran on a stream the current one has been ordered behind: both are this device's
+                    #  current stream of the same caller thread, or the entry's event says so)
+                    torch.cuda.current_stream(src.device).wait_event(ent[5])
+                    dst = hit
+                else:
+                    dst = old[i] if old is not None else torch.empty((h, w, c), dtype=_act_dtype(prec), device=src.device)
+                    _capi.check(lib.scenerf_hip_maps_chw_to_hwc(src.data_ptr(), dst.data_ptr(), c, h, w, prec, _stream(src.device)),
+                                "maps_chw_to_hwc")
+                    if cacheable:
+                        self.convert_cache[i] = (t, t._version, t.data_ptr(), ckey, dst, torch.cuda.current_stream(src.device).record_event())
             self.hwc.append(dst)
             self.shapes.append((c, h, w))
 
@@ -302,7 +328,9 @@ class PrepareMaps(torch.autograd.Function):
     def forward(ctx, holder: MapHolder, *chw):
         holder.convert(chw)
         ctx.holder = holder
-        if any(ctx.needs_input_grad[1:]):
+        # (needs_input_grad is the tensors' requires_grad whatever the grad mode: a metric-only render under torch.no_grad() of maps that
+        #  are trained elsewhere in the step must not zero 420 MB of accumulators nobody will read)
+        if any(ctx.needs_input_grad[1:]) and getattr(holder, "grad_mode", True):
             if PREFILL_AT == 0:
                 holder.prefill_grad_accumulators()
             else:
@@ -423,6 +451,7 @@ class PackedMLP:
         self._pack_stream = pack_stream
         self._split = bool(split and pack_stream is not None and prec == 1)
         self._pending = None
+        self._packed_ev = None           # event behind the complete pack (set by launch_pack / below)
         if pack_stream is not None:
             # the parameters were last written on the current stream: an event HERE, so that a deferred launch does not also wait for
             # the kernels the current stream is given in between
@@ -482,6 +511,7 @@ class PackedMLP:
             self._pending = (ccfg, pack_stream, params_written, done)
             return
         self._pending = None
+        self._packed_ev = self._ready_rest if self._ready_rest is not None else self._ready    # (kept: a later session that reuses the operands)
         # if no consumer ever waits on the event (exception, graph dropped): the allocator must not hand these blocks to a tenant of
         # another stream while the pack is still pending
         for t in (self.gflat, self.act_buf, self.f32_buf):
@@ -721,6 +751,13 @@ class MlpHolder:
         self.defer_pack = False      # pack on the side stream (the radiance MLP: first used after the gaussian head's chain)
         self.split_pack = False      # ... in two calls, a forward's operands first (the gaussian head: its forward is the step's first GEMM)
         self.grad_mode = True        # torch.is_grad_enabled() where the session was opened (inside Function.forward it is always off)
+        self.pack_cache: Optional[dict] = None   # caller-owned, valid while the parameters cannot change (one trainer forward): see PackMLP
+
+
+def _pack_key(params, cfg, dev):
+    cid = C.c_ulonglong(0)
+    _capi.check(_capi.load().scenerf_hip_stream_capture_id(_stream(dev), C.byref(cid)), "stream_capture_id")
+    return (cfg.precision_code, cid.value, tuple((id(t), t._version, t.data_ptr()) for t in params))
 
 
 class PackMLP(torch.autograd.Function):
@@ -735,7 +772,27 @@ class PackMLP(torch.autograd.Function):
             holder.packed = GenericPackedMLP(params, d_out, cfg, trainable=bool(holder.grad_mode))
             ctx.holder = holder
             return torch.empty(1, device=params[0].device)
+        cache, key = holder.pack_cache, None
+        if cache is not None:
+            # the trainer's per-image step opens 2 S sessions on the same parameters (S trained renders, S metric-only renders under
+            # no_grad: scenerf.py:154-201): a metric-only session reads the operands the last session packed instead of packing them
+            # again (3 + 3 launches, 44 MB written per session).  Only inside the caller's scope (training.TrainingMixin.forward: no
+            # optimizer step in there), and still keyed by tensor identity, version counter, address and stream capture
+            key = _pack_key(params, cfg, params[0].device)
+            ent = cache.get(d_out)
+            if not holder.grad_mode and ent is not None and ent[0] == key:
+                pk = ent[1]
+                pk.launch_pack()
+                if pk._packed_ev is not None:
+                    torch.cuda.current_stream(pk.device).wait_event(pk._packed_ev)
+                holder.packed = pk
+                ctx.holder = holder
+                return torch.empty(1, device=params[0].device)
         holder.packed = PackedMLP(params, d_out, cfg, pack_stream=side, defer=CHAIN_FIRST, split=CHAIN_FIRST and holder.split_pack)
+        if cache is not None:
+            if side is None:
+                holder.packed._packed_ev = torch.cuda.current_stream(params[0].device).record_event()
+            cache[d_out] = (key, holder.packed)
         ctx.holder = holder
         return torch.empty(1, device=params[0].device)   # autograd token: its value is never read (no fill launch)
 
@@ -1194,7 +1251,8 @@ class RenderSession:
 
     def __init__(self, cfg: RenderConfig, x_rgb: Dict[str, torch.Tensor], mlp_params: Sequence[torch.Tensor],
                  mlpg_params: Sequence[torch.Tensor], grad_sync=None, grad_sync_async=None, debug_aux: bool = False,
-                 rng: Optional[torch.Tensor] = None, events: Optional[dict] = None):
+                 rng: Optional[torch.Tensor] = None, events: Optional[dict] = None, convert_cache: Optional[dict] = None,
+                 pack_cache: Optional[dict] = None):
         """``events``: a caller-owned dict; a training session's backward leaves ``events["param_grads_ready"]`` there -- an event of the
         backward's stream behind which BOTH MLPs' parameter gradients are complete (the feature-map gradients may still be running on
         the side stream: whoever reads them goes through PrepareMaps.backward, which waits)."""
@@ -1203,6 +1261,8 @@ class RenderSession:
             cfg = dataclasses.replace(cfg, hwc_scales=hwc, direct_scales=tuple(i for i in cfg.direct_scales if i not in hwc))
         _require_cuda(chw[0], "x_rgb map 0")
         self.device = chw[0].device
+        self._convert_cache = convert_cache
+        self._pack_cache = pack_cache        # see PackMLP.forward: only a caller inside which the parameters cannot change passes one
         with _on(self.device):
             self._open(cfg, chw, mlp_params, mlpg_params, grad_sync, grad_sync_async, debug_aux)
         if rng is not None:
@@ -1242,12 +1302,15 @@ class RenderSession:
         # stream sets up the rays and gathers the head's features (~55 us before its first GEMM), the radiance MLP's behind them
         # (first read ~0.3 ms into the step).  The side stream runs them in this order: head, then radiance MLP.
         self.mlp.grad_mode = self.mlpg.grad_mode = torch.is_grad_enabled()
+        self.mlp.pack_cache = self.mlpg.pack_cache = self._pack_cache
         self.mlp.defer_pack = True
         self.mlpg.defer_pack = DEFER_HEAD_PACK
         self.mlpg.split_pack = SPLIT_HEAD_PACK
         self.tok_mlpg = PackMLP.apply(self.mlpg, 2, cfg, *mlpg_params)
         self.tok_mlp = PackMLP.apply(self.mlp, 4, cfg, *mlp_params)
         self.maps = MapHolder(cfg)
+        self.maps.convert_cache = self._convert_cache
+        self.maps.grad_mode = torch.is_grad_enabled()
         if debug_aux:
             self.maps.debug_aux = {}
         self.tok_maps = PrepareMaps.apply(self.maps, *chw)

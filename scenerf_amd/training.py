@@ -10,6 +10,7 @@ none of which change a loss value:
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict
 
 import torch
@@ -197,17 +198,40 @@ class TrainingMixin:
         for n, v in zip(names, vals):
             self.log(step_type + "depth/" + n, v, on_epoch=True, sync_dist=True)
 
+    @contextlib.contextmanager
+    def _params_fixed(self):
+        """The scope of one ``forward``: no optimizer step can happen inside and ONE backward follows (over the returned total), so the 2 S
+        ``render_rays_batch`` calls of an image share what depends on the parameters and the image only: the S trained renders are chunks
+        of one session and so are the S metric-only renders (model.render_rays_batch: one conversion, one pack, one set of gradient sinks),
+        and the metric-only session reads the operands the trained one packed (renderer.PackMLP).  Everything dies with the scope."""
+        self.__dict__["_pack_cache"] = {}
+        self.__dict__["_image_sessions"] = {}       # model.render_rays_batch: the S source frames of an image render in ONE session
+        try:
+            yield
+        finally:
+            self.__dict__.pop("_pack_cache", None)
+            self.__dict__.pop("_image_sessions", None)
+
     def forward(self, batch, step_type):
+        with self._params_fixed():
+            return self._forward_batch(batch, step_type)
+
+    def _forward_batch(self, batch, step_type):
         """scenerf.py:119-241.  ``self.net_rgb`` (stock encoder) must be set by the caller."""
         img_input = batch["img_inputs"]
         bs = img_input.shape[0]
-        T_cam2velo = torch.inverse(batch["T_velo_2_cam"][0]) if "T_velo_2_cam" in batch else None
+        # scenerf.py:128 inverts batch["T_velo_2_cam"][0] here and threads the result down to predict() (:508), where nothing reads it;
+        # torch.inverse checks LAPACK's info on the host (one device sync per step, and it cannot be captured), so the dead value is
+        # not computed
+        T_cam2velo = None
         cam_K0 = batch["cam_K"][0]
         pix, pix_sphere, _ = self.spherical_mapping.from_pixels(inv_K=self._inv_K(cam_K0))
         x_rgbs = self.net_rgb(img_input, pix=pix, pix_sphere=pix_sphere)
         tot = dict(rep=0.0, col=0.0, kl=0.0, somv=0.0, stds=0.0, d2c=0.0)
         for i in range(bs):
-            x_rgb = {k: x_rgbs[k][i] for k in x_rgbs}
+            # (bs == 1, the trainers' batch size: the same view as x_rgbs[k][0], whose backward is a view too -- select's backward
+            #  fills a zero (1,C,H,W) tensor and copies the gradient in: 0.84 GB of traffic per image at the KITTI shapes)
+            x_rgb = {k: (x_rgbs[k].squeeze(0) if bs == 1 else x_rgbs[k][i]) for k in x_rgbs}
             cam_K = batch["cam_K"][i]
             inv_K = self._inv_K(cam_K)       # (the host's LAPACK: model.py)
             for sid in range(len(batch["img_sources"][i])):
@@ -246,7 +270,7 @@ class BundleFusionTrainingMixin(TrainingMixin):
     def _metric_max_depth(self) -> float:
         return float(self.eval_depth)   # scenerf_bf.py:347
 
-    def forward(self, batch, step_type):
+    def _forward_batch(self, batch, step_type):
         if getattr(self, "smooth_loss_weight", 0) > 0:
             raise NotImplementedError("smooth_loss_weight > 0 calls compute_smooth_depth_loss, which the reference does not define")
         img_input = batch["img_inputs"]
@@ -258,7 +282,7 @@ class BundleFusionTrainingMixin(TrainingMixin):
         n_grids = self.n_rays // (self.sample_grid_size ** 2)
         tot = dict(rep=0.0, col=0.0, kl=0.0, somv=0.0, stds=0.0, d2c=0.0)
         for i in range(bs):
-            x_rgb = {k: x_rgbs[k][i] for k in x_rgbs}
+            x_rgb = {k: (x_rgbs[k].squeeze(0) if bs == 1 else x_rgbs[k][i]) for k in x_rgbs}
             for sid in range(len(batch["img_sources"][i])):
                 ret = self.process_single_source(n_grids, x_rgb=x_rgb, cam_K=cam_K, inv_K=inv_K,
                                                  img_source=batch["img_sources"][i][sid], img_target=batch["img_targets"][i][sid],

@@ -404,8 +404,58 @@ def test_graphed_fn_replays_the_trainers_multi_source_step():
     spread = _rel(pa, pb)
     rel = _rel(pa, [p.detach() for p in opt.param_groups[0]["params"]])
     assert rel <= 3 * spread + 2e-4, (spread, rel, la, got)
-    assert abs(got[-1] - la[-1]) <= 3 * abs(lb[-1] - la[-1]) + 2e-3 * (1 + abs(la[-1])), (la, lb, got)
+    # (the loss itself is a noisy observer: per-pixel min(reprojection, identity) over bf16 renders -- five runs of the same eager steps
+    #  gave 1.0065 .. 1.0094 at the fifth step, replays 1.0041 .. 1.0085 (tools/trainer_cache_probe.py); a replay that drew OTHER pixels or
+    #  noise than the eager step would be off by the step-to-step scale, 0.98 .. 1.11)
+    assert abs(got[-1] - la[-1]) <= 3 * abs(lb[-1] - la[-1]) + 1.5e-2 * (1 + abs(la[-1])), (la, lb, got)
+    assert max(abs(a - b) for a, b in zip(got, la[W:])) <= 3e-2, (la, got)
     assert all(v.grad is not None and bool(torch.isfinite(v.grad).all()) for v in maps.values())
+
+
+def test_the_trainers_metric_only_sessions_reuse_the_packed_operands_of_the_step_and_nothing_older():
+    """training.TrainingMixin.forward opens a scope in which the parameters cannot change and after which one backward runs: the S trained
+    renders of the image are chunks of ONE session (shared gradient sinks), the S metric-only renders of another, which reads the operands
+    the first packed (model.render_rays_batch, renderer.PackMLP).  Same first-step gradients (to the atomics' order), the same logged
+    metrics bit for bit, the same loss as without the scope; the scope ends with ``forward`` (a no_grad render after an optimizer step
+    packs again: it sees the new weights)."""
+    import contextlib
+
+    def run(scoped):
+        m, opt, maps, batch = _trainer_setup(47)
+        logged = {}
+        m.log = lambda name, v, **k: logged.setdefault(name, []).append(v.detach().clone() if torch.is_tensor(v) else v)
+        if not scoped:
+            m._params_fixed = contextlib.nullcontext
+        first = None
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            for v in maps.values():
+                v.grad = None
+            loss = m.step(batch, "train")
+            loss.backward()
+            if first is None:      # the first step's gradients: same parameters, same pixels and noise in both runs
+                first = [p.grad.detach().clone() for p in opt.param_groups[0]["params"]] + [maps[k].grad.detach().clone() for k in sorted(maps)]
+            opt.step()
+        assert "_pack_cache" not in m.__dict__ and "_image_sessions" not in m.__dict__
+        with torch.no_grad():
+            after = m.render_rays_batch(batch["cam_K"][0], batch["T_source2infers"][0][0], {k: v.detach() for k, v in maps.items()},
+                                        sampled_pixels=batch["loc2d_with_depths"][0][0], ray_batch_size=256)["depth"].clone()
+        torch.cuda.synchronize()
+        return float(loss.detach()), logged, after, first
+
+    la, ga, aa, fa = run(True)
+    lb, gb, ab, fb = run(False)
+    # one session per image (S source frames accumulate into the same sinks) against one session per source frame + autograd's additions
+    for x, y in zip(fa, fb):
+        assert float((x - y).abs().max()) <= 2e-3 * float(y.abs().max()) + 1e-12, (x.shape, float((x - y).abs().max()), float(y.abs().max()))
+    metric = lambda k: k.rsplit("/", 1)[-1] in ("abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3")      # noqa: E731
+    assert set(ga) == set(gb) and any(metric(k) for k in ga)
+    for k in ga:
+        if metric(k):      # the metric-only renders (evaluate_depth): same operands, same kernels -> identical
+            # (the first step's: the second step's parameters already carry the run-to-run order of the first backward's atomics)
+            assert len(ga[k]) == 4 and all(torch.equal(x, y) for x, y in zip(ga[k][:2], gb[k][:2])), k
+    assert abs(la - lb) <= 2e-3 * (1 + abs(lb))      # (the trained sessions are untouched; run-to-run atomics order through two AdamW steps)
+    assert float((aa - ab).abs().max()) <= 2e-2 * float(ab.abs().max())
 
 
 def test_a_failed_capture_leaves_a_process_that_can_step_eagerly():

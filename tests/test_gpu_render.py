@@ -1153,3 +1153,62 @@ def test_render_image_n512_at_the_benched_chunk_against_the_oracle():
     # N = 512): depth rel 3.5e-2 on the chunk's later rays, 5e-5 on its first ones
     assert float(rel.max()) < 4.5e-4 and float(rel.median()) < 8e-5, (float(rel.max()), float(rel.median()))
     assert float(cerr.max()) < 2e-4, float(cerr.max())
+
+
+@pytest.mark.gpu
+def test_converted_maps_are_reused_for_the_same_tensors_and_follow_their_version_counters():
+    """SceneRF.cache_converted_maps (round 6): the S source frames of one image hand the SAME (C,H,W) map tensors to render_rays_batch
+    (scenerf.py:154-156) -- their (H,W,C) copies are made once and reused, keyed by tensor identity and version counter: a second call
+    on the same tensors reuses the buffers (same result), an in-place edit of a map is seen by the next call (same result as a model
+    without the cache)."""
+    from scenerf_amd import synth
+    kw = dict(sphere_W=376, sphere_H=114, n_pts_uni=32, n_pts_per_gaussian=8)
+    R = 64
+    mlp, mlpg = synth.mlp_state(41, 4), synth.mlp_state(42, 2, out_scale=4.0)
+    maps = {k: v.to(DEV) for k, v in synth.feature_maps(376, 114, 43, smooth=False).items()}
+    pix = synth.stride2_pixels((1220, 370), R, 44).to(DEV)
+    nu, ng = synth.sampling_noise(R, 32, 32, 45)
+    K, T = synth.kitti_cam_K().to(DEV), synth.rel_pose(2.0, 10.0).to(DEV)
+
+    def model(cache):
+        m = SceneRF(som_sigma=2.0, std=2.0, add_fov_hor=20, add_fov_ver=8, precision="bf16", **kw).to(DEV)
+        m.mlp.load_state_dict(mlp)
+        m.mlp_gaussian.load_state_dict(mlpg)
+        m.cache_converted_maps = cache
+        return m
+
+    def render(m):
+        with torch.no_grad():
+            return m.render_rays_batch(K, T, maps, sampled_pixels=pix, ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
+
+    m = model(True)
+    o1 = render(m)
+    bufs = {i: e[4] for i, e in m._convert_cache.items()}
+    assert bufs, "no level was converted (all read in place?)"
+    o2 = render(m)
+    assert all(m._convert_cache[i][4] is b for i, b in bufs.items())              # the same converted buffers: no second conversion
+    assert all(torch.equal(o1[k], o2[k]) for k in OUT_KEYS)
+    with torch.no_grad():
+        maps["1_1"].mul_(0.5)                                                     # new values in the same tensor: its version moved
+    o3 = render(m)
+    assert m._convert_cache[0][4] is not bufs[0] or m._convert_cache[0][1] != 0
+    ref = render(model(False))
+    assert all(torch.equal(o3[k], ref[k]) for k in OUT_KEYS)
+    assert not torch.equal(o3["color"], o1["color"])
+
+    # the trained sessions of one image (maps that require grad, autograd on): converted once, each session's map gradients its own
+    def trained(m):
+        mg = {k: v.clone().requires_grad_(True) for k, v in maps.items()}
+        tot = 0.0
+        for j in range(2):
+            o = m.render_rays_batch(K, T, mg, sampled_pixels=pix, ray_batch_size=R, noise=(nu.to(DEV), ng.to(DEV)))
+            if j == 0 and m.cache_converted_maps:
+                first = {i: e[4] for i, e in m._convert_cache.items()}
+            tot = tot + o["depth"].mean() + o["color"].mean()
+        if m.cache_converted_maps:
+            assert first and all(m._convert_cache[i][4] is b for i, b in first.items())
+        tot.backward()
+        return {k: v.grad for k, v in mg.items()}
+    ga, gb = trained(model(True)), trained(model(False))
+    for k in ga:
+        assert float((ga[k] - gb[k]).abs().max()) <= 1e-3 * float(gb[k].abs().max()) + 1e-12, k
