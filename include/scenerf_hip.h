@@ -383,6 +383,15 @@ int scenerf_hip_source_loss_backward(const float* color, const float* col_src, c
                                      int R, int G, float w_rep, float w_col, float w_d2c, float* g_color, float* g_depth, float* g_loss_kl,
                                      float* g_gmeans, scenerf_stream_t stream);
 
+/* The depth metrics of one evaluation (reference scenerf/loss/depth_metrics.py:3-24, called per source frame from scenerf.py:322-346 /
+ * scenerf_bf.py:340-366): pred clamped to [min_depth, max_depth], then abs_rel, sq_rel, rmse, rmse_log and the three threshold
+ * accuracies (max(gt/pred, pred/gt) < 1.25^k) as means over the n entries -- over the entries with mask[i] != 0 when mask is given (bytes;
+ * == the reference's gt[mask], pred[mask]; an empty selection gives zeros).  out8 (device fp32 [8]) = {abs_rel, sq_rel, rmse, rmse_log,
+ * a1, a2, a3, number of entries used}.  One launch of one block, sums in double in a fixed order (no atomics): replaces ~35 elementwise /
+ * reduction launches per source frame of the trainer's step. */
+int scenerf_hip_depth_errors(const float* gt, const float* pred, const unsigned char* mask /* nullable */, int64_t n, float min_depth,
+                             float max_depth, float* out8, scenerf_stream_t stream);
+
 /* ---- ResnetFC of any shape, forward only (fp32) ---------------------------------------------------------------- */
 /* resnetfc.py:67-164 is generic in n_blocks / d_hidden; SceneRF instantiates 3 x 512 (scenerf.py:100-114) and the fast kernels above are
  * built for that.  BASELINE.json configs[0] names a 1-block, 128-wide net: this entry evaluates ANY ResnetFC(d_in=42, d_latent=2480) on the

@@ -258,6 +258,50 @@ __global__ __launch_bounds__(256) void source_loss_bwd_kernel(const float* color
     }
 }
 
+// ---- depth metrics of one evaluation (loss/depth_metrics.py:3-24): the seven means in one launch of one block ------------------------
+#define DM_THREADS 1024
+__global__ __launch_bounds__(DM_THREADS) void depth_errors_kernel(const float* __restrict__ gt, const float* __restrict__ pred,
+                                                                  const unsigned char* __restrict__ mask, long long n, float min_depth,
+                                                                  float max_depth, float* __restrict__ out) {
+    __shared__ double s_part[DM_THREADS / 64][8];
+    // {abs_rel, sq_rel, (gt - pred)^2, (log gt - log pred)^2, [thresh < 1.25], [< 1.25^2], [< 1.25^3], count}: per-thread sums in double
+    double t[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+    const float th1 = 1.25f, th2 = 1.25f * 1.25f, th3 = 1.25f * 1.25f * 1.25f;
+    for (long long i = threadIdx.x; i < n; i += DM_THREADS) {
+        if (mask && !mask[i]) continue;
+        const float g = gt[i];
+        const float p = fminf(fmaxf(pred[i], min_depth), max_depth);
+        const float d = g - p, thr = fmaxf(g / p, p / g), dl = logf(g) - logf(p);
+        t[0] += (double)(fabsf(d) / g); t[1] += (double)(d * d / g); t[2] += (double)(d * d); t[3] += (double)(dl * dl);
+        t[4] += thr < th1 ? 1. : 0.; t[5] += thr < th2 ? 1. : 0.; t[6] += thr < th3 ? 1. : 0.; t[7] += 1.;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        double v = t[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        t[k] = v;
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_part[wv][k] = t[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a[8];
+        for (int k = 0; k < 8; ++k) {
+            a[k] = 0.;
+            for (int w = 0; w < DM_THREADS / 64; ++w) a[k] += s_part[w][k];
+        }
+        const double den = a[7] > 1. ? a[7] : 1.;      // (an empty mask: all zeros, where the reference skips the logging)
+        out[0] = (float)(a[0] / den); out[1] = (float)(a[1] / den);
+        out[2] = (float)sqrt(a[2] / den); out[3] = (float)sqrt(a[3] / den);
+        out[4] = (float)(a[4] / den); out[5] = (float)(a[5] / den); out[6] = (float)(a[6] / den);
+        out[7] = (float)a[7];
+    }
+}
+
 extern "C" {
 
 int scenerf_hip_loss_side_forward(const float* pix, const float* color, const float* depth, const float* img_source,
@@ -333,6 +377,16 @@ int scenerf_hip_source_loss_backward(const float* color, const float* col_src, c
     source_loss_bwd_kernel<<<cdiv(R, 256), 256, 0, s>>>(color, col_src, valid, dterm_ddepth, gmeans, depth, closest, out8, g_total, R, G, w_rep,
                                                          w_col, w_d2c, g_color, g_depth, g_loss_kl, g_gmeans);
     SRF_LAUNCH_CHECK("source_loss_bwd_kernel");
+    return 0;
+}
+
+int scenerf_hip_depth_errors(const float* gt, const float* pred, const unsigned char* mask, int64_t n, float min_depth, float max_depth,
+                             float* out8, scenerf_stream_t stream) {
+    SRF_CHECK(gt && pred && out8 && n >= 0, "depth_errors: bad args");
+    hipStream_t s = as_stream(stream);
+    SrfLaunchScope ps(s, "depth_errors", 0, (double)n * 9);
+    depth_errors_kernel<<<1, DM_THREADS, 0, s>>>(gt, pred, mask, (long long)n, min_depth, max_depth, out8);
+    SRF_LAUNCH_CHECK("depth_errors_kernel");
     return 0;
 }
 

@@ -30,6 +30,19 @@ def depth_errors(gt: torch.Tensor, pred: torch.Tensor, min_depth: float = 1e-3, 
     """loss/depth_metrics.py:3-24 on device: abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3.  With ``mask`` the means run over the
     masked entries only (== the reference's ``gt[mask], pred[mask]``, without the boolean indexing's host sync; all zeros if the
     mask is empty, where the reference skips the logging)."""
+    if pred.is_cuda:
+        # one launch (csrc/loss.hip: depth_errors_kernel) instead of ~35: the trainer evaluates this once per source frame
+        from . import _capi
+        gt_, pr_ = gt.detach().reshape(-1).float().contiguous(), pred.detach().reshape(-1).float().contiguous()
+        mk = None if mask is None else mask.reshape(-1).to(torch.uint8).contiguous()
+        if gt_.numel() != pr_.numel() or (mk is not None and mk.numel() != pr_.numel()):
+            raise RuntimeError("depth_errors: gt, pred and mask must have the same number of entries")
+        out = torch.empty(8, dtype=torch.float32, device=pred.device)
+        with torch.cuda.device(pred.device):
+            _capi.check(_capi.load().scenerf_hip_depth_errors(gt_.data_ptr(), pr_.data_ptr(), _capi.ptr(mk), pr_.numel(), float(min_depth),
+                                                              float(max_depth), out.data_ptr(),
+                                                              torch.cuda.current_stream(pred.device).cuda_stream), "depth_errors")
+        return tuple(out[i] for i in range(7))
     pred = pred.clamp(min=min_depth, max=max_depth)
     if mask is None:
         mean = lambda t: t.float().mean()

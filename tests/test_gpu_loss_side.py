@@ -157,3 +157,24 @@ def test_source_loss_in_kernel_noise_is_standard_normal_and_advances():
     a = source_loss(out, *args, noise=None, noise_scale=0.0, rng_state=st)[1]
     b = source_loss(out, *args, noise=None)[1]
     assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_depth_errors_kernel_matches_the_reference_metrics_and_the_host_version():
+    """scenerf_hip_depth_errors (one launch) against (i) the metrics the reference's compute_depth_errors returned for the golden pair
+    (loss/depth_metrics.py:3-24, tests/golden/loss_side.npz) and (ii) training.depth_errors' elementwise version on the CPU for clamped
+    predictions, masks (scenerf_bf.py:201-205), an empty mask and a 300,000-entry case (one block strides over it)."""
+    from scenerf_amd.training import depth_errors
+    gt, pred = torch.from_numpy(G["depth/gt"]), torch.from_numpy(G["depth/pred"])
+    got = torch.stack(depth_errors(gt.to(DEV), pred.to(DEV))).double().cpu().numpy()
+    np.testing.assert_allclose(got, G["depth/metrics"], rtol=2e-6, atol=1e-9)
+    g = torch.Generator().manual_seed(3)
+    for n, masked, md in ((1200, False, 80.0), (1200, True, 10.0), (7, True, 80.0), (300000, True, 80.0), (64, "empty", 80.0)):
+        gt = torch.rand(n, generator=g) * 90 + 0.5
+        pred = gt * (1 + 0.3 * torch.randn(n, generator=g)) + 0.01
+        pred[::17] = 200.0
+        pred[::23] = -1.0
+        mask = None if not masked else (torch.zeros(n, dtype=torch.bool) if masked == "empty" else torch.rand(n, generator=g) > 0.4)
+        want = torch.stack(depth_errors(gt, pred, max_depth=md, mask=mask)).double().numpy()
+        got = torch.stack(depth_errors(gt.to(DEV), pred.to(DEV), max_depth=md, mask=None if mask is None else mask.to(DEV))).double().cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-7, err_msg=str((n, masked, md)))     # (fp32 means on the host, double sums in the kernel)
