@@ -71,6 +71,10 @@ MAIN_WGRAD_OVERLAP = True    # radiance MLP's weight gradients on the library's 
 DEFER_HEAD_PACK = True     # (tools/ab_step.py toggles this)
 GRADS_BEHIND_HEAD = True   # the radiance MLP's weight / feature-map gradients start only when the gaussian head's backward kernels are done
 MAP_GRADS_ON_SIDE = True   # ... and its feature-map gradients run on the side stream, unjoined until the accumulators' next consumer
+# ... also in sessions of several chunks (the trainer's S source frames per image, RenderChunk._backward): measured on the trainer's step,
+# same box, three alternations -- replayed 7.59 / 7.58 / 7.60 ms against 7.23 / 7.23 / 7.37 without, eager equal (7.46 vs 7.47): the next
+# chunk's head backward queues behind the previous chunk's scatter on the side stream and the join holds its weight gradients back.  Off.
+MAP_GRADS_ON_SIDE_MULTI = False
 SPLIT_HEAD_PACK = True     # the head's pack in two calls, its forward's operands first
 
 
@@ -308,19 +312,27 @@ class MapHolder:
         if ev is not None:
             torch.cuda.current_stream(self.hwc[0].device).wait_event(ev)
 
-    def grad_accumulators(self) -> List[torch.Tensor]:
+    def grad_accumulators(self, wait: bool = True) -> List[torch.Tensor]:
+        """``wait=False``: only the buffers (their addresses) -- for a caller that launches its scatter on the stream the previous one ran
+        on (the side stream: in order behind it) and must not pull the current stream behind the previous chunk's scatter."""
         if self.gmaps is None:
             self._alloc_gmaps(True)
-        ev, self._gmaps_ready = getattr(self, "_gmaps_ready", None), None
-        if ev is not None:
-            torch.cuda.current_stream(self.gmaps[0].device).wait_event(ev)
+        if wait:
+            ev, self._gmaps_ready = getattr(self, "_gmaps_ready", None), None
+            cur = torch.cuda.current_stream(self.gmaps[0].device)
+            # (recorded on the side stream; a consumer ON the side stream is behind it already -- and a stream waiting for its own event
+            #  inside a capture ends in a segfault of hipStreamEndCapture, ROCm 7.2: the gaussian head's backward of the NEXT chunk)
+            if ev is not None and cur != _side_stream(self.gmaps[0].device):
+                cur.wait_event(ev)
+            elif ev is not None:
+                self._gmaps_ready = ev       # still what the next consumer on another stream has to wait for
         return self.gmaps
 
     def map_ptr_array(self):
         return (C.c_void_p * 5)(*[t.data_ptr() for t in self.hwc])
 
-    def gmap_ptr_array(self):
-        return (C.c_void_p * 5)(*[t.data_ptr() for t in self.grad_accumulators()])
+    def gmap_ptr_array(self, wait: bool = True):
+        return (C.c_void_p * 5)(*[t.data_ptr() for t in self.grad_accumulators(wait)])
 
 
 class PrepareMaps(torch.autograd.Function):
@@ -949,7 +961,8 @@ def _mlp_backward(ccfg, cfg: RenderConfig, maps: MapHolder, pk: PackedMLP, run: 
     dH = torch.empty((run.M, 4 * D_H), dtype=act, device=dev)
     dN = torch.empty((3, run.M, D_H), dtype=act, device=dev)
     g = pk.grad_sink()
-    gm = C.byref(maps.gmap_ptr_array()) if want_map_grads else None
+    # (scatter on maps_stream: in that stream's order behind the previous chunk's -- the current stream does not wait for it)
+    gm = C.byref(maps.gmap_ptr_array(wait=maps_stream is None)) if want_map_grads else None
     split = (sync_async is not None or maps_stream is not None) and gm is not None
 
     def call(cc):
@@ -1188,6 +1201,8 @@ class RenderChunk(torch.autograd.Function):
         side = _side_stream(dev)
         do_head = bool(ctx.needs_input_grad[12] or want_maps)
         head_done = []
+        side_maps = bool(MAP_GRADS_ON_SIDE and want_maps and GRADS_BEHIND_HEAD and do_head and ctx.needs_input_grad[11]
+                         and (ctx.mlpg.single_chunk or MAP_GRADS_ON_SIDE_MULTI))
 
         def main_backward():
             if ctx.needs_input_grad[11] or want_maps:
@@ -1197,7 +1212,9 @@ class RenderChunk(torch.autograd.Function):
                 join = (lambda: main.wait_event(head_done[0])) if (GRADS_BEHIND_HEAD and head_done) else None
                 # MAP_GRADS_ON_SIDE (single-chunk training sessions): the weight gradients stay on THIS stream, the feature-map
                 # gradients go to the side stream (the head's backward there is over: joined above) and are not waited for here
-                on_side = MAP_GRADS_ON_SIDE and want_maps and join is not None and ctx.mlpg.single_chunk and ctx.needs_input_grad[11]
+                # (round 6, later: any number of chunks -- the S source frames of an image are chunks of one session in the trainer's step:
+                #  a chunk's scatter follows the previous chunk's on the side stream, the chain of the next chunk runs beside its tail)
+                on_side = side_maps and join is not None
                 ccm = ccfg
                 if MAIN_WGRAD_OVERLAP and not on_side:
                     ccm = type(ccfg).from_buffer_copy(ccfg)
@@ -1222,7 +1239,9 @@ class RenderChunk(torch.autograd.Function):
 
         if do_head:
             if want_maps:
-                ctx.maps.grad_accumulators()   # allocate + zero on the main stream before the fork
+                # allocate + zero on the main stream before the fork; (side_maps: every scatter of this backward is launched on the side
+                # stream, behind the previous chunk's -- the main stream has nothing to wait for)
+                ctx.maps.grad_accumulators(wait=not side_maps)
             ctx.mlpg.packed.grad_sink()
             # (the head's backward is launched FIRST here although it is not the chain: launched second it shares the replayed graph's
             #  second queue with the radiance MLP's weight gradients, and that queue runs the deeper fork's kernels first -- the head's
