@@ -343,6 +343,34 @@ def _allreduce_report(world, steps_recorded):
                     "before the feature-gradient scatter); the head's all-reduce (21.7 MB) runs in stream order on the backward's side stream"}
 
 
+def _collective_probe(world, dev, numel, reps=10):
+    """One gradient collective ON ITS OWN (the packed fp32 sink of one MLP: `numel` floats, the size both of the step's all-reduces have),
+    `reps` times back to back on the gradient communicator, every rank: per-rank us per collective and the bus bandwidth that implies
+    (2 (N-1)/N x bytes / time: the ring's per-link figure, to read against xGMI's ~153 GB/s per link).  The captured step cannot bracket
+    its collectives with events (they are graph nodes); this is the same collective outside the graph, so that a first N-GPU run says by
+    itself whether RCCL's ring -- not the step around it -- is the slow part.  A collective: every rank calls it."""
+    buf = torch.ones(numel, dtype=torch.float32, device=dev)
+    cuda = buf.is_cuda
+    sdist.allreduce_mean_(buf)                     # (first use of this size: not timed)
+    if cuda:
+        torch.cuda.synchronize()
+    torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sdist.allreduce_mean_(buf)
+    if cuda:
+        torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / reps * 1e6
+    allr = [None] * world
+    torch.distributed.all_gather_object(allr, round(us, 1))
+    worst = max(allr)
+    return {"bytes": numel * 4, "reps": reps, "us_per_collective_per_rank": allr,
+            "bus_GB_per_s": round(2 * (world - 1) / max(world, 1) * numel * 4 / (worst * 1e-6) / 1e9, 2) if worst > 0 else None,
+            "backend": torch.distributed.get_backend(),
+            "note": "the step issues two of these per source frame (gaussian head early on the side stream, radiance MLP asynchronously under "
+                    "the feature-gradient scatter); on the captured path they are graph nodes and cannot be timed in place"}
+
+
 class _StubModel:
     """--dry-run: stands in for SceneRF on a CPU/gloo process group: its step issues the renderer's collectives in the renderer's order
     through the same two hooks (grad_sync in stream order for the gaussian head, grad_sync_async started early / finished late for the
@@ -1161,6 +1189,9 @@ def main():
             step()
         allreduce = _allreduce_report(world, 3)
         sdist.TIMING = None
+        if torch.distributed.is_initialized() and torch.distributed.get_world_size() == world and (world > 1 or forced):
+            # (5,541,892 floats: renderer.PackedMLP's sink of the radiance MLP; --dry-run: the stub's 4 KiB)
+            allreduce["standalone"] = _collective_probe(world, dev, 1024 if dry else 5_541_892)
         sdist.verify_step_collectives()   # every rank issued the same number of gradient collectives (an error, not a hang, if not)
 
     roof = roof_c = None

@@ -125,6 +125,8 @@ def test_bench_control_flow_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert len(d["allreduce"]["per_rank_ms_per_step"]) == 2
+    alone = d["allreduce"]["standalone"]          # the same collective outside the step, per rank (what a first N-GPU run reads first)
+    assert len(alone["us_per_collective_per_rank"]) == 2 and all(u > 0 for u in alone["us_per_collective_per_rank"]) and alone["bytes"] == 4096
 
 
 def test_bench_falls_back_on_every_rank_when_one_capture_fails():
