@@ -354,3 +354,31 @@ def test_bench_reads_each_roofline_from_its_own_counter_file():
     assert wg and wg["kernel_fn"].startswith("wgrad_tr_kernel") and wg["bytes_per_launch"] > 1e9
     tail = bench._tail_traffic(128)
     assert tail and "_tail_" in tail["source"] and 1.0 <= tail["tail_fwd"]["ratio"] <= 1.3 and 1.0 <= tail["tail_bwd"]["ratio"] <= 1.3
+
+
+def test_roofline_min_names_the_worst_big_mfma_bound_kernel_and_the_useful_fraction_excludes_padding():
+    """bench.py::_roofline_extras (VERDICT r05 item 4): `roofline` stays the LONGEST kernel; `roofline_min` = the lowest fraction of the
+    MFMA peak among the MFMA-bound kernels above 10 % of the step -- small kernels and the atomics-bound feature-map scatter do not
+    compete, and two kernels trading the longest place do not move it; `roofline_useful_frac` prices the dominant kernel without the
+    lin_in problem's padded columns."""
+    import os
+    import sys
+    import types
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    rows = 153600
+    mk = lambda name, ms, tflops: {"name": name, "total_ms": ms, "launches": 1, "flops": tflops * 1e12 * ms * 1e-3}      # noqa: E731
+    ks = [mk("mlp_fwd_fused", 0.60, 940.0), mk("mlp_bwd_fused", 0.49, 1000.0), mk("gemm_wgrad_fc", 0.66, 970.0),
+          mk("gemm_dfeat_scatter", 0.24, 250.0), mk("mlp_fwd_fused/g", 0.12, 170.0)]
+    args = types.SimpleNamespace(step_ms_for_roofline=2.35, rows_per_launch=rows)
+    out = bench._roofline_extras(ks, 2500.0, 1, args)
+    assert out["roofline_min_kernel"] == "mlp_fwd_fused" and abs(out["roofline_min_frac"] - 0.376) < 1e-3
+    assert set(out["roofline_min"]["candidates"]) == {"mlp_fwd_fused", "mlp_bwd_fused", "gemm_wgrad_fc"}
+    # the wgrad and forward kernels trade the longest place: the selection does not move
+    ks[0]["total_ms"], ks[0]["flops"] = 0.67, 940.0e12 * 0.67e-3
+    assert bench._roofline_extras(ks, 2500.0, 1, args)["roofline_min_kernel"] == "mlp_fwd_fused"
+    # useful fraction of the dominant kernel: its FLOPs minus lin_in's 214 padded columns (2 x rows x 512 x 214)
+    ks[0]["total_ms"], ks[0]["flops"] = 0.60, 940.0e12 * 0.60e-3
+    pad = 2.0 * rows * 512 * (256 - 42)
+    want = (ks[2]["flops"] - pad) / 0.66e-3 / 1e12 / 2500.0
+    assert abs(out["roofline_useful_frac"] - want) < 1e-4 and out["roofline_useful_frac"] < 970.0 / 2500.0
