@@ -28,6 +28,63 @@ import os
 import sys
 import time
 
+
+
+def _supervise():
+    """One GPU, started by hand or by the driver (no WORLD_SIZE): run the measurement in a CHILD process and start it again -- at most
+    twice -- if the child is killed by SIGABRT.  Why: on some boxes of the pool the HSA runtime aborts ~1 in 12-24 processes of the
+    training step with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION -- this tree and the round-5 tree alike (DESIGN.md section 5.0 / 7;
+    tools/stress_trees.sh) -- and an abort cannot be caught in-process.  Every restart is on the record: stderr says so when it happens, and
+    the JSON line of the run that finished carries `process_restarts` and the reasons.  Nothing is retried for any other exit code.  Only
+    the standard library is imported before this point (the parent never initialises the GPU)."""
+    argv = sys.argv[1:]
+    if os.environ.get("SRF_BENCH_CHILD") or "WORLD_SIZE" in os.environ or "-h" in argv or "--help" in argv:
+        return
+    if "--dry-run" in argv and not os.environ.get("SRF_BENCH_SUPERVISE"):      # (tests/test_dist_gloo.py supervises a dry run)
+        return
+    gpus = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            gpus = argv[i + 1]
+        elif a.startswith("--gpus="):
+            gpus = a.split("=", 1)[1]
+    if str(gpus) != "1":
+        return      # N > 1 started by hand: _self_launch (torch.distributed.run owns the ranks)
+    import signal
+    import subprocess
+    env = dict(os.environ, SRF_BENCH_CHILD="1")
+    restarts = []
+    while True:
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE, text=True)
+        out = p.communicate()[0]
+        rc = p.returncode
+        if rc in (-signal.SIGABRT, 128 + signal.SIGABRT) and len(restarts) < 2:
+            restarts.append("child process %d killed by SIGABRT after printing %d bytes" % (p.pid, len(out)))
+            sys.stderr.write("[bench.py] %s: starting the measurement again (%d of 2)\n" % (restarts[-1], len(restarts)))
+            sys.stderr.flush()
+            continue
+        break
+    lines = out.splitlines()
+    if restarts:
+        for i in range(len(lines) - 1, -1, -1):
+            if lines[i].startswith("{"):
+                try:
+                    d = json.loads(lines[i])
+                    d["process_restarts"] = len(restarts)
+                    d["process_restart_reasons"] = restarts
+                    lines[i] = json.dumps(d)
+                except ValueError:
+                    pass
+                break
+    if lines:
+        sys.stdout.write("\n".join(lines) + "\n")
+    sys.stdout.flush()
+    sys.exit(rc if rc >= 0 else 128 - rc)
+
+
+if __name__ == "__main__":
+    _supervise()
+
 # ranks of a process group (N > 1, or --force-dist): more hardware queues than the runtime's default 4 BEFORE the runtime initialises -- with
 # RCCL's stream in the process the renderer's three streams otherwise share queues and the eagerly issued step serialises (scenerf_amd.dist.
 # more_hw_queues: 3.02 -> 2.65 ms per step); the one-process line is left as the runtime comes
@@ -154,6 +211,8 @@ def parse():
     ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE",
                     help="development: set a module-level knob (or class attribute) of scenerf_amd before the run, e.g. --set renderer.PREFILL_AT=3, "
                          "--set model.SceneRF.share_image_sessions=False")
+    ap.add_argument("--cfg", action="append", default=[], metavar="FIELD=VALUE",
+                    help="development: set a field of the models' RenderConfig (kernel-path selectors), e.g. --cfg fwd_kernel=\"'ring'\"")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed region (no eager / other-entry / drop-in / steady-state / roofline legs): what a profiler should see")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short BASELINE configs[3] (BundleFusion) and configs[4] (inference) legs")
@@ -224,6 +283,11 @@ def make_model(args, dev, precision=None):
                 precision=precision or args.precision, device_rng=not getattr(args, "host_rng", False)).to(dev)
     m.mlp.load_state_dict(synth.mlp_state(1, 4))
     m.mlp_gaussian.load_state_dict(synth.mlp_state(2, 2, out_scale=4.0))
+    for kv in getattr(args, "cfg", None) or []:      # development: --cfg fwd_kernel='ring'
+        import ast
+        k, v = kv.split("=", 1)
+        assert hasattr(m.render_cfg, k), k
+        setattr(m.render_cfg, k, ast.literal_eval(v))
     return m
 
 
@@ -1007,6 +1071,12 @@ class _StubGraphed:
 
 def main():
     args = parse()
+    hook = os.environ.get("SRF_BENCH_TEST_ABORT")      # tests/test_dist_gloo.py: a child that dies like the HSA runtime's abort does
+    if hook and os.environ.get("SRF_BENCH_CHILD"):
+        if hook == "always" or not os.path.exists(hook):
+            if hook != "always":
+                open(hook, "w").close()
+            os.abort()
     if args.dry_run:
         os.environ.setdefault("SRF_DIST_BACKEND", "gloo")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
