@@ -458,6 +458,59 @@ def test_the_trainers_metric_only_sessions_reuse_the_packed_operands_of_the_step
     assert float((aa - ab).abs().max()) <= 2e-2 * float(ab.abs().max())
 
 
+def test_bundlefusion_trainer_step_shares_one_session_per_image():
+    """scenerf_bf.py:124-247 through BundleFusionTrainingMixin.forward on the GPU (3 source frames of n_rays // grid^2 rays, depth metrics
+    at the sampled pixels under a mask): the sources are chunks of one session -- same total and the same gradients of every parameter
+    and every map (to the atomics' order) as with one session per source and autograd's additions."""
+    import contextlib
+    from scenerf_amd.model import SceneRFBundleFusion
+    S, R = 3, 1024
+
+    def run(scoped):
+        torch.manual_seed(5)
+        torch.cuda.manual_seed(5)
+        m = SceneRFBundleFusion(som_sigma=0.02, std=0.1, add_fov_hor=14, add_fov_ver=11, sphere_W=960, sphere_H=720, n_pts_uni=64,
+                                n_pts_per_gaussian=8, max_sample_depth=12, precision="bf16", device_rng=True, n_rays=R, sample_grid_size=2).to(DEV)
+        m.mlp.load_state_dict(synth.mlp_state(11, 4))
+        m.mlp_gaussian.load_state_dict(synth.mlp_state(12, 2, out_scale=0.5))
+        m._device_rng_state(torch.device(DEV)).copy_(torch.tensor([9, 0, 0], dtype=torch.int64))
+        maps = {k: v.to(DEV).requires_grad_(True) for k, v in synth.feature_maps(960, 720, 13).items()}
+
+        class Enc(torch.nn.Module):
+            def forward(self, img, pix=None, pix_sphere=None):
+                return {k: v.unsqueeze(0) for k, v in maps.items()}
+
+        m.net_rgb = Enc()
+        m.device_pixel_draw = True
+        from scenerf_amd.loss_side import make_rng_state
+        object.__setattr__(m, "_loss_rng", make_rng_state(torch.device(DEV), seed=5))
+        if not scoped:
+            m._params_fixed = contextlib.nullcontext
+        g = torch.Generator().manual_seed(6)
+        img = lambda: torch.rand(3, 480, 640, generator=g).to(DEV)      # noqa: E731
+        K = synth.bundlefusion_cam_K().to(DEV)
+        depth = lambda: (torch.rand(480, 640, generator=g) * 6 * (torch.rand(480, 640, generator=g) > 0.2)).to(DEV)      # noqa: E731
+        batch = {"img_inputs": torch.rand(1, 3, 480, 640, generator=g).to(DEV), "cam_K_depth": [K],
+                 "img_sources": [[img() for _ in range(S)]], "img_targets": [[img() for _ in range(S)]],
+                 "T_source2targets": [[synth.rel_pose(0.1 + 0.1 * i, 3.0).to(DEV) for i in range(S)]],
+                 "T_source2infers": [[synth.rel_pose(0.2 + 0.1 * i, 0.0).to(DEV) for i in range(S)]],
+                 "source_depths": [[depth() for _ in range(S)]]}
+        logged = {}
+        m.log = lambda name, v, **k: logged.setdefault(name, []).append(float(v))
+        loss = m.step(batch, "train")
+        loss.backward()
+        torch.cuda.synchronize()
+        ps = list(m.mlp.parameters()) + list(m.mlp_gaussian.parameters())
+        return float(loss), [p.grad.clone() for p in ps] + [maps[k].grad.clone() for k in sorted(maps)], logged
+
+    la, ga, lga = run(True)
+    lb, gb, lgb = run(False)
+    assert abs(la - lb) <= 1e-5 * (1 + abs(lb)), (la, lb)                     # the forward is the same arithmetic
+    assert set(lga) == set(lgb) and any(k.endswith("abs_rel") for k in lga)
+    for x, y in zip(ga, gb):
+        assert float((x - y).abs().max()) <= 2e-3 * float(y.abs().max()) + 1e-12, (x.shape, float((x - y).abs().max()), float(y.abs().max()))
+
+
 def test_a_failed_capture_leaves_a_process_that_can_step_eagerly():
     """`build_on_all_ranks` promises: if a capture fails, the step is issued eagerly instead.  A capture that fails HALF-WAY (here: a loss that
     reads a value back to the host inside the captured step) must therefore leave no capture open, the caller's stream current, no stale
