@@ -164,9 +164,10 @@ class TrainingMixin:
         weighted total is already one differentiable scalar (``fused_total``) and the individual terms are only logged."""
         if ret.get("fused") is not None:
             total_src, terms = ret["fused"]
-            tot["fused_total"] = tot.get("fused_total", 0.0) + total_src
-            for key, i in (("rep", 1), ("col", 2), ("kl", 3), ("d2c", 4), ("somv", 5), ("stds", 6)):
-                tot[key] = tot[key] + terms[i]
+            tot["fused_total"] = total_src if "fused_total" not in tot else tot["fused_total"] + total_src
+            # the logged terms as ONE vector (one launch per further source frame instead of six scalar additions per source)
+            t = terms.detach()
+            tot["fused_terms"] = t if "fused_terms" not in tot else tot["fused_terms"] + t
             return
         tot["somv"] = tot["somv"] + ret["min_som_vars"].mean()
         tot["kl"] = tot["kl"] + ret["loss_kl"].mean()
@@ -178,6 +179,20 @@ class TrainingMixin:
     def _combine(self, tot, bs, step_type):
         """scenerf.py:203-238: the weighted total and the logged terms."""
         det = lambda t: t.detach() if torch.is_tensor(t) else t
+        if "fused_terms" in tot:
+            # every source frame's loss came out of the fused kernel: the weighted total is already one differentiable scalar, the logged
+            # means are six entries of one vector (out8 of scenerf_hip_source_loss_forward: {total, rep, col, kl, d2c, som_vars, stds, valid})
+            v = tot["fused_terms"] / bs
+            if self.use_reprojection:
+                self.log(step_type + "/loss_reprojection", v[1], on_epoch=True, sync_dist=True)
+            if self.use_color:
+                self.log(step_type + "/loss_color", v[2], on_epoch=True, sync_dist=True)
+            self.log(step_type + "/loss_som_kl", v[3], on_epoch=True, sync_dist=True)
+            self.log(step_type + "/min_som_vars", v[5], on_epoch=True, sync_dist=True)
+            self.log(step_type + "/loss_dist2closest_gauss", v[4], on_epoch=True, sync_dist=True)
+            total = tot["fused_total"] / bs
+            self.log(step_type + "/total_loss", det(total), on_epoch=True, sync_dist=True)
+            return {"total_loss": total}
         total = 0.0
         if self.use_reprojection:
             total = total + tot["rep"] / bs * self.reproj_weight
