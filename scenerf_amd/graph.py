@@ -142,6 +142,7 @@ class GraphedStep:
             # with "invalid argument" (tools/capture_abort_probe.py: with fresh ones the eager step runs again)
             from . import renderer
             renderer.reset_side_streams()
+            getattr(self.model, "__dict__", {}).pop("_metric_streams", None)      # (training.TrainingMixin's second stream, forked into it too)
             self._opt_stream = None
             self.graph = None
             raise
@@ -161,9 +162,10 @@ class GraphedStep:
             for p, d in opt.state.items():
                 st[p] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in d.items()}
         hyper = {gi: h[0].detach().clone() for gi, h in getattr(opt, "_hyper", {}).items()} if opt is not None else {}
+        more = [t for t in getattr(self.model, "_rng_states", {}).values() if t is not rng_model and t.device == torch.device(dev)]
         return dict(params=[p.detach().clone() for p in self._params], opt_state=st, hyper=hyper,
                     cuda_rng=torch.cuda.get_rng_state(dev), rng_model=(rng_model, rng_model.clone()) if rng_model is not None else None,
-                    extra=[(t, t.detach().clone()) for t in extra])
+                    extra=[(t, t.detach().clone()) for t in list(extra) + more])
 
     def _restore(self, snap, dev):
         opt = self.optimizer

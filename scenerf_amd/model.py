@@ -357,14 +357,18 @@ class SceneRF(TrainingMixin, _Base):
         -- a captured hipGraph holds its address and every replay advances the call counter on the device.  The seed comes from torch's
         CPU generator when the state is first needed (``torch.manual_seed`` makes a run repeatable); ``reseed_device_rng`` resets it."""
         st = self.__dict__.setdefault("_rng_states", {})
-        key = torch.device(dev).index
+        # (lane 1: the trainer's metric-only renders when they run on a stream of their own beside the trained renders -- two renders in
+        #  flight must not advance one call counter: training.TrainingMixin.overlap_metric_renders)
+        lane = int(self.__dict__.get("_rng_lane", 0))
+        key = torch.device(dev).index if lane == 0 else (torch.device(dev).index, lane)
         if key not in st:
             st[key] = torch.tensor([int(torch.randint(0, 2 ** 62, (1,)).item()), 0, 0], dtype=torch.int64, device=dev)
         return st[key]
 
     def reseed_device_rng(self, seed: int) -> None:
-        for t in self.__dict__.get("_rng_states", {}).values():
-            t.copy_(torch.tensor([int(seed), 0, 0], dtype=torch.int64))
+        for key, t in self.__dict__.get("_rng_states", {}).items():
+            lane = key[1] if isinstance(key, tuple) else 0
+            t.copy_(torch.tensor([(int(seed) + 0x9E3779B97F4A7C15 * lane) % (2 ** 62), 0, 0], dtype=torch.int64))
 
     def render_rays_batch(self, cam_K, T_source2infer, x_rgb: Dict[str, torch.Tensor], depth_window=100,
                           T_cam2velo=None, sampled_pixels=None, ray_batch_size=128, noise=None):

@@ -240,6 +240,19 @@ class TrainingMixin:
             self.__dict__.pop("_pack_cache", None)
             self.__dict__.pop("_image_sessions", None)
 
+    # The metric-only renders (scenerf.py:190-201: a no_grad render of the lidar pixels per source frame, read by nothing but the depth
+    # metrics) on a stream of their own, beside the trained renders: a render starts with ~0.3 ms of small dependent kernels (ray setup,
+    # the gaussian head on 75 CUs, the sampler, encode + gather) before its MFMA-bound radiance forward -- issued beside another render's
+    # radiance forward they cost nothing.  The sampler noise of that stream comes from a second call counter (model._device_rng_state).
+    overlap_metric_renders = True
+
+    def _metric_stream(self, dev):
+        st = self.__dict__.setdefault("_metric_streams", {})
+        key = torch.device(dev).index
+        if key not in st:
+            st[key] = torch.cuda.Stream(device=dev)
+        return st[key]
+
     def forward(self, batch, step_type):
         with self._params_fixed():
             return self._forward_batch(batch, step_type)
@@ -256,6 +269,11 @@ class TrainingMixin:
         pix, pix_sphere, _ = self.spherical_mapping.from_pixels(inv_K=self._inv_K(cam_K0))
         x_rgbs = self.net_rgb(img_input, pix=pix, pix_sphere=pix_sphere)
         tot = dict(rep=0.0, col=0.0, kl=0.0, somv=0.0, stds=0.0, d2c=0.0)
+        side = None
+        if self.overlap_metric_renders and "loc2d_with_depths" in batch and img_input.is_cuda:
+            main = torch.cuda.current_stream(img_input.device)
+            side = self._metric_stream(img_input.device)
+            side.wait_event(main.record_event())        # the maps (and whatever made them) are in front of this point
         for i in range(bs):
             # (bs == 1, the trainers' batch size: the same view as x_rgbs[k][0], whose backward is a view too -- select's backward
             #  fills a zero (1,C,H,W) tensor and copies the gradient in: 0.84 GB of traffic per image at the KITTI shapes)
@@ -271,9 +289,20 @@ class TrainingMixin:
                 self._accumulate(tot, ret)
                 if "loc2d_with_depths" in batch:   # depth metrics on the lidar pixels, scenerf.py:190-201
                     gt_pix = batch["loc2d_with_depths"][i][sid].float()
-                    with torch.no_grad():
-                        r = self.render_rays_batch(cam_K, T_s2i, x_rgb, ray_batch_size=gt_pix.shape[0], sampled_pixels=gt_pix)
-                    self.evaluate_depth(step_type, batch["lidar_depths"][i][sid], r["depth"])
+                    if side is None:
+                        with torch.no_grad():
+                            r = self.render_rays_batch(cam_K, T_s2i, x_rgb, ray_batch_size=gt_pix.shape[0], sampled_pixels=gt_pix)
+                        self.evaluate_depth(step_type, batch["lidar_depths"][i][sid], r["depth"])
+                    else:
+                        self.__dict__["_rng_lane"] = 1
+                        try:
+                            with torch.cuda.stream(side), torch.no_grad():
+                                r = self.render_rays_batch(cam_K, T_s2i, x_rgb, ray_batch_size=gt_pix.shape[0], sampled_pixels=gt_pix)
+                                self.evaluate_depth(step_type, batch["lidar_depths"][i][sid], r["depth"])
+                        finally:
+                            self.__dict__.pop("_rng_lane", None)
+        if side is not None:
+            main.wait_stream(side)       # the logged metrics are read behind this point
         return self._combine(tot, bs, step_type)
 
     def step(self, batch, step_type):
