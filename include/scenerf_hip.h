@@ -193,6 +193,12 @@ int scenerf_hip_clear_last_error(void);
  * written inside a capture lives in that graph's memory and only has its contents during a replay, so a cache entry made under capture id
  * X may be reused under X only (scenerf_amd/renderer.py: the converted feature maps of one image, shared by its S source frames). */
 int scenerf_hip_stream_capture_id(scenerf_stream_t stream, unsigned long long* id);
+/* A stream of the LOWEST priority the device offers (hipDeviceGetStreamPriorityRange: numerically the largest value; PyTorch's own
+ * streams stop at the default priority, which is not the lowest on this hardware).  For work that should only take compute units nobody
+ * else is waiting for: the trainer's metric-only renders beside the trained ones (scenerf_amd/training.py).  *priority receives the value
+ * used, *is_lower whether it is below the default (0).  Destroy with scenerf_hip_stream_destroy (never while work is pending on it). */
+int scenerf_hip_stream_create_lowest_priority(scenerf_stream_t* stream, int* priority, int* is_lower);
+int scenerf_hip_stream_destroy(scenerf_stream_t stream);
 
 /* One-time setup for the CURRENT device (hipSetDevice) and this configuration: kernel attributes (dynamic LDS sizes), the chunk-descriptor
  * tables of the fused ResnetFC kernels (uploaded asynchronously on `stream`), the zero page.  Every entry point does this lazily on

@@ -122,6 +122,8 @@ _PROTOS = {
     "scenerf_hip_last_error": (C.c_char_p, []),
     "scenerf_hip_clear_last_error": (C.c_int, []),
     "scenerf_hip_stream_capture_id": (C.c_int, [vp, C.POINTER(C.c_ulonglong)]),
+    "scenerf_hip_stream_create_lowest_priority": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "scenerf_hip_stream_destroy": (C.c_int, [vp]),
     "scenerf_hip_depth_errors": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float, C.c_float, vp, vp]),
     "scenerf_hip_prepare": (C.c_int, [C.POINTER(Cfg), vp]),
     "scenerf_hip_maps_chw_to_hwc": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),

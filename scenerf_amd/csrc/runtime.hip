@@ -95,6 +95,24 @@ int scenerf_hip_abi_version(void) { return SCENERF_HIP_ABI_VERSION; }
 // point of this library checks hipGetLastError() behind its launches and would report that stale error for a launch that succeeded.
 // Whoever catches a failed capture and carries on eagerly (scenerf_amd.graph.build_on_all_ranks) clears it here.  Returns the code.
 int scenerf_hip_clear_last_error(void) { return (int)hipGetLastError(); }
+int scenerf_hip_stream_create_lowest_priority(scenerf_stream_t* stream, int* priority, int* is_lower) {
+    SRF_CHECK(stream, "stream_create_lowest_priority: stream is null");
+    int least = 0, greatest = 0;
+    SRF_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess, "stream_create_lowest_priority: no priority range");
+    hipStream_t s = nullptr;
+    SRF_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) == hipSuccess, "stream_create_lowest_priority: hipStreamCreateWithPriority failed");
+    int got = 0;
+    if (hipStreamGetPriority(s, &got) != hipSuccess) got = least;
+    *stream = (scenerf_stream_t)s;
+    if (priority) *priority = got;
+    if (is_lower) *is_lower = got > 0 ? 1 : 0;
+    return 0;
+}
+int scenerf_hip_stream_destroy(scenerf_stream_t stream) {
+    SRF_CHECK(stream, "stream_destroy: stream is null");
+    SRF_CHECK(hipStreamDestroy(as_stream(stream)) == hipSuccess, "stream_destroy: hipStreamDestroy failed");
+    return 0;
+}
 int scenerf_hip_stream_capture_id(scenerf_stream_t stream, unsigned long long* id) {
     SRF_CHECK(id, "stream_capture_id: id is null");
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;

@@ -93,19 +93,36 @@ class TrainingMixin:
         m = valid.float()
         return (loss * m).sum() / m.sum().clamp(min=1.0)   # == loss[valid].mean()
 
+    def _stride2_grid(self, dev, dtype):
+        gkey = (dev, dtype, tuple(self.img_size))
+        cache = self.__dict__.setdefault("_stride2_grids", {})
+        grid = cache.get(gkey)
+        if grid is None:      # the stride-2 pixel grid of scenerf.py:253-260: a function of the image size, built once per device
+            xs = torch.arange(0, self.img_size[0], 2, device=dev, dtype=dtype)
+            ys = torch.arange(0, self.img_size[1], 2, device=dev, dtype=dtype)
+            gx, gy = torch.meshgrid(xs, ys, indexing="ij")
+            grid = cache[gkey] = torch.stack([gx, gy], dim=2).reshape(-1, 2)
+        return grid
+
+    def _predraw(self, batch, n_rays, cam_K):
+        """``device_pixel_draw``: the per-source pixel subsets of the whole batch, drawn before the first render -- the same calls on the
+        same generator in the same order, only earlier: a randperm is a dozen small sort launches, and between two renders they wait for
+        compute units behind the radiance forward of the metric-only render on the other stream (0.4 ms instead of 0.1 in the trace)."""
+        if not getattr(self, "device_pixel_draw", False) or not cam_K.is_cuda:
+            return
+        n = self._stride2_grid(cam_K.device, cam_K.dtype).shape[0]
+        self.__dict__["_predrawn_idx"] = [torch.randperm(n, device=cam_K.device)[:n_rays]
+                                          for srcs in batch["img_sources"] for _ in srcs]
+
     def process_single_source(self, n_rays, x_rgb, cam_K, inv_K, img_source, img_target, T_source2target, T_source2infer,
                               T_cam2velo, step_type) -> Dict[str, torch.Tensor]:
         """scenerf.py:243-320."""
         dev = cam_K.device
-        gkey = (dev, cam_K.dtype, tuple(self.img_size))
-        cache = self.__dict__.setdefault("_stride2_grids", {})
-        grid = cache.get(gkey)
-        if grid is None:      # the stride-2 pixel grid of scenerf.py:253-260: a function of the image size, built once per device
-            xs = torch.arange(0, self.img_size[0], 2, device=dev, dtype=cam_K.dtype)
-            ys = torch.arange(0, self.img_size[1], 2, device=dev, dtype=cam_K.dtype)
-            gx, gy = torch.meshgrid(xs, ys, indexing="ij")
-            grid = cache[gkey] = torch.stack([gx, gy], dim=2).reshape(-1, 2)
-        if getattr(self, "device_pixel_draw", False):
+        grid = self._stride2_grid(dev, cam_K.dtype)
+        drawn = self.__dict__.get("_predrawn_idx")
+        if drawn:
+            idx = drawn.pop(0)       # (device_pixel_draw inside forward: drawn for all source frames of the batch up front, see _predraw)
+        elif getattr(self, "device_pixel_draw", False):
             # the same draw on the DEVICE generator: no host round trip, and capturable (scenerf_amd.graph.GraphedFn replays the whole
             # per-image step with fresh pixels per replay: torch's CUDA generator is graph-safe)
             idx = torch.randperm(grid.shape[0], device=dev)[:n_rays]
@@ -239,6 +256,7 @@ class TrainingMixin:
         finally:
             self.__dict__.pop("_pack_cache", None)
             self.__dict__.pop("_image_sessions", None)
+            self.__dict__.pop("_predrawn_idx", None)
 
     # The metric-only renders (scenerf.py:190-201: a no_grad render of the lidar pixels per source frame, read by nothing but the depth
     # metrics) on a stream of their own, beside the trained renders: a render starts with ~0.3 ms of small dependent kernels (ray setup,
@@ -246,11 +264,32 @@ class TrainingMixin:
     # radiance forward they cost nothing.  The sampler noise of that stream comes from a second call counter (model._device_rng_state).
     overlap_metric_renders = True
 
+    # Below the default priority (HIP has such a level, 1; PyTorch's own streams stop at 0) so that the metric-only renders only take
+    # compute units nobody waits for: measured on the trainer's step, same box, three alternations (profiles/r06_r_*) -- issued eagerly
+    # 6.69-6.79 ms against 6.60-6.75 at the default priority, REPLAYED 8.75-9.32 ms against 6.41-6.60: a captured graph with a
+    # low-priority branch loses the overlap altogether.  Off.
+    metric_stream_low_priority = False
+
     def _metric_stream(self, dev):
         st = self.__dict__.setdefault("_metric_streams", {})
         key = torch.device(dev).index
         if key not in st:
-            st[key] = torch.cuda.Stream(device=dev)
+            s = None
+            if self.metric_stream_low_priority:
+                # the metric-only renders should take the compute units nobody is waiting for: their radiance forward otherwise shares
+                # the dispatcher round-robin with the trained render's small dependent kernels and doubles their latency
+                import ctypes
+                from . import _capi
+                h, pr, low = ctypes.c_void_p(), ctypes.c_int(0), ctypes.c_int(0)
+                with torch.cuda.device(dev):
+                    _capi.check(_capi.load().scenerf_hip_stream_create_lowest_priority(ctypes.byref(h), ctypes.byref(pr), ctypes.byref(low)),
+                                "stream_create_lowest_priority")
+                if low.value:
+                    s = torch.cuda.ExternalStream(h.value, device=dev)     # (lives as long as the process: never destroyed under pending work)
+                else:
+                    _capi.load().scenerf_hip_stream_destroy(h)
+                self.__dict__["_metric_stream_priority"] = pr.value
+            st[key] = s if s is not None else torch.cuda.Stream(device=dev)
         return st[key]
 
     def forward(self, batch, step_type):
@@ -269,6 +308,8 @@ class TrainingMixin:
         pix, pix_sphere, _ = self.spherical_mapping.from_pixels(inv_K=self._inv_K(cam_K0))
         x_rgbs = self.net_rgb(img_input, pix=pix, pix_sphere=pix_sphere)
         tot = dict(rep=0.0, col=0.0, kl=0.0, somv=0.0, stds=0.0, d2c=0.0)
+        if "_image_sessions" in self.__dict__:      # (inside forward's scope, which clears the list)
+            self._predraw(batch, self.n_rays, cam_K0)
         side = None
         if self.overlap_metric_renders and "loc2d_with_depths" in batch and img_input.is_cuda:
             main = torch.cuda.current_stream(img_input.device)
@@ -338,6 +379,8 @@ class BundleFusionTrainingMixin(TrainingMixin):
         x_rgbs = self.net_rgb(img_input, pix=pix, pix_sphere=pix_sphere)
         n_grids = self.n_rays // (self.sample_grid_size ** 2)
         tot = dict(rep=0.0, col=0.0, kl=0.0, somv=0.0, stds=0.0, d2c=0.0)
+        if "_image_sessions" in self.__dict__:
+            self._predraw(batch, n_grids, cam_K)
         for i in range(bs):
             x_rgb = {k: (x_rgbs[k].squeeze(0) if bs == 1 else x_rgbs[k][i]) for k in x_rgbs}
             for sid in range(len(batch["img_sources"][i])):
