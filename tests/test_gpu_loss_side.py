@@ -178,3 +178,59 @@ def test_depth_errors_kernel_matches_the_reference_metrics_and_the_host_version(
         want = torch.stack(depth_errors(gt, pred, max_depth=md, mask=mask)).double().numpy()
         got = torch.stack(depth_errors(gt.to(DEV), pred.to(DEV), max_depth=md, mask=None if mask is None else mask.to(DEV))).double().cpu().numpy()
         np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-7, err_msg=str((n, masked, md)))     # (fp32 means on the host, double sums in the kernel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["kitti", "bundlefusion"])
+def test_trainer_forward_on_the_gpu_matches_the_reference_loop(variant):
+    """The reference's own ``forward`` (scenerf.py:119-241 / scenerf_bf.py:124-247) run around a deterministic fake renderer and encoder
+    minted these totals and logged values (tests/golden/make_golden_{kitti,bf}_forward.py).  On CUDA tensors scenerf_amd's loop takes the
+    paths the CPU test (tests/test_loss_side.py) does not: the whole per-source loss in one kernel each way, the logged terms as one
+    vector, the depth metrics in one launch, the per-image scope (pixel subsets drawn up front stays off: host draw like the reference)
+    and, for KITTI, the metric-only renders on a stream of their own."""
+    from bf_fakes import FakeNetRgb, fake_batch, fake_batch_kitti, fake_render
+    from scenerf_amd.model import SceneRF, SceneRFBundleFusion
+
+    def to_dev(x):
+        if torch.is_tensor(x):
+            return x.to(DEV)
+        if isinstance(x, np.ndarray):
+            return torch.from_numpy(x).to(DEV)
+        if isinstance(x, (list, tuple)):
+            return [to_dev(v) for v in x]
+        return x
+
+    if variant == "kitti":
+        g = np.load(os.path.join(HERE, "golden", "kitti_forward.npz"))
+        m = SceneRF(som_sigma=2.0, img_size=(64, 48), n_rays=200, sphere_H=48, sphere_W=64)
+        batch, seed = fake_batch_kitti(seed=4), 6
+    else:
+        g = np.load(os.path.join(HERE, "golden", "bf_forward.npz"))
+        m = SceneRFBundleFusion(som_sigma=2.0, img_size=(64, 48), n_rays=256, sample_grid_size=2, sphere_H=48, sphere_W=64, eval_depth=10)
+        batch, seed = fake_batch(seed=3), 5
+    m = m.to(DEV)
+    batch = {k: to_dev(v) for k, v in batch.items()}
+
+    class Enc(torch.nn.Module):
+        def forward(self, img, pix=None, pix_sphere=None):
+            return {k: v.to(DEV) for k, v in FakeNetRgb()(img.cpu()).items()}
+
+    m.net_rgb = Enc()
+    m.render_rays_batch = lambda cam_K, T, x_rgb, ray_batch_size=None, sampled_pixels=None, **k: {
+        kk: vv.to(DEV) for kk, vv in fake_render(sampled_pixels.cpu(), T.cpu()).items()}
+    m.fused_loss_noise = "torch"            # the tie-breaking noise through torch.randn, which the golden run replaced by zeros
+    logs = {}
+    m.log = lambda key, val, **k: logs.setdefault(key, []).append(val.detach().clone() if torch.is_tensor(val) else val)
+    orig = torch.randn
+    torch.randn = lambda *a, **k: torch.zeros(*a, **{kk: vv for kk, vv in k.items() if kk in ("device", "dtype")})
+    try:
+        torch.manual_seed(seed)
+        out = m.forward(batch, "train")
+    finally:
+        torch.randn = orig
+    torch.cuda.synchronize()
+    assert abs(float(out["total_loss"]) - float(g["total_loss"])) < 5e-6 * (1 + abs(float(g["total_loss"])))
+    keys = [k[4:] for k in g.files if k.startswith("log/")]
+    assert sorted(keys) == sorted(logs), (sorted(set(keys) ^ set(logs)))
+    for k in keys:
+        np.testing.assert_allclose(np.asarray([float(v) for v in logs[k]]), g["log/" + k], rtol=3e-5, atol=3e-6, err_msg=k)

@@ -382,3 +382,19 @@ def test_roofline_min_names_the_worst_big_mfma_bound_kernel_and_the_useful_fract
     pad = 2.0 * rows * 512 * (256 - 42)
     want = (ks[2]["flops"] - pad) / 0.66e-3 / 1e12 / 2500.0
     assert abs(out["roofline_useful_frac"] - want) < 1e-4 and out["roofline_useful_frac"] < 970.0 / 2500.0
+
+
+def test_the_trainers_per_image_scope_ends_with_forward_whatever_happens():
+    """training.TrainingMixin._params_fixed: the shared sessions, the packed-operand cache and the pre-drawn pixel subsets exist only while
+    ``forward`` runs -- a render_rays_batch call after it (validation, another optimizer step in between) must never see them."""
+    m = SceneRF(som_sigma=2.0, img_size=(64, 48), n_rays=16, sphere_H=48, sphere_W=64)
+    keys = ("_pack_cache", "_image_sessions", "_predrawn_idx")
+    with m._params_fixed():
+        assert "_pack_cache" in m.__dict__ and "_image_sessions" in m.__dict__
+        m.__dict__["_predrawn_idx"] = [torch.zeros(1)]
+    assert not any(k in m.__dict__ for k in keys)
+    with pytest.raises(RuntimeError):
+        with m._params_fixed():
+            raise RuntimeError("a step that fails half-way")
+    assert not any(k in m.__dict__ for k in keys)
+    assert m.share_image_sessions and m.cache_converted_maps and m.overlap_metric_renders and not m.metric_stream_low_priority
