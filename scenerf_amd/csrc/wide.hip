@@ -806,6 +806,14 @@ __global__ __launch_bounds__(H_THREADS) void mlp_wide_kernel(FusedArgs p) {
 #undef H_LW
 #undef H_GROUP_TOP
 #undef H_WPTR
+    // The weight ring's registers die here with loads still in flight: the branch-free K loop requests the blocks of the four chunks
+    // BEHIND the last one (zero-padded descriptors: block 0) and nobody ever waits for them.  Those requests are inline asm (H_LW): the
+    // compiler does not know that sixteen writes to wr[][] are pending, takes the registers for the tail's store addresses -- and a load
+    // that lands late overwrites a pointer.  Found in round 6 as HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in 1 of 12-46 processes on
+    // boxes whose GPU was busy with other work too, and in 2 of 12 processes when three ran at once (memory latency decides whether the
+    // load or the compiler's reuse comes first; tools/preempt_stress.sh).  Everything this wave requested has landed before the
+    // registers are handed back:
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     H_LANE();
     // ---- tail: the last layer's output goes out four pieces at a time (four LDS reads in flight, then four stores)
     const bool do_out = MODE == 0 && p.logits;

@@ -81,3 +81,30 @@ def test_exact_wait_counts_what_a_chunk_issues(isa, mode, ws):
     for m2 in (2, 3, 4):
         b2, _ = _kernel(isa, m2)
         assert "s_waitcnt vmcnt(15)" in b2 and first not in b2
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_nothing_is_stored_behind_the_last_ring_load_before_everything_has_landed(isa, mode):
+    """Round 6: the K loop's weight loads are inline asm with register outputs; the loop is branch-free and requests four chunks past the
+    last one into ring registers that die with the loop.  The compiler does not know those writes are pending and reuses the registers for
+    the tail's store addresses -- a late load then overwrites a pointer (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION, 1 in 12-46 processes
+    on a busy GPU).  In the ISA: between the LAST inline-asm ring load of a kernel and the first vector-memory store behind it there must
+    be an `s_waitcnt vmcnt(0)`."""
+    body, name = _kernel(isa, mode)
+    lines = body.split("\n")
+    inasm, last, wait_at = False, -1, -1
+    for i, ln in enumerate(lines):
+        if "#ASMSTART" in ln:
+            inasm = True
+        elif "#ASMEND" in ln:
+            inasm = False
+        elif inasm and re.match(r"\s*global_load_dwordx4\s+v\[\d+:\d+\],\s*v\d+,\s*s\[\d+:\d+\]", ln):
+            last = i            # (saddr form with a register destination: H_LW)
+        elif inasm and re.match(r"\s*s_waitcnt\s+vmcnt\(0\)\s*$", ln):
+            wait_at = i         # (the hand-written one: the compiler's own waits are outside the asm blocks)
+    assert last > 0, name + ": no inline-asm ring load found (did H_LW change form?)"
+    # (text order: the tail is laid out behind every K-loop body in all five instantiations; the stores between the textually last ring
+    #  load and the wait are the K loop's own stream-out and the epilogues, in front of which the ring is still live)
+    assert wait_at > last, name + ": no hand-written `s_waitcnt vmcnt(0)` behind the last ring load (the tail's stores would use registers " \
+                                  "that pending loads still write)"
+    assert any(re.match(r"\s*global_store", ln) for ln in lines[wait_at:]), name + ": no tail store behind the wait (did the tail move?)"
