@@ -16,9 +16,12 @@
 //     fragment address of chunk k is base ^ ((k & 7) << 5) + (k >> 3) * 256 (the A buffer's XOR swizzle only involves k mod 8);
 //   * weights: the wave streams exactly ITS 4 KiB of a w_stream block (four coalesced 1-KiB global_load_dwordx4, already in fragment
 //     layout) four chunks ahead -- every weight byte enters the CU once per 128 rows; nothing is shared between waves in a K loop:
-//     no barrier in it.  The loads are plain loads (the compiler counts vmcnt: at the top of a chunk the 12 youngest -- three chunks --
-//     may be outstanding); the activation stores and the DMA are inline asm and only make that wait conservative (loads return in
-//     order: a count <= 12 still implies the chunk's own four loads have landed);
+//     no barrier in it.  The ring's first fill is plain loads; inside the K loop the loads are inline asm (saddr form: H_LW) and every
+//     use sits behind a hand-counted `s_waitcnt vmcnt` (at the top of a chunk the 12 youngest loads -- three chunks -- plus the
+//     stream-out's stores may be outstanding).  The compiler does NOT know that an asm load's destination is written later: the ring
+//     registers must stay live until everything requested has landed -- the loop requests four chunks past the last one, so the
+//     kernel's tail begins with `s_waitcnt vmcnt(0)` (round 6: without it a late load overwrote a store address of the tail, an
+//     aperture violation in 1 of 12-46 processes on a busy GPU; tests/test_wide_isa.py guards the wait);
 //   * the resident A operand (relu of the previous layer / the running gradient, 128 rows x 1 KiB, XOR-swizzled 16-byte slots) fills
 //     128 KiB of LDS; the streamed operand of the lin_in / lin_z segments (X3 / Z columns, 4 KiB per chunk) goes global -> LDS by DMA
 //     (global_load_lds) in ROUNDS: all of layer 0's chunks at once into the (still unused) A buffer + a 24-KiB stage, the lin_z tails of
