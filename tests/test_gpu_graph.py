@@ -458,6 +458,30 @@ def test_the_trainers_metric_only_sessions_reuse_the_packed_operands_of_the_step
     assert float((aa - ab).abs().max()) <= 2e-2 * float(ab.abs().max())
 
 
+def test_validation_step_under_no_grad_takes_the_same_path_and_gives_the_same_loss():
+    """Lightning's validation_step runs ``forward`` under torch.no_grad(): every render of the image is metric-only then (two no_grad
+    sessions: the trained renders' pixels and the lidar pixels, the latter on the second stream), nothing is kept for a backward.  Same
+    seeds, same parameters: the total equals the training forward's (the no_grad instantiation of the radiance forward rounds where the
+    training one does), and the scope is gone afterwards."""
+    def run(grad):
+        m, opt, maps, batch = _trainer_setup(53)
+        logged = {}
+        m.log = lambda name, v, **k: logged.setdefault(name, []).append(float(v))
+        with torch.enable_grad() if grad else torch.no_grad():
+            loss = m.step(batch, "train" if grad else "val")
+        torch.cuda.synchronize()
+        assert "_image_sessions" not in m.__dict__ and "_pack_cache" not in m.__dict__
+        assert loss.requires_grad == grad
+        return float(loss), {k.split("/", 1)[-1]: v for k, v in logged.items()}
+
+    lt, gt_ = run(True)
+    lv, gv = run(False)
+    assert abs(lt - lv) <= 2e-5 * (1 + abs(lt)), (lt, lv)
+    assert set(gt_) == set(gv)
+    for k in gt_:
+        assert all(abs(a - b) <= 1e-4 * (1 + abs(a)) for a, b in zip(gt_[k], gv[k])), k
+
+
 def test_bundlefusion_trainer_step_shares_one_session_per_image():
     """scenerf_bf.py:124-247 through BundleFusionTrainingMixin.forward on the GPU (3 source frames of n_rays // grid^2 rays, depth metrics
     at the sampled pixels under a mask): the sources are chunks of one session -- same total and the same gradients of every parameter
