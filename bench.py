@@ -56,7 +56,15 @@ def _supervise():
     restarts = []
     while True:
         p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE, text=True)
-        out = p.communicate()[0]
+
+        def _forward(signum, _frame, child=p):      # whoever stops the bench stops the measurement too
+            child.send_signal(signum)
+        old = {sg: signal.signal(sg, _forward) for sg in (signal.SIGTERM, signal.SIGINT)}
+        try:
+            out = p.communicate()[0]
+        finally:
+            for sg, h in old.items():
+                signal.signal(sg, h)
         rc = p.returncode
         if rc in (-signal.SIGABRT, 128 + signal.SIGABRT) and len(restarts) < 2:
             restarts.append("child process %d killed by SIGABRT after printing %d bytes" % (p.pid, len(out)))
