@@ -1201,7 +1201,13 @@ class RenderChunk(torch.autograd.Function):
         side = _side_stream(dev)
         do_head = bool(ctx.needs_input_grad[12] or want_maps)
         head_done = []
-        side_maps = bool(MAP_GRADS_ON_SIDE and want_maps and GRADS_BEHIND_HEAD and do_head and ctx.needs_input_grad[11]
+        # (not with gradient collectives in the session: the head's all-reduce runs on the side stream in front of the scatter, and a
+        #  captured step then replays the head's backward + all-reduce in FRONT of the chain -- one RCCL rank, replayed: 3.29 ms against
+        #  2.62 with the scatter on the main stream, 2.59 issued eagerly; profiles/r06_u_*)
+        #  -- issued eagerly the side-stream scatter stays: 2.59 against 2.71 ms)
+        collectives = (ctx.mlpg.grad_sync is not None or ctx.mlp.grad_sync_async is not None or ctx.mlp.grad_sync is not None) \
+            and torch.cuda.is_current_stream_capturing()
+        side_maps = bool(MAP_GRADS_ON_SIDE and want_maps and GRADS_BEHIND_HEAD and do_head and ctx.needs_input_grad[11] and not collectives
                          and (ctx.mlpg.single_chunk or MAP_GRADS_ON_SIDE_MULTI))
 
         def main_backward():
