@@ -108,3 +108,51 @@ def test_nothing_is_stored_behind_the_last_ring_load_before_everything_has_lande
     assert wait_at > last, name + ": no hand-written `s_waitcnt vmcnt(0)` behind the last ring load (the tail's stores would use registers " \
                                   "that pending loads still write)"
     assert any(re.match(r"\s*global_store", ln) for ln in lines[wait_at:]), name + ": no tail store behind the wait (did the tail move?)"
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_the_compiler_copies_no_ring_register_once_the_asm_loads_have_started(isa, mode):
+    """The other half of the same premise: the compiler believes an inline-asm load's destination is defined at once.  If it decided to
+    COPY a ring register (a phi move at a loop back-edge, a re-assignment between two code regions) the copy would read a register whose
+    load may still be in flight.  Today it does not: every register-to-register move of a ring register sits in front of the first asm
+    load, where the ring is filled by plain loads the compiler waits for itself."""
+    body, name = _kernel(isa, mode)
+    lines = body.split("\n")
+    inasm, first, ring = False, None, set()
+    for i, ln in enumerate(lines):
+        if "#ASMSTART" in ln:
+            inasm = True
+        elif "#ASMEND" in ln:
+            inasm = False
+        elif inasm:
+            m = re.match(r"\s*global_load_dwordx4\s+v\[(\d+):(\d+)\],\s*v\d+,\s*s\[\d+:\d+\]", ln)
+            if m:
+                ring.update(range(int(m.group(1)), int(m.group(2)) + 1))
+                first = i if first is None else first
+    assert first is not None and len(ring) >= 64
+    # (a ring register is an ordinary register again behind the tail's hand-written `s_waitcnt vmcnt(0)`: only moves in front of it count)
+    inasm, tail_wait = False, len(lines)
+    for i, ln in enumerate(lines):
+        if "#ASMSTART" in ln:
+            inasm = True
+        elif "#ASMEND" in ln:
+            inasm = False
+        elif inasm and re.match(r"\s*s_waitcnt\s+vmcnt\(0\)\s*$", ln) and i > first:
+            tail_wait = i
+    inasm, bad = False, []
+    for ln in lines[first:tail_wait]:
+        if "#ASMSTART" in ln:
+            inasm = True
+        elif "#ASMEND" in ln:
+            inasm = False
+        elif not inasm:
+            t = ln.strip()
+            # (a fragment is four registers: on gfx950 its copy is a pair of v_mov_b64 / v_pk_mov_b32 -- the prologue's re-assignments of
+            #  the plain-loaded ring look exactly like that; single v_mov_b32 of a register that serves the ring in ANOTHER region are
+            #  address copies at loop back-edges and not meant here)
+            m = re.match(r"v_(?:mov_b64_e32|pk_mov_b32)\s+v\[?(\d+)(?::\d+)?\]?,\s*v\[?(\d+)(?::(\d+))?\]?", t)
+            if m:
+                src = set(range(int(m.group(2)), int(m.group(3) or m.group(2)) + 1))
+                if src & ring:
+                    bad.append(t)
+    assert not bad, "%s: compiler-made copies of ring registers between the first asm load and the tail: %s" % (name, bad[:5])
