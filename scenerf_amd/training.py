@@ -314,6 +314,7 @@ class TrainingMixin:
         if self.overlap_metric_renders and "loc2d_with_depths" in batch and img_input.is_cuda:
             main = torch.cuda.current_stream(img_input.device)
             side = self._metric_stream(img_input.device)
+            self._inv_K(batch["cam_K"][0])              # (sample 0's inverse intrinsics: uploaded in front of the event below)
             side.wait_event(main.record_event())        # the maps (and whatever made them) are in front of this point
         for i in range(bs):
             # (bs == 1, the trainers' batch size: the same view as x_rgbs[k][0], whose backward is a view too -- select's backward
@@ -321,6 +322,11 @@ class TrainingMixin:
             x_rgb = {k: (x_rgbs[k].squeeze(0) if bs == 1 else x_rgbs[k][i]) for k in x_rgbs}
             cam_K = batch["cam_K"][i]
             inv_K = self._inv_K(cam_K)       # (the host's LAPACK: model.py)
+            if side is not None and i > 0:
+                # (the inverse of this sample's intrinsics may have been uploaded on the main stream just now: the second stream reads it
+                #  too.  Sample 0's is in front of the first event; for further samples of a batch the second stream falls in behind the
+                #  previous sample's renders here)
+                side.wait_event(main.record_event())
             for sid in range(len(batch["img_sources"][i])):
                 T_s2i = batch["T_source2infers"][i][sid]
                 ret = self.process_single_source(self.n_rays, x_rgb=x_rgb, cam_K=cam_K, inv_K=inv_K,
@@ -329,8 +335,8 @@ class TrainingMixin:
                                                  T_cam2velo=T_cam2velo, step_type=step_type)
                 self._accumulate(tot, ret)
                 if "loc2d_with_depths" in batch:   # depth metrics on the lidar pixels, scenerf.py:190-201
-                    gt_pix = batch["loc2d_with_depths"][i][sid].float()
                     if side is None:
+                        gt_pix = batch["loc2d_with_depths"][i][sid].float()
                         with torch.no_grad():
                             r = self.render_rays_batch(cam_K, T_s2i, x_rgb, ray_batch_size=gt_pix.shape[0], sampled_pixels=gt_pix)
                         self.evaluate_depth(step_type, batch["lidar_depths"][i][sid], r["depth"])
@@ -338,6 +344,10 @@ class TrainingMixin:
                         self.__dict__["_rng_lane"] = 1
                         try:
                             with torch.cuda.stream(side), torch.no_grad():
+                                # (EVERYTHING the second stream reads must have been made in front of an event it waited for, or be
+                                #  made on it: the int -> float cast of the lidar pixels was a main-stream kernel once, and under load
+                                #  the metric render read its output early -- found by running two test suites at once, round 6)
+                                gt_pix = batch["loc2d_with_depths"][i][sid].float()
                                 r = self.render_rays_batch(cam_K, T_s2i, x_rgb, ray_batch_size=gt_pix.shape[0], sampled_pixels=gt_pix)
                                 self.evaluate_depth(step_type, batch["lidar_depths"][i][sid], r["depth"])
                         finally:
